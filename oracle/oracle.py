@@ -1,0 +1,647 @@
+"""CPU oracle for the PreWorld camera->voxel occupancy hot path (numpy + C via ctypes).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by preworld_amd/.  Each function cites the reference
+file:line it restates (paths relative to /root/reference).  State dicts use the
+reference's parameter names so reference fixtures load unchanged.
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libpw_oracle.so')
+_lib = None
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force=False):
+    """Compile oracle/pw_oracle.c with gcc (Makefile in this directory)."""
+    src = os.path.join(_HERE, 'pw_oracle.c')
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.check_call(['make', '-C', _HERE, '-B', 'libpw_oracle.so'],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.pwo_version.restype = ctypes.c_int
+        _lib.pwo_num_threads.restype = ctypes.c_int
+        _lib.pwo_voxel_prepare.restype = ctypes.c_int64
+        _lib.pwo_bev_pool_bp_prepare.restype = ctypes.c_int
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=c_f32p):
+    return a.ctypes.data_as(t)
+
+
+def num_threads():
+    return lib().pwo_num_threads()
+
+
+def set_num_threads(n):
+    lib().pwo_set_num_threads(int(n))
+
+
+# --------------------------------------------------------------------------- geometry
+def create_frustum(depth_cfg, input_size, downsample):
+    """view_transformer.py:84-112 -> (D,H,W,3) float32."""
+    H_in, W_in = int(input_size[0]), int(input_size[1])
+    downsample = int(downsample)
+    Hf, Wf = H_in // downsample, W_in // downsample
+    depth_cfg = [float(v) for v in depth_cfg]
+    D = len(np.arange(depth_cfg[0], depth_cfg[1], depth_cfg[2]))
+    out = np.empty((D, Hf, Wf, 3), np.float32)
+    lib().pwo_create_frustum(D, Hf, Wf, ctypes.c_float(depth_cfg[0]),
+                             ctypes.c_float(depth_cfg[2]), H_in, W_in, _p(out))
+    return out
+
+
+def grid_infos(grid_config):
+    """view_transformer.py:66-82: lower bound, interval (fp32) and integer size."""
+    axes = [grid_config[k] for k in ('x', 'y', 'z')]
+    lower = np.array([c[0] for c in axes], np.float32)
+    interval = np.array([c[2] for c in axes], np.float32)
+    size = [int(np.float32((c[1] - c[0]) / c[2])) for c in axes]
+    return lower, interval, size
+
+
+def camera_matrices(sensor2ego, cam2imgs, post_rots):
+    """inverse(post_rots), R @ inverse(K), t  (view_transformer.py:141-150)."""
+    s = _f32(sensor2ego).reshape(-1, 4, 4)
+    k = _f32(cam2imgs).reshape(-1, 3, 3)
+    r = _f32(post_rots).reshape(-1, 3, 3)
+    BN = s.shape[0]
+    ipr = np.empty((BN, 3, 3), np.float32)
+    comb = np.empty((BN, 3, 3), np.float32)
+    tr = np.empty((BN, 3), np.float32)
+    lib().pwo_camera_matrices(BN, _p(s), _p(k), _p(r), _p(ipr), _p(comb), _p(tr))
+    return ipr, comb, tr
+
+
+def lidar_coor(frustum, inv_post_rot, post_trans, combine, trans, bda, B, N):
+    """view_transformer.py:114-153 with the 3x3 inverses already applied."""
+    D, H, W, _ = frustum.shape
+    coor = np.empty((B, N, D, H, W, 3), np.float32)
+    lib().pwo_lidar_coor(B, N, D, H, W, _p(_f32(frustum)), _p(_f32(inv_post_rot)),
+                         _p(_f32(post_trans)), _p(_f32(combine)), _p(_f32(trans)),
+                         _p(_f32(bda)), _p(coor))
+    return coor
+
+
+def voxel_index(coor, lower, interval, size):
+    B = coor.shape[0]
+    n_per_b = int(np.prod(coor.shape[1:5]))
+    vox = np.empty((B * n_per_b,), np.int32)
+    lib().pwo_voxel_index(ctypes.c_size_t(n_per_b), B, _p(_f32(coor)), _p(_f32(lower)),
+                          _p(_f32(interval)), size[0], size[1], size[2], _p(vox, c_i32p))
+    return vox
+
+
+def voxel_pooling_prepare_v2(coor, lower, interval, size):
+    """view_transformer.py:203-261 -> (ranks_bev, ranks_depth, ranks_feat, starts, lengths)
+    or five Nones when nothing is kept."""
+    B, N, D, H, W, _ = coor.shape
+    vox = voxel_index(coor, lower, interval, size)
+    n_total = vox.shape[0]
+    n_vox = B * size[0] * size[1] * size[2]
+    rb = np.empty(n_total, np.int32)
+    rd = np.empty(n_total, np.int32)
+    rf = np.empty(n_total, np.int32)
+    st = np.empty(min(n_total, n_vox), np.int32)
+    ln = np.empty(min(n_total, n_vox), np.int32)
+    ni = ctypes.c_int32(0)
+    kept = lib().pwo_voxel_prepare(ctypes.c_size_t(n_total), n_vox, _p(vox, c_i32p), D, H * W,
+                                   _p(rb, c_i32p), _p(rd, c_i32p), _p(rf, c_i32p),
+                                   _p(st, c_i32p), _p(ln, c_i32p), ctypes.byref(ni))
+    if kept == 0:
+        return None, None, None, None, None
+    return rb[:kept].copy(), rd[:kept].copy(), rf[:kept].copy(), \
+        st[:ni.value].copy(), ln[:ni.value].copy()
+
+
+def bev_pool_v2_forward(depth, feat, out, ranks_depth, ranks_feat, ranks_bev,
+                        interval_lengths, interval_starts):
+    """bev_pool.cpp:30-57 argument order (lengths before starts); out is in/out."""
+    c = feat.shape[-1]
+    lib().pwo_bev_pool_v2_forward(c, len(interval_lengths), _p(depth), _p(feat),
+                                  _p(ranks_depth, c_i32p), _p(ranks_feat, c_i32p),
+                                  _p(ranks_bev, c_i32p), _p(interval_starts, c_i32p),
+                                  _p(interval_lengths, c_i32p), _p(out))
+
+
+def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+                interval_starts, interval_lengths):
+    """bev_pool.py:86-92: returns (B,C,Z,Y,X)."""
+    depth = _f32(depth)
+    feat = _f32(feat)
+    out = np.zeros(bev_feat_shape, np.float32)
+    bev_pool_v2_forward(depth, feat, out, ranks_depth, ranks_feat, ranks_bev,
+                        interval_lengths, interval_starts)
+    return np.ascontiguousarray(out.transpose(0, 4, 1, 2, 3))
+
+
+def bev_pool_v2_backward(out_grad, depth, feat, ranks_depth, ranks_feat, ranks_bev):
+    """bev_pool.py:43-83 -> (depth_grad, feat_grad). out_grad is (B,Z,Y,X,C)."""
+    depth = _f32(depth)
+    feat = _f32(feat)
+    out_grad = _f32(out_grad)
+    n = len(ranks_bev)
+    n_pix = int(np.prod(feat.shape[:-1]))
+    ob = np.empty(n, np.int32)
+    od = np.empty(n, np.int32)
+    of = np.empty(n, np.int32)
+    st = np.empty(n_pix, np.int32)
+    ln = np.empty(n_pix, np.int32)
+    ni = lib().pwo_bev_pool_bp_prepare(ctypes.c_int64(n), n_pix, _p(ranks_bev, c_i32p),
+                                       _p(ranks_depth, c_i32p), _p(ranks_feat, c_i32p),
+                                       _p(ob, c_i32p), _p(od, c_i32p), _p(of, c_i32p),
+                                       _p(st, c_i32p), _p(ln, c_i32p))
+    dg = np.zeros_like(depth)
+    fg = np.zeros_like(feat)
+    lib().pwo_bev_pool_v2_backward(feat.shape[-1], ni, _p(out_grad), _p(depth), _p(feat),
+                                   _p(od, c_i32p), _p(of, c_i32p), _p(ob, c_i32p),
+                                   _p(st, c_i32p), _p(ln, c_i32p), _p(dg), _p(fg))
+    return dg, fg
+
+
+def lss_view_transform(depth, tran_feat, sensor2ego, cam2imgs, post_rots, post_trans, bda,
+                       grid_config, input_size, downsample):
+    """LSSViewTransformer.view_transform_core (accelerate=False) view_transformer.py:269-291.
+    depth (B,N,D,H,W), tran_feat (B,N,C,H,W) -> bev_feat (B,C,Z,Y,X)."""
+    B, N = depth.shape[:2]
+    frustum = create_frustum(grid_config['depth'], input_size, downsample)
+    lower, interval, size = grid_infos(grid_config)
+    ipr, comb, tr = camera_matrices(sensor2ego, cam2imgs, post_rots)
+    coor = lidar_coor(frustum, ipr, post_trans, comb, tr, bda, B, N)
+    rb, rd, rf, st, ln = voxel_pooling_prepare_v2(coor, lower, interval, size)
+    C = tran_feat.shape[2]
+    if rb is None:
+        return np.zeros((B, C, size[2], size[1], size[0]), np.float32)
+    feat = np.ascontiguousarray(_f32(tran_feat).transpose(0, 1, 3, 4, 2))
+    return bev_pool_v2(depth, feat, rd, rf, rb, (B, size[2], size[1], size[0], C), st, ln)
+
+
+# --------------------------------------------------------------------------- conv stack
+def conv3d(x, w, bias=None, stride=1, pad=1):
+    x = _f32(x)
+    w = _f32(w)
+    N, Cin, D, H, W = x.shape
+    Cout, _, k = w.shape[:3]
+    Do = (D + 2 * pad - k) // stride + 1
+    Ho = (H + 2 * pad - k) // stride + 1
+    Wo = (W + 2 * pad - k) // stride + 1
+    y = np.empty((N, Cout, Do, Ho, Wo), np.float32)
+    b = _p(_f32(bias)) if bias is not None else None
+    lib().pwo_conv3d(_p(x), _p(w), b, N, Cin, D, H, W, Cout, k, stride, pad, _p(y))
+    return y
+
+
+def bn_act(x, sd, prefix, residual=None, relu=False, eps=1e-5):
+    """BatchNorm3d.eval() (+residual, +ReLU) in place on x."""
+    N, C = x.shape[:2]
+    sp = int(np.prod(x.shape[2:]))
+    g, b = _f32(sd[prefix + '.weight']), _f32(sd[prefix + '.bias'])
+    m, v = _f32(sd[prefix + '.running_mean']), _f32(sd[prefix + '.running_var'])
+    r = _p(_f32(residual)) if residual is not None else None
+    lib().pwo_bn_act(_p(x), N, C, ctypes.c_size_t(sp), _p(g), _p(b), _p(m), _p(v),
+                     ctypes.c_float(eps), r, int(relu))
+    return x
+
+
+def relu_(x):
+    lib().pwo_relu(_p(x), ctypes.c_size_t(x.size))
+    return x
+
+
+def conv_module(x, sd, prefix, stride=1, pad=1, relu=False, residual=None):
+    """mmcv ConvModule conv(no bias)->BN3d->act (order conv,norm,act)."""
+    y = conv3d(x, sd[prefix + '.conv.weight'], sd.get(prefix + '.conv.bias'), stride, pad)
+    return bn_act(y, sd, prefix + '.bn', residual=residual, relu=relu)
+
+
+def basic_block3d(x, sd, prefix, stride=1):
+    """resnet.py:88-123: relu(conv2(conv1(x)) + downsample(x))."""
+    if (prefix + '.downsample.conv.weight') in sd:
+        identity = conv_module(x, sd, prefix + '.downsample', stride=stride)
+    else:
+        identity = x
+    y = conv_module(x, sd, prefix + '.conv1', stride=stride, relu=True)
+    return conv_module(y, sd, prefix + '.conv2', residual=identity, relu=True)
+
+
+def custom_resnet3d(x, sd, prefix, num_layer, stride, backbone_output_ids=None):
+    """resnet.py:126-184."""
+    ids = range(len(num_layer)) if backbone_output_ids is None else backbone_output_ids
+    feats = []
+    for lid, nl in enumerate(num_layer):
+        for b in range(nl):
+            x = basic_block3d(x, sd, '%s.layers.%d.%d' % (prefix, lid, b),
+                              stride=stride[lid] if b == 0 else 1)
+        if lid in ids:
+            feats.append(x)
+    return feats
+
+
+def upsample_trilinear(x, s):
+    x = _f32(x)
+    N, C, D, H, W = x.shape
+    y = np.empty((N, C, D * s, H * s, W * s), np.float32)
+    lib().pwo_upsample_trilinear_ac(_p(x), N * C, D, H, W, s, _p(y))
+    return y
+
+
+def lss_fpn3d(feats, sd, prefix):
+    """lss_fpn.py:132-148 (levels=3)."""
+    x8, x16, x32 = feats
+    x = np.concatenate([x8, upsample_trilinear(x16, 2), upsample_trilinear(x32, 4)], axis=1)
+    return conv_module(x, sd, prefix + '.conv', pad=0, relu=True)
+
+
+def final_conv(x, sd, prefix='final_conv'):
+    """preworld.py:72-79 ConvModule(bias=True, no norm, default act ReLU); then
+    .permute(0,4,3,2,1) -> (B,X,Y,Z,C) (preworld_temporal_traj.py:222)."""
+    y = conv3d(x, sd[prefix + '.conv.weight'], sd[prefix + '.conv.bias'], 1, 1)
+    relu_(y)
+    return np.ascontiguousarray(y.transpose(0, 4, 3, 2, 1))
+
+
+def occ_head(voxel_feat, sd, prefix='occupancy_head'):
+    """occupancy_head.py:124-177 with num_level=1, use_deblock=False: the soft-weight
+    branch is numerically the identity (softmax over 1 channel, same-size interpolate).
+    voxel_feat (1,32,X,Y,Z) -> logits (1,18,X,Y,Z)."""
+    x = conv3d(voxel_feat, sd[prefix + '.occ_convs.0.0.weight'], None, 1, 1)
+    bn_act(x, sd, prefix + '.occ_convs.0.1', relu=True)
+    x = conv3d(x, sd[prefix + '.occ_pred_conv.0.weight'], None, 1, 0)
+    bn_act(x, sd, prefix + '.occ_pred_conv.1', relu=True)
+    return conv3d(x, sd[prefix + '.occ_pred_conv.3.weight'], None, 1, 0)
+
+
+def linear(x, w, b, act=0):
+    x = _f32(x)
+    M = int(np.prod(x.shape[:-1]))
+    In = x.shape[-1]
+    Out = w.shape[0]
+    y = np.empty(x.shape[:-1] + (Out,), np.float32)
+    lib().pwo_linear(_p(x), ctypes.c_size_t(M), In, _p(_f32(w)),
+                     _p(_f32(b)) if b is not None else None, Out, act, _p(y))
+    return y
+
+
+def plan_head(ego, sd, prefix='plan_head'):
+    """preworld_temporal_traj.py:121-127: 21->256 ReLU ->256 ReLU ->32."""
+    h = linear(ego, sd[prefix + '.0.weight'], sd[prefix + '.0.bias'], 1)
+    h = linear(h, sd[prefix + '.2.weight'], sd[prefix + '.2.bias'], 1)
+    return linear(h, sd[prefix + '.4.weight'], sd[prefix + '.4.bias'], 0)
+
+
+def forecast_step(v, e, sd, prefix='fusion_head'):
+    """preworld_temporal_traj.py:335-342; v (..., C) channels-last, e (C,)."""
+    v = _f32(v)
+    C = v.shape[-1]
+    M = v.size // C
+    out = np.empty_like(v)
+    lib().pwo_forecast_step(_p(v), ctypes.c_size_t(M), C, _p(_f32(e)),
+                            _p(_f32(sd[prefix + '.0.weight'])), _p(_f32(sd[prefix + '.0.bias'])),
+                            _p(_f32(sd[prefix + '.2.weight'])), _p(_f32(sd[prefix + '.2.bias'])),
+                            _p(out))
+    return out
+
+
+def argmax_u8(x):
+    x = _f32(x)
+    C = x.shape[-1]
+    out = np.empty(x.shape[:-1], np.uint8)
+    lib().pwo_argmax_u8(_p(x), ctypes.c_size_t(x.size // C), C, _p(out, c_u8p))
+    return out
+
+
+def occ_decode(voxel_feats_xyzc, sd):
+    """preworld_temporal_traj.py:306-324: OccHead on (1,C,X,Y,Z), argmax over classes.
+    returns (occ uint8 (X,Y,Z), logits (X,Y,Z,18))."""
+    vf = np.ascontiguousarray(voxel_feats_xyzc[0].transpose(3, 0, 1, 2))[None]
+    logits = occ_head(vf, sd)[0].transpose(1, 2, 3, 0)
+    logits = np.ascontiguousarray(logits)
+    return argmax_u8(logits), logits
+
+
+def attribute_decode(voxel_feats, sd, test_threshold=8.5, num_classes=18):
+    """preworld_temporal_traj.py:231-250: density/semantic MLP decode."""
+    h = linear(voxel_feats, sd['density_mlp.0.weight'], sd['density_mlp.0.bias'], 2)
+    dens = linear(h, sd['density_mlp.2.weight'], sd['density_mlp.2.bias'], 2)[..., 0]
+    h = linear(voxel_feats, sd['semantic_mlp.0.weight'], sd['semantic_mlp.0.bias'], 2)
+    sem = linear(h, sd['semantic_mlp.2.weight'], sd['semantic_mlp.2.bias'], 0)
+    occ = np.where(dens > test_threshold, argmax_u8(sem), num_classes - 1).astype(np.uint8)
+    return occ, dens, sem
+
+
+def encoder_forward(bev_adj, bev_key, sd):
+    """bevdet_occ.py:266-267 + bevdet.py:52-58: cat([adj,key]) -> backbone -> neck."""
+    x = np.concatenate([bev_adj, bev_key], axis=1)
+    feats = custom_resnet3d(x, sd, 'img_bev_encoder_backbone', [1, 2, 4], [1, 2, 2])
+    return lss_fpn3d(feats, sd, 'img_bev_encoder_neck')
+
+
+def pre_process(bev, sd):
+    """bevdet_occ.py:164: CustomResNet3D(numC_input=32, num_layer=[1], stride=[1])."""
+    return custom_resnet3d(bev, sd, 'pre_process_net', [1], [1])[0]
+
+
+def preworld4d_decode(voxel_feats, ego, sd, n_steps=6, post_finetune=True):
+    """preworld_temporal_traj.py:303-368 (post-finetune) / :224-301 (attribute decode).
+    voxel_feats (1,X,Y,Z,C).  Returns list of uint8 (X,Y,Z) states and list of features."""
+    e = plan_head(_f32(ego).reshape(1, -1), sd)[0]
+    states, feats = [], [voxel_feats]
+    v = voxel_feats
+    dec = (lambda f: occ_decode(f, sd)[0]) if post_finetune else \
+        (lambda f: attribute_decode(f, sd)[0][0])
+    states.append(dec(v))
+    for _ in range(n_steps):
+        v = forecast_step(v, e, sd)
+        feats.append(v)
+        states.append(dec(v))
+    return states, feats
+
+
+# --------------------------------------------------------------------------- render head
+class NerfConsts:
+    """nerf_head.py:105-162 buffers/constants for a given config."""
+
+    def __init__(self, point_cloud_range=(-40, -40, -1, 40, 40, 5.4), voxel_size=0.4, radius=39,
+                 step_size=0.5, alpha_init=1e-6, fast_color_thres=1e-7, world_size=(200, 200, 16)):
+        xyz_min = np.array(point_cloud_range[:3], np.float32)
+        xyz_max = np.array(point_cloud_range[3:], np.float32)
+        rng = xyz_max - xyz_min
+        self.bg_len = np.float32((rng[0] // 2 - radius) / radius)
+        self.radius = radius
+        self.scene_center = ((xyz_min + xyz_max) * np.float32(0.5)).astype(np.float32)
+        self.scene_radius = np.array([radius] * 3, np.float32)
+        z_ = np.float32(rng[2] / rng[0])
+        self.xyz_min = np.array([-1 - self.bg_len, -1 - self.bg_len, -z_], np.float32)
+        self.xyz_max = np.array([1 + self.bg_len, 1 + self.bg_len, z_], np.float32)
+        self.act_shift = np.float32(np.log(1 / (1 - alpha_init) - 1))
+        self.step_size = step_size
+        self.world_len = world_size[0]
+        self.fast_color_thres = fast_color_thres
+
+    def t_table(self):
+        """nerf_head.py:35-43 (uses torch.linspace semantics, fp32)."""
+        # the reference evaluates this with bg_len a 0-dim fp32 tensor: every op rounds to fp32
+        f = np.float32
+        N_inner = int(f(f(f(2) / f(f(2) + f(f(2) * self.bg_len))) * f(self.world_len)) / f(self.step_size)) + 1
+        N_outer = N_inner // 15
+
+        def linspace(a, b, n):
+            # nerf_head.py:37-38 call torch.linspace; its vectorised CPU kernel rounds a few
+            # entries differently from the scalar formula, so use torch itself when present.
+            try:
+                import torch
+                return torch.linspace(a, b, n).numpy()
+            except ImportError:
+                a, b = np.float32(a), np.float32(b)
+                step = np.float32((b - a) / np.float32(n - 1))
+                i = np.arange(n)
+                lo = (a + step * i.astype(np.float32)).astype(np.float32)
+                hi = (b - step * (n - i - 1).astype(np.float32)).astype(np.float32)
+                return np.where(i < n // 2, lo, hi).astype(np.float32)
+
+        b_inner = linspace(0, 2, N_inner + 1)
+        b_outer = (np.float32(2) / linspace(1, 1 / 64, N_outer + 1)).astype(np.float32)
+        t = np.concatenate([(b_inner[1:] + b_inner[:-1]) * np.float32(0.5),
+                            (b_outer[1:] + b_outer[:-1]) * np.float32(0.5)]).astype(np.float32)
+        return t
+
+
+def sample_ray(rays_o, rays_d, consts, bda):
+    t = consts.t_table()
+    R, S = rays_o.shape[0], t.shape[0]
+    pts = np.empty((R, S, 3), np.float32)
+    inner = np.empty((R, S), np.uint8)
+    lib().pwo_sample_ray(R, S, _p(_f32(rays_o)), _p(_f32(rays_d)), _p(t),
+                         _p(consts.scene_center), _p(consts.scene_radius),
+                         ctypes.c_float(consts.bg_len), _p(_f32(bda)), _p(pts), _p(inner, c_u8p))
+    return pts, inner.astype(bool), t
+
+
+def cumdist_thres(dist, thres):
+    dist = _f32(dist)
+    R, S = dist.shape
+    m = np.empty((R, S), np.uint8)
+    lib().pwo_cumdist_thres(R, S, _p(dist), ctypes.c_float(thres), _p(m, c_u8p))
+    return m.astype(bool)
+
+
+def grid_sample_xyz(grid_cxyz, xyz, consts):
+    g = _f32(grid_cxyz)
+    C, X, Y, Z = g.shape
+    xyz = _f32(xyz).reshape(-1, 3)
+    out = np.empty((xyz.shape[0], C), np.float32)
+    lib().pwo_grid_sample_xyz(_p(g), C, X, Y, Z, _p(xyz), ctypes.c_size_t(xyz.shape[0]),
+                              _p(consts.xyz_min), _p(consts.xyz_max), _p(out))
+    return out
+
+
+def raw2alpha(density, shift, interval):
+    d = _f32(density).reshape(-1)
+    e = np.empty_like(d)
+    a = np.empty_like(d)
+    lib().pwo_raw2alpha(_p(d), ctypes.c_float(shift), ctypes.c_float(interval),
+                        ctypes.c_size_t(d.size), _p(e), _p(a))
+    return e, a
+
+
+def raw2alpha_backward(exp_d, grad_back, interval):
+    e = _f32(exp_d)
+    g = _f32(grad_back)
+    out = np.empty_like(e)
+    lib().pwo_raw2alpha_backward(_p(e), _p(g), ctypes.c_float(interval),
+                                 ctypes.c_size_t(e.size), _p(out))
+    return out
+
+
+def alpha2weight(alpha, ray_id, n_rays):
+    a = _f32(alpha)
+    rid = np.ascontiguousarray(ray_id, dtype=np.int64)
+    n = a.size
+    w = np.empty(n, np.float32)
+    T = np.empty(n, np.float32)
+    last = np.empty(n_rays, np.float32)
+    i_s = np.empty(n_rays, np.int64)
+    i_e = np.empty(n_rays, np.int64)
+    lib().pwo_alpha2weight(_p(a), _p(rid, c_i64p), ctypes.c_size_t(n), n_rays, _p(w), _p(T),
+                           _p(last), _p(i_s, c_i64p), _p(i_e, c_i64p))
+    return w, T, last, i_s, i_e
+
+
+def alpha2weight_backward(alpha, weight, T, last, i_s, i_e, n_rays, grad_w, grad_last):
+    n = alpha.size
+    g = np.empty(n, np.float32)
+    lib().pwo_alpha2weight_backward(_p(_f32(alpha)), _p(_f32(weight)), _p(_f32(T)),
+                                    _p(_f32(last)), _p(i_s, c_i64p), _p(i_e, c_i64p), n_rays,
+                                    _p(_f32(grad_w)), _p(_f32(grad_last)), ctypes.c_size_t(n),
+                                    _p(g))
+    return g
+
+
+def segment_sum(src, index, n_seg):
+    src = _f32(src)
+    C = 1 if src.ndim == 1 else src.shape[1]
+    idx = np.ascontiguousarray(index, dtype=np.int64)
+    out = np.empty((n_seg, C), np.float32)
+    lib().pwo_segment_sum(_p(src), _p(idx, c_i64p), ctypes.c_size_t(idx.size), C, n_seg, _p(out))
+    return out[:, 0] if src.ndim == 1 else out
+
+
+def render_one_scene(rays_o, rays_d, bda, density, semantic, color, consts):
+    """nerf_head.py:165-269.  density (X,Y,Z), semantic (X,Y,Z,17), color (X,Y,Z,3)."""
+    pts, inner, t = sample_ray(rays_o, rays_d, consts, bda)
+    R, S = inner.shape
+    mask = inner.copy()
+    dist_thres = np.float32((2 + 2 * float(consts.bg_len)) / consts.world_len * consts.step_size * 0.95)
+    d = pts[:, 1:] - pts[:, :-1]
+    dist = np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)
+    mask[:, 1:] |= cumdist_thres(dist, dist_thres)
+    ray_id = np.repeat(np.arange(R), S).reshape(R, S)[mask]
+    step_id = np.tile(np.arange(S), R).reshape(R, S)[mask]
+    xyz = pts[mask]
+    tt = np.broadcast_to(t[None], (R, S))[mask]
+    dens = grid_sample_xyz(density[None], xyz, consts)[:, 0]
+    sem = grid_sample_xyz(np.ascontiguousarray(semantic.transpose(3, 0, 1, 2)), xyz, consts)
+    col = grid_sample_xyz(np.ascontiguousarray(color.transpose(3, 0, 1, 2)), xyz, consts)
+    _, alpha = raw2alpha(dens, consts.act_shift, 0.5)
+    m1 = alpha > consts.fast_color_thres
+    ray_id, step_id, tt, dens, alpha, sem, col = [a[m1] for a in (ray_id, step_id, tt, dens, alpha, sem, col)]
+    weights, T, last, i_s, i_e = alpha2weight(alpha, ray_id, R)
+    m2 = weights > consts.fast_color_thres
+    ray_id, step_id, tt, alpha, sem, col, weights = [a[m2] for a in (ray_id, step_id, tt, alpha, sem, col, weights)]
+    s = (1 - 1 / (1 + tt)).astype(np.float32)
+    return dict(alphainv_last=last, weights=weights, ray_id=ray_id, step_id=step_id, s=s, t=tt,
+                N_ray=R, semantic=sem, color=col, mask1=m1, mask2=m2, sample_mask=mask)
+
+
+def render_outputs(res, consts):
+    """nerf_head.py:331-353."""
+    depth = (segment_sum(res['weights'] * res['s'], res['ray_id'], res['N_ray'])
+             + np.float32(1e-7)) * np.float32(consts.radius)
+    sem = segment_sum(res['weights'][:, None] * res['semantic'], res['ray_id'], res['N_ray'])
+    col = segment_sum(res['weights'][:, None] * res['color'], res['ray_id'], res['N_ray'])
+    return depth.astype(np.float32), sem, col
+
+
+def flatten_eff_distloss(w, m, interval, ray_id):
+    """torch_efficient_distloss.flatten_eff_distloss (un-vendored dependency, PyPI
+    torch_efficient_distloss; algorithm = Mip-NeRF-360 distortion loss, segmented prefix sums):
+    loss = sum_i [ (1/3) interval w_i^2 + 2 w_i (m_i Wcum_i - WMcum_i) ] / n_rays,
+    with exclusive per-ray prefix sums Wcum, WMcum.  PARITY UNPINNED."""
+    w = w.astype(np.float64)
+    m = m.astype(np.float64)
+    n_rays = int(ray_id.max()) + 1 if len(ray_id) else 1
+    wm = w * m
+    cw = np.cumsum(w)
+    cwm = np.cumsum(wm)
+    first = np.r_[True, ray_id[1:] != ray_id[:-1]] if len(ray_id) else np.zeros(0, bool)
+    seg_start_cw = np.where(first, cw - w, 0)
+    seg_start_cwm = np.where(first, cwm - wm, 0)
+    idx = np.maximum.accumulate(np.where(first, np.arange(len(w)), 0)) if len(w) else np.zeros(0, int)
+    w_pre = (cw - w) - seg_start_cw[idx]
+    wm_pre = (cwm - wm) - seg_start_cwm[idx]
+    uni = (1 / 3) * interval * (w ** 2)
+    bi = 2 * w * (m * w_pre - wm_pre)
+    return float((uni.sum() + bi.sum()) / n_rays)
+
+
+def nerf_losses(res, depth, sem, col, target_depth, target_sem, target_col, class_weights,
+                weight_entropy_last=0.01, weight_distortion=0.01):
+    """nerf_head.py:271-299 (fp64 numpy restatement of scalar losses)."""
+    out = {}
+    d = np.log(depth.astype(np.float64) + 1e-7) - np.log(target_depth.astype(np.float64))
+    out['loss_render_depth'] = float(np.sqrt((d ** 2).mean() - 0.85 * d.mean() ** 2))
+    z = sem.astype(np.float64)
+    z = z - z.max(1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(1, keepdims=True))
+    tgt = target_sem.astype(np.int64)
+    wts = class_weights[tgt]
+    out['loss_render_semantic'] = float(-(wts * logp[np.arange(len(tgt)), tgt]).sum() / wts.sum())
+    out['loss_render_color'] = float(np.abs(col.astype(np.float64) - target_col).mean(0).sum())
+    p = np.clip(res['alphainv_last'].astype(np.float64), 1e-6, 1 - 1e-6)
+    out['loss_sdf_entropy'] = float(weight_entropy_last * -(p * np.log(p) + (1 - p) * np.log(1 - p)).mean())
+    n_max = len(res['t'])
+    out['loss_sdf_distortion'] = weight_distortion * flatten_eff_distloss(
+        res['weights'], res['s'], 1 / max(n_max, 1), res['ray_id'])
+    return out
+
+
+# --------------------------------------------------------------------------- metric
+CLASS_NAMES = ['others', 'barrier', 'bicycle', 'bus', 'car', 'construction_vehicle', 'motorcycle',
+               'pedestrian', 'traffic_cone', 'trailer', 'truck', 'driveable_surface', 'other_flat',
+               'sidewalk', 'terrain', 'manmade', 'vegetation', 'free']
+
+
+class MetricMIoU:
+    """occ_metrics.py:52-185 (hist_info / per_class_iu / add_batch / count_miou)."""
+
+    def __init__(self, num_classes=18, use_lidar_mask=False, use_image_mask=False):
+        self.num_classes = num_classes
+        self.use_lidar_mask = use_lidar_mask
+        self.use_image_mask = use_image_mask
+        self.hist = np.zeros((num_classes, num_classes), np.int64)
+        self.cnt = 0
+
+    def add_batch(self, pred, gt, mask_lidar=None, mask_camera=None):
+        self.cnt += 1
+        mask = mask_camera if self.use_image_mask else (mask_lidar if self.use_lidar_mask else None)
+        p = np.ascontiguousarray(pred, np.uint8).reshape(-1)
+        g = np.ascontiguousarray(gt, np.uint8).reshape(-1)
+        m = np.ascontiguousarray(mask, np.uint8).reshape(-1) if mask is not None else None
+        lib().pwo_confusion_hist(_p(p, c_u8p), _p(g, c_u8p), _p(m, c_u8p) if m is not None else None,
+                                 ctypes.c_size_t(p.size), self.num_classes, _p(self.hist, c_i64p))
+
+    def per_class_iu(self):
+        h = self.hist.astype(np.float64)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return np.diag(h) / (h.sum(1) + h.sum(0) - np.diag(h))
+
+    def count_miou(self):
+        iu = self.per_class_iu()
+        return round(float(np.nanmean(iu[:self.num_classes - 1])) * 100, 2), iu
+
+
+# --------------------------------------------------------------------------- synthetic rig
+def synthetic_rig(n_cams=6, dx=0.0, dtype=np.float32):
+    """SURVEY.md 8d analytic 6-camera rig (nuScenes-like). Returns dict of (1,N,...) arrays."""
+    yaws = [55, 0, -55, -110, 180, 110][:n_cams] if n_cams > 1 else [0]
+    base = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], np.float64)
+    s2e = np.zeros((1, len(yaws), 4, 4), np.float64)
+    for i, y in enumerate(yaws):
+        a = math.radians(y)
+        Rz = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]])
+        s2e[0, i, :3, :3] = Rz @ base
+        s2e[0, i, :3, 3] = [1.5 * math.cos(a) + dx, 1.5 * math.sin(a), 1.5]
+        s2e[0, i, 3, 3] = 1
+    K = np.array([[1266.4, 0, 816.27], [0, 1266.4, 491.5], [0, 0, 1]], np.float64)
+    n = len(yaws)
+    return dict(
+        sensor2ego=s2e.astype(dtype),
+        intrin=np.broadcast_to(K, (1, n, 3, 3)).astype(dtype).copy(),
+        post_rot=np.broadcast_to(np.diag([0.88, 0.88, 1.0]), (1, n, 3, 3)).astype(dtype).copy(),
+        post_tran=np.broadcast_to(np.array([0.0, -280.0, 0.0]), (1, n, 3)).astype(dtype).copy(),
+        bda=np.eye(3, dtype=dtype)[None].copy(),
+    )

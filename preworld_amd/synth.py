@@ -1,0 +1,146 @@
+"""Seeded synthetic inputs and weights (numpy only; no torch, no oracle).
+
+Used by bench.py, __graft_entry__.smoke(), tools/gen_golden.py and the tests so that
+every side regenerates identical tensors from a seed instead of shipping them as
+fixtures.  Uses numpy's legacy RandomState, whose streams are stable across numpy
+versions.  Shapes/kwargs follow SURVEY.md 8b/8d (reference configs
+configs/preworld/nuscenes/bevstereo-occ.py:90-108, preworld-7frame-finetune.py).
+"""
+import math
+
+import numpy as np
+
+GRID_CONFIG_FULL = {'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 0.4],
+                    'depth': [1.0, 45.0, 0.5]}
+# C1 (BASELINE.json configs[0]): 1 camera, 100x100x8 grid
+GRID_CONFIG_C1 = {'x': [-40, 40, 0.8], 'y': [-40, 40, 0.8], 'z': [-1, 5.4, 0.8],
+                  'depth': [1.0, 45.0, 0.5]}
+INPUT_SIZE = (512, 1408)
+DOWNSAMPLE = 16
+
+
+def synthetic_rig(n_cams=6, dx=0.0, dtype=np.float32):
+    """Analytic nuScenes-like 6-camera rig. dx = ego translation of the
+    adjacent frame along x.  Returns (1,N,...) arrays keyed like the reference's inputs
+    (sensor2ego, intrin, post_rot, post_tran, bda) -- view_transformer.py:791-796."""
+    yaws = [55, 0, -55, -110, 180, 110][:n_cams] if n_cams > 1 else [0]
+    base = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], np.float64)
+    n = len(yaws)
+    s2e = np.zeros((1, n, 4, 4), np.float64)
+    for i, y in enumerate(yaws):
+        a = math.radians(y)
+        Rz = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]])
+        s2e[0, i, :3, :3] = Rz @ base
+        s2e[0, i, :3, 3] = [1.5 * math.cos(a) + dx, 1.5 * math.sin(a), 1.5]
+        s2e[0, i, 3, 3] = 1
+    K = np.array([[1266.4, 0, 816.27], [0, 1266.4, 491.5], [0, 0, 1]], np.float64)
+    return dict(
+        sensor2ego=s2e.astype(dtype),
+        intrin=np.broadcast_to(K, (1, n, 3, 3)).astype(dtype).copy(),
+        post_rot=np.broadcast_to(np.diag([0.88, 0.88, 1.0]), (1, n, 3, 3)).astype(dtype).copy(),
+        post_tran=np.broadcast_to(np.array([0.0, -280.0, 0.0]), (1, n, 3)).astype(dtype).copy(),
+        bda=np.eye(3, dtype=dtype)[None].copy(),
+    )
+
+
+def lift_inputs(seed, B=1, N=6, D=88, H=32, W=88, C=32):
+    """depth = softmax(N(0,1)) over D bins, feat ~ N(0,1): (B,N,D,H,W), (B,N,C,H,W)."""
+    rs = np.random.RandomState(seed)
+    logits = rs.standard_normal((B, N, D, H, W)).astype(np.float32)
+    logits -= logits.max(2, keepdims=True)
+    e = np.exp(logits)
+    depth = (e / e.sum(2, keepdims=True)).astype(np.float32)
+    feat = rs.standard_normal((B, N, C, H, W)).astype(np.float32)
+    return depth, feat
+
+
+def _conv_w(rs, cout, cin, k):
+    fan_in = cin * k ** 3
+    return (rs.standard_normal((cout, cin, k, k, k)) * math.sqrt(2.0 / fan_in)).astype(np.float32)
+
+
+def _bn(rs, sd, prefix, c):
+    sd[prefix + '.weight'] = (rs.rand(c) + 0.5).astype(np.float32)
+    sd[prefix + '.bias'] = (rs.standard_normal(c) * 0.1).astype(np.float32)
+    sd[prefix + '.running_mean'] = (rs.standard_normal(c) * 0.1).astype(np.float32)
+    sd[prefix + '.running_var'] = (rs.rand(c) + 0.5).astype(np.float32)
+
+
+def _conv_module(rs, sd, prefix, cin, cout, k=3):
+    sd[prefix + '.conv.weight'] = _conv_w(rs, cout, cin, k)
+    _bn(rs, sd, prefix + '.bn', cout)
+
+
+def _resnet3d(rs, sd, prefix, numC_input, num_layer, num_channels):
+    cur = numC_input
+    for lid, nl in enumerate(num_layer):
+        for b in range(nl):
+            p = '%s.layers.%d.%d' % (prefix, lid, b)
+            cin = cur if b == 0 else num_channels[lid]
+            _conv_module(rs, sd, p + '.conv1', cin, num_channels[lid])
+            _conv_module(rs, sd, p + '.conv2', num_channels[lid], num_channels[lid])
+            if b == 0:
+                _conv_module(rs, sd, p + '.downsample', cin, num_channels[lid])
+        cur = num_channels[lid]
+
+
+def _linear(rs, sd, prefix, fin, fout):
+    sd[prefix + '.weight'] = (rs.standard_normal((fout, fin)) / math.sqrt(fin)).astype(np.float32)
+    sd[prefix + '.bias'] = (rs.standard_normal(fout) * 0.1).astype(np.float32)
+
+
+def synth_state_dict(seed=0, out_dim=32, num_classes=18):
+    """Random weights for every hot-path module with the reference's state-dict keys
+    (SURVEY.md 8b): pre_process_net, img_bev_encoder_backbone, img_bev_encoder_neck,
+    final_conv, occupancy_head, density/semantic/color_mlp, plan_head, fusion_head."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    _resnet3d(rs, sd, 'pre_process_net', 32, [1], [32])
+    _resnet3d(rs, sd, 'img_bev_encoder_backbone', 64, [1, 2, 4], [32, 64, 128])
+    _conv_module(rs, sd, 'img_bev_encoder_neck.conv', 224, 32, k=1)
+    sd['final_conv.conv.weight'] = _conv_w(rs, out_dim, 32, 3)
+    sd['final_conv.conv.bias'] = (rs.standard_normal(out_dim) * 0.1).astype(np.float32)
+    # OccHead (occupancy_head.py:80-105): occ_convs.0 = [conv3 32->16, BN, ReLU];
+    # occ_pred_conv = [1x1 16->8, BN, ReLU, 1x1 8->18]; voxel_soft_weights likewise
+    sd['occupancy_head.occ_convs.0.0.weight'] = _conv_w(rs, 16, 32, 3)
+    _bn(rs, sd, 'occupancy_head.occ_convs.0.1', 16)
+    sd['occupancy_head.occ_pred_conv.0.weight'] = _conv_w(rs, 8, 16, 1)
+    _bn(rs, sd, 'occupancy_head.occ_pred_conv.1', 8)
+    sd['occupancy_head.occ_pred_conv.3.weight'] = _conv_w(rs, num_classes, 8, 1)
+    sd['occupancy_head.voxel_soft_weights.0.weight'] = _conv_w(rs, 8, 16, 1)
+    _bn(rs, sd, 'occupancy_head.voxel_soft_weights.1', 8)
+    sd['occupancy_head.voxel_soft_weights.3.weight'] = _conv_w(rs, 1, 8, 1)
+    for name, outs in (('density_mlp', 2), ('semantic_mlp', num_classes - 1), ('color_mlp', 3)):
+        _linear(rs, sd, name + '.0', out_dim, out_dim * 2)
+        _linear(rs, sd, name + '.2', out_dim * 2, outs)
+    _linear(rs, sd, 'plan_head.0', 21, 256)
+    _linear(rs, sd, 'plan_head.2', 256, 256)
+    _linear(rs, sd, 'plan_head.4', 256, out_dim)
+    _linear(rs, sd, 'fusion_head.0', out_dim * 2, out_dim * 4)
+    _linear(rs, sd, 'fusion_head.2', out_dim * 4, out_dim)
+    return sd
+
+
+def ego_state(seed):
+    return np.random.RandomState(seed).standard_normal((1, 1, 21)).astype(np.float32)
+
+
+def render_grids(seed, X=200, Y=200, Z=16, n_sem=17):
+    """density (X,Y,Z) sparse positive, semantic (X,Y,Z,17), color (X,Y,Z,3)."""
+    rs = np.random.RandomState(seed)
+    raw = rs.standard_normal((X, Y, Z)).astype(np.float32) * 4 - 6
+    density = np.where(raw > 20, raw, np.log1p(np.exp(np.minimum(raw, 20)))).astype(np.float32)
+    semantic = rs.standard_normal((X, Y, Z, n_sem)).astype(np.float32)
+    color = rs.standard_normal((X, Y, Z, 3)).astype(np.float32)
+    return density, semantic, color
+
+
+def rays(seed, R, n_cams=6):
+    """(R,3) origins at the rig's camera centres, (R,3) directions mostly horizontal."""
+    rs = np.random.RandomState(seed)
+    rig = synthetic_rig(n_cams)
+    cam = rs.randint(0, n_cams, R)
+    o = rig['sensor2ego'][0, :, :3, 3][cam].astype(np.float32)
+    d = rs.standard_normal((R, 3)).astype(np.float32)
+    d[:, 2] *= 0.15
+    return o, d

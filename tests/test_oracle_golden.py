@@ -1,0 +1,228 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors generated from the imported
+reference (tools/gen_golden.py) and the reference's own KAT.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from preworld_amd import synth as S
+
+
+# ----------------------------------------------------------------------------- KAT
+def test_kat_bev_pool_v2(golden):
+    """The reference's only known-answer test: mmdet3d/ops/bev_pool_v2/bev_pool.py:145-176."""
+    g = golden('kat_bev_pool_v2.npz')
+    out = O.bev_pool_v2(g['depth'], g['feat'], g['ranks_depth'], g['ranks_feat'], g['ranks_bev'],
+                        (1, 1, 2, 2, 2), g['interval_starts'], g['interval_lengths'])
+    assert abs(float(out.sum()) - 4.4) < 1e-6                      # :169
+    np.testing.assert_array_equal(out, g['out'])
+    # backward of loss = sum(out): out_grad = ones in (B,Z,Y,X,C)
+    dg, fg = O.bev_pool_v2_backward(np.ones((1, 2, 2, 2, 1), np.float32), g['depth'], g['feat'],
+                                    g['ranks_depth'], g['ranks_feat'], g['ranks_bev'])
+    np.testing.assert_allclose(dg, g['depth_grad'])                # :170-173
+    np.testing.assert_allclose(fg, g['feat_grad'])                 # :174-176
+
+
+# ----------------------------------------------------------------------------- geometry
+def _grid_cfg(g):
+    return {'x': list(g['grid_x']), 'y': list(g['grid_y']), 'z': list(g['grid_z']),
+            'depth': list(g['grid_depth'])}
+
+
+def test_frustum_and_coor_bit_exact(golden):
+    g = golden('lss_small.npz')
+    fr = O.create_frustum(list(g['grid_depth']), tuple(g['input_size']), int(g['downsample']))
+    np.testing.assert_array_equal(fr, g['frustum'])
+    tr = g['sensor2ego'][:, :, :3, 3].reshape(-1, 3)
+    coor = O.lidar_coor(fr, g['inv_post_rot'].reshape(-1, 3, 3), g['post_tran'].reshape(-1, 3),
+                        g['combine'].reshape(-1, 3, 3), tr, g['bda'], 1, 2)
+    # bit-identical to the reference's get_lidar_coor given the same 3x3 inverses
+    np.testing.assert_array_equal(coor, g['coor'])
+
+
+def test_closed_form_inverse_close_to_torch(golden):
+    g = golden('lss_small.npz')
+    ipr, comb, tr = O.camera_matrices(g['sensor2ego'], g['intrin'], g['post_rot'])
+    np.testing.assert_allclose(ipr, g['inv_post_rot'].reshape(-1, 3, 3), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(comb, g['combine'].reshape(-1, 3, 3), rtol=1e-5,
+                               atol=1e-6 * np.abs(comb).max())
+    np.testing.assert_array_equal(tr, g['sensor2ego'][:, :, :3, 3].reshape(-1, 3))
+
+
+def _multiset_equal(st, ln, a, b):
+    return all(sorted(a[s:s + l]) == sorted(b[s:s + l]) for s, l in zip(st, ln))
+
+
+def test_ranks_small(golden):
+    g = golden('lss_small.npz')
+    lower, interval, size = O.grid_infos(_grid_cfg(g))
+    rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(g['coor'], lower, interval, size)
+    np.testing.assert_array_equal(rb, g['ranks_bev'])
+    np.testing.assert_array_equal(st, g['interval_starts'])
+    np.testing.assert_array_equal(ln, g['interval_lengths'])
+    # the reference's argsort is unstable: order inside a voxel is unspecified
+    assert _multiset_equal(st, ln, rd, g['ranks_depth'])
+    assert _multiset_equal(st, ln, rf, g['ranks_feat'])
+    # ours is the stable order
+    for s, l in zip(st, ln):
+        assert np.all(np.diff(rd[s:s + l]) > 0)
+
+
+def test_pool_small_fwd_bwd(golden):
+    g = golden('lss_small.npz')
+    gc = _grid_cfg(g)
+    bev = O.lss_view_transform(g['depth'], g['feat'], g['sensor2ego'], g['intrin'], g['post_rot'],
+                               g['post_tran'], g['bda'], gc, tuple(g['input_size']),
+                               int(g['downsample']))
+    np.testing.assert_allclose(bev, g['bev_feat'], rtol=1e-5, atol=1e-6)
+    lower, interval, size = O.grid_infos(gc)
+    rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(g['coor'], lower, interval, size)
+    feat = np.ascontiguousarray(g['feat'].transpose(0, 1, 3, 4, 2))
+    og = np.ascontiguousarray(g['out_grad'].transpose(0, 2, 3, 4, 1))      # (B,Z,Y,X,C)
+    dg, fg = O.bev_pool_v2_backward(og, g['depth'], feat, rd, rf, rb)
+    np.testing.assert_allclose(dg, g['depth_grad'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fg.transpose(0, 1, 4, 2, 3), g['feat_grad'], rtol=1e-5, atol=1e-6)
+
+
+def test_empty_and_out_of_range():
+    """no point inside the grid -> five Nones (view_transformer.py:237-238,253-254)."""
+    coor = np.full((1, 1, 2, 2, 2, 3), 1000.0, np.float32)
+    lower, interval, size = O.grid_infos(S.GRID_CONFIG_FULL)
+    assert O.voxel_pooling_prepare_v2(coor, lower, interval, size) == (None,) * 5
+    # trunc-toward-zero: a point at -0.3 voxel units is kept in voxel 0
+    coor = np.zeros((1, 1, 1, 1, 1, 3), np.float32)
+    coor[..., 0] = -40.0 - 0.3 * 0.4
+    coor[..., 1] = -40.0
+    coor[..., 2] = -1.0
+    rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(coor, lower, interval, size)
+    assert list(rb) == [0]
+
+
+@pytest.mark.timeout(300)
+def test_full_size_stats(golden):
+    g = golden('lss_full_stats.npz')
+    rig = S.synthetic_rig(6)
+    gc = S.GRID_CONFIG_FULL
+    fr = O.create_frustum(gc['depth'], S.INPUT_SIZE, S.DOWNSAMPLE)
+    ipr, comb, tr = O.camera_matrices(rig['sensor2ego'], rig['intrin'], rig['post_rot'])
+    coor = O.lidar_coor(fr, ipr, rig['post_tran'].reshape(-1, 3), comb, tr, rig['bda'], 1, 6)
+    lower, interval, size = O.grid_infos(gc)
+    assert size == [200, 200, 16]
+    rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(coor, lower, interval, size)
+    # closed-form 3x3 inverse vs torch.inverse moves a handful of boundary points
+    assert abs(len(rb) - int(g['P_kept'])) <= 64
+    assert abs(len(st) - int(g['n_intervals'])) <= 64
+    assert abs(int(ln.max()) - int(g['max_len'])) <= 4
+    depth, feat = S.lift_inputs(int(g['seed_lift']))
+    featc = np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2))
+    bev = O.bev_pool_v2(depth, featc, rd, rf, rb, (1, 16, 200, 200, 32), st, ln)
+    rows = bev[0].reshape(32, -1)[:, g['sample_voxel_idx']].T
+    bad = np.abs(rows - g['sample_rows']).max(1) > 1e-4
+    assert bad.mean() < 0.01            # rows touched by a moved boundary point
+    assert abs(float(bev.astype(np.float64).sum()) - float(g['bev_sum'])) < 1e-3 * float(g['bev_abs_sum'])
+
+
+# ----------------------------------------------------------------------------- conv stack
+def test_conv_stack_small(golden):
+    g = golden('conv_stack_small.npz')
+    sd = S.synth_state_dict(int(g['seed_sd']))
+    Z, Y, X = [int(v) for v in g['shape']]
+    rs = np.random.RandomState(int(g['seed_in']))
+    bev_key = rs.standard_normal((1, 32, Z, Y, X)).astype(np.float32)
+    bev_adj = rs.standard_normal((1, 32, Z, Y, X)).astype(np.float32)
+    tol = dict(rtol=2e-4, atol=2e-4)
+    pk = O.pre_process(bev_key, sd)
+    pa = O.pre_process(bev_adj, sd)
+    np.testing.assert_allclose(pk, g['pre_key'], **tol)
+    np.testing.assert_allclose(pa, g['pre_adj'], **tol)
+    x = np.concatenate([pa, pk], 1)
+    feats = O.custom_resnet3d(x, sd, 'img_bev_encoder_backbone', [1, 2, 4], [1, 2, 2])
+    for f, k in zip(feats, ('enc0', 'enc1', 'enc2')):
+        assert f.shape == g[k].shape
+        np.testing.assert_allclose(f, g[k], **tol)
+    nk = O.lss_fpn3d(feats, sd, 'img_bev_encoder_neck')
+    np.testing.assert_allclose(nk, g['neck'], **tol)
+    vf = O.final_conv(nk, sd)
+    np.testing.assert_allclose(vf.transpose(0, 4, 3, 2, 1), g['final_conv'], **tol)
+    occ, logits = O.occ_decode(vf, sd)
+    np.testing.assert_allclose(logits.transpose(3, 0, 1, 2)[None], g['logits'], rtol=5e-4, atol=5e-4)
+    assert (occ == g['occ']).mean() > 0.999
+
+
+def test_forecast_small(golden):
+    g = golden('forecast_small.npz')
+    sd = S.synth_state_dict(int(g['seed_sd']))
+    v = np.random.RandomState(int(g['seed_v'])).standard_normal((1, 8, 8, 4, 32)).astype(np.float32)
+    ego = S.ego_state(int(g['seed_ego']))
+    e = O.plan_head(ego.reshape(1, 21), sd)
+    np.testing.assert_allclose(e, g['ego_feat'], rtol=1e-4, atol=1e-5)
+    cur = v
+    for k in range(6):
+        cur = O.forecast_step(cur, e[0], sd)
+        np.testing.assert_allclose(cur, g['states'][k + 1], rtol=2e-4, atol=2e-4)
+    occ, dens, sem = O.attribute_decode(v, sd)
+    np.testing.assert_allclose(dens, g['density'][..., 0], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sem, g['semantic'], rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- render
+def test_render_small(golden):
+    g = golden('render_small.npz')
+    consts = O.NerfConsts()
+    np.testing.assert_allclose(consts.xyz_min, g['xyz_min'], rtol=1e-6)
+    np.testing.assert_allclose(consts.xyz_max, g['xyz_max'], rtol=1e-6)
+    np.testing.assert_allclose(consts.act_shift, g['act_shift'][0], rtol=1e-6)
+    t = consts.t_table()
+    assert t.shape == (417,)
+    np.testing.assert_array_equal(t, g['t'])
+    density, semantic, color = S.render_grids(int(g['seed_grid']))
+    o, d = S.rays(int(g['seed_rays']), int(g['R']))
+    pts, inner, _ = O.sample_ray(o, d, consts, g['bda'])
+    np.testing.assert_allclose(pts[:, ::8], g['ray_pts'], rtol=1e-5, atol=1e-6)
+    assert (inner == g['inner_mask']).mean() > 0.9999
+    res = O.render_one_scene(o, d, g['bda'], density, semantic, color, consts)
+    depth, sem, col = O.render_outputs(res, consts)
+    assert abs(len(res['weights']) - len(g['weights'])) <= 2
+    np.testing.assert_allclose(res['alphainv_last'], g['alphainv_last'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(depth, g['render_depth'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(sem, g['render_semantic'], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(col, g['render_color'], rtol=1e-3, atol=1e-3)
+
+
+def test_alpha2weight_backward_matches_finite_difference():
+    rs = np.random.RandomState(0)
+    n_rays, per = 5, 12
+    alpha = (rs.rand(n_rays * per) * 0.2).astype(np.float32)
+    ray_id = np.repeat(np.arange(n_rays), per)
+    w, T, last, i_s, i_e = O.alpha2weight(alpha, ray_id, n_rays)
+    gw = rs.standard_normal(alpha.size).astype(np.float32)
+    gl = rs.standard_normal(n_rays).astype(np.float32)
+    g = O.alpha2weight_backward(alpha, w, T, last, i_s, i_e, n_rays, gw, gl)
+
+    def f(a):
+        a = a.astype(np.float64)
+        tot = 0.0
+        for r in range(n_rays):
+            Tc = 1.0
+            for i in range(r * per, (r + 1) * per):
+                tot += gw[i] * Tc * a[i]
+                Tc *= 1 - a[i]
+            tot += gl[r] * Tc
+        return tot
+    num = np.zeros_like(alpha, dtype=np.float64)
+    for i in range(alpha.size):
+        ap = alpha.astype(np.float64).copy(); ap[i] += 1e-6
+        am = alpha.astype(np.float64).copy(); am[i] -= 1e-6
+        num[i] = (f(ap) - f(am)) / 2e-6
+    np.testing.assert_allclose(g, num, rtol=2e-3, atol=2e-4)
+
+
+# ----------------------------------------------------------------------------- metric
+def test_metric_miou(golden):
+    g = golden('metric_miou.npz')
+    m = O.MetricMIoU(num_classes=18, use_image_mask=True)
+    for p, gt, k in zip(g['pred'], g['gt'], g['mask']):
+        m.add_batch(p, gt, None, k)
+    np.testing.assert_array_equal(m.hist, g['hist'].astype(np.int64))
+    miou, iu = m.count_miou()
+    assert miou == float(g['miou'])
+    np.testing.assert_allclose(iu, g['iou'], rtol=1e-12)

@@ -1,0 +1,492 @@
+"""Generate tests/golden/*.npz by importing the reference's Python modules.
+
+Runs ONLY in the development container (needs /root/reference, which does not exist
+on the GPU box).  It contains no reference source: it pre-seeds sys.modules with
+minimal stand-ins for the packages the reference imports but this image lacks
+(mmcv, mmdet, torch_scatter, ...), loads the reference files with importlib and
+records inputs -> outputs as data fixtures.  The three native extensions the
+reference binds (bev_pool_v2_ext, render_utils_cuda, ub360_utils_cuda) are CUDA-only
+and cannot be built here, so they are bound to oracle/pw_oracle.c; for those three
+the fixtures pin the reference's *Python wrappers + composition*, and the only
+independent pin of the kernel arithmetic itself is the reference KAT
+(mmdet3d/ops/bev_pool_v2/bev_pool.py:145-176) recorded in kat_bev_pool_v2.npz.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+OUT = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, REPO)
+from oracle import oracle as O  # noqa: E402
+from preworld_amd import synth as S  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shim
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+class _Registry:
+    def __init__(self, *a, **k):
+        self.d = {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.d[name or cls.__name__] = cls
+            return cls
+        return deco(module) if module is not None else deco
+
+
+def _build_norm_layer(cfg, num_features, postfix=''):
+    t = cfg['type']
+    assert t in ('BN3d', 'BN', 'SyncBN', 'BN2d', 'BN1d')
+    layer = {'BN3d': nn.BatchNorm3d, 'SyncBN': nn.BatchNorm3d, 'BN': nn.BatchNorm2d,
+             'BN2d': nn.BatchNorm2d, 'BN1d': nn.BatchNorm1d}[t](num_features)
+    return 'bn' + str(postfix), layer
+
+
+def _build_conv_layer(cfg, *args, **kwargs):
+    cfg = dict(cfg or dict(type='Conv2d'))
+    t = cfg.pop('type')
+    layer = {'Conv2d': nn.Conv2d, 'Conv3d': nn.Conv3d, 'Conv1d': nn.Conv1d,
+             'deconv3d': nn.ConvTranspose3d}[t]
+    return layer(*args, **kwargs, **cfg)
+
+
+class _ConvModule(nn.Module):
+    """mmcv-full 1.6.0 ConvModule defaults: order conv->norm->act, act_cfg=ReLU,
+    bias='auto' (= no norm).  Third-party semantics, parity unpinned."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias='auto', conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type='ReLU'), inplace=True, **kw):
+        super().__init__()
+        if bias == 'auto':
+            bias = norm_cfg is None
+        self.conv = _build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size,
+                                      stride=stride, padding=padding, dilation=dilation,
+                                      groups=groups, bias=bias)
+        self.with_norm = norm_cfg is not None
+        if self.with_norm:
+            _, self.bn = _build_norm_layer(norm_cfg, out_channels)
+        self.with_act = act_cfg is not None
+        if self.with_act:
+            assert act_cfg['type'] == 'ReLU'
+            self.activate = nn.ReLU(inplace=act_cfg.get('inplace', inplace))
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.bn(x)
+        if self.with_act:
+            x = self.activate(x)
+        return x
+
+
+def _identity_deco(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+class _NativeStubs:
+    """Bind the reference's three CUDA-only extensions to the C oracle."""
+
+    @staticmethod
+    def bev_pool_v2_forward(depth, feat, out, ranks_depth, ranks_feat, ranks_bev,
+                            interval_lengths, interval_starts):
+        o = out.numpy()
+        O.bev_pool_v2_forward(depth.numpy(), feat.numpy(), o, ranks_depth.numpy(),
+                              ranks_feat.numpy(), ranks_bev.numpy(), interval_lengths.numpy(),
+                              interval_starts.numpy())
+
+    @staticmethod
+    def bev_pool_v2_backward(out_grad, depth_grad, feat_grad, depth, feat, ranks_depth,
+                             ranks_feat, ranks_bev, interval_lengths, interval_starts):
+        import ctypes
+        c = feat.shape[-1]
+        O.lib().pwo_bev_pool_v2_backward(
+            c, len(interval_lengths), O._p(out_grad.numpy()), O._p(depth.numpy()),
+            O._p(feat.numpy()), O._p(ranks_depth.numpy(), O.c_i32p),
+            O._p(ranks_feat.numpy(), O.c_i32p), O._p(ranks_bev.numpy(), O.c_i32p),
+            O._p(interval_starts.numpy(), O.c_i32p), O._p(interval_lengths.numpy(), O.c_i32p),
+            O._p(depth_grad.numpy()), O._p(feat_grad.numpy()))
+
+    @staticmethod
+    def raw2alpha(density, shift, interval):
+        e, a = O.raw2alpha(density.detach().numpy(), float(shift), float(interval))
+        return torch.from_numpy(e), torch.from_numpy(a)
+
+    @staticmethod
+    def raw2alpha_backward(exp, grad_back, interval):
+        return torch.from_numpy(O.raw2alpha_backward(exp.numpy(), grad_back.numpy(), float(interval)))
+
+    @staticmethod
+    def alpha2weight(alpha, ray_id, n_rays):
+        return tuple(torch.from_numpy(x) for x in
+                     O.alpha2weight(alpha.detach().numpy(), ray_id.numpy(), int(n_rays)))
+
+    @staticmethod
+    def alpha2weight_backward(alpha, weight, T, last, i_s, i_e, n_rays, gw, gl):
+        return torch.from_numpy(O.alpha2weight_backward(
+            alpha.detach().numpy(), weight.numpy(), T.numpy(), last.numpy(), i_s.numpy(),
+            i_e.numpy(), int(n_rays), gw.contiguous().numpy(), gl.contiguous().numpy()))
+
+    @staticmethod
+    def cumdist_thres(dist, thres):
+        return torch.from_numpy(O.cumdist_thres(dist.numpy(), float(thres)))
+
+
+def _segment_coo(src, index, out, reduce='sum'):
+    assert reduce == 'sum'
+    return out.index_add_(0, index, src)
+
+
+def install_shim():
+    reg = _Registry()
+    _mod('mmcv')
+    _mod('mmcv.cnn', build_conv_layer=_build_conv_layer, build_norm_layer=_build_norm_layer,
+         build_upsample_layer=None, ConvModule=_ConvModule, MODELS=reg)
+    _mod('mmcv.cnn.bricks')
+    _mod('mmcv.cnn.bricks.conv_module', ConvModule=_ConvModule)
+    _mod('mmcv.runner', BaseModule=nn.Module, force_fp32=_identity_deco, auto_fp16=_identity_deco)
+    _mod('mmcv.utils', Registry=_Registry)
+    _mod('mmdet')
+    _mod('mmdet.models', NECKS=reg, HEADS=reg, BACKBONES=reg, DETECTORS=reg)
+    _mod('mmdet.models.builder', build_loss=lambda cfg: None)
+    _mod('mmdet.models.backbones')
+    _mod('mmdet.models.backbones.resnet', BasicBlock=nn.Module, Bottleneck=nn.Module,
+         ResNet=nn.Module)
+    _mod('mmdet.core', reduce_mean=lambda x: x)
+    _mod('torch_scatter', segment_coo=_segment_coo)
+    _mod('torch_efficient_distloss', flatten_eff_distloss=None)
+    _mod('cv2')
+    _mod('termcolor', colored=lambda s, *a, **k: s)
+    _mod('mmdet3d')
+    _mod('mmdet3d.models', builder=types.SimpleNamespace())
+    _mod('mmdet3d.models.builder', NECKS=reg, HEADS=reg, BACKBONES=reg)
+    _mod('mmdet3d.models.necks')
+    _mod('mmdet3d.models.backbones')
+    _mod('mmdet3d.models.heads')
+    _mod('mmdet3d.models.nerf')
+    _mod('mmdet3d.ops')
+    _mod('mmdet3d.ops.bev_pool_v2', bev_pool_v2_ext=_NativeStubs)
+
+
+def load_ref(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def randomize_bn(module, gen):
+    for m in module.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+
+
+def sd_np(module, prefix=''):
+    return {prefix + k: v.detach().numpy().copy() for k, v in module.state_dict().items()
+            if 'num_batches_tracked' not in k}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_kat(bp):
+    """G1: the reference's own known-answer test, run through its Python wrapper on CPU."""
+    depth = torch.tensor([0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9]).view(1, 1, 2, 2, 2).requires_grad_()
+    feat = torch.ones(1, 1, 2, 2, 2, requires_grad=True)
+    rd = torch.tensor([0, 4, 1, 6]).int()
+    rf = torch.tensor([0, 0, 1, 2]).int()
+    rb = torch.tensor([0, 0, 1, 1]).int()
+    kept = torch.ones(4, dtype=torch.bool)
+    kept[1:] = rb[1:] != rb[:-1]
+    st = torch.where(kept)[0].int()
+    ln = torch.zeros_like(st)
+    ln[:-1] = st[1:] - st[:-1]
+    ln[-1] = 4 - st[-1]
+    out = bp.bev_pool_v2(depth, feat, rd, rf, rb, (1, 1, 2, 2, 2), st, ln)
+    loss = out.sum()
+    loss.backward()
+    # expected values as asserted by the reference (bev_pool.py:169-176)
+    assert abs(loss.item() - 4.4) < 1e-6
+    exp_dg = np.array([2., 2., 0., 0., 2., 0., 2., 0.], np.float32).reshape(1, 1, 2, 2, 2)
+    exp_fg = np.array([1.0, 1.0, 0.4, 0.4, 0.8, 0.8, 0., 0.], np.float32).reshape(1, 1, 2, 2, 2)
+    assert np.allclose(depth.grad.numpy(), exp_dg) and np.allclose(feat.grad.numpy(), exp_fg)
+    save('kat_bev_pool_v2.npz', depth=depth.detach().numpy(), feat=feat.detach().numpy(),
+         ranks_depth=rd.numpy(), ranks_feat=rf.numpy(), ranks_bev=rb.numpy(),
+         interval_starts=st.numpy(), interval_lengths=ln.numpy(), out=out.detach().numpy(),
+         loss=np.float32(4.4), depth_grad=exp_dg, feat_grad=exp_fg)
+
+
+def make_vt(vtm, grid_config, input_size, downsample, C):
+    vt = vtm.LSSViewTransformer(grid_config=grid_config, input_size=input_size,
+                                downsample=downsample, in_channels=8, out_channels=C,
+                                collapse_z=False)
+    return vt
+
+
+def gen_geometry(vtm):
+    """G2/G3: geometry + ranks + pooling through the reference's LSSViewTransformer."""
+    g = torch.Generator().manual_seed(0)
+    # reduced config, full tensors (2 cams, D=8, 4x11 feature map, 20x20x4 grid, C=8)
+    grid_small = {'x': [-40, 40, 4.0], 'y': [-40, 40, 4.0], 'z': [-1, 5.4, 1.6],
+                  'depth': [1.0, 45.0, 5.5]}
+    rig = S.synthetic_rig(6)
+    sel = [1, 4]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    s2e = t(rig['sensor2ego'][:, sel]); K = t(rig['intrin'][:, sel])
+    pr = t(rig['post_rot'][:, sel]).clone(); pt = t(rig['post_tran'][:, sel]).clone()
+    pr[:, :, 0, 0] = 0.25; pr[:, :, 1, 1] = 0.25     # 64x176 input / 1600x900 sensor-ish
+    pt[:, :, 1] = -80.0
+    bda = torch.tensor([[[0.98, 0.05, 0.0], [-0.05, 0.98, 0.0], [0.0, 0.0, 1.0]]])
+    vt = make_vt(vtm, grid_small, (64, 176), 16, 8)
+    D = vt.D
+    coor = vt.get_lidar_coor(s2e, None, K, pr, pt, bda)
+    rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(coor)
+    depth = torch.softmax(torch.randn(1, 2, D, 4, 11, generator=g), 2)
+    feat = torch.randn(1, 2, 8, 4, 11, generator=g)
+    depth_g = depth.clone().requires_grad_()
+    feat_g = feat.clone().requires_grad_()
+    bev = vt.voxel_pooling_v2(coor, depth_g, feat_g)
+    gout = torch.randn(bev.shape, generator=g)
+    (bev * gout).sum().backward()
+    save('lss_small.npz', sensor2ego=s2e.numpy(), intrin=K.numpy(), post_rot=pr.numpy(),
+         post_tran=pt.numpy(), bda=bda.numpy(),
+         inv_post_rot=torch.inverse(pr).numpy(),
+         combine=s2e[:, :, :3, :3].matmul(torch.inverse(K)).numpy(),
+         frustum=vt.frustum.numpy(), coor=coor.numpy(),
+         ranks_bev=rb.numpy(), ranks_depth=rd.numpy(), ranks_feat=rf.numpy(),
+         interval_starts=st.numpy(), interval_lengths=ln.numpy(),
+         depth=depth.numpy(), feat=feat.numpy(), bev_feat=bev.detach().numpy(),
+         out_grad=gout.numpy(), depth_grad=depth_g.grad.numpy(), feat_grad=feat_g.grad.numpy(),
+         grid_x=np.array(grid_small['x']), grid_y=np.array(grid_small['y']),
+         grid_z=np.array(grid_small['z']), grid_depth=np.array(grid_small['depth']),
+         input_size=np.array([64, 176]), downsample=np.array(16))
+
+    # full-size config: statistics + sampled rows only
+    grid_full = {'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 0.4],
+                 'depth': [1.0, 45.0, 0.5]}
+    vt = make_vt(vtm, grid_full, (512, 1408), 16, 32)
+    args = [t(rig[k]) for k in ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda')]
+    coor = vt.get_lidar_coor(args[0], None, args[1], args[2], args[3], args[4])
+    rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(coor)
+    coorv = ((coor - vt.grid_lower_bound) / vt.grid_interval)
+    n_trunc_not_floor = int(((coorv.long() != coorv.floor().long()).any(-1)
+                             & (coorv.long() >= 0).all(-1)
+                             & (coorv.long()[..., 0] < 200) & (coorv.long()[..., 1] < 200)
+                             & (coorv.long()[..., 2] < 16)).sum())
+    depth, feat = [torch.from_numpy(a) for a in S.lift_inputs(5)]
+    bev = vt.voxel_pooling_v2(coor, depth, feat)           # (1,32,16,200,200)
+    idx = torch.randint(0, 640000, (1024,), generator=g)
+    rows = bev[0].reshape(32, -1)[:, idx].T.contiguous()   # (1024, 32)
+    # per-voxel multiset signature of the sort (order inside a voxel is unspecified)
+    lens_hist = np.bincount(ln.numpy(), minlength=1)
+    save('lss_full_stats.npz', P_kept=np.int64(len(rb)), n_intervals=np.int64(len(st)),
+         max_len=np.int64(ln.max()), lens_hist=lens_hist,
+         sum_ranks_bev=np.int64(rb.long().sum()), sum_ranks_depth=np.int64(rd.long().sum()),
+         sum_ranks_feat=np.int64(rf.long().sum()),
+         n_trunc_not_floor=np.int64(n_trunc_not_floor),
+         coor_sample_idx=idx.numpy(), coor_sample=coor.reshape(-1, 3)[idx * 2].numpy(),
+         interval_starts_head=st[:64].numpy(), interval_lengths_head=ln[:64].numpy(),
+         ranks_bev_head=rb[:256].numpy(), ranks_bev_tail=rb[-256:].numpy(),
+         bev_sum=np.float64(bev.double().sum()), bev_abs_sum=np.float64(bev.double().abs().sum()),
+         sample_voxel_idx=idx.numpy(), sample_rows=rows.numpy(), seed_lift=np.int64(5))
+
+
+def load_sd(module, sd, prefix):
+    """Copy the numpy state dict (reference key names) into a reference module."""
+    own = module.state_dict()
+    for k in own:
+        if 'num_batches_tracked' in k:
+            continue
+        own[k].copy_(torch.from_numpy(sd[prefix + k]))
+
+
+def gen_conv_stack(res, fpn, occ):
+    """G4/G6: CustomResNet3D / LSSFPN3D / final_conv / OccHead at reduced spatial size with
+    weights from preworld_amd.synth.synth_state_dict(seed=11) (regenerated by the tests)."""
+    sd = S.synth_state_dict(11)
+    pre = res.CustomResNet3D(numC_input=32, with_cp=False, num_layer=[1], num_channels=[32],
+                             stride=[1], backbone_output_ids=[0]).eval()
+    enc = res.CustomResNet3D(numC_input=64, num_layer=[1, 2, 4], with_cp=False,
+                             num_channels=[32, 64, 128], stride=[1, 2, 2],
+                             backbone_output_ids=[0, 1, 2]).eval()
+    neck = fpn.LSSFPN3D(in_channels=224, out_channels=32).eval()
+    head = occ.OccHead(with_cp=False, use_deblock=False,
+                       norm_cfg=dict(type='SyncBN', requires_grad=True), soft_weights=True,
+                       final_occ_size=[200, 200, 16], empty_idx=17, num_level=1,
+                       in_channels=[32], out_channel=18,
+                       point_cloud_range=[-40, -40, -1, 40, 40, 5.4]).eval()
+    fconv = _ConvModule(32, 32, kernel_size=3, stride=1, padding=1, bias=True,
+                        conv_cfg=dict(type='Conv3d')).eval()
+    with torch.no_grad():
+        load_sd(pre, sd, 'pre_process_net.')
+        load_sd(enc, sd, 'img_bev_encoder_backbone.')
+        load_sd(neck, sd, 'img_bev_encoder_neck.')
+        load_sd(head, sd, 'occupancy_head.')
+        load_sd(fconv, sd, 'final_conv.')
+        Z, Y, X = 8, 16, 16
+        rs = np.random.RandomState(12)
+        bev_key = torch.from_numpy(rs.standard_normal((1, 32, Z, Y, X)).astype(np.float32))
+        bev_adj = torch.from_numpy(rs.standard_normal((1, 32, Z, Y, X)).astype(np.float32))
+        pk = pre(bev_key)[0]
+        pa = pre(bev_adj)[0]
+        feats = enc(torch.cat([pa, pk], 1))
+        nk = neck(feats)
+        fc = fconv(nk)
+        vf = fc.permute(0, 4, 3, 2, 1).contiguous()                 # (1,X,Y,Z,C)
+        logits = head([vf[0].permute(3, 0, 1, 2).unsqueeze(0)])['output_voxels'][0]
+        occ_pred = logits[0].permute(1, 2, 3, 0).argmax(-1).to(torch.uint8)
+    save('conv_stack_small.npz', seed_sd=np.int64(11), seed_in=np.int64(12),
+         shape=np.array([Z, Y, X]), pre_key=pk.numpy(), pre_adj=pa.numpy(),
+         enc0=feats[0].numpy(), enc1=feats[1].numpy(), enc2=feats[2].numpy(), neck=nk.numpy(),
+         final_conv=fc.numpy(), logits=logits.numpy(), occ=occ_pred.numpy())
+
+
+def gen_forecast():
+    """G5: forecast recursion + attribute MLPs: torch modules with the reference's layer
+    shapes (preworld_temporal_traj.py:81-132) driven exactly as :329-368 does (the detector
+    class itself cannot be imported -- SURVEY 8c)."""
+    sd = S.synth_state_dict(11)
+    plan = nn.Sequential(nn.Linear(21, 256), nn.ReLU(inplace=True), nn.Linear(256, 256),
+                         nn.ReLU(inplace=True), nn.Linear(256, 32))
+    fusion = nn.Sequential(nn.Linear(64, 128), nn.Softplus(), nn.Linear(128, 32))
+    dens = nn.Sequential(nn.Linear(32, 64), nn.Softplus(), nn.Linear(64, 2), nn.Softplus())
+    sem = nn.Sequential(nn.Linear(32, 64), nn.Softplus(), nn.Linear(64, 17))
+    col = nn.Sequential(nn.Linear(32, 64), nn.Softplus(), nn.Linear(64, 3))
+    with torch.no_grad():
+        for name, m in (('plan_head', plan), ('fusion_head', fusion), ('density_mlp', dens),
+                        ('semantic_mlp', sem), ('color_mlp', col)):
+            load_sd(m, sd, name + '.')
+        rs = np.random.RandomState(13)
+        v = torch.from_numpy(rs.standard_normal((1, 8, 8, 4, 32)).astype(np.float32))
+        ego = torch.from_numpy(S.ego_state(14))
+        states = [v]
+        x_, y_, z_ = 8, 8, 4
+        vf = v
+        for _ in range(6):
+            es = ego.reshape(1, 21)
+            ef = plan(es).unsqueeze(1).unsqueeze(1).unsqueeze(1)
+            ef = ef.repeat_interleave(z_, dim=3).repeat_interleave(y_, dim=2).repeat_interleave(x_, dim=1)
+            fused = fusion(torch.cat([vf, ef], dim=-1)) + vf
+            states.append(fused)
+            vf = fused.clone()
+        d = dens(v)
+        s = sem(v)
+        c = col(v)
+        ego_feat = plan(ego.reshape(1, 21))
+    save('forecast_small.npz', seed_sd=np.int64(11), seed_v=np.int64(13), seed_ego=np.int64(14),
+         ego_feat=ego_feat.numpy(), states=np.stack([s_.numpy() for s_ in states]),
+         density=d.numpy(), semantic=s.numpy(), color=c.numpy())
+
+
+def gen_render(nh):
+    """G7: NerfHead.sample_ray / render_one_scene / render_* through the reference Python."""
+    head = nh.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4,
+                       scene_center=[0, 0, 2.2], radius=39, use_depth_sup=True,
+                       weight_depth=1.0, weight_semantic=1.0, weight_color=1.0)
+    density, semantic, color = [torch.from_numpy(a) for a in S.render_grids(21)]
+    R = 64
+    o, d = [torch.from_numpy(a) for a in S.rays(22, R)]
+    bda = torch.tensor([[0.98, 0.05, 0.0], [-0.05, 0.98, 0.0], [0.0, 0.0, 1.0]])
+    with torch.no_grad():
+        pts, inner, t = nh.sample_ray(o, d, head.step_size, head.scene_center, head.scene_radius,
+                                      head.bg_len, head.world_len, bda)
+        res = head.render_one_scene(o, d, bda, density, semantic, color, mask=None)
+        res['N_ray'] = R
+        depth = head.render_depth(res)
+        sem = head.render_semantic(res)
+        col = head.render_color(res)
+    save('render_small.npz', seed_grid=np.int64(21), seed_rays=np.int64(22), R=np.int64(R),
+         bda=bda.numpy(), t=t.numpy(), ray_pts=pts.numpy()[:, ::8].copy(),
+         inner_mask=inner.numpy(),
+         weights=res['weights'].numpy(), ray_id=res['ray_id'].numpy(), s=res['s'].numpy(),
+         alphainv_last=res['alphainv_last'].numpy(), render_depth=depth.numpy(),
+         render_semantic=sem.numpy(), render_color=col.numpy(),
+         xyz_min=head.xyz_min.numpy(), xyz_max=head.xyz_max.numpy(),
+         act_shift=head.act_shift.numpy(), bg_len=np.float32(head.bg_len),
+         scene_center=head.scene_center.numpy())
+
+
+def gen_metric(om):
+    """G8: Metric_mIoU on seeded random labels."""
+    rng = np.random.RandomState(4)
+    m = om.Metric_mIoU(num_classes=18, use_image_mask=True)
+    preds, gts, masks = [], [], []
+    for _ in range(3):
+        gt = rng.randint(0, 18, (200, 200, 16)).astype(np.uint8)
+        pred = np.where(rng.rand(200, 200, 16) < 0.6, gt, rng.randint(0, 18, gt.shape)).astype(np.uint8)
+        mc = rng.rand(200, 200, 16) < 0.7
+        m.add_batch(pred, gt, None, mc)
+        preds.append(pred[::8, ::8]); gts.append(gt[::8, ::8]); masks.append(mc[::8, ::8])
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, iu, cnt, miou = m.count_miou()
+    # small-sample version for the committed fixture
+    m2 = om.Metric_mIoU(num_classes=18, use_image_mask=True)
+    for p, g_, k in zip(preds, gts, masks):
+        m2.add_batch(p, g_, None, k)
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, iu2, _, miou2 = m2.count_miou()
+    save('metric_miou.npz', pred=np.stack(preds), gt=np.stack(gts), mask=np.stack(masks),
+         hist=m2.hist, iou=iu2, miou=np.float64(miou2))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    install_shim()
+    bp = load_ref('mmdet3d.ops.bev_pool_v2.bev_pool', 'mmdet3d/ops/bev_pool_v2/bev_pool.py')
+    torch.cuda.amp.autocast_mode  # noqa: B018 (import check)
+    vtm = load_ref('mmdet3d.models.necks.view_transformer', 'mmdet3d/models/necks/view_transformer.py')
+    res = load_ref('mmdet3d.models.backbones.resnet', 'mmdet3d/models/backbones/resnet.py')
+    fpn = load_ref('mmdet3d.models.necks.lss_fpn', 'mmdet3d/models/necks/lss_fpn.py')
+    occ = load_ref('mmdet3d.models.heads.occupancy_head', 'mmdet3d/models/heads/occupancy_head.py')
+    om = load_ref('ref_occ_metrics', 'mmdet3d/datasets/occ_metrics.py')
+    # nerf utils JIT-compile CUDA at import: provide the module instead
+    _mod('mmdet3d.models.nerf.utils')
+    ut_src = types.ModuleType('mmdet3d.models.nerf.utils')
+    import torch.utils.cpp_extension as cpp_ext
+    real_load = cpp_ext.load
+    cpp_ext.load = lambda name, **kw: _NativeStubs
+    sys.modules['turtle'] = types.ModuleType('turtle')
+    sys.modules['turtle'].forward = None
+    try:
+        ut = load_ref('mmdet3d.models.nerf.utils', 'mmdet3d/models/nerf/utils.py')
+    finally:
+        cpp_ext.load = real_load
+    nh = load_ref('mmdet3d.models.nerf.nerf_head', 'mmdet3d/models/nerf/nerf_head.py')
+    gen_kat(bp)
+    gen_geometry(vtm)
+    gen_conv_stack(res, fpn, occ)
+    gen_forecast()
+    gen_render(nh)
+    gen_metric(om)
+
+
+if __name__ == '__main__':
+    main()
