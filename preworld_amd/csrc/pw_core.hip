@@ -1,0 +1,31 @@
+// Error state, version and device query for libpreworld_hip.so.
+#include "pw_common.h"
+
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void pw_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+PW_API int pw_version(void) { return 100; }
+
+PW_API const char* pw_last_error(void) { return g_err; }
+
+PW_API int pw_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len) {
+  int dev = 0;
+  PW_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  PW_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (arch_name && arch_name_len > 0) {
+    strncpy(arch_name, prop.gcnArchName, (size_t)arch_name_len - 1);
+    arch_name[arch_name_len - 1] = 0;
+  }
+  return PW_OK;
+}

@@ -1,0 +1,201 @@
+"""GPU parity: LSS geometry / rank build / voxel pooling (HIP, through the C ABI) against
+the CPU oracle and the golden vectors.  Integer outputs are compared bit-exact; the pooled
+fp32 sums are bit-exact too because kernel and oracle share op order with FMA contraction off."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from preworld_amd import ops
+from preworld_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+def test_kat_reference_abi(golden):
+    """mmdet3d/ops/bev_pool_v2/bev_pool.py:145-176 on the HIP op (C=1 -> generic kernels)."""
+    g = golden('kat_bev_pool_v2.npz')
+    depth = T(g['depth']).requires_grad_()
+    feat = T(g['feat']).requires_grad_()
+    out = ops.bev_pool_v2(depth, feat, T(g['ranks_depth']), T(g['ranks_feat']), T(g['ranks_bev']),
+                          (1, 1, 2, 2, 2), T(g['interval_starts']), T(g['interval_lengths']))
+    loss = out.sum()
+    loss.backward()
+    assert abs(loss.item() - 4.4) < 1e-6
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), g['out'])
+    np.testing.assert_allclose(depth.grad.cpu().numpy(), g['depth_grad'])
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), g['feat_grad'])
+
+
+def test_camera_matrices_bit_exact():
+    rig = S.synthetic_rig(6, dx=-2.5)
+    ipr, comb, tr = ops.lss_camera_matrices(T(rig['sensor2ego']), T(rig['intrin']), T(rig['post_rot']))
+    o_ipr, o_comb, o_tr = O.camera_matrices(rig['sensor2ego'], rig['intrin'], rig['post_rot'])
+    np.testing.assert_array_equal(ipr.cpu().numpy().reshape(-1, 3, 3), o_ipr)
+    np.testing.assert_array_equal(comb.cpu().numpy().reshape(-1, 3, 3), o_comb)
+    np.testing.assert_array_equal(tr.cpu().numpy().reshape(-1, 3), o_tr)
+
+
+def _prepare(gc, input_size, downsample, rig, B, N):
+    fr = O.create_frustum(gc['depth'], input_size, downsample)
+    lower, interval, size = O.grid_infos(gc)
+    ipr, comb, tr = ops.lss_camera_matrices(T(rig['sensor2ego']), T(rig['intrin']), T(rig['post_rot']))
+    vox, coor = ops.lss_voxel_index(T(fr), ipr, T(rig['post_tran']), comb, tr, T(rig['bda']),
+                                    lower, interval, size, B, N, return_coor=True)
+    return fr, lower, interval, size, vox, coor
+
+
+def test_golden_small_coor_and_ranks(golden):
+    g = golden('lss_small.npz')
+    gc = {'x': list(g['grid_x']), 'y': list(g['grid_y']), 'z': list(g['grid_z']),
+          'depth': list(g['grid_depth'])}
+    lower, interval, size = O.grid_infos(gc)
+    tr = T(g['sensor2ego'][:, :, :3, 3])
+    # with the reference's own torch.inverse matrices the coordinates are bit-identical
+    vox, coor = ops.lss_voxel_index(T(g['frustum']), T(g['inv_post_rot']), T(g['post_tran']),
+                                    T(g['combine']), tr, T(g['bda']), lower, interval, size, 1, 2,
+                                    return_coor=True)
+    np.testing.assert_array_equal(coor.cpu().numpy(), g['coor'])
+    n_vox = size[0] * size[1] * size[2]
+    seg_start, order = ops.segment_sort(vox, n_vox)
+    D, H, W = g['frustum'].shape[:3]
+    rb, rd, rf, st, ln = ops.lss_ranks(seg_start, order, n_vox, D, H * W)
+    np.testing.assert_array_equal(rb.cpu().numpy(), g['ranks_bev'])
+    np.testing.assert_array_equal(st.cpu().numpy(), g['interval_starts'])
+    np.testing.assert_array_equal(ln.cpu().numpy(), g['interval_lengths'])
+    o = O.voxel_pooling_prepare_v2(g['coor'], lower, interval, size)
+    np.testing.assert_array_equal(rd.cpu().numpy(), o[1])      # stable order == oracle's
+    np.testing.assert_array_equal(rf.cpu().numpy(), o[2])
+    # pooled output vs the reference's (B,C,Z,Y,X)
+    feat = T(np.ascontiguousarray(g['feat'].transpose(0, 1, 3, 4, 2)))
+    depth = T(g['depth'])
+    bev = ops.bev_pool_v2(depth, feat, rd, rf, rb, (1, size[2], size[1], size[0], 8), st, ln)
+    np.testing.assert_allclose(bev.cpu().numpy(), g['bev_feat'], rtol=1e-5, atol=1e-6)
+    dense = ops.bev_pool_dense(depth, feat, seg_start, order, n_vox, D, H * W)
+    np.testing.assert_array_equal(dense.view(1, size[2], size[1], size[0], 8).permute(0, 4, 1, 2, 3)
+                                  .cpu().numpy(), bev.cpu().numpy())
+    # backward through the autograd wrapper
+    depth_g = depth.clone().requires_grad_()
+    feat_g = feat.clone().requires_grad_()
+    out = ops.bev_pool_v2(depth_g, feat_g, rd, rf, rb, (1, size[2], size[1], size[0], 8), st, ln)
+    (out * T(g['out_grad'])).sum().backward()
+    np.testing.assert_allclose(depth_g.grad.cpu().numpy(), g['depth_grad'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(feat_g.grad.permute(0, 1, 4, 2, 3).cpu().numpy(), g['feat_grad'],
+                               rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('cfg', ['C1', 'full', 'full_adj_b2'])
+def test_full_size_bit_exact_vs_oracle(cfg):
+    """BASELINE configs: C1 (1 cam, 100x100x8) and the 6-cam 200x200x16 grid, plus B=2 with a
+    translated adjacent-frame rig.  Every integer output and the pooled sums are bit-exact."""
+    if cfg == 'C1':
+        gc, N, B = S.GRID_CONFIG_C1, 1, 1
+        rig = S.synthetic_rig(1)
+    elif cfg == 'full':
+        gc, N, B = S.GRID_CONFIG_FULL, 6, 1
+        rig = S.synthetic_rig(6)
+    else:
+        gc, N, B = S.GRID_CONFIG_FULL, 6, 2
+        r0, r1 = S.synthetic_rig(6), S.synthetic_rig(6, dx=-2.5)
+        rig = {k: np.concatenate([r0[k], r1[k]], 0) for k in r0}
+        rig['bda'][1] = np.array([[0.99, 0.1, 0], [-0.1, 0.99, 0], [0, 0, 1.0]], np.float32)
+    fr, lower, interval, size, vox, coor = _prepare(gc, S.INPUT_SIZE, S.DOWNSAMPLE, rig, B, N)
+    o_ipr, o_comb, o_tr = O.camera_matrices(rig['sensor2ego'], rig['intrin'], rig['post_rot'])
+    o_coor = O.lidar_coor(fr, o_ipr, rig['post_tran'].reshape(-1, 3), o_comb, o_tr, rig['bda'], B, N)
+    np.testing.assert_array_equal(coor.cpu().numpy(), o_coor)
+    np.testing.assert_array_equal(vox.cpu().numpy(), O.voxel_index(o_coor, lower, interval, size))
+    n_vox = B * size[0] * size[1] * size[2]
+    D, H, W = fr.shape[:3]
+    seg_start, order = ops.segment_sort(vox, n_vox)
+    got = ops.lss_ranks(seg_start, order, n_vox, D, H * W)
+    want = O.voxel_pooling_prepare_v2(o_coor, lower, interval, size)
+    for a, b, name in zip(got, want, ('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths')):
+        np.testing.assert_array_equal(a.cpu().numpy(), b, err_msg=name)
+    depth, feat = S.lift_inputs(7, B=B, N=N)
+    featc = np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2))
+    o_bev = O.bev_pool_v2(depth, featc, want[1], want[2], want[0],
+                          (B, size[2], size[1], size[0], 32), want[3], want[4])
+    d_t, f_t = T(depth), T(featc)
+    dense = ops.bev_pool_dense(d_t, f_t, seg_start, order, n_vox, D, H * W)
+    dense = dense.view(B, size[2], size[1], size[0], 32).permute(0, 4, 1, 2, 3).cpu().numpy()
+    np.testing.assert_array_equal(dense, o_bev)
+    ref_abi = ops.bev_pool_v2(d_t, f_t, got[1], got[2], got[0], (B, size[2], size[1], size[0], 32),
+                              got[3], got[4]).cpu().numpy()
+    np.testing.assert_array_equal(ref_abi, o_bev)
+
+
+def test_full_size_properties(golden):
+    """Size-independent properties at BASELINE's full size: linearity in feat, conservation
+    (sum of pooled == sum over kept points of depth*feat), idempotent re-run, golden stats."""
+    g = golden('lss_full_stats.npz')
+    rig = S.synthetic_rig(6)
+    fr, lower, interval, size, vox, _ = _prepare(S.GRID_CONFIG_FULL, S.INPUT_SIZE, S.DOWNSAMPLE,
+                                                 rig, 1, 6)
+    n_vox = 640000
+    seg_start, order = ops.segment_sort(vox, n_vox)
+    kept = int(seg_start[-1])
+    assert abs(kept - int(g['P_kept'])) <= 64                # closed-form vs LAPACK 3x3 inverse
+    lens = (seg_start[1:] - seg_start[:-1])
+    assert abs(int((lens > 0).sum()) - int(g['n_intervals'])) <= 64
+    # sortedness / permutation property of the order array
+    o = order[:kept].long()
+    assert torch.unique(o).numel() == kept
+    assert bool((vox[o] >= 0).all())
+    assert bool((vox[o][1:] >= vox[o][:-1]).all())
+    depth, feat = S.lift_inputs(int(g['seed_lift']))
+    d_t = T(depth)
+    f_t = T(np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2)))
+    a = ops.bev_pool_dense(d_t, f_t, seg_start, order, n_vox, 88, 32 * 88)
+    b = ops.bev_pool_dense(d_t, f_t, seg_start, order, n_vox, 88, 32 * 88)
+    assert torch.equal(a, b)                                   # deterministic
+    a2 = ops.bev_pool_dense(d_t, (f_t * 2).contiguous(), seg_start, order, n_vox, 88, 32 * 88)
+    assert torch.equal(a2, a * 2)                              # exact linearity (power of two)
+    pf = (o // (88 * 32 * 88)) * (32 * 88) + o % (32 * 88)
+    direct = (d_t.view(-1)[o].double()[:, None] * f_t.view(-1, 32)[pf].double()).sum(0)
+    np.testing.assert_allclose(a.double().sum(0).cpu().numpy(), direct.cpu().numpy(), rtol=1e-6)
+    rows = a[torch.from_numpy(g['sample_voxel_idx']).to(DEV)].cpu().numpy()
+    bad = np.abs(rows - g['sample_rows']).max(1) > 1e-4
+    assert bad.mean() < 0.01
+
+
+def test_edge_cases():
+    lower, interval, size = O.grid_infos(S.GRID_CONFIG_FULL)
+    # nothing inside the grid -> five Nones like view_transformer.py:237-238
+    vox = torch.full((1000,), -1, device=DEV, dtype=torch.int32)
+    seg_start, order = ops.segment_sort(vox, 640000)
+    assert int(seg_start[-1]) == 0
+    assert ops.lss_ranks(seg_start, order, 640000, 8, 125) == (None,) * 5
+    out = ops.bev_pool_dense(torch.rand(1000, device=DEV), torch.rand(125, 32, device=DEV),
+                             seg_start, order, 640000, 8, 125)
+    assert float(out.abs().max()) == 0.0
+    # every point in ONE voxel (maximum collision): long-segment path
+    n = 5000
+    vox = torch.full((n,), 12345, device=DEV, dtype=torch.int32)
+    seg_start, order = ops.segment_sort(vox, 640000)
+    assert torch.equal(order, torch.arange(n, device=DEV, dtype=torch.int32))
+    depth = torch.rand(n, device=DEV)
+    feat = torch.rand(n // 8, 32, device=DEV)
+    out = ops.bev_pool_dense(depth, feat, seg_start, order, 640000, 8, n // 8)
+    pf = torch.arange(n, device=DEV) % (n // 8)
+    acc = torch.zeros(32, device=DEV)
+    ref = np.zeros(32, np.float32)
+    dn, fn = depth.cpu().numpy(), feat.cpu().numpy()
+    for i in range(n):
+        ref = (ref + fn[int(pf[i])] * dn[i]).astype(np.float32)
+    np.testing.assert_array_equal(out[12345].cpu().numpy(), ref)
+    assert float(out.abs().sum()) == pytest.approx(float(np.abs(ref).sum()), rel=1e-6)
+    # ragged channel count (not a multiple of 4) takes the generic kernels
+    feat5 = torch.rand(n // 8, 5, device=DEV)
+    out5 = ops.bev_pool_dense(depth, feat5, seg_start, order, 640000, 8, n // 8)
+    np.testing.assert_allclose(out5[12345].cpu().numpy(),
+                               (feat5[pf].double() * depth.double()[:, None]).sum(0).cpu().numpy(),
+                               rtol=1e-5)
+    # bad arguments raise (no silent fallback)
+    with pytest.raises(Exception):
+        ops.bev_pool_dense(depth.cpu(), feat, seg_start, order, 640000, 8, n // 8)
