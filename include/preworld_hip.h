@@ -108,6 +108,62 @@ int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_
                       const int32_t* order, int64_t n_voxels, int c, int D, int HW, float* out,
                       void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * A6-A9, A11  3-D convolution on channels-last activations, exact-fp32 MFMA implicit GEMM.
+ * Replaces torch Conv3d(+BatchNorm3d eval)(+residual)(+ReLU) as composed by
+ * mmdet3d/models/backbones/resnet.py:88-184, necks/lss_fpn.py:120-129,
+ * detectors/preworld.py:72-79, heads/occupancy_head.py:80-105.
+ *   x        (B, D, H, W, Cin) fp32, Cin % 32 == 0
+ *   wpk      packed weights, float[Cin/32][ksize^3][cout_total/32][64][16] with
+ *            wpk[ch][tap][nt][h*32+j][s] = w[nt*32+j][ch*32+h*16+s][tap]  (w = torch
+ *            (Cout,Cin,kD,kH,kW); columns >= Cout zero) -- built by preworld_amd.ops.pack_conv_weight
+ *   scale,bias  float[cout_total] or NULL: y = acc*scale + bias  (BatchNorm eval folded, or conv bias)
+ *   residual    same layout as y0 or NULL (added before ReLU; BasicBlock3D.forward resnet.py:120-123)
+ *   y0 (B,Do,Ho,Wo,cout0) gets packed columns [0,cout0); y1 (B,Do,Ho,Wo,cout1) gets columns
+ *   [roundup32(cout0), +cout1) or is NULL -- lets conv1 and downsample of a BasicBlock3D share
+ *   one pass over x.  ksize in {1,3} (pad = ksize/2), stride in {1,2}.
+ *   algo: 0 auto, 1 LDS-tiled kernel (k3 s1), 2 gather kernel. */
+int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const float* bias,
+                    const float* residual, float* y0, float* y1, int B, int D, int H, int W,
+                    int Cin, int cout_total, int cout0, int cout1, int ksize, int stride,
+                    int relu0, int relu1, int algo, void* stream);
+
+/* A8  LSSFPN3D fused (mmdet3d/models/necks/lss_fpn.py:132-148): out = ReLU(BN(W8 x8 +
+ * up2(y16) + up4(y32))) where y16/y32 are the 1x1x1 conv already applied at 1/2 and 1/4
+ * resolution (32 channels each; interpolation and 1x1x1 conv commute).  trilinear,
+ * align_corners=True.  x8 (B,D,H,W,Cin8), wpk8 packed [Cin8/32][1][1][64][16], out (B,D,H,W,32). */
+int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const float* y32,
+                  const float* scale, const float* bias, float* out, int B, int D, int H, int W,
+                  int Cin8, int D2, int H2, int W2, int D4, int H4, int W4, int relu, void* stream);
+
+/* A11  OccHead fused (mmdet3d/models/heads/occupancy_head.py:124-177, num_level=1,
+ * use_deblock=False): conv3x3x3 Cin->16 + BN + ReLU, 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18,
+ * argmax -> uint8, in one kernel.  x (B,D,H,W,Cin); wpk packed (cout padded to 32);
+ * scale/bias float[32] (folded BN of occ_convs.0.1); w1 [8][16], s1/b1 [8] (folded BN of
+ * occ_pred_conv.1), w2 [18][8]; occ uint8[B*D*H*W]; logits float[B*D*H*W][18] or NULL. */
+int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, const float* bias,
+                      const float* w1, const float* s1, const float* b1, const float* w2,
+                      uint8_t* occ, float* logits, int B, int D, int H, int W, int Cin, int n_mid,
+                      int n_hid, int n_cls, void* stream);
+
+/* A10  state-conditioned forecast (mmdet3d/models/detectors/preworld_temporal_traj.py:329-368).
+ * pw_forecast_pack: fusion_head.{0,2}.weight ([128][64], [32][128]) -> per-lane MFMA operand
+ *   order, w1p/w2p float[4096] each (once per weight update).
+ * pw_forecast_prologue: per sample, e = plan_head(ego) (21->256 ReLU->256 ReLU->32) and the
+ *   hoisted ego term c1 = fusion_head.0.weight[:,32:] e + fusion_head.0.bias;
+ *   ego (n_samples, ego_dim), ego_feat (n_samples,32), c1 (n_samples,128).
+ * pw_forecast_steps: v_{k+1} = v_k + W2 softplus(W1a v_k + c1) + b2 for k < n_steps, all steps
+ *   in registers; v0 (n_samples*n_vox, 32) channels-last; states float[n_steps][n_samples*n_vox][32]. */
+int pw_forecast_pack(const float* fusion_w1, const float* fusion_w2, float* w1p, float* w2p,
+                     void* stream);
+int pw_forecast_prologue(const float* ego, int n_samples, int ego_dim, const float* plan_w0,
+                         const float* plan_b0, const float* plan_w2, const float* plan_b2,
+                         const float* plan_w4, const float* plan_b4, const float* fusion_w1,
+                         const float* fusion_b1, float* ego_feat, float* c1, void* stream);
+int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
+                      const float* w2p, const float* c1, const float* fusion_b2, int n_steps,
+                      float* states, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

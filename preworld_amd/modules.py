@@ -153,3 +153,432 @@ class LSSViewTransformer(nn.Module):
 
     def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda):
         return None
+
+
+# =====================================================================================
+# voxel encoder: ConvModule / BasicBlock3D / CustomResNet3D / LSSFPN3D
+# =====================================================================================
+def to_channels_last_3d(x):
+    """(B,C,D,H,W) logical tensor -> contiguous channels-last storage (B,D,H,W,C).
+    Free when x is already a view of such a buffer (everything this package returns is)."""
+    y = x.permute(0, 2, 3, 4, 1)
+    return y if y.is_contiguous() else y.contiguous()
+
+
+def from_channels_last_3d(y):
+    """(B,D,H,W,C) storage -> (B,C,D,H,W) view (what the reference's callers index)."""
+    return y.permute(0, 4, 1, 2, 3)
+
+
+class _PackedCache:
+    """Packed/folded weights are derived data: rebuilt lazily when parameters change."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors if t is not None)
+        if key != self._key:
+            with torch.no_grad():
+                self._val = build()
+            self._key = key
+        return self._val
+
+
+class ConvModule3d(nn.Module):
+    """mmcv ConvModule restricted to what the hot path uses (conv_cfg=Conv3d, norm_cfg=BN3d or
+    None, act ReLU or None; order conv -> norm -> act).  Child names `conv` / `bn` keep the
+    reference's state-dict keys (`...conv.weight`, `...bn.running_mean`, ...)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias='auto',
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True):
+        super().__init__()
+        assert conv_cfg is None or conv_cfg.get('type') == 'Conv3d'
+        if bias == 'auto':
+            bias = norm_cfg is None
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride,
+                              padding=padding, bias=bias)
+        self.with_norm = norm_cfg is not None
+        if self.with_norm:
+            assert norm_cfg['type'] in ('BN3d', 'SyncBN', 'BN')
+            self.bn = nn.BatchNorm3d(out_channels)
+        self.with_activation = act_cfg is not None
+        if self.with_activation:
+            assert act_cfg['type'] == 'ReLU'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        assert padding == kernel_size // 2
+        self._cache = _PackedCache()
+
+    def folded(self):
+        """(packed weight, scale[cout32], bias[cout32]) for the HIP conv."""
+        params = [self.conv.weight, self.conv.bias]
+        if self.with_norm:
+            params += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+
+        def build():
+            wpk = ops.pack_conv_weight(self.conv.weight)
+            if self.with_norm:
+                sc, bi = ops.fold_bn(self.bn.weight, self.bn.bias, self.bn.running_mean,
+                                     self.bn.running_var, self.bn.eps, self.conv.bias)
+            else:
+                sc = torch.ones_like(self.conv.weight[:, 0, 0, 0, 0])
+                bi = self.conv.bias.float() if self.conv.bias is not None else torch.zeros_like(sc)
+            return wpk, ops._pad32(sc, 1.0), ops._pad32(bi, 0.0)
+        return self._cache.get(params, build)
+
+    def _check_eval(self):
+        if self.training and self.with_norm:
+            raise NotImplementedError('HIP voxel encoder runs BatchNorm in eval mode only '
+                                      '(call .eval()); training-mode BN is not built yet')
+
+    def forward_cl(self, x_cl, residual=None, algo=0):
+        """channels-last in -> channels-last out"""
+        self._check_eval()
+        wpk, sc, bi = self.folded()
+        return ops.conv3d_ndhwc(x_cl, wpk, sc, bi, residual=residual, cout0=self.out_channels,
+                                ksize=self.kernel_size, stride=self.stride,
+                                relu0=self.with_activation, algo=algo)
+
+    def forward(self, x):
+        return from_channels_last_3d(self.forward_cl(to_channels_last_3d(x)))
+
+
+class BasicBlock3D(nn.Module):
+    """mmdet3d/models/backbones/resnet.py:88-123: relu(conv2(conv1(x)) + downsample(x)).
+    conv1 and downsample read the same input, so they run as ONE conv with 2*Cout columns."""
+
+    def __init__(self, channels_in, channels_out, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = ConvModule3d(channels_in, channels_out, 3, stride=stride, padding=1, bias=False,
+                                  conv_cfg=dict(type='Conv3d'), norm_cfg=dict(type='BN3d'),
+                                  act_cfg=dict(type='ReLU', inplace=True))
+        self.conv2 = ConvModule3d(channels_out, channels_out, 3, stride=1, padding=1, bias=False,
+                                  conv_cfg=dict(type='Conv3d'), norm_cfg=dict(type='BN3d'),
+                                  act_cfg=None)
+        self.downsample = downsample
+        self._cache = _PackedCache()
+
+    def forward_cl(self, x):
+        c1, c2, ds = self.conv1, self.conv2, self.downsample
+        c1._check_eval()
+        if ds is not None:
+            params = [c1.conv.weight, c1.bn.weight, c1.bn.bias, c1.bn.running_mean, c1.bn.running_var,
+                      ds.conv.weight, ds.bn.weight, ds.bn.bias, ds.bn.running_mean, ds.bn.running_var]
+
+            def build():
+                w1, s1, b1 = c1.folded()
+                wd, sd, bd = ds.folded()
+                return (torch.cat([w1, wd], dim=2).contiguous(), torch.cat([s1, sd]).contiguous(),
+                        torch.cat([b1, bd]).contiguous())
+            wpk, sc, bi = self._cache.get(params, build)
+            y, identity = ops.conv3d_ndhwc(x, wpk, sc, bi, cout0=c1.out_channels,
+                                           cout1=ds.out_channels, ksize=3, stride=c1.stride,
+                                           relu0=True, relu1=False)
+        else:
+            identity = x
+            y = c1.forward_cl(x)
+        w2, s2, b2 = c2.folded()
+        return ops.conv3d_ndhwc(y, w2, s2, b2, residual=identity, cout0=c2.out_channels, ksize=3,
+                                stride=1, relu0=True)
+
+    def forward(self, x):
+        return from_channels_last_3d(self.forward_cl(to_channels_last_3d(x)))
+
+
+class CustomResNet3D(nn.Module):
+    """mmdet3d/models/backbones/resnet.py:126-184 (same kwargs, same `layers.{s}.{b}` keys)."""
+
+    def __init__(self, numC_input, num_layer=[2, 2, 2], num_channels=None, stride=[2, 2, 2],
+                 backbone_output_ids=None, with_cp=False):
+        super().__init__()
+        assert len(num_layer) == len(stride)
+        num_channels = [numC_input * 2 ** (i + 1) for i in range(len(num_layer))] \
+            if num_channels is None else num_channels
+        self.backbone_output_ids = range(len(num_layer)) \
+            if backbone_output_ids is None else backbone_output_ids
+        layers = []
+        curr = numC_input
+        for i in range(len(num_layer)):
+            layer = [BasicBlock3D(curr, num_channels[i], stride=stride[i],
+                                  downsample=ConvModule3d(curr, num_channels[i], 3, stride=stride[i],
+                                                          padding=1, bias=False,
+                                                          conv_cfg=dict(type='Conv3d'),
+                                                          norm_cfg=dict(type='BN3d'), act_cfg=None))]
+            curr = num_channels[i]
+            layer.extend([BasicBlock3D(curr, curr) for _ in range(num_layer[i] - 1)])
+            layers.append(nn.Sequential(*layer))
+        self.layers = nn.Sequential(*layers)
+        self.with_cp = with_cp
+
+    def forward_cl(self, x):
+        feats = []
+        for lid, layer in enumerate(self.layers):
+            for blk in layer:
+                x = blk.forward_cl(x)
+            if lid in self.backbone_output_ids:
+                feats.append(x)
+        return feats
+
+    def forward(self, x):
+        return [from_channels_last_3d(f) for f in self.forward_cl(to_channels_last_3d(x))]
+
+
+class LSSFPN3D(nn.Module):
+    """mmdet3d/models/necks/lss_fpn.py:103-148 (levels=3).  The 1x1x1 conv is applied before the
+    trilinear upsampling (they commute), so neither the upsampled maps nor the 224-channel
+    concat are ever materialised -- see pw_fpn3d_fuse in include/preworld_hip.h."""
+
+    def __init__(self, in_channels, out_channels, levels=3, with_cp=False):
+        super().__init__()
+        assert levels == 3, 'PreWorld configs use levels=3'
+        assert out_channels == 32, 'fused neck kernel is built for out_channels=32'
+        self.levels = levels
+        self.conv = ConvModule3d(in_channels, out_channels, 1, stride=1, padding=0, bias=False,
+                                 conv_cfg=dict(type='Conv3d'), norm_cfg=dict(type='BN3d'),
+                                 act_cfg=dict(type='ReLU', inplace=True))
+        self.with_cp = with_cp
+        self._cache = _PackedCache()
+
+    def forward_cl(self, feats):
+        x8, x16, x32 = feats
+        c8, c16, c32 = x8.shape[-1], x16.shape[-1], x32.shape[-1]
+        cm = self.conv
+        cm._check_eval()
+        params = [cm.conv.weight, cm.bn.weight, cm.bn.bias, cm.bn.running_mean, cm.bn.running_var]
+
+        def build():
+            w = cm.conv.weight
+            assert w.shape[1] == c8 + c16 + c32
+            sc, bi = ops.fold_bn(cm.bn.weight, cm.bn.bias, cm.bn.running_mean, cm.bn.running_var,
+                                 cm.bn.eps)
+            return (ops.pack_conv_weight(w[:, :c8].contiguous()),
+                    ops.pack_conv_weight(w[:, c8:c8 + c16].contiguous()),
+                    ops.pack_conv_weight(w[:, c8 + c16:].contiguous()), sc, bi)
+        w8, w16, w32, sc, bi = self._cache.get(params, build)
+        y16 = ops.conv3d_ndhwc(x16, w16, ksize=1)
+        y32 = ops.conv3d_ndhwc(x32, w32, ksize=1)
+        return ops.fpn3d_fuse(x8, w8, y16, y32, sc, bi, relu=True)
+
+    def forward(self, feats):
+        return from_channels_last_3d(self.forward_cl([to_channels_last_3d(f) for f in feats]))
+
+
+# =====================================================================================
+# heads
+# =====================================================================================
+class OccHead(nn.Module):
+    """mmdet3d/models/heads/occupancy_head.py:45-177 for the configuration PreWorld uses
+    (num_level=1, use_deblock=False, soft_weights=True): with one level the soft-weight branch
+    is softmax over a single channel (== 1) times a same-size interpolate (== identity), so it
+    does not change the logits; its parameters are kept so checkpoints load.
+
+    forward(voxel_feats=[(1,C,X,Y,Z)]) -> {'output_voxels': [(1,18,X,Y,Z)]} like the reference;
+    decode(...) returns the uint8 argmax directly from the fused kernel."""
+
+    def __init__(self, in_channels, out_channel, num_level=1, soft_weights=False,
+                 conv_cfg=dict(type='Conv3d', bias=False),
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True),
+                 point_cloud_range=[-40., -40., -1., 40., 40., 5.4], final_occ_size=[200, 200, 16],
+                 empty_idx=17, balance_cls_weight=True, with_cp=False, use_deblock=False):
+        super().__init__()
+        if type(in_channels) is not list:
+            in_channels = [in_channels]
+        assert num_level == 1 and not use_deblock, 'PreWorld uses num_level=1, use_deblock=False'
+        assert norm_cfg['type'] in ('SyncBN', 'BN3d', 'BN'), 'PreWorld uses SyncBN (eval == BN)'
+        assert conv_cfg.get('bias', False) is False
+        self.in_channels, self.out_channel, self.num_level = in_channels, out_channel, num_level
+        self.with_cp, self.use_deblock, self.empty_idx = with_cp, use_deblock, empty_idx
+        mid = in_channels[0] // 2
+        self.occ_convs = nn.ModuleList([nn.Sequential(
+            nn.Conv3d(in_channels[0], mid, 3, stride=1, padding=1, bias=False),
+            nn.BatchNorm3d(mid), nn.ReLU(inplace=True))])
+        self.occ_pred_conv = nn.Sequential(
+            nn.Conv3d(mid, mid // 2, 1, bias=False), nn.BatchNorm3d(mid // 2), nn.ReLU(inplace=True),
+            nn.Conv3d(mid // 2, out_channel, 1, bias=False))
+        self.soft_weights = soft_weights
+        self.num_point_sampling_feat = num_level
+        if soft_weights:
+            self.voxel_soft_weights = nn.Sequential(
+                nn.Conv3d(mid, mid // 2, 1, bias=False), nn.BatchNorm3d(mid // 2),
+                nn.ReLU(inplace=True), nn.Conv3d(mid // 2, self.num_point_sampling_feat, 1, bias=False))
+        self._cache = _PackedCache()
+
+    def _folded(self, transposed=False):
+        c0, bn0 = self.occ_convs[0][0], self.occ_convs[0][1]
+        c1, bn1, c2 = self.occ_pred_conv[0], self.occ_pred_conv[1], self.occ_pred_conv[3]
+        params = [c0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, c1.weight,
+                  bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, c2.weight]
+
+        def build():
+            s0, b0 = ops.fold_bn(bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, bn0.eps)
+            s1, b1 = ops.fold_bn(bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps)
+            w0 = c0.weight
+            return (ops.pack_conv_weight(w0), ops.pack_conv_weight(w0.permute(0, 1, 4, 3, 2).contiguous()),
+                    ops._pad32(s0, 1.0), ops._pad32(b0, 0.0),
+                    c1.weight.reshape(c1.weight.shape[0], -1).float().contiguous(), s1, b1,
+                    c2.weight.reshape(c2.weight.shape[0], -1).float().contiguous())
+        wpk, wpk_t, s0, b0, w1, s1, b1, w2 = self._cache.get(params, build)
+        return (wpk_t if transposed else wpk), s0, b0, w1, s1, b1, w2
+
+    def decode_cl(self, x_cl, want_logits=False, transposed=False):
+        """x_cl (B,D,H,W,C) channels-last -> uint8 argmax (B,D,H,W) [, logits (B,D,H,W,18)].
+        The reference feeds (1,C,X,Y,Z), i.e. kernel axes (kD,kH,kW) <-> (X,Y,Z).  With
+        transposed=True, x_cl is the encoder's native (B,Z,Y,X,C) buffer and the kernel taps are
+        permuted instead of the 82 MB activation; the result is then the
+        (Z,Y,X) array whose .permute(0,3,2,1) view is the reference's (X,Y,Z) output."""
+        if self.training:
+            raise NotImplementedError('OccHead HIP path is eval-only')
+        wpk, s0, b0, w1, s1, b1, w2 = self._folded(transposed)
+        return ops.occ_head_fused(x_cl, wpk, s0, b0, w1, s1, b1, w2, want_logits=want_logits)
+
+    def forward(self, voxel_feats, **kwargs):
+        assert type(voxel_feats) is list and len(voxel_feats) == self.num_level
+        _, logits = self.decode_cl(to_channels_last_3d(voxel_feats[0]), want_logits=True)
+        return {'output_voxels': [from_channels_last_3d(logits)]}
+
+
+# =====================================================================================
+# detector-level composition of the hot path
+# =====================================================================================
+class PreWorld4DTraj(nn.Module):
+    """Hot-path half of mmdet3d/models/detectors/preworld_temporal_traj.py:26-370 (and of its
+    base classes bevdet_occ.py:167-269, bevdet.py:52-58): everything downstream of the
+    image-view features.  Attribute names match the reference detector, so a reference
+    checkpoint's `pre_process_net.*`, `img_bev_encoder_backbone.*`, `img_bev_encoder_neck.*`,
+    `final_conv.*`, `occupancy_head.*`, `plan_head.*`, `fusion_head.*`, `density_mlp.*`,
+    `semantic_mlp.*`, `color_mlp.*` keys load with strict=False (the image backbone / neck /
+    DepthNet stay on PyTorch-ROCm and are outside this class).
+
+    simple_test_from_lift() consumes, per frame, the softmaxed depth (B*N,D,H,W) and context
+    features (B*N,C,H,W) that LSSViewTransformerBEVDepth.forward produces at
+    view_transformer.py:798-801 plus the camera tensors, and returns the reference's result
+    dict {semantic_occ_{k}s, geo_occ_{k}s} with uint8 (X,Y,Z) arrays as torch tensors on the GPU
+    (call .cpu().numpy() to get exactly the reference's payload; keeping them on the device
+    avoids the reference's 14 D2H syncs per sample).
+    """
+
+    def __init__(self, img_view_transformer, img_bev_encoder_backbone, img_bev_encoder_neck,
+                 pre_process=None, occupancy_head=None, out_dim=32, num_classes=18,
+                 test_threshold=8.5, if_post_finetune=True, final_softplus=True, with_prev=True,
+                 num_adj=1, empty_idx=17, **kwargs):
+        super().__init__()
+        vt = dict(img_view_transformer)
+        vt.pop('type', None)
+        for k in ('loss_depth_weight', 'depthnet_cfg'):
+            vt.pop(k, None)
+        self.img_view_transformer = LSSViewTransformer(**vt)
+        bb = dict(img_bev_encoder_backbone); bb.pop('type', None)
+        self.img_bev_encoder_backbone = CustomResNet3D(**bb)
+        nk = dict(img_bev_encoder_neck); nk.pop('type', None)
+        self.img_bev_encoder_neck = LSSFPN3D(**nk)
+        self.pre_process = pre_process is not None
+        if self.pre_process:
+            pp = dict(pre_process); pp.pop('type', None)
+            self.pre_process_net = CustomResNet3D(**pp)
+        C = self.img_view_transformer.out_channels
+        self.out_dim, self.num_classes = out_dim, num_classes
+        self.test_threshold, self.if_post_finetune = test_threshold, if_post_finetune
+        self.with_prev, self.num_adj, self.empty_idx = with_prev, num_adj, empty_idx
+        self.final_conv = ConvModule3d(C, out_dim, 3, stride=1, padding=1, bias=True,
+                                       conv_cfg=dict(type='Conv3d'))
+        self.density_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                         nn.Linear(out_dim * 2, 2),
+                                         *([nn.Softplus()] if final_softplus else []))
+        self.semantic_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                          nn.Linear(out_dim * 2, num_classes - 1))
+        self.color_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                       nn.Linear(out_dim * 2, 3))
+        oh = dict(occupancy_head or dict(in_channels=[out_dim], out_channel=num_classes,
+                                         norm_cfg=dict(type='SyncBN'), soft_weights=True))
+        oh.pop('type', None)
+        self.occupancy_head = OccHead(**oh)
+        self.velocity_dim, self.past_frame = 3, 5
+        self.plan_head = nn.Sequential(nn.Linear(self.velocity_dim * (self.past_frame + 2), 256),
+                                       nn.ReLU(inplace=True), nn.Linear(256, 256),
+                                       nn.ReLU(inplace=True), nn.Linear(256, out_dim))
+        self.fusion_head = nn.Sequential(nn.Linear(out_dim * 2, out_dim * 4), nn.Softplus(),
+                                         nn.Linear(out_dim * 4, out_dim))
+        self._fc_cache = _PackedCache()
+
+    # ---- bevdet.py:52-58
+    def bev_encoder_cl(self, x_cl):
+        return self.img_bev_encoder_neck.forward_cl(self.img_bev_encoder_backbone.forward_cl(x_cl))
+
+    # ---- bevdet_occ.py:141-165 minus the image encoder / DepthNet
+    def lift_frame_cl(self, depth, tran_feat, sensor2keyego, intrin, post_rot, post_tran, bda):
+        vt = self.img_view_transformer
+        B, N = sensor2keyego.shape[:2]
+        H, W = depth.shape[-2:]
+        inp = [depth.new_empty(B, N, 1, H, W), sensor2keyego, None, intrin, post_rot, post_tran, bda]
+        keep = vt.collapse_z
+        vt.collapse_z = False
+        try:
+            bev, _ = vt.view_transform(inp, depth, tran_feat)
+        finally:
+            vt.collapse_z = keep
+        x = to_channels_last_3d(bev)
+        if self.pre_process:
+            x = self.pre_process_net.forward_cl(x)[0]
+        return x
+
+    # ---- bevdet_occ.py:167-269 (frame loop, [adj, key] concat, with_prev=False -> zeros)
+    def extract_voxel_feat_cl(self, frames):
+        """frames: list ordered [key, adj, ...] of dicts(depth, tran_feat, sensor2keyego, intrin,
+        post_rot, post_tran, bda).  Returns final_conv output, channels-last (B,Z,Y,X,out_dim)."""
+        key = self.lift_frame_cl(**frames[0])
+        if self.with_prev and len(frames) > 1:
+            adj = [self.lift_frame_cl(**f) for f in frames[1:1 + self.num_adj]]
+        else:
+            adj = [torch.zeros_like(key) for _ in range(self.num_adj)]
+        x = torch.cat(adj[::-1] + [key], dim=-1)          # channel order [adjacent, key] (:266)
+        x = self.bev_encoder_cl(x)
+        return self.final_conv.forward_cl(x)              # conv + bias + ReLU (preworld.py:72-79)
+
+    def _forecast_weights(self):
+        fh = self.fusion_head
+        return self._fc_cache.get([fh[0].weight, fh[2].weight],
+                                  lambda: ops.forecast_pack(fh[0].weight.float().contiguous(),
+                                                            fh[2].weight.float().contiguous()))
+
+    # ---- preworld_temporal_traj.py:329-368: all recursion steps in one kernel
+    def forecast_cl(self, v_cl, ego_states, n_steps=6):
+        """v_cl (B,Z,Y,X,C); ego_states (B,1,21) (always temporal_ego_states[0], :331).
+        Returns states (n_steps,B,Z,Y,X,C) and the ego feature (B,32)."""
+        ph, fh = self.plan_head, self.fusion_head
+        B = v_cl.shape[0]
+        ego = ego_states.reshape(B, -1).float().contiguous()
+        plan = [(ph[0].weight.contiguous(), ph[0].bias), (ph[2].weight.contiguous(), ph[2].bias),
+                (ph[4].weight.contiguous(), ph[4].bias)]
+        ef, c1 = ops.forecast_prologue(ego, plan, fh[0].weight.contiguous(), fh[0].bias)
+        w1p, w2p = self._forecast_weights()
+        states = ops.forecast_steps(v_cl, B, w1p, w2p, c1, fh[2].bias, n_steps)
+        return states, ef
+
+    # ---- preworld_temporal_traj.py:212-370 (post-finetune branch) from lifted inputs
+    @torch.no_grad()
+    def simple_test_from_lift(self, frames, temporal_ego_states, n_steps=6, want_logits=False):
+        assert self.if_post_finetune, 'attribute-MLP decode (if_post_finetune=False) is not built yet'
+        v0 = self.extract_voxel_feat_cl(frames)                       # (B,Z,Y,X,C)
+        res = {}
+        feats = [v0]
+        if n_steps > 0:
+            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps)
+            feats += [states[k] for k in range(n_steps)]
+        logits_all = []
+        for k, f in enumerate(feats):
+            out = self.occupancy_head.decode_cl(f, want_logits=want_logits, transposed=True)
+            occ = out[0] if want_logits else out
+            if want_logits:
+                logits_all.append(out[1])
+            occ_xyz = occ.permute(0, 3, 2, 1)                          # (B,X,Y,Z) view
+            geo = torch.where(occ_xyz != self.empty_idx, torch.zeros_like(occ_xyz),
+                              torch.full_like(occ_xyz, self.num_classes - 1))
+            # the reference indexes batch element 0 (:306) and names states 0s..6s (:361)
+            res['semantic_occ_%ds' % k] = [occ_xyz[0]]
+            res['geo_occ_%ds' % k] = [geo[0]]
+        if want_logits:
+            res['logits'] = logits_all
+        res['voxel_feats'] = feats
+        return res

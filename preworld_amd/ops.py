@@ -203,3 +203,134 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
     x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
                               interval_starts, interval_lengths)
     return x.permute(0, 4, 1, 2, 3)
+
+
+# ------------------------------------------------------------------------------ conv3d
+def pack_conv_weight(w, cout_total=None):
+    """torch Conv3d weight (Cout, Cin, k, k, k) -> the MFMA operand order documented in
+    include/preworld_hip.h: float[Cin/32][k^3][cout_total/32][64][16] with
+    wpk[ch][tap][nt][h*32+j][s] = w[nt*32+j][ch*32+h*16+s][tap]; columns >= Cout are zero."""
+    Cout, Cin, k = w.shape[0], w.shape[1], w.shape[2]
+    if Cin % 32:
+        raise _lib.PreworldHipError('Cin must be a multiple of 32, got %d' % Cin)
+    if cout_total is None:
+        cout_total = (Cout + 31) // 32 * 32
+    taps = k ** 3
+    wp = w.new_zeros(cout_total, Cin, taps)
+    wp[:Cout] = w.reshape(Cout, Cin, taps)
+    nt, nch = cout_total // 32, Cin // 32
+    wp = wp.view(nt, 32, nch, 2, 16, taps)              # (nt, j, ch, h, s, tap)
+    wp = wp.permute(2, 5, 0, 3, 1, 4).contiguous()      # (ch, tap, nt, h, j, s)
+    return wp.view(nch, taps, nt, 64, 16).float().contiguous()
+
+
+def pack_conv_weights_concat(ws):
+    """Concatenate several convs over the SAME input along packed output columns, each padded
+    to a multiple of 32 columns (conv1 + downsample of a BasicBlock3D share one pass)."""
+    return torch.cat([pack_conv_weight(w) for w in ws], dim=2).contiguous()
+
+
+def fold_bn(bn_weight, bn_bias, running_mean, running_var, eps=1e-5, conv_bias=None):
+    """BatchNorm(eval) -> per-channel (scale, bias): y = conv*scale + bias."""
+    inv = 1.0 / torch.sqrt(running_var.float() + eps)
+    scale = bn_weight.float() * inv if bn_weight is not None else inv
+    bias = (bn_bias.float() if bn_bias is not None else 0) - running_mean.float() * scale
+    if conv_bias is not None:
+        bias = bias + conv_bias.float() * scale
+    return scale.contiguous(), bias.contiguous()
+
+
+def _pad32(v, fill):
+    n = v.numel()
+    n32 = (n + 31) // 32 * 32
+    if n32 == n:
+        return v.contiguous()
+    out = v.new_full((n32,), fill)
+    out[:n] = v
+    return out
+
+
+def conv3d_ndhwc(x, wpk, scale=None, bias=None, residual=None, cout0=None, cout1=0, ksize=3,
+                 stride=1, relu0=False, relu1=False, algo=0, out0=None, out1=None):
+    """x (B,D,H,W,Cin) channels-last -> y0 (B,Do,Ho,Wo,cout0) [, y1 (B,Do,Ho,Wo,cout1)].
+    scale/bias: per packed column (length cout_total, see include/preworld_hip.h)."""
+    B, D, H, W, Cin = x.shape
+    nch, taps, nt = wpk.shape[:3]
+    cout_total = nt * 32
+    if cout0 is None:
+        cout0 = cout_total
+    pad = ksize // 2
+    Do = (D + 2 * pad - ksize) // stride + 1
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (W + 2 * pad - ksize) // stride + 1
+    y0 = out0 if out0 is not None else torch.empty(B, Do, Ho, Wo, cout0, device=x.device, dtype=_f32)
+    y1 = None
+    if cout1:
+        y1 = out1 if out1 is not None else torch.empty(B, Do, Ho, Wo, cout1, device=x.device, dtype=_f32)
+    if scale is not None and scale.numel() != cout_total:
+        raise _lib.PreworldHipError('scale must have cout_total=%d entries' % cout_total)
+    if bias is not None and bias.numel() != cout_total:
+        raise _lib.PreworldHipError('bias must have cout_total=%d entries' % cout_total)
+    if nch * 32 != Cin or taps != ksize ** 3:
+        raise _lib.PreworldHipError('packed weight does not match Cin/ksize')
+    _lib.call('pw_conv3d_ndhwc', _chk(x, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _p(scale), _p(bias),
+              _p(residual), _chk(y0, _f32, 'y0'), _p(y1), B, D, H, W, Cin, cout_total, cout0, cout1,
+              ksize, stride, int(relu0), int(relu1), algo, _stream())
+    return (y0, y1) if cout1 else y0
+
+
+def fpn3d_fuse(x8, wpk8, y16, y32, scale, bias, relu=True, out=None):
+    """LSSFPN3D tail: ReLU(BN(W8 x8 + up2(y16) + up4(y32))) -- lss_fpn.py:132-148."""
+    B, D, H, W, C8 = x8.shape
+    if out is None:
+        out = torch.empty(B, D, H, W, 32, device=x8.device, dtype=_f32)
+    _lib.call('pw_fpn3d_fuse', _chk(x8, _f32, 'x8'), _chk(wpk8, _f32, 'wpk8'), _chk(y16, _f32, 'y16'),
+              _chk(y32, _f32, 'y32'), _p(scale), _p(bias), _chk(out, _f32, 'out'), B, D, H, W, C8,
+              y16.shape[1], y16.shape[2], y16.shape[3], y32.shape[1], y32.shape[2], y32.shape[3],
+              int(relu), _stream())
+    return out
+
+
+def occ_head_fused(x, wpk, scale, bias, w1, s1, b1, w2, want_logits=False, occ=None):
+    """OccHead (occupancy_head.py:124-177) on channels-last x (B,D,H,W,32):
+    returns uint8 argmax (B,D,H,W) and, if asked, logits (B,D,H,W,18)."""
+    B, D, H, W, Cin = x.shape
+    if occ is None:
+        occ = torch.empty(B, D, H, W, device=x.device, dtype=torch.uint8)
+    logits = torch.empty(B, D, H, W, 18, device=x.device, dtype=_f32) if want_logits else None
+    _lib.call('pw_occ_head_fused', _chk(x, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
+              _chk(bias, _f32, 'bias'), _chk(w1, _f32, 'w1'), _chk(s1, _f32, 's1'), _chk(b1, _f32, 'b1'),
+              _chk(w2, _f32, 'w2'), _p(occ), _p(logits), B, D, H, W, Cin, 16, 8, 18, _stream())
+    return (occ, logits) if want_logits else occ
+
+
+def forecast_pack(fusion_w1, fusion_w2):
+    w1p = torch.empty(4096, device=fusion_w1.device, dtype=_f32)
+    w2p = torch.empty(4096, device=fusion_w1.device, dtype=_f32)
+    _lib.call('pw_forecast_pack', _chk(fusion_w1, _f32, 'fusion_head.0.weight'),
+              _chk(fusion_w2, _f32, 'fusion_head.2.weight'), _p(w1p), _p(w2p), _stream())
+    return w1p, w2p
+
+
+def forecast_prologue(ego, plan, fusion_w1, fusion_b1):
+    """ego (n_samples, 21); plan = [(w0,b0),(w2,b2),(w4,b4)] -> (ego_feat (n,32), c1 (n,128))."""
+    n, dim = ego.shape
+    ef = torch.empty(n, 32, device=ego.device, dtype=_f32)
+    c1 = torch.empty(n, 128, device=ego.device, dtype=_f32)
+    (w0, b0), (w2, b2), (w4, b4) = plan
+    _lib.call('pw_forecast_prologue', _chk(ego, _f32, 'ego'), n, dim, _chk(w0, _f32, 'w0'),
+              _chk(b0, _f32, 'b0'), _chk(w2, _f32, 'w2'), _chk(b2, _f32, 'b2'), _chk(w4, _f32, 'w4'),
+              _chk(b4, _f32, 'b4'), _chk(fusion_w1, _f32, 'fw1'), _chk(fusion_b1, _f32, 'fb1'),
+              _p(ef), _p(c1), _stream())
+    return ef, c1
+
+
+def forecast_steps(v0, n_samples, w1p, w2p, c1, fusion_b2, n_steps, states=None):
+    """v0 (n_samples, ..., 32) channels-last -> states (n_steps, *v0.shape)."""
+    n_total = v0.numel() // 32
+    if states is None:
+        states = torch.empty((n_steps,) + tuple(v0.shape), device=v0.device, dtype=_f32)
+    _lib.call('pw_forecast_steps', _chk(v0, _f32, 'v0'), n_total // n_samples, n_samples,
+              _chk(w1p, _f32, 'w1p'), _chk(w2p, _f32, 'w2p'), _chk(c1, _f32, 'c1'),
+              _chk(fusion_b2, _f32, 'fb2'), n_steps, _chk(states, _f32, 'states'), _stream())
+    return states

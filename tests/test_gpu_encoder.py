@@ -1,0 +1,216 @@
+"""GPU parity: MFMA conv3d, fused neck, fused OccHead, forecast recursion and their
+composition (HIP through the C ABI) against the CPU oracle and the golden vectors generated
+from the imported reference.  fp32 everywhere; the MFMA accumulates K in a different order
+than the oracle's scalar loops, so tolerances are rtol=2e-4 / atol=2e-4 on O(1) activations
+(same bound the oracle itself meets against the reference's torch-CPU output)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from preworld_amd import modules as M
+from preworld_amd import ops
+from preworld_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = dict(rtol=2e-4, atol=2e-4)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def cl(x):      # numpy (B,C,D,H,W) -> torch channels-last (B,D,H,W,C) on device
+    return T(np.ascontiguousarray(x.transpose(0, 2, 3, 4, 1)))
+
+
+def ncdhw(y):   # torch (B,D,H,W,C) -> numpy (B,C,D,H,W)
+    return y.permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
+
+
+def _rand_conv(rs, cout, cin, k):
+    return (rs.standard_normal((cout, cin, k, k, k)) * np.sqrt(2.0 / (cin * k ** 3))).astype(np.float32)
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 4, 8, 8), (2, 32, 5, 11, 13), (1, 64, 3, 9, 17),
+                                   (1, 128, 4, 6, 10)])
+@pytest.mark.parametrize('cout', [32, 64, 16])
+@pytest.mark.parametrize('algo', [1, 2])
+def test_conv3d_k3s1_vs_oracle(shape, cout, algo):
+    rs = np.random.RandomState(hash((shape, cout)) % 2 ** 31)
+    x = rs.standard_normal(shape).astype(np.float32)
+    w = _rand_conv(rs, cout, shape[1], 3)
+    scale = (rs.rand(cout) + 0.5).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32)
+    res = rs.standard_normal((shape[0], cout) + shape[2:]).astype(np.float32)
+    want = O.conv3d(x, w, None, 1, 1) * scale[None, :, None, None, None] + bias[None, :, None, None, None]
+    want = np.maximum(want + res, 0)
+    wpk = ops.pack_conv_weight(T(w))
+    got = ops.conv3d_ndhwc(cl(x), wpk, ops._pad32(T(scale), 1.0), ops._pad32(T(bias), 0.0),
+                           residual=cl(res), cout0=cout, ksize=3, stride=1, relu0=True, algo=algo)
+    np.testing.assert_allclose(ncdhw(got), want, **TOL)
+
+
+@pytest.mark.parametrize('shape,cout', [((1, 32, 8, 12, 12), 64), ((2, 64, 5, 9, 7), 128),
+                                        ((1, 32, 16, 20, 20), 64)])
+def test_conv3d_stride2_and_1x1(shape, cout):
+    rs = np.random.RandomState(7)
+    x = rs.standard_normal(shape).astype(np.float32)
+    w = _rand_conv(rs, cout, shape[1], 3)
+    want = O.conv3d(x, w, None, 2, 1)
+    got = ops.conv3d_ndhwc(cl(x), ops.pack_conv_weight(T(w)), cout0=cout, ksize=3, stride=2)
+    np.testing.assert_allclose(ncdhw(got), want, **TOL)
+    w1 = _rand_conv(rs, 32, shape[1], 1)
+    b1 = rs.standard_normal(32).astype(np.float32)
+    want = O.conv3d(x, w1, b1, 1, 0)
+    got = ops.conv3d_ndhwc(cl(x), ops.pack_conv_weight(T(w1)), None, T(b1), cout0=32, ksize=1)
+    np.testing.assert_allclose(ncdhw(got), want, **TOL)
+
+
+def test_conv3d_two_outputs_share_input():
+    """BasicBlock3D's conv1 (+BN+ReLU) and downsample (+BN) in one pass == two separate convs."""
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((1, 32, 6, 10, 12)).astype(np.float32)
+    wa, wb = _rand_conv(rs, 32, 32, 3), _rand_conv(rs, 32, 32, 3)
+    wpk = ops.pack_conv_weights_concat([T(wa), T(wb)])
+    y0, y1 = ops.conv3d_ndhwc(cl(x), wpk, cout0=32, cout1=32, ksize=3, relu0=True, relu1=False)
+    np.testing.assert_allclose(ncdhw(y0), np.maximum(O.conv3d(x, wa), 0), **TOL)
+    np.testing.assert_allclose(ncdhw(y1), O.conv3d(x, wb), **TOL)
+
+
+def test_conv3d_bad_arguments_raise():
+    x = torch.zeros(1, 4, 8, 8, 24, device=DEV)
+    with pytest.raises(Exception):
+        ops.conv3d_ndhwc(x, torch.zeros(1, 27, 1, 64, 16, device=DEV), ksize=3)   # Cin % 32 != 0
+
+
+def _load(module, sd, prefix):
+    own = module.state_dict()
+    with torch.no_grad():
+        for k in own:
+            if 'num_batches_tracked' not in k:
+                own[k].copy_(torch.from_numpy(sd[prefix + k]))
+
+
+def _net(grid=None):
+    net = M.PreWorld4DTraj(
+        img_view_transformer=dict(type='LSSViewTransformerBEVStereo',
+                                  grid_config=grid or S.GRID_CONFIG_FULL, input_size=S.INPUT_SIZE,
+                                  in_channels=512, out_channels=32, sid=False, collapse_z=False,
+                                  loss_depth_weight=0.05, depthnet_cfg=dict(), downsample=16),
+        img_bev_encoder_backbone=dict(type='CustomResNet3D', numC_input=64, num_layer=[1, 2, 4],
+                                      with_cp=False, num_channels=[32, 64, 128], stride=[1, 2, 2],
+                                      backbone_output_ids=[0, 1, 2]),
+        img_bev_encoder_neck=dict(type='LSSFPN3D', in_channels=224, out_channels=32),
+        pre_process=dict(type='CustomResNet3D', numC_input=32, with_cp=False, num_layer=[1],
+                         num_channels=[32], stride=[1], backbone_output_ids=[0]),
+        occupancy_head=dict(type='OccHead', with_cp=False, use_deblock=False,
+                            norm_cfg=dict(type='SyncBN', requires_grad=True), soft_weights=True,
+                            final_occ_size=[200, 200, 16], empty_idx=17, num_level=1,
+                            in_channels=[32], out_channel=18,
+                            point_cloud_range=[-40, -40, -1, 40, 40, 5.4]),
+        if_post_finetune=True)
+    return net
+
+
+def _load_net(seed):
+    sd = S.synth_state_dict(seed)
+    net = _net()
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()},
+                                              strict=False)
+    assert not unexpected
+    assert all('depth_net' in k or 'num_batches_tracked' in k for k in missing), missing
+    return net.to(DEV).eval(), sd
+
+
+def test_conv_stack_golden(golden):
+    """pre_process -> CustomResNet3D -> LSSFPN3D -> final_conv -> OccHead against the tensors the
+    imported reference modules produced (tests/golden/conv_stack_small.npz)."""
+    g = golden('conv_stack_small.npz')
+    net, sd = _load_net(int(g['seed_sd']))
+    Z, Y, X = [int(v) for v in g['shape']]
+    rs = np.random.RandomState(int(g['seed_in']))
+    bev_key = rs.standard_normal((1, 32, Z, Y, X)).astype(np.float32)
+    bev_adj = rs.standard_normal((1, 32, Z, Y, X)).astype(np.float32)
+    with torch.no_grad():
+        pk = net.pre_process_net.forward_cl(cl(bev_key))[0]
+        pa = net.pre_process_net.forward_cl(cl(bev_adj))[0]
+        np.testing.assert_allclose(ncdhw(pk), g['pre_key'], **TOL)
+        np.testing.assert_allclose(ncdhw(pa), g['pre_adj'], **TOL)
+        feats = net.img_bev_encoder_backbone.forward_cl(torch.cat([pa, pk], -1))
+        for f, k in zip(feats, ('enc0', 'enc1', 'enc2')):
+            np.testing.assert_allclose(ncdhw(f), g[k], **TOL)
+        nk = net.img_bev_encoder_neck.forward_cl(feats)
+        np.testing.assert_allclose(ncdhw(nk), g['neck'], **TOL)
+        fc = net.final_conv.forward_cl(nk)
+        np.testing.assert_allclose(ncdhw(fc), g['final_conv'], **TOL)
+        # reference path: OccHead.forward on the (1,C,X,Y,Z) view
+        vf_xyz = fc.permute(0, 4, 3, 2, 1)[0].permute(3, 0, 1, 2).unsqueeze(0)
+        logits = net.occupancy_head([vf_xyz])['output_voxels'][0]
+        np.testing.assert_allclose(logits.cpu().numpy(), g['logits'], rtol=5e-4, atol=5e-4)
+        # fast path: native (Z,Y,X) buffer + permuted taps gives the same occupancy
+        occ, lg = net.occupancy_head.decode_cl(fc, want_logits=True, transposed=True)
+        np.testing.assert_allclose(lg.permute(0, 4, 3, 2, 1).cpu().numpy(), g['logits'],
+                                   rtol=5e-4, atol=5e-4)
+        occ_xyz = occ.permute(0, 3, 2, 1)[0].cpu().numpy()
+        assert (occ_xyz == g['occ']).mean() > 0.999
+        assert np.array_equal(occ_xyz, lg.permute(0, 3, 2, 1, 4)[0].argmax(-1).cpu().numpy())
+    # module-level (B,C,D,H,W) API == reference call convention
+    with torch.no_grad():
+        out = net.pre_process_net(T(bev_key))[0]
+    np.testing.assert_allclose(out.cpu().numpy(), g['pre_key'], **TOL)
+
+
+def test_forecast_golden(golden):
+    g = golden('forecast_small.npz')
+    net, sd = _load_net(int(g['seed_sd']))
+    v = np.random.RandomState(int(g['seed_v'])).standard_normal((1, 8, 8, 4, 32)).astype(np.float32)
+    ego = S.ego_state(int(g['seed_ego']))
+    with torch.no_grad():
+        states, ef = net.forecast_cl(T(v), T(ego), 6)
+    np.testing.assert_allclose(ef.cpu().numpy(), g['ego_feat'], rtol=1e-4, atol=1e-5)
+    for k in range(6):
+        np.testing.assert_allclose(states[k].cpu().numpy(), g['states'][k + 1], **TOL)
+
+
+def test_forecast_ragged_and_batched():
+    """voxel counts that are not a multiple of 32, two samples with different ego states."""
+    net, sd = _load_net(5)
+    rs = np.random.RandomState(1)
+    v = rs.standard_normal((2, 3, 5, 7, 32)).astype(np.float32)
+    ego = rs.standard_normal((2, 1, 21)).astype(np.float32)
+    with torch.no_grad():
+        states, ef = net.forecast_cl(T(v), T(ego), 3)
+    for b in range(2):
+        e = O.plan_head(ego[b].reshape(1, 21), sd)[0]
+        cur = v[b]
+        for k in range(3):
+            cur = O.forecast_step(cur, e, sd)
+            np.testing.assert_allclose(states[k, b].cpu().numpy(), cur, **TOL)
+
+
+@pytest.mark.parametrize('shape', [(16, 200, 200), (8, 100, 100)])
+def test_full_size_tiled_vs_gather_and_oracle_crop(shape):
+    """BASELINE grid sizes: the LDS-tiled and the gather kernels are independent implementations
+    and must agree everywhere; a crop (with halo) is checked against the oracle."""
+    D, H, W = shape
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.standard_normal((1, D, H, W, 32)).astype(np.float32)).to(DEV)
+    w = _rand_conv(rs, 32, 32, 3)
+    wpk = ops.pack_conv_weight(T(w))
+    a = ops.conv3d_ndhwc(x, wpk, ksize=3, algo=1)
+    b = ops.conv3d_ndhwc(x, wpk, ksize=3, algo=2)
+    assert float((a - b).abs().max()) < 2e-4
+    # linearity: conv(2x) == 2 conv(x) exactly (power of two scaling)
+    a2 = ops.conv3d_ndhwc((x * 2).contiguous(), wpk, ksize=3, algo=1)
+    assert torch.equal(a2, a * 2)
+    # oracle on a corner crop (zero padding side) and an interior crop
+    for (d0, h0, w0) in [(0, 0, 0), (D - 6, H // 2, W - 12)]:
+        xc = x[:, d0:d0 + 6, h0:h0 + 12, w0:w0 + 12].permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
+        want = O.conv3d(xc, w)
+        got = ncdhw(a[:, d0:d0 + 6, h0:h0 + 12, w0:w0 + 12])
+        # compare voxels whose 3x3x3 support lies inside the crop or on the true boundary
+        sl = (slice(None), slice(None),
+              slice(0 if d0 == 0 else 1, 5), slice(0 if h0 == 0 else 1, 11), slice(0 if w0 == 0 else 1, 11))
+        np.testing.assert_allclose(got[sl], want[sl], **TOL)

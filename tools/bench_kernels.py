@@ -62,6 +62,61 @@ def bench_lss():
     return res
 
 
+def bench_enc():
+    dev = 'cuda:0'
+    rs = np.random.RandomState(0)
+    res = {}
+    x32 = torch.randn(1, 16, 200, 200, 32, device=dev)
+    x64 = torch.randn(1, 16, 200, 200, 64, device=dev)
+    w = lambda co, ci, k=3: ops.pack_conv_weight(torch.randn(co, ci, k, k, k, device=dev) * 0.05)
+    sc, bi = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+    sc64, bi64 = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    def flops(ci, co, nv=640000, taps=27):
+        return 2.0 * nv * taps * ci * co
+    for name, x, wp, kw, fl in [
+        ('k3s1_32_32_tiled', x32, w(32, 32), dict(algo=1), flops(32, 32)),
+        ('k3s1_32_32_gather', x32, w(32, 32), dict(algo=2), flops(32, 32)),
+        ('k3s1_32_64_tiled', x32, w(64, 32), dict(algo=1), flops(32, 64)),
+        ('k3s1_64_64_tiled', x64, w(64, 64), dict(algo=1), flops(64, 64)),
+        ('k3s1_32_16pad_tiled', x32, w(16, 32), dict(algo=1, cout0=16), flops(32, 32)),
+    ]:
+        y = ops.conv3d_ndhwc(x, wp, ksize=3, **kw)
+        t = timeit(lambda: ops.conv3d_ndhwc(x, wp, ksize=3, **kw), iters=10)
+        res[name + '_us'] = t
+        res[name + '_TFLOPs'] = fl / t / 1e6
+    xs = torch.randn(1, 8, 100, 100, 64, device=dev)
+    wp = w(64, 64)
+    t = timeit(lambda: ops.conv3d_ndhwc(xs, wp, ksize=3, algo=1), iters=10)
+    res['L1_64_64_tiled_us'] = t; res['L1_64_64_tiled_TFLOPs'] = flops(64, 64, 80000) / t / 1e6
+    xs2 = torch.randn(1, 4, 50, 50, 128, device=dev)
+    wp = w(128, 128)
+    t = timeit(lambda: ops.conv3d_ndhwc(xs2, wp, ksize=3, algo=1), iters=10)
+    res['L2_128_128_tiled_us'] = t; res['L2_128_128_tiled_TFLOPs'] = flops(128, 128, 10000) / t / 1e6
+    t = timeit(lambda: ops.conv3d_ndhwc(xs2, wp, ksize=3, algo=2), iters=10)
+    res['L2_128_128_gather_us'] = t
+    wp = w(64, 32)
+    t = timeit(lambda: ops.conv3d_ndhwc(x32, wp, ksize=3, stride=2), iters=10)
+    res['s2_32_64_gather_us'] = t
+    # neck
+    y16 = torch.randn(1, 8, 100, 100, 32, device=dev); y32 = torch.randn(1, 4, 50, 50, 32, device=dev)
+    w8 = w(32, 32, 1)
+    t = timeit(lambda: ops.fpn3d_fuse(x32, w8, y16, y32, sc, bi), iters=10)
+    res['fpn_fuse_us'] = t; res['fpn_fuse_GBps'] = 164e6 / t / 1e3
+    # occ head
+    w1 = torch.randn(8, 16, device=dev); s1 = torch.ones(8, device=dev); b1 = torch.zeros(8, device=dev)
+    w2 = torch.randn(18, 8, device=dev); wp = w(16, 32)
+    t = timeit(lambda: ops.occ_head_fused(x32, wp, sc, bi, w1, s1, b1, w2), iters=10)
+    res['occ_head_us'] = t; res['occ_head_TFLOPs_useful'] = flops(32, 16) / t / 1e6
+    # forecast
+    fw1 = torch.randn(128, 64, device=dev) * 0.1; fw2 = torch.randn(32, 128, device=dev) * 0.1
+    w1p, w2p = ops.forecast_pack(fw1, fw2)
+    c1 = torch.randn(1, 128, device=dev); fb2 = torch.randn(32, device=dev)
+    st = torch.empty(6, 1, 16, 200, 200, 32, device=dev)
+    t = timeit(lambda: ops.forecast_steps(x32, 1, w1p, w2p, c1, fb2, 6, states=st), iters=5)
+    res['forecast6_us'] = t; res['forecast6_TFLOPs'] = 6 * 640000 * 2 * (32 * 128 * 2) / t / 1e6
+    return res
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--what', default='lss')
@@ -69,4 +124,6 @@ if __name__ == '__main__':
     out = {}
     if 'lss' in a.what:
         out['lss'] = bench_lss()
+    if 'enc' in a.what:
+        out['enc'] = bench_enc()
     print(json.dumps(out, indent=1))
