@@ -71,10 +71,16 @@ int pw_lss_voxel_index(int B, int N, int D, int H, int W, const float* frustum,
  * (bev_pool.py:47-57) need.  Outputs:
  *   seg_start  int32[n_keys+1]  dense exclusive prefix (seg_start[n_keys] = kept count)
  *   order      int32[n]         order[0..kept) = original indices, ascending inside a segment
+ *   order_aux  int32[n] or NULL order_aux[pos] = (id/aux_div)*aux_mod + id%aux_mod for id=order[pos]
+ *                               (LSS: aux_div=D*H*W, aux_mod=H*W gives ranks_feat, :219-224)
+ *   long_list  int32[n/(long_threshold+1)+1] or NULL: keys whose segment has more than
+ *              long_threshold entries (unordered), count in n_long (device int32)
  * workspace: pw_segment_sort_workspace_bytes(n, n_keys) bytes, 256-byte aligned. */
 size_t pw_segment_sort_workspace_bytes(int64_t n, int64_t n_keys);
 int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void* workspace,
-                    size_t workspace_bytes, int32_t* seg_start, int32_t* order, void* stream);
+                    size_t workspace_bytes, int32_t* seg_start, int32_t* order, int aux_div,
+                    int aux_mod, int32_t* order_aux, int long_threshold, int32_t* long_list,
+                    int32_t* n_long, void* stream);
 
 /* A3c  expand the sort into the reference's five tensors (view_transformer.py:246-261):
  * ranks_bev/ranks_depth/ranks_feat int32[>=kept], interval_starts/lengths int32[>=n_intervals]
@@ -103,10 +109,12 @@ int pw_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* fea
 
 /* A4 (fused fast path)  dense voxel-driven pooling: every voxel of out (n_voxels, C),
  * channels-last = (B,Z,Y,X,C), is written exactly once (sum or zero) -- no memset, no permute.
- * seg_start/order come from pw_segment_sort over the voxel ids; D/HW as above. */
+ * seg_start/order/order_feat(=order_aux)/long_list/n_long come from pw_segment_sort over the
+ * voxel ids (long_list/n_long may be NULL).  Sums run in ascending point order per voxel. */
 int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_start,
-                      const int32_t* order, int64_t n_voxels, int c, int D, int HW, float* out,
-                      void* stream);
+                      const int32_t* order, const int32_t* order_feat, int64_t n_voxels, int c,
+                      int long_threshold, const int32_t* long_list, const int32_t* n_long,
+                      float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A6-A9, A11  3-D convolution on channels-last activations, exact-fp32 MFMA implicit GEMM.
@@ -151,7 +159,8 @@ int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, cons
  *   order, w1p/w2p float[4096] each (once per weight update).
  * pw_forecast_prologue: per sample, e = plan_head(ego) (21->256 ReLU->256 ReLU->32) and the
  *   hoisted ego term c1 = fusion_head.0.weight[:,32:] e + fusion_head.0.bias;
- *   ego (n_samples, ego_dim), ego_feat (n_samples,32), c1 (n_samples,128).
+ *   ego (n_samples, ego_dim), ego_feat (n_samples,32), c1 (n_samples,128) in natural order and
+ *   c1p (n_samples,128) in the MFMA accumulator order pw_forecast_steps consumes.
  * pw_forecast_steps: v_{k+1} = v_k + W2 softplus(W1a v_k + c1) + b2 for k < n_steps, all steps
  *   in registers; v0 (n_samples*n_vox, 32) channels-last; states float[n_steps][n_samples*n_vox][32]. */
 int pw_forecast_pack(const float* fusion_w1, const float* fusion_w2, float* w1p, float* w2p,
@@ -159,10 +168,15 @@ int pw_forecast_pack(const float* fusion_w1, const float* fusion_w2, float* w1p,
 int pw_forecast_prologue(const float* ego, int n_samples, int ego_dim, const float* plan_w0,
                          const float* plan_b0, const float* plan_w2, const float* plan_b2,
                          const float* plan_w4, const float* plan_b4, const float* fusion_w1,
-                         const float* fusion_b1, float* ego_feat, float* c1, void* stream);
+                         const float* fusion_b1, float* ego_feat, float* c1, float* c1p,
+                         void* stream);
 int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
-                      const float* w2p, const float* c1, const float* fusion_b2, int n_steps,
+                      const float* w2p, const float* c1p, const float* fusion_b2, int n_steps,
                       float* states, void* stream);
+
+/* nn.Softplus(beta=1, threshold=20) elementwise (the activation inside fusion_head and the
+ * attribute MLPs, preworld_temporal_traj.py:81-132), same device function as the fused kernels. */
+int pw_softplus(const float* x, float* y, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

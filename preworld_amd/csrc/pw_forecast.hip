@@ -29,8 +29,22 @@ constexpr int W2P = 4 * 4 * 64 * 4;   // packed W2  floats  [t][rq][lane][4]
 
 __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__device__ __forceinline__ float softplus_t20(float x) {   // nn.Softplus(beta=1, threshold=20)
-  return x > 20.f ? x : log1pf(expf(x));
+// nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x)).  Branch-free form
+// max(x,0) + log1p(exp(-|x|)) on the hardware exp2/log2 units:
+//   exp(-a): n = rint(a*log2e), r = a - n*ln2 (two-constant Cody-Waite, exact), 2^-n * exp2(-r*log2e)
+//   log1p(t), t in (0,1]: u = 1+t, log(u) + (t-(u-1))/u   (restores the bits lost rounding 1+t)
+// max abs error vs the fp64 value < 3e-7 over [-100, 100] (tests/test_gpu_encoder.py).
+__device__ __forceinline__ float softplus_t20(float x) {
+  const float a = fabsf(x);
+  const float n = rintf(a * 1.44269504088896341f);
+  float r = fmaf(n, -0.693145751953125f, a);          // ln2 hi (exact product for |n| < 2^11)
+  r = fmaf(n, -1.42860682030941723212e-6f, r);        // ln2 lo
+  float t = __builtin_amdgcn_exp2f(-r * 1.44269504088896341f);
+  t = ldexpf(t, -(int)n);                             // exp(-|x|), 0 for |x| > ~104
+  const float u = 1.f + t;
+  const float l = __builtin_amdgcn_logf(u) * 0.693147180559945309f + (t - (u - 1.f)) * __builtin_amdgcn_rcpf(u);
+  const float sp = fmaxf(x, 0.f) + l;
+  return x > 20.f ? x : sp;
 }
 
 // ------------------------------------------------------------------------------------
@@ -42,7 +56,7 @@ k_forecast_prologue(const float* __restrict__ ego, int ego_dim, const float* __r
                     const float* __restrict__ b2, const float* __restrict__ w4,
                     const float* __restrict__ b4, const float* __restrict__ fw1,
                     const float* __restrict__ fb1, float* __restrict__ ego_feat,
-                    float* __restrict__ c1) {
+                    float* __restrict__ c1, float* __restrict__ c1p) {
   __shared__ float h1[256], h2[256], e[C];
   const int t = threadIdx.x, s = blockIdx.x;
   const float* x = ego + (size_t)s * ego_dim;
@@ -66,6 +80,10 @@ k_forecast_prologue(const float* __restrict__ ego, int ego_dim, const float* __r
     acc = fb1[t];
     for (int i = 0; i < C; ++i) acc += e[i] * fw1[t * 2 * C + C + i];
     c1[(size_t)s * HID + t] = acc;
+    // D-register order for the main kernel: c1p[s][h][tile*16 + r] = c1[tile*32 + row_of(r,h)]
+    const int tile = t >> 5, row = t & 31;
+    const int h = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+    c1p[(size_t)s * HID + h * 64 + tile * 16 + r] = acc;
   }
 }
 
@@ -88,10 +106,10 @@ __global__ void k_forecast_pack(const float* __restrict__ fw1, const float* __re
 // ------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_forecast(const float* __restrict__ v0, long long n_vox_per_sample, int n_samples,
            const float* __restrict__ w1p, const float* __restrict__ w2p,
-           const float* __restrict__ c1, const float* __restrict__ fb2, int n_steps,
+           const float* __restrict__ c1p, const float* __restrict__ fb2, int n_steps,
            float* __restrict__ states /* [n_steps][n_samples*n_vox][C] */) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* l_w1 = lds;
@@ -118,7 +136,7 @@ k_forecast(const float* __restrict__ v0, long long n_vox_per_sample, int n_sampl
     const bool valid = m < n_total;
     if (!valid) m = n_total - 1;
     const int sample = (int)(m / n_vox_per_sample);
-    const float* c1s = c1 + (size_t)sample * HID;
+    const float* c1s = c1p + (size_t)sample * HID + h * 64;
     // this lane's 16 channels of its voxel: channel row_of(4q+e, h) = e + 8q + 4h
     float v[16];
     const float* src = v0 + (size_t)m * C + 4 * h;
@@ -128,36 +146,40 @@ k_forecast(const float* __restrict__ v0, long long n_vox_per_sample, int n_sampl
       v[4 * q + 0] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
     }
     for (int step = 0; step < n_steps; ++step) {
-      f32x16 hid[4];
+      f32x16 o;
 #pragma unroll
+      for (int s = 0; s < 16; ++s) o[s] = b2r[s];
+      // one 32-wide hidden tile at a time: GEMM1 tile -> softplus -> its K-slice of GEMM2,
+      // so only 16 hidden registers are live; the loop stays rolled so that ~4 waves per SIMD
+      // are resident and one wave's softplus (VALU) overlaps the others' MFMAs
+#pragma unroll 1
       for (int t = 0; t < 4; ++t) {
-        // C operand = hoisted ego term c1[t*32 + row]
+        f32x16 hid;
+        // C operand = hoisted ego term, already in D-register order
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hid[t][r] = c1s[t * 32 + row_of(r, h)];
+        for (int q = 0; q < 4; ++q) {
+          const float4 c4 = *reinterpret_cast<const float4*>(c1s + t * 16 + q * 4);
+          hid[4 * q + 0] = c4.x; hid[4 * q + 1] = c4.y; hid[4 * q + 2] = c4.z; hid[4 * q + 3] = c4.w;
+        }
 #pragma unroll
         for (int sq = 0; sq < 4; ++sq) {
           const float4 a4 = *reinterpret_cast<const float4*>(l_w1 + ((t * 4 + sq) * 64 + lane) * 4);
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], v[4 * sq + e], hid[t], 0, 0, 0);
+            hid = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], v[4 * sq + e], hid, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hid[t][r] = softplus_t20(hid[t][r]);
-      }
-      f32x16 o;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) o[s] = b2r[s];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int r = 0; r < 16; ++r) hid[r] = softplus_t20(hid[r]);
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const float4 a4 = *reinterpret_cast<const float4*>(l_w2 + ((t * 4 + rq) * 64 + lane) * 4);
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], hid[t][4 * rq + e], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], hid[4 * rq + e], o, 0, 0, 0);
         }
+      }
 #pragma unroll
       for (int s = 0; s < 16; ++s) v[s] = o[s] + v[s];   // residual connection (:342)
       if (valid) {
@@ -183,22 +205,23 @@ PW_API int pw_forecast_pack(const float* fusion_w1, const float* fusion_w2, floa
 PW_API int pw_forecast_prologue(const float* ego, int n_samples, int ego_dim, const float* plan_w0,
                                 const float* plan_b0, const float* plan_w2, const float* plan_b2,
                                 const float* plan_w4, const float* plan_b4, const float* fusion_w1,
-                                const float* fusion_b1, float* ego_feat, float* c1, void* stream) {
+                                const float* fusion_b1, float* ego_feat, float* c1, float* c1p,
+                                void* stream) {
   PW_CHECK_ARG(ego && plan_w0 && plan_b0 && plan_w2 && plan_b2 && plan_w4 && plan_b4 && fusion_w1 &&
-                   fusion_b1 && ego_feat && c1,
+                   fusion_b1 && ego_feat && c1 && c1p,
                "pw_forecast_prologue: null pointer");
   PW_CHECK_ARG(n_samples > 0 && ego_dim > 0, "pw_forecast_prologue: bad sizes");
   hipLaunchKernelGGL(k_forecast_prologue, dim3(n_samples), dim3(256), 0, pw_stream(stream), ego,
                      ego_dim, plan_w0, plan_b0, plan_w2, plan_b2, plan_w4, plan_b4, fusion_w1,
-                     fusion_b1, ego_feat, c1);
+                     fusion_b1, ego_feat, c1, c1p);
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
 
 PW_API int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_samples,
-                             const float* w1p, const float* w2p, const float* c1,
+                             const float* w1p, const float* w2p, const float* c1p,
                              const float* fusion_b2, int n_steps, float* states, void* stream) {
-  PW_CHECK_ARG(v0 && w1p && w2p && c1 && fusion_b2 && states, "pw_forecast_steps: null pointer");
+  PW_CHECK_ARG(v0 && w1p && w2p && c1p && fusion_b2 && states, "pw_forecast_steps: null pointer");
   PW_CHECK_ARG(n_vox_per_sample > 0 && n_samples > 0 && n_steps > 0, "pw_forecast_steps: bad sizes");
   PW_CHECK_ARG((((uintptr_t)v0 | (uintptr_t)states | (uintptr_t)w1p | (uintptr_t)w2p) & 15) == 0,
                "pw_forecast_steps: pointers must be 16-B aligned");
@@ -206,10 +229,25 @@ PW_API int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_sa
   long long n_tiles = (n_vox_per_sample * n_samples + 31) / 32;
   long long want = (n_tiles + 3) / 4;
   // compute-bound on the fp32 MFMA: 4 blocks of 4 waves per CU saturate the 4 SIMDs
-  unsigned nb = (unsigned)(want < 1024 ? want : 1024);
+  unsigned nb = (unsigned)(want < 1280 ? want : 1280);   // 5 blocks x 256 CUs
   hipLaunchKernelGGL(k_forecast, dim3(nb), dim3(256), lds_bytes, pw_stream(stream), v0,
-                     (long long)n_vox_per_sample, n_samples, w1p, w2p, c1, fusion_b2, n_steps,
+                     (long long)n_vox_per_sample, n_samples, w1p, w2p, c1p, fusion_b2, n_steps,
                      states);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// elementwise nn.Softplus(beta=1, threshold=20) with the same device function the fused
+// kernels use (exposed for the attribute MLPs and for accuracy tests)
+__global__ void k_softplus(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = softplus_t20(x[i]);
+}
+
+PW_API int pw_softplus(const float* x, float* y, int64_t n, void* stream) {
+  PW_CHECK_ARG(x && y && n > 0, "pw_softplus: bad arguments");
+  hipLaunchKernelGGL(k_softplus, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0, pw_stream(stream), x,
+                     y, (long long)n);
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

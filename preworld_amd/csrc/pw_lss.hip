@@ -283,10 +283,15 @@ k_scatter(const int32_t* __restrict__ keys, int64_t n, const int32_t* __restrict
 
 // in-segment rank sort: the scatter order inside a segment is whatever the atomics gave;
 // ids are distinct, so final position = number of smaller ids in the segment.
+// Optional by-products for the pooling kernel:
+//   order_aux[pos] = (id / aux_div) * aux_mod + id % aux_mod   (LSS: the feat-pixel index,
+//                    view_transformer.py:219-224, so pooling does no integer division)
+//   long_list      = keys whose segment is longer than long_threshold (handled by whole waves)
 __global__ void __launch_bounds__(256)
 k_ranksort(const int32_t* __restrict__ keys, const int32_t* __restrict__ seg_start,
            const int32_t* __restrict__ tmp, const int32_t* __restrict__ kept_ptr,
-           int32_t* __restrict__ order) {
+           int32_t* __restrict__ order, int aux_div, int aux_mod, int32_t* __restrict__ order_aux,
+           int long_threshold, int32_t* __restrict__ long_list, int32_t* __restrict__ n_long) {
   int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= *kept_ptr) return;
   int id = tmp[pos];
@@ -295,6 +300,8 @@ k_ranksort(const int32_t* __restrict__ keys, const int32_t* __restrict__ seg_sta
   int r = 0;
   for (int j = s; j < e; ++j) r += tmp[j] < id;
   order[s + r] = id;
+  if (order_aux) order_aux[s + r] = (id / aux_div) * aux_mod + id % aux_mod;
+  if (long_list && pos == s && e - s > long_threshold) long_list[atomicAdd(n_long, 1)] = k;
 }
 
 PW_API size_t pw_segment_sort_workspace_bytes(int64_t n, int64_t n_keys) {
@@ -305,8 +312,9 @@ PW_API size_t pw_segment_sort_workspace_bytes(int64_t n, int64_t n_keys) {
 }
 
 PW_API int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void* workspace,
-                           size_t workspace_bytes, int32_t* seg_start, int32_t* order,
-                           void* stream) {
+                           size_t workspace_bytes, int32_t* seg_start, int32_t* order, int aux_div,
+                           int aux_mod, int32_t* order_aux, int long_threshold, int32_t* long_list,
+                           int32_t* n_long, void* stream) {
   PW_CHECK_ARG(n > 0 && n_keys > 0 && keys && workspace && seg_start && order,
                "pw_segment_sort: bad arguments");
   PW_CHECK_ARG(n < ((int64_t)1 << 31) && n_keys < ((int64_t)1 << 31) - 1,
@@ -317,6 +325,8 @@ PW_API int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void*
     return PW_ENOSPC;
   }
   PW_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "pw_segment_sort: workspace must be 256-B aligned");
+  PW_CHECK_ARG(!order_aux || (aux_div > 0 && aux_mod > 0), "pw_segment_sort: aux_div/aux_mod must be > 0");
+  PW_CHECK_ARG(!long_list || (n_long && long_threshold > 0), "pw_segment_sort: long_list needs n_long and a threshold");
   hipStream_t st = pw_stream(stream);
   char* ws = (char*)workspace;
   int32_t* count = (int32_t*)ws;
@@ -328,13 +338,15 @@ PW_API int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void*
   int32_t* sums = (int32_t*)ws;
   // count and cursor are adjacent: one memset
   PW_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)((char*)tmp - (char*)count), st));
+  if (long_list) PW_CHECK_HIP(hipMemsetAsync(n_long, 0, sizeof(int32_t), st));
   unsigned nbk = (unsigned)pw_cdiv(n, 256);
   hipLaunchKernelGGL(k_hist, dim3(nbk), dim3(256), 0, st, keys, n, count);
   int rc = scan_exclusive_i32(count, seg_start, n_keys + 1, sums, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_scatter, dim3(nbk), dim3(256), 0, st, keys, n, seg_start, cursor, tmp);
   hipLaunchKernelGGL(k_ranksort, dim3(nbk), dim3(256), 0, st, keys, seg_start, tmp,
-                     seg_start + n_keys, order);
+                     seg_start + n_keys, order, aux_div, aux_mod, order_aux, long_threshold, long_list,
+                     n_long);
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
@@ -417,29 +429,67 @@ __device__ __forceinline__ void fma4_nc(float4& acc, const float4& f, float d) {
   acc.w = acc.w + f.w * d;
 }
 
-// dense, voxel-driven: writes every voxel row once
+// dense, voxel-driven: writes every voxel row once.  order_feat[pos] is the feat-pixel index
+// of sorted point pos.  Segments longer than long_threshold (a few hundred near-camera voxels
+// hold up to ~1300 points) are taken by whole waves in the first LONG_BLOCKS blocks, which
+// start first and run under the bulk sweep: 64 (pixel, depth) pairs are fetched in one
+// coalesced go, then broadcast lane by lane so the sum keeps its sequential point order.
+constexpr int LONG_BLOCKS = 64;     // x 4 waves
+
 template <int LPV>
 __global__ void __launch_bounds__(256)
 k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
              const int32_t* __restrict__ seg_start, const int32_t* __restrict__ order,
-             int64_t n_voxels, int DHW, int HW, float4* __restrict__ out) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int sub = (int)(gid % LPV);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x / LPV;
+             const int32_t* __restrict__ order_feat, int64_t n_voxels, int long_threshold,
+             const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
+             float4* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPV;
+  const int long_blocks = long_list ? LONG_BLOCKS : 0;
+  if ((int)blockIdx.x < long_blocks) {
+    const int nl = *n_long;
+    for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < nl; li += LONG_BLOCKS * 4) {
+      const int64_t v = long_list[li];
+      const int s = seg_start[v], e = seg_start[v + 1];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int base = s; base < e; base += 64) {
+        const int n = min(64, e - base);
+        const int idx = base + min(lane, n - 1);
+        const int my_pf = order_feat[idx];
+        const float my_d = depth[order[idx]];
+        for (int k0 = 0; k0 < n; k0 += POOL_UNROLL) {
+          float d[POOL_UNROLL];
+          float4 f[POOL_UNROLL];
+#pragma unroll
+          for (int u = 0; u < POOL_UNROLL; ++u) {          // 8 independent gathers in flight
+            const int kk = min(k0 + u, n - 1);             // wave-uniform lane select
+            const int pf = __builtin_amdgcn_readlane(my_pf, kk);
+            d[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_d), kk));
+            f[u] = feat[(int64_t)pf * LPV + sub];
+          }
+#pragma unroll
+          for (int u = 0; u < POOL_UNROLL; ++u)
+            if (k0 + u < n) fma4_nc(acc, f[u], d[u]);
+        }
+      }
+      if (lane < LPV) out[v * LPV + sub] = acc;     // every LPV-group holds the same sums
+    }
+    return;
+  }
+  const int64_t gid = (int64_t)(blockIdx.x - long_blocks) * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)(gridDim.x - long_blocks) * blockDim.x / LPV;
   for (int64_t v = gid / LPV; v < n_voxels; v += stride) {
     const int s = seg_start[v], e = seg_start[v + 1];
+    if (long_list && e - s > long_threshold) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = s; i < e; i += POOL_UNROLL) {
-      int id[POOL_UNROLL];
       float d[POOL_UNROLL];
       float4 f[POOL_UNROLL];
 #pragma unroll
-      for (int u = 0; u < POOL_UNROLL; ++u) id[u] = order[min(i + u, e - 1)];
-#pragma unroll
       for (int u = 0; u < POOL_UNROLL; ++u) {
-        d[u] = depth[id[u]];
-        int pf = (id[u] / DHW) * HW + id[u] % HW;
-        f[u] = feat[(int64_t)pf * LPV + sub];
+        const int j = min(i + u, e - 1);
+        d[u] = depth[order[j]];
+        f[u] = feat[(int64_t)order_feat[j] * LPV + sub];
       }
 #pragma unroll
       for (int u = 0; u < POOL_UNROLL; ++u)
@@ -499,18 +549,16 @@ k_pool_intervals_generic(int c, int n_intervals, const float* __restrict__ depth
 __global__ void __launch_bounds__(256)
 k_pool_dense_generic(int c, const float* __restrict__ depth, const float* __restrict__ feat,
                      const int32_t* __restrict__ seg_start, const int32_t* __restrict__ order,
-                     int64_t n_voxels, int DHW, int HW, float* __restrict__ out) {
+                     const int32_t* __restrict__ order_feat, int64_t n_voxels,
+                     float* __restrict__ out) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t v = idx / c;
   int ch = (int)(idx % c);
   if (v >= n_voxels) return;
   int s = seg_start[v], e = seg_start[v + 1];
   float psum = 0.f;
-  for (int i = s; i < e; ++i) {
-    int id = order[i];
-    int pf = (id / DHW) * HW + id % HW;
-    psum = psum + feat[(int64_t)pf * c + ch] * depth[id];
-  }
+  for (int i = s; i < e; ++i)
+    psum = psum + feat[(int64_t)order_feat[i] * c + ch] * depth[order[i]];
   out[v * c + ch] = psum;
 }
 
@@ -532,24 +580,25 @@ static bool lpv_supported(int c) {
   }
 
 PW_API int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_start,
-                             const int32_t* order, int64_t n_voxels, int c, int D, int HW,
-                             float* out, void* stream) {
-  PW_CHECK_ARG(depth && feat && seg_start && order && out && n_voxels > 0 && c > 0 && D > 0 &&
-                   HW > 0,
+                             const int32_t* order, const int32_t* order_feat, int64_t n_voxels,
+                             int c, int long_threshold, const int32_t* long_list,
+                             const int32_t* n_long, float* out, void* stream) {
+  PW_CHECK_ARG(depth && feat && seg_start && order && order_feat && out && n_voxels > 0 && c > 0,
                "pw_bev_pool_dense: bad arguments");
+  PW_CHECK_ARG(!long_list || (n_long && long_threshold > 0), "pw_bev_pool_dense: long_list needs n_long");
   hipStream_t st = pw_stream(stream);
-  int DHW = D * HW;
   if (lpv_supported(c) && ((uintptr_t)feat & 15) == 0 && ((uintptr_t)out & 15) == 0) {
     int lpv = c / 4;
-    // memory-bound: cap the grid at ~8 blocks/CU and grid-stride (256 CUs)
+    // memory-bound: cap the grid at ~8 blocks/CU x 256 CUs and grid-stride
     int64_t want = pw_cdiv(n_voxels * lpv, 256);
-    unsigned nb = (unsigned)(want < 2048 * 4 ? want : 2048 * 4);
+    unsigned nb = (unsigned)(want < 2048 ? want : 2048) + (long_list ? LONG_BLOCKS : 0);
     PW_DISPATCH_LPV(lpv, hipLaunchKernelGGL((k_pool_dense<L>), dim3(nb), dim3(256), 0, st, depth,
-                                            (const float4*)feat, seg_start, order, n_voxels, DHW,
-                                            HW, (float4*)out));
+                                            (const float4*)feat, seg_start, order, order_feat,
+                                            n_voxels, long_threshold, long_list, n_long,
+                                            (float4*)out));
   } else {
     hipLaunchKernelGGL(k_pool_dense_generic, dim3((unsigned)pw_cdiv(n_voxels * c, 256)), dim3(256),
-                       0, st, c, depth, feat, seg_start, order, n_voxels, DHW, HW, out);
+                       0, st, c, depth, feat, seg_start, order, order_feat, n_voxels, out);
   }
   PW_CHECK_LAUNCH();
   return PW_OK;

@@ -92,15 +92,16 @@ class LSSViewTransformer(nn.Module):
         vox = ops.lss_voxel_index(self._frustum_on(sensor2ego), ipr, post_trans.contiguous().float(),
                                   comb, tr, bda.contiguous().float(), lower, interval, size, B, N)
         n_vox = B * size[0] * size[1] * size[2]
-        seg_start, order = ops.segment_sort(vox, n_vox)
-        return seg_start, order, n_vox
+        H, W = self.frustum.shape[1:3]
+        return ops.segment_sort(vox, n_vox, aux_div=self.D * H * W, aux_mod=H * W,
+                                long_threshold=ops.LONG_SEGMENT)
 
     # ---- view_transformer.py:203-261 (takes the camera tensors instead of coor: the 17.8 MB
     # coordinate tensor is never materialised; use get_lidar_coor() if you need it)
     def voxel_pooling_prepare_v2(self, sensor2ego, cam2imgs, post_rots, post_trans, bda):
-        seg_start, order, n_vox = self._sort(sensor2ego, cam2imgs, post_rots, post_trans, bda)
+        vs = self._sort(sensor2ego, cam2imgs, post_rots, post_trans, bda)
         H, W = self.frustum.shape[1:3]
-        return ops.lss_ranks(seg_start, order, n_vox, self.D, H * W)
+        return ops.lss_ranks(vs.seg_start, vs.order, vs.n_keys, self.D, H * W)
 
     # ---- view_transformer.py:155-174,263-267
     def init_acceleration_v2(self, input):
@@ -116,9 +117,10 @@ class LSSViewTransformer(nn.Module):
         B, N, C, H, W = input[0].shape
         _, _, size = self._grid()
         if self.accelerate and self._cache is not None:
-            seg_start, order, n_vox = self._cache
+            vs = self._cache
         else:
-            seg_start, order, n_vox = self._sort(input[1], input[3], input[4], input[5], input[6])
+            vs = self._sort(input[1], input[3], input[4], input[5], input[6])
+        seg_start, order, n_vox = vs.seg_start, vs.order, vs.n_keys
         feat = tran_feat.view(B, N, self.out_channels, H, W).permute(0, 1, 3, 4, 2).contiguous().float()
         dep = depth.view(B, N, self.D, H, W).contiguous().float()
         if (dep.requires_grad or feat.requires_grad) and torch.is_grad_enabled():
@@ -130,7 +132,7 @@ class LSSViewTransformer(nn.Module):
                 bev = ops.bev_pool_v2(dep, feat, rd, rf, rb,
                                       (B, size[2], size[1], size[0], self.out_channels), st, ln)
         else:
-            out = ops.bev_pool_dense(dep, feat, seg_start, order, n_vox, self.D, H * W)
+            out = ops.bev_pool_dense(dep, feat, vs)
             bev = out.view(B, size[2], size[1], size[0], self.out_channels).permute(0, 4, 1, 2, 3)
         if self.collapse_z:
             bev = torch.cat(bev.unbind(dim=2), 1)
@@ -551,9 +553,9 @@ class PreWorld4DTraj(nn.Module):
         ego = ego_states.reshape(B, -1).float().contiguous()
         plan = [(ph[0].weight.contiguous(), ph[0].bias), (ph[2].weight.contiguous(), ph[2].bias),
                 (ph[4].weight.contiguous(), ph[4].bias)]
-        ef, c1 = ops.forecast_prologue(ego, plan, fh[0].weight.contiguous(), fh[0].bias)
+        ef, _, c1p = ops.forecast_prologue(ego, plan, fh[0].weight.contiguous(), fh[0].bias)
         w1p, w2p = self._forecast_weights()
-        states = ops.forecast_steps(v_cl, B, w1p, w2p, c1, fh[2].bias, n_steps)
+        states = ops.forecast_steps(v_cl, B, w1p, w2p, c1p, fh[2].bias, n_steps)
         return states, ef
 
     # ---- preworld_temporal_traj.py:212-370 (post-finetune branch) from lifted inputs

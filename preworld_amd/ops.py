@@ -83,18 +83,33 @@ def lss_voxel_index(frustum, inv_post_rot, post_trans, combine, trans, bda, lowe
     return (vox, coor) if return_coor else vox
 
 
-def segment_sort(keys, n_keys):
+LONG_SEGMENT = 64   # voxels holding more points than this are pooled by whole waves
+
+
+class VoxelSort:
+    """Result of the device counting sort over voxel ids (all tensors stay on the GPU)."""
+    __slots__ = ('seg_start', 'order', 'order_feat', 'long_list', 'n_long', 'n_keys')
+
+    def __init__(self, seg_start, order, order_feat, long_list, n_long, n_keys):
+        self.seg_start, self.order, self.order_feat = seg_start, order, order_feat
+        self.long_list, self.n_long, self.n_keys = long_list, n_long, n_keys
+
+
+def segment_sort(keys, n_keys, aux_div=0, aux_mod=0, long_threshold=0):
     """Stable counting sort of indices by int32 key (key<0 dropped).
-    Returns seg_start int32[n_keys+1], order int32[n]."""
+    Returns VoxelSort(seg_start int32[n_keys+1], order int32[n], order_feat, long_list, n_long)."""
     n = keys.numel()
     dev = keys.device
     nbytes = _lib.call_size('pw_segment_sort_workspace_bytes', n, n_keys)
     ws = _workspace(nbytes, dev)
     seg_start = torch.empty(n_keys + 1, device=dev, dtype=_i32)
     order = torch.empty(n, device=dev, dtype=_i32)
+    aux = torch.empty(n, device=dev, dtype=_i32) if aux_div else None
+    ll = torch.empty(n // (long_threshold + 1) + 1, device=dev, dtype=_i32) if long_threshold else None
+    nl = torch.empty(1, device=dev, dtype=_i32) if long_threshold else None
     _lib.call('pw_segment_sort', n, n_keys, _chk(keys, _i32, 'keys'), _p(ws), nbytes, _p(seg_start),
-              _p(order), _stream())
-    return seg_start, order
+              _p(order), aux_div, aux_mod, _p(aux), long_threshold, _p(ll), _p(nl), _stream())
+    return VoxelSort(seg_start, order, aux, ll, nl, n_keys)
 
 
 def lss_ranks(seg_start, order, n_voxels, D, HW):
@@ -120,13 +135,18 @@ def lss_ranks(seg_start, order, n_voxels, D, HW):
     return rb[:kept], rd[:kept], rf[:kept], st[:ni], ln[:ni]
 
 
-def bev_pool_dense(depth, feat, seg_start, order, n_voxels, D, HW, out=None):
-    """Write-once dense pooling.  depth (B,N,D,H,W) flat, feat (B,N,H,W,C) -> (n_voxels, C)."""
+def bev_pool_dense(depth, feat, vs, out=None):
+    """Write-once dense pooling.  depth (B,N,D,H,W) flat, feat (B,N,H,W,C), vs = VoxelSort built
+    with aux_div=D*H*W, aux_mod=H*W  ->  (n_voxels, C)."""
     C = feat.shape[-1]
+    if vs.order_feat is None:
+        raise _lib.PreworldHipError('bev_pool_dense needs a VoxelSort built with aux_div/aux_mod')
     if out is None:
-        out = torch.empty(n_voxels, C, device=feat.device, dtype=_f32)
+        out = torch.empty(vs.n_keys, C, device=feat.device, dtype=_f32)
     _lib.call('pw_bev_pool_dense', _chk(depth, _f32, 'depth'), _chk(feat, _f32, 'feat'),
-              _chk(seg_start, _i32, 'seg_start'), _chk(order, _i32, 'order'), n_voxels, C, D, HW,
+              _chk(vs.seg_start, _i32, 'seg_start'), _chk(vs.order, _i32, 'order'),
+              _chk(vs.order_feat, _i32, 'order_feat'), vs.n_keys, C,
+              LONG_SEGMENT if vs.long_list is not None else 0, _p(vs.long_list), _p(vs.n_long),
               _chk(out, _f32, 'out'), _stream())
     return out
 
@@ -181,8 +201,9 @@ class QuickCumsumCuda(torch.autograd.Function):
         ranks_bev, depth, feat, ranks_feat, ranks_depth = ctx.saved_tensors
         n_pix = feat.numel() // feat.shape[-1]
         # re-sort by feat pixel (bev_pool.py:47-57) with the same device counting sort
-        seg_start, order = segment_sort(ranks_feat.contiguous(), n_pix)
-        order = order[:ranks_feat.numel()].long()
+        vs = segment_sort(ranks_feat.contiguous(), n_pix)
+        seg_start = vs.seg_start
+        order = vs.order[:ranks_feat.numel()].long()
         rf, rd, rb = ranks_feat[order].contiguous(), ranks_depth[order].contiguous(), \
             ranks_bev[order].contiguous()
         lens = seg_start[1:] - seg_start[:-1]
@@ -313,24 +334,32 @@ def forecast_pack(fusion_w1, fusion_w2):
 
 
 def forecast_prologue(ego, plan, fusion_w1, fusion_b1):
-    """ego (n_samples, 21); plan = [(w0,b0),(w2,b2),(w4,b4)] -> (ego_feat (n,32), c1 (n,128))."""
+    """ego (n_samples, 21); plan = [(w0,b0),(w2,b2),(w4,b4)] ->
+    (ego_feat (n,32), c1 (n,128) natural order, c1p (n,128) accumulator order)."""
     n, dim = ego.shape
     ef = torch.empty(n, 32, device=ego.device, dtype=_f32)
     c1 = torch.empty(n, 128, device=ego.device, dtype=_f32)
+    c1p = torch.empty(n, 128, device=ego.device, dtype=_f32)
     (w0, b0), (w2, b2), (w4, b4) = plan
     _lib.call('pw_forecast_prologue', _chk(ego, _f32, 'ego'), n, dim, _chk(w0, _f32, 'w0'),
               _chk(b0, _f32, 'b0'), _chk(w2, _f32, 'w2'), _chk(b2, _f32, 'b2'), _chk(w4, _f32, 'w4'),
               _chk(b4, _f32, 'b4'), _chk(fusion_w1, _f32, 'fw1'), _chk(fusion_b1, _f32, 'fb1'),
-              _p(ef), _p(c1), _stream())
-    return ef, c1
+              _p(ef), _p(c1), _p(c1p), _stream())
+    return ef, c1, c1p
 
 
-def forecast_steps(v0, n_samples, w1p, w2p, c1, fusion_b2, n_steps, states=None):
+def forecast_steps(v0, n_samples, w1p, w2p, c1p, fusion_b2, n_steps, states=None):
     """v0 (n_samples, ..., 32) channels-last -> states (n_steps, *v0.shape)."""
     n_total = v0.numel() // 32
     if states is None:
         states = torch.empty((n_steps,) + tuple(v0.shape), device=v0.device, dtype=_f32)
     _lib.call('pw_forecast_steps', _chk(v0, _f32, 'v0'), n_total // n_samples, n_samples,
-              _chk(w1p, _f32, 'w1p'), _chk(w2p, _f32, 'w2p'), _chk(c1, _f32, 'c1'),
+              _chk(w1p, _f32, 'w1p'), _chk(w2p, _f32, 'w2p'), _chk(c1p, _f32, 'c1p'),
               _chk(fusion_b2, _f32, 'fb2'), n_steps, _chk(states, _f32, 'states'), _stream())
     return states
+
+
+def softplus(x):
+    y = torch.empty_like(x)
+    _lib.call('pw_softplus', _chk(x, _f32, 'x'), _p(y), x.numel(), _stream())
+    return y

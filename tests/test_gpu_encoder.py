@@ -146,7 +146,8 @@ def test_conv_stack_golden(golden):
         fc = net.final_conv.forward_cl(nk)
         np.testing.assert_allclose(ncdhw(fc), g['final_conv'], **TOL)
         # reference path: OccHead.forward on the (1,C,X,Y,Z) view
-        vf_xyz = fc.permute(0, 4, 3, 2, 1)[0].permute(3, 0, 1, 2).unsqueeze(0)
+        vf = M.from_channels_last_3d(fc).permute(0, 4, 3, 2, 1)      # (B,X,Y,Z,C) as :222
+        vf_xyz = vf[0].permute(3, 0, 1, 2).unsqueeze(0)                # (1,C,X,Y,Z) as :306-307
         logits = net.occupancy_head([vf_xyz])['output_voxels'][0]
         np.testing.assert_allclose(logits.cpu().numpy(), g['logits'], rtol=5e-4, atol=5e-4)
         # fast path: native (Z,Y,X) buffer + permuted taps gives the same occupancy
@@ -214,3 +215,14 @@ def test_full_size_tiled_vs_gather_and_oracle_crop(shape):
         sl = (slice(None), slice(None),
               slice(0 if d0 == 0 else 1, 5), slice(0 if h0 == 0 else 1, 11), slice(0 if w0 == 0 else 1, 11))
         np.testing.assert_allclose(got[sl], want[sl], **TOL)
+
+
+def test_softplus_accuracy():
+    """hardware exp2/log2 softplus vs fp64 torch over the whole useful range."""
+    x = torch.cat([torch.linspace(-100, 100, 200001), torch.tensor([-1e4, -30.0, -1e-8, 0.0, 1e-8, 19.999, 20.0, 20.001, 88.0, 1e4])]).to(DEV)
+    y = ops.softplus(x.contiguous())
+    ref = torch.nn.functional.softplus(x.double().cpu())
+    err = (y.double().cpu() - ref).abs()
+    rel = err / ref.clamp_min(1e-30)
+    assert float(err.max()) < 3e-6
+    assert float(torch.minimum(err / 3e-7, rel / 2e-6).max()) <= 1.0   # abs 3e-7 or rel 2e-6

@@ -18,6 +18,10 @@ def T(a, dtype=None):
     return t.to(dtype) if dtype is not None else t
 
 
+def vsort(vox, n_vox, D, HW):
+    return ops.segment_sort(vox, n_vox, aux_div=D * HW, aux_mod=HW, long_threshold=ops.LONG_SEGMENT)
+
+
 def test_kat_reference_abi(golden):
     """mmdet3d/ops/bev_pool_v2/bev_pool.py:145-176 on the HIP op (C=1 -> generic kernels)."""
     g = golden('kat_bev_pool_v2.npz')
@@ -63,8 +67,9 @@ def test_golden_small_coor_and_ranks(golden):
                                     return_coor=True)
     np.testing.assert_array_equal(coor.cpu().numpy(), g['coor'])
     n_vox = size[0] * size[1] * size[2]
-    seg_start, order = ops.segment_sort(vox, n_vox)
     D, H, W = g['frustum'].shape[:3]
+    vs = vsort(vox, n_vox, D, H * W)
+    seg_start, order = vs.seg_start, vs.order
     rb, rd, rf, st, ln = ops.lss_ranks(seg_start, order, n_vox, D, H * W)
     np.testing.assert_array_equal(rb.cpu().numpy(), g['ranks_bev'])
     np.testing.assert_array_equal(st.cpu().numpy(), g['interval_starts'])
@@ -77,7 +82,7 @@ def test_golden_small_coor_and_ranks(golden):
     depth = T(g['depth'])
     bev = ops.bev_pool_v2(depth, feat, rd, rf, rb, (1, size[2], size[1], size[0], 8), st, ln)
     np.testing.assert_allclose(bev.cpu().numpy(), g['bev_feat'], rtol=1e-5, atol=1e-6)
-    dense = ops.bev_pool_dense(depth, feat, seg_start, order, n_vox, D, H * W)
+    dense = ops.bev_pool_dense(depth, feat, vs)
     np.testing.assert_array_equal(dense.view(1, size[2], size[1], size[0], 8).permute(0, 4, 1, 2, 3)
                                   .cpu().numpy(), bev.cpu().numpy())
     # backward through the autograd wrapper
@@ -112,8 +117,16 @@ def test_full_size_bit_exact_vs_oracle(cfg):
     np.testing.assert_array_equal(vox.cpu().numpy(), O.voxel_index(o_coor, lower, interval, size))
     n_vox = B * size[0] * size[1] * size[2]
     D, H, W = fr.shape[:3]
-    seg_start, order = ops.segment_sort(vox, n_vox)
+    vs = vsort(vox, n_vox, D, H * W)
+    seg_start, order = vs.seg_start, vs.order
     got = ops.lss_ranks(seg_start, order, n_vox, D, H * W)
+    # the feat-pixel payload equals ranks_feat; the long list holds exactly the > LONG_SEGMENT voxels
+    np.testing.assert_array_equal(vs.order_feat[:len(got[2])].cpu().numpy(), got[2].cpu().numpy())
+    lens = (seg_start[1:] - seg_start[:-1])
+    long_ref = torch.nonzero(lens > ops.LONG_SEGMENT).flatten().cpu().numpy()
+    nl = int(vs.n_long)
+    assert nl == len(long_ref) and nl > 0
+    np.testing.assert_array_equal(np.sort(vs.long_list[:nl].cpu().numpy()), long_ref)
     want = O.voxel_pooling_prepare_v2(o_coor, lower, interval, size)
     for a, b, name in zip(got, want, ('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths')):
         np.testing.assert_array_equal(a.cpu().numpy(), b, err_msg=name)
@@ -122,7 +135,7 @@ def test_full_size_bit_exact_vs_oracle(cfg):
     o_bev = O.bev_pool_v2(depth, featc, want[1], want[2], want[0],
                           (B, size[2], size[1], size[0], 32), want[3], want[4])
     d_t, f_t = T(depth), T(featc)
-    dense = ops.bev_pool_dense(d_t, f_t, seg_start, order, n_vox, D, H * W)
+    dense = ops.bev_pool_dense(d_t, f_t, vs)
     dense = dense.view(B, size[2], size[1], size[0], 32).permute(0, 4, 1, 2, 3).cpu().numpy()
     np.testing.assert_array_equal(dense, o_bev)
     ref_abi = ops.bev_pool_v2(d_t, f_t, got[1], got[2], got[0], (B, size[2], size[1], size[0], 32),
@@ -138,7 +151,8 @@ def test_full_size_properties(golden):
     fr, lower, interval, size, vox, _ = _prepare(S.GRID_CONFIG_FULL, S.INPUT_SIZE, S.DOWNSAMPLE,
                                                  rig, 1, 6)
     n_vox = 640000
-    seg_start, order = ops.segment_sort(vox, n_vox)
+    vs = vsort(vox, n_vox, 88, 32 * 88)
+    seg_start, order = vs.seg_start, vs.order
     kept = int(seg_start[-1])
     assert abs(kept - int(g['P_kept'])) <= 64                # closed-form vs LAPACK 3x3 inverse
     lens = (seg_start[1:] - seg_start[:-1])
@@ -151,10 +165,10 @@ def test_full_size_properties(golden):
     depth, feat = S.lift_inputs(int(g['seed_lift']))
     d_t = T(depth)
     f_t = T(np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2)))
-    a = ops.bev_pool_dense(d_t, f_t, seg_start, order, n_vox, 88, 32 * 88)
-    b = ops.bev_pool_dense(d_t, f_t, seg_start, order, n_vox, 88, 32 * 88)
+    a = ops.bev_pool_dense(d_t, f_t, vs)
+    b = ops.bev_pool_dense(d_t, f_t, vs)
     assert torch.equal(a, b)                                   # deterministic
-    a2 = ops.bev_pool_dense(d_t, (f_t * 2).contiguous(), seg_start, order, n_vox, 88, 32 * 88)
+    a2 = ops.bev_pool_dense(d_t, (f_t * 2).contiguous(), vs)
     assert torch.equal(a2, a * 2)                              # exact linearity (power of two)
     pf = (o // (88 * 32 * 88)) * (32 * 88) + o % (32 * 88)
     direct = (d_t.view(-1)[o].double()[:, None] * f_t.view(-1, 32)[pf].double()).sum(0)
@@ -171,20 +185,20 @@ def test_edge_cases():
     lower, interval, size = O.grid_infos(S.GRID_CONFIG_FULL)
     # nothing inside the grid -> five Nones like view_transformer.py:237-238
     vox = torch.full((1000,), -1, device=DEV, dtype=torch.int32)
-    seg_start, order = ops.segment_sort(vox, 640000)
-    assert int(seg_start[-1]) == 0
-    assert ops.lss_ranks(seg_start, order, 640000, 8, 125) == (None,) * 5
-    out = ops.bev_pool_dense(torch.rand(1000, device=DEV), torch.rand(125, 32, device=DEV),
-                             seg_start, order, 640000, 8, 125)
+    vs = vsort(vox, 640000, 8, 125)
+    assert int(vs.seg_start[-1]) == 0
+    assert ops.lss_ranks(vs.seg_start, vs.order, 640000, 8, 125) == (None,) * 5
+    out = ops.bev_pool_dense(torch.rand(1000, device=DEV), torch.rand(125, 32, device=DEV), vs)
     assert float(out.abs().max()) == 0.0
     # every point in ONE voxel (maximum collision): long-segment path
     n = 5000
     vox = torch.full((n,), 12345, device=DEV, dtype=torch.int32)
-    seg_start, order = ops.segment_sort(vox, 640000)
-    assert torch.equal(order, torch.arange(n, device=DEV, dtype=torch.int32))
+    vs = vsort(vox, 640000, 8, n // 8)
+    assert torch.equal(vs.order, torch.arange(n, device=DEV, dtype=torch.int32))
+    assert int(vs.n_long) == 1 and int(vs.long_list[0]) == 12345
     depth = torch.rand(n, device=DEV)
     feat = torch.rand(n // 8, 32, device=DEV)
-    out = ops.bev_pool_dense(depth, feat, seg_start, order, 640000, 8, n // 8)
+    out = ops.bev_pool_dense(depth, feat, vs)
     pf = torch.arange(n, device=DEV) % (n // 8)
     acc = torch.zeros(32, device=DEV)
     ref = np.zeros(32, np.float32)
@@ -195,10 +209,13 @@ def test_edge_cases():
     assert float(out.abs().sum()) == pytest.approx(float(np.abs(ref).sum()), rel=1e-6)
     # ragged channel count (not a multiple of 4) takes the generic kernels
     feat5 = torch.rand(n // 8, 5, device=DEV)
-    out5 = ops.bev_pool_dense(depth, feat5, seg_start, order, 640000, 8, n // 8)
+    out5 = ops.bev_pool_dense(depth, feat5, vs)
+    # and without the long-segment list (plain sequential groups)
+    vs_plain = ops.segment_sort(vox, 640000, aux_div=n, aux_mod=n // 8)
+    assert torch.equal(ops.bev_pool_dense(depth, feat, vs_plain), out)
     np.testing.assert_allclose(out5[12345].cpu().numpy(),
                                (feat5[pf].double() * depth.double()[:, None]).sum(0).cpu().numpy(),
                                rtol=1e-5)
     # bad arguments raise (no silent fallback)
     with pytest.raises(Exception):
-        ops.bev_pool_dense(depth.cpu(), feat, seg_start, order, 640000, 8, n // 8)
+        ops.bev_pool_dense(depth.cpu(), feat, vs)

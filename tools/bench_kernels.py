@@ -45,10 +45,12 @@ def bench_lss():
     res['camera_matrices_us'] = timeit(lambda: ops.lss_camera_matrices(s2e, K, pr))
     vox = ops.lss_voxel_index(fr, ipr, pt, comb, tr, bda, lower, interval, size, 1, 6)
     res['voxel_index_us'] = timeit(lambda: ops.lss_voxel_index(fr, ipr, pt, comb, tr, bda, lower, interval, size, 1, 6))
-    seg_start, order = ops.segment_sort(vox, 640000)
-    res['segment_sort_us'] = timeit(lambda: ops.segment_sort(vox, 640000))
+    srt = lambda: ops.segment_sort(vox, 640000, aux_div=88 * 32 * 88, aux_mod=32 * 88, long_threshold=ops.LONG_SEGMENT)
+    vs = srt()
+    seg_start, order = vs.seg_start, vs.order
+    res['segment_sort_us'] = timeit(srt)
     out = torch.empty(640000, 32, device=dev)
-    res['pool_dense_us'] = timeit(lambda: ops.bev_pool_dense(d_t, f_t, seg_start, order, 640000, 88, 32 * 88, out=out))
+    res['pool_dense_us'] = timeit(lambda: ops.bev_pool_dense(d_t, f_t, vs, out=out))
     kept = int(seg_start[-1])
     alg = 82e6 + 5.95e6 + 2.16e6 + kept * 4 + 2.56e6
     res['pool_dense_GBps'] = alg / res['pool_dense_us'] / 1e3
@@ -110,7 +112,7 @@ def bench_enc():
     # forecast
     fw1 = torch.randn(128, 64, device=dev) * 0.1; fw2 = torch.randn(32, 128, device=dev) * 0.1
     w1p, w2p = ops.forecast_pack(fw1, fw2)
-    c1 = torch.randn(1, 128, device=dev); fb2 = torch.randn(32, device=dev)
+    c1 = torch.randn(1, 128, device=dev) * 0.1; fb2 = torch.randn(32, device=dev)
     st = torch.empty(6, 1, 16, 200, 200, 32, device=dev)
     t = timeit(lambda: ops.forecast_steps(x32, 1, w1p, w2p, c1, fb2, 6, states=st), iters=5)
     res['forecast6_us'] = t; res['forecast6_TFLOPs'] = 6 * 640000 * 2 * (32 * 128 * 2) / t / 1e6
