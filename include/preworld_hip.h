@@ -174,6 +174,55 @@ int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_samples, 
                       const float* w2p, const float* c1p, const float* fusion_b2, int n_steps,
                       float* states, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * A14/A16/A17  render ops with the reference's semantics on compacted point arrays
+ * (mmdet3d/models/nerf/cuda/render_utils.cpp:120-167, ub360_utils.cpp:15-18; kernels
+ * render_utils_kernel.cu:431-443,507-517,577-677, ub360_utils_kernel.cu:13-47).  fp32 only
+ * (the reference dispatches float/double; every call site passes float).
+ *   pw_raw2alpha:           exp_d = exp(density+shift); alpha = 1-(1+exp_d)^(-interval)
+ *   pw_raw2alpha_backward:  grad = min(exp_d,1e10)*(1+exp_d)^(-interval-1)*interval*grad_back
+ *   pw_alpha2weight:        ray_id int64[n_pts] sorted; fills weight/T [n_pts], alphainv_last
+ *                           [n_rays], i_start/i_end int64[n_rays] (all initialised here)
+ *   pw_alpha2weight_backward, pw_cumdist_thres (dist (n_rays,n_pts) -> uint8 mask) */
+int pw_raw2alpha(const float* density, float shift, float interval, int64_t n, float* exp_d,
+                 float* alpha, void* stream);
+int pw_raw2alpha_backward(const float* exp_d, const float* grad_back, float interval, int64_t n,
+                          float* grad, void* stream);
+int pw_alpha2weight(const float* alpha, const int64_t* ray_id, int64_t n_pts, int n_rays,
+                    float* weight, float* T, float* alphainv_last, int64_t* i_start,
+                    int64_t* i_end, void* stream);
+int pw_alpha2weight_backward(const float* alpha, const float* weight, const float* T,
+                             const float* alphainv_last, const int64_t* i_start,
+                             const int64_t* i_end, int n_rays, const float* grad_weights,
+                             const float* grad_last, int64_t n_pts, float* grad, void* stream);
+int pw_cumdist_thres(const float* dist, float thres, int n_rays, int n_pts, uint8_t* mask,
+                     void* stream);
+
+/* A13-A18 fused forward of NerfHead.render_one_scene + render_depth/semantic/color
+ * (mmdet3d/models/nerf/nerf_head.py:32-55,165-269,331-353), one wavefront per ray.
+ *   rays_o/rays_d (n_rays,3); t float[n_samples] (<= 448); grid = packed attribute grid
+ *   (Z,Y,X,grid_channels) channels-last holding sigma at c_sigma, n_sem(=17) semantic logits at
+ *   c_sem.., rgb at c_rgb..; consts_host = 27 HOST floats: scene_center[3], scene_radius[3],
+ *   bda[9], xyz_min[3], xyz_max[3], bg_len, act_shift, interval, dist_thres, fast_color_thres,
+ *   depth_scale(=radius).
+ *   outputs: out_depth (n_rays), out_sem (n_rays,17), out_rgb (n_rays,3), out_last (n_rays) =
+ *   alphainv_last; optional out_counts int32 (n_rays,3) = #samples after each of the reference's
+ *   three compactions, out_weights (n_rays,n_samples) dense weights (0 where culled), out_mask
+ *   uint8 (n_rays,n_samples) the inner|cumdist mask. */
+int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, const float* t,
+                   int n_samples, const float* grid, int X, int Y, int Z, int grid_channels,
+                   int c_sigma, int c_sem, int n_sem, int c_rgb, const float* consts_host,
+                   float* out_depth, float* out_sem, float* out_rgb, float* out_last,
+                   int32_t* out_counts, float* out_weights, uint8_t* out_mask, void* stream);
+
+/* A12  attribute projection (preworld_temporal_traj.py:81-104): density/semantic/color MLPs
+ * (each 32 -> 64 Softplus -> {2,17,3}) fused; v0 (n_vox,32) channels-last; out (n_vox,24) packed
+ * {density_prob[2], semantic[17], color[3], 0, 0}.  w1p/w2p: float[6144] per-lane MFMA operand
+ * order, b1p float[2][96] accumulator order, b2 float[32] (built by preworld_amd.ops.pack_attr_mlp).
+ * final_softplus: apply Softplus to the two density outputs (final_softplus=True configs). */
+int pw_attr_mlp(const float* v0, int64_t n_vox, const float* w1p, const float* w2p,
+                const float* b1p, const float* b2, int final_softplus, float* out, void* stream);
+
 /* nn.Softplus(beta=1, threshold=20) elementwise (the activation inside fusion_head and the
  * attribute MLPs, preworld_temporal_traj.py:81-132), same device function as the fused kernels. */
 int pw_softplus(const float* x, float* y, int64_t n, void* stream);

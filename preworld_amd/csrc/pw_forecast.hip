@@ -237,6 +237,109 @@ PW_API int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_sa
   return PW_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// A12  attribute projection: density_mlp / semantic_mlp / color_mlp
+// (mmdet3d/models/detectors/preworld_temporal_traj.py:81-104, used at :231-250 and in
+// forward_train before the render head).  The three 32 -> 64 Softplus -> {2,17,3} MLPs run as
+// one transposed MFMA chain: hidden = 192 rows (6 tiles), outputs = 32 rows of a block-
+// diagonal second layer (22 used).  The result is written as ONE packed channels-last grid
+//   [voxel][24] = { density_prob[0..1], semantic[0..16], color[0..2], 0, 0 }
+// which is exactly what pw_render_rays gathers from (96 B per corner).
+// ------------------------------------------------------------------------------------
+constexpr int ATTR_TILES = 6;
+constexpr int ATTR_WP = ATTR_TILES * 4 * 64 * 4;    // 6144 floats per packed matrix
+constexpr int ATTR_GC = 24;
+
+__global__ void __launch_bounds__(256, 3)
+k_attr_mlp(const float* __restrict__ v0, long long n_vox, const float* __restrict__ w1p,
+           const float* __restrict__ w2p, const float* __restrict__ b1p /* [2][96] */,
+           const float* __restrict__ b2 /* [32] */, int final_softplus, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* l_w1 = lds;
+  float* l_w2 = lds + ATTR_WP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  for (int k = tid; k < ATTR_WP / 4; k += 256) {
+    reinterpret_cast<float4*>(l_w1)[k] = reinterpret_cast<const float4*>(w1p)[k];
+    reinterpret_cast<float4*>(l_w2)[k] = reinterpret_cast<const float4*>(w2p)[k];
+  }
+  __syncthreads();
+  float b2r[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) b2r[s] = b2[row_of(s, h)];
+  const float* b1s = b1p + h * (ATTR_TILES * 16);
+  const long long n_tiles = (n_vox + 31) / 32;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles;
+       tile += (long long)gridDim.x * 4) {
+    long long m = tile * 32 + j;
+    const bool valid = m < n_vox;
+    if (!valid) m = n_vox - 1;
+    float v[16];
+    const float* src = v0 + (size_t)m * C + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 t4 = *reinterpret_cast<const float4*>(src + 8 * q);
+      v[4 * q + 0] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+    }
+    f32x16 o;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) o[s] = b2r[s];
+#pragma unroll 1
+    for (int t = 0; t < ATTR_TILES; ++t) {
+      f32x16 hid;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 c4 = *reinterpret_cast<const float4*>(b1s + t * 16 + q * 4);
+        hid[4 * q + 0] = c4.x; hid[4 * q + 1] = c4.y; hid[4 * q + 2] = c4.z; hid[4 * q + 3] = c4.w;
+      }
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) {
+        const float4 a4 = *reinterpret_cast<const float4*>(l_w1 + ((t * 4 + sq) * 64 + lane) * 4);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          hid = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], v[4 * sq + e], hid, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[r] = softplus_t20(hid[r]);
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 a4 = *reinterpret_cast<const float4*>(l_w2 + ((t * 4 + rq) * 64 + lane) * 4);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], hid[4 * rq + e], o, 0, 0, 0);
+      }
+    }
+    if (final_softplus && h == 0) {           // rows 0,1 = density_prob live in lane half 0, regs 0,1
+      o[0] = softplus_t20(o[0]);
+      o[1] = softplus_t20(o[1]);
+    }
+    if (valid) {
+      float* dst = out + (size_t)m * ATTR_GC + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)             // rows 8q+4h .. +3 for q = 0..2 cover channels 0..23
+        *reinterpret_cast<float4*>(dst + 8 * q) =
+            make_float4(o[4 * q + 0], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+  }
+}
+
+PW_API int pw_attr_mlp(const float* v0, int64_t n_vox, const float* w1p, const float* w2p,
+                       const float* b1p, const float* b2, int final_softplus, float* out,
+                       void* stream) {
+  PW_CHECK_ARG(v0 && w1p && w2p && b1p && b2 && out && n_vox > 0, "pw_attr_mlp: bad arguments");
+  PW_CHECK_ARG((((uintptr_t)v0 | (uintptr_t)out | (uintptr_t)w1p | (uintptr_t)w2p) & 15) == 0,
+               "pw_attr_mlp: pointers must be 16-B aligned");
+  const size_t lds_bytes = (size_t)ATTR_WP * 2 * 4;    // 48 KB
+  long long want = ((n_vox + 31) / 32 + 3) / 4;
+  unsigned nb = (unsigned)(want < 768 ? want : 768);    // 3 blocks x 256 CUs
+  hipLaunchKernelGGL(k_attr_mlp, dim3(nb), dim3(256), lds_bytes, pw_stream(stream), v0,
+                     (long long)n_vox, w1p, w2p, b1p, b2, final_softplus, out);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
 // elementwise nn.Softplus(beta=1, threshold=20) with the same device function the fused
 // kernels use (exposed for the attribute MLPs and for accuracy tests)
 __global__ void k_softplus(const float* __restrict__ x, float* __restrict__ y, long long n) {

@@ -1,0 +1,461 @@
+// Volume-rendering attribute-projection head for gfx950.  Replaces (reference paths):
+//   mmdet3d/models/nerf/cuda/render_utils_kernel.cu:431-443,507-517   raw2alpha (+backward)
+//   mmdet3d/models/nerf/cuda/render_utils_kernel.cu:577-677           alpha2weight (+backward)
+//   mmdet3d/models/nerf/cuda/ub360_utils_kernel.cu:13-47              cumdist_thres
+//   mmdet3d/models/nerf/nerf_head.py:32-55,165-269,331-353            sample_ray, render_one_scene,
+//                                                                     render_depth/semantic/color
+// Two layers:
+//  (1) the five ops with the reference's semantics on compacted point arrays, so that the
+//      reference's autograd wrappers (mmdet3d/models/nerf/utils.py:26-68) can bind to them;
+//  (2) pw_render_rays: the whole forward of render_one_scene + render_* fused, ONE WAVEFRONT PER
+//      RAY.  The 417 candidate samples of a ray live in registers (7 per lane); the three
+//      data-dependent compactions of the reference (inner|cumdist mask, alpha > 1e-7,
+//      weight > 1e-7) become predicates, the two inherently sequential recurrences (cumulative
+//      distance with reset, transmittance with early stop) run as wave-uniform scans over
+//      v_readlane, and only surviving samples gather the 8 x 24-channel corners of the packed
+//      attribute grid.  Nothing of size (rays x samples) ever reaches HBM unless asked for.
+// Compiled with -ffp-contract=off: sample positions / masks follow the oracle's op order.
+#include "pw_common.h"
+
+// ------------------------------------------------------------------------------------
+// (1) reference-ABI ops
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_raw2alpha(const float* __restrict__ density, float shift, float interval, int64_t n,
+            float* __restrict__ exp_d, float* __restrict__ alpha) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float e = expf(density[i] + shift);      // can be inf
+  exp_d[i] = e;
+  alpha[i] = 1.f - powf(1.f + e, -interval);
+}
+
+__global__ void __launch_bounds__(256)
+k_raw2alpha_bwd(const float* __restrict__ exp_d, const float* __restrict__ grad_back,
+                float interval, int64_t n, float* __restrict__ grad) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // min(exp_d, 1e10) * pow(1+exp_d, -interval-1) * interval * grad_back, the 1e10 literal makes
+  // the product double in the reference (render_utils_kernel.cu:515)
+  const double m = (double)exp_d[i] < 1e10 ? (double)exp_d[i] : 1e10;
+  grad[i] = (float)(m * (double)powf(1.f + exp_d[i], -interval - 1.f) * (double)interval *
+                    (double)grad_back[i]);
+}
+
+// __set_i_for_segment_start_end (render_utils_kernel.cu:607-617); the host-side
+// `i_end[ray_id[n-1]] = n` fix-up (:635) is the index == n_pts case here.
+__global__ void __launch_bounds__(256)
+k_segment_bounds(const int64_t* __restrict__ ray_id, int64_t n_pts, int64_t* __restrict__ i_start,
+                 int64_t* __restrict__ i_end) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == n_pts && n_pts > 0) { i_end[ray_id[n_pts - 1]] = n_pts; return; }
+  if (0 < idx && idx < n_pts && ray_id[idx] != ray_id[idx - 1]) {
+    i_start[ray_id[idx]] = idx;
+    i_end[ray_id[idx - 1]] = idx;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_alpha2weight(const float* __restrict__ alpha, int n_rays, float* __restrict__ weight,
+               float* __restrict__ T, float* __restrict__ alphainv_last,
+               const int64_t* __restrict__ i_start, int64_t* __restrict__ i_end) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const int i_s = (int)i_start[r], i_e_max = (int)i_end[r];
+  float T_cum = 1.f;
+  int i;
+  for (i = i_s; i < i_e_max; ++i) {
+    T[i] = T_cum;
+    weight[i] = T_cum * alpha[i];
+    T_cum = (float)((double)T_cum * (1. - (double)alpha[i]));   // `1. - alpha` is double (:596)
+    if ((double)T_cum < 1e-3) { i += 1; break; }
+  }
+  i_end[r] = i;
+  alphainv_last[r] = T_cum;
+}
+
+__global__ void __launch_bounds__(256)
+k_alpha2weight_bwd(const float* __restrict__ alpha, const float* __restrict__ weight,
+                   const float* __restrict__ T, const float* __restrict__ alphainv_last,
+                   const int64_t* __restrict__ i_start, const int64_t* __restrict__ i_end,
+                   int n_rays, const float* __restrict__ grad_weights,
+                   const float* __restrict__ grad_last, float* __restrict__ grad) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const int i_s = (int)i_start[r], i_e = (int)i_end[r];
+  float back_cum = grad_last[r] * alphainv_last[r];
+  for (int i = i_e - 1; i >= i_s; --i) {
+    grad[i] = (float)((double)(grad_weights[i] * T[i]) -
+                      (double)back_cum / (1. - (double)alpha[i] + 1e-10));
+    back_cum += grad_weights[i] * weight[i];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_cumdist_thres(const float* __restrict__ dist, float thres, int n_rays, int n_pts,
+                uint8_t* __restrict__ mask) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  float cum = 0.f;
+  const int64_t base = (int64_t)r * n_pts;
+  for (int i = 0; i < n_pts; ++i) {
+    cum += dist[base + i];
+    const bool over = cum > thres;
+    cum *= (float)(!over);
+    mask[base + i] = (uint8_t)over;
+  }
+}
+
+PW_API int pw_raw2alpha(const float* density, float shift, float interval, int64_t n, float* exp_d,
+                        float* alpha, void* stream) {
+  if (n == 0) return PW_OK;
+  PW_CHECK_ARG(density && exp_d && alpha && n > 0, "pw_raw2alpha: bad arguments");
+  hipLaunchKernelGGL(k_raw2alpha, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0, pw_stream(stream),
+                     density, shift, interval, n, exp_d, alpha);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_raw2alpha_backward(const float* exp_d, const float* grad_back, float interval,
+                                 int64_t n, float* grad, void* stream) {
+  if (n == 0) return PW_OK;
+  PW_CHECK_ARG(exp_d && grad_back && grad && n > 0, "pw_raw2alpha_backward: bad arguments");
+  hipLaunchKernelGGL(k_raw2alpha_bwd, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0,
+                     pw_stream(stream), exp_d, grad_back, interval, n, grad);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// weight/T/alphainv_last/i_start/i_end are initialised here (zeros/ones/ones/zeros/zeros) exactly as
+// alpha2weight_cuda does (render_utils_kernel.cu:624-631)
+__global__ void __launch_bounds__(256)
+k_a2w_init(int64_t n_pts, int n_rays, float* weight, float* T, float* last, int64_t* i_start,
+           int64_t* i_end) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pts) { weight[i] = 0.f; T[i] = 1.f; }
+  if (i < n_rays) { last[i] = 1.f; i_start[i] = 0; i_end[i] = 0; }
+}
+
+PW_API int pw_alpha2weight(const float* alpha, const int64_t* ray_id, int64_t n_pts, int n_rays,
+                           float* weight, float* T, float* alphainv_last, int64_t* i_start,
+                           int64_t* i_end, void* stream) {
+  PW_CHECK_ARG(n_pts >= 0 && n_rays >= 0, "pw_alpha2weight: bad sizes");
+  PW_CHECK_ARG(weight && T && alphainv_last && i_start && i_end, "pw_alpha2weight: null output");
+  hipStream_t st = pw_stream(stream);
+  int64_t m = n_pts > n_rays ? n_pts : n_rays;
+  if (m == 0) return PW_OK;
+  hipLaunchKernelGGL(k_a2w_init, dim3((unsigned)pw_cdiv(m, 256)), dim3(256), 0, st, n_pts, n_rays,
+                     weight, T, alphainv_last, i_start, i_end);
+  if (n_pts > 0) {
+    PW_CHECK_ARG(alpha && ray_id, "pw_alpha2weight: null input");
+    hipLaunchKernelGGL(k_segment_bounds, dim3((unsigned)pw_cdiv(n_pts + 1, 256)), dim3(256), 0, st,
+                       ray_id, n_pts, i_start, i_end);
+    hipLaunchKernelGGL(k_alpha2weight, dim3((unsigned)pw_cdiv(n_rays, 256)), dim3(256), 0, st, alpha,
+                       n_rays, weight, T, alphainv_last, i_start, i_end);
+  }
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_alpha2weight_backward(const float* alpha, const float* weight, const float* T,
+                                    const float* alphainv_last, const int64_t* i_start,
+                                    const int64_t* i_end, int n_rays, const float* grad_weights,
+                                    const float* grad_last, int64_t n_pts, float* grad,
+                                    void* stream) {
+  PW_CHECK_ARG(n_pts >= 0 && n_rays >= 0, "pw_alpha2weight_backward: bad sizes");
+  if (n_pts == 0) return PW_OK;
+  PW_CHECK_ARG(alpha && weight && T && alphainv_last && i_start && i_end && grad_weights &&
+                   grad_last && grad,
+               "pw_alpha2weight_backward: null pointer");
+  hipStream_t st = pw_stream(stream);
+  PW_CHECK_HIP(hipMemsetAsync(grad, 0, (size_t)n_pts * 4, st));
+  if (n_rays > 0)
+    hipLaunchKernelGGL(k_alpha2weight_bwd, dim3((unsigned)pw_cdiv(n_rays, 256)), dim3(256), 0, st,
+                       alpha, weight, T, alphainv_last, i_start, i_end, n_rays, grad_weights,
+                       grad_last, grad);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_cumdist_thres(const float* dist, float thres, int n_rays, int n_pts, uint8_t* mask,
+                            void* stream) {
+  if (n_rays == 0 || n_pts == 0) return PW_OK;
+  PW_CHECK_ARG(dist && mask && n_rays > 0 && n_pts > 0, "pw_cumdist_thres: bad arguments");
+  hipLaunchKernelGGL(k_cumdist_thres, dim3((unsigned)pw_cdiv(n_rays, 256)), dim3(256), 0,
+                     pw_stream(stream), dist, thres, n_rays, n_pts, mask);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// (2) fused forward: one wavefront per ray
+// ------------------------------------------------------------------------------------
+struct RenderArgs {
+  const float* rays_o;     // (R,3)
+  const float* rays_d;     // (R,3)
+  const float* t;          // (S) sample distances (nerf_head.py:35-43)
+  const float* grid;       // packed attribute grid (Z,Y,X,GC) channels-last
+  float center[3], radius[3], bda[9], xyz_min[3], xyz_max[3];
+  float bg_len, act_shift, interval, dist_thres, fast_thres, depth_scale;
+  int R, S, X, Y, Z, GC, c_sigma, c_sem, n_sem, c_rgb;
+  float* out_depth;        // (R)
+  float* out_sem;          // (R, n_sem)
+  float* out_rgb;          // (R, 3)
+  float* out_last;         // (R)   alphainv_last
+  int* out_counts;         // (R, 3): #masked, #alpha>thr, #weight>thr  (or null)
+  float* out_weights;      // (R, S) dense per-sample weights, 0 where culled (or null)
+  uint8_t* out_mask;       // (R, S) inner|cumdist sample mask (or null)
+};
+
+constexpr int RPASS = 7;   // 7 x 64 = 448 >= 417 samples per ray
+
+// trilinear corner set-up following ATen grid_sampler_3d (align_corners=True, zeros padding)
+// with the reference's axis flip (nerf_head.py:211): grid axes (X,Y,Z) <-> torch (D,H,W).
+struct Tri {
+  int x0, y0, z0;
+  float wx0, wx1, wy0, wy1, wz0, wz1;
+};
+
+__device__ __forceinline__ Tri tri_setup(const RenderArgs& a, float px, float py, float pz) {
+  Tri t;
+  const float gx = ((px - a.xyz_min[0]) / (a.xyz_max[0] - a.xyz_min[0])) * 2.f - 1.f;
+  const float gy = ((py - a.xyz_min[1]) / (a.xyz_max[1] - a.xyz_min[1])) * 2.f - 1.f;
+  const float gz = ((pz - a.xyz_min[2]) / (a.xyz_max[2] - a.xyz_min[2])) * 2.f - 1.f;
+  const float fx = ((gx + 1.f) / 2.f) * (float)(a.X - 1);
+  const float fy = ((gy + 1.f) / 2.f) * (float)(a.Y - 1);
+  const float fz = ((gz + 1.f) / 2.f) * (float)(a.Z - 1);
+  const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
+  // clamp the integer base far outside the grid so the bounds test below cannot overflow
+  t.x0 = (int)fminf(fmaxf(x0f, -2.f), (float)a.X + 1.f);
+  t.y0 = (int)fminf(fmaxf(y0f, -2.f), (float)a.Y + 1.f);
+  t.z0 = (int)fminf(fmaxf(z0f, -2.f), (float)a.Z + 1.f);
+  t.wx1 = fx - x0f; t.wx0 = (x0f + 1.f) - fx;
+  t.wy1 = fy - y0f; t.wy0 = (y0f + 1.f) - fy;
+  t.wz1 = fz - z0f; t.wz0 = (z0f + 1.f) - fz;
+  return t;
+}
+
+// iterate the 8 corners in ATen's accumulation order (torch D=our X outermost, W=our Z innermost)
+#define PW_FOR_CORNERS(t, BODY)                                                        \
+  _Pragma("unroll") for (int cx = 0; cx < 2; ++cx)                                     \
+  _Pragma("unroll") for (int cy = 0; cy < 2; ++cy)                                     \
+  _Pragma("unroll") for (int cz = 0; cz < 2; ++cz) {                                   \
+    const int xi = t.x0 + cx, yi = t.y0 + cy, zi = t.z0 + cz;                          \
+    const float wgt = ((cz ? t.wz1 : t.wz0) * (cy ? t.wy1 : t.wy0)) * (cx ? t.wx1 : t.wx0); \
+    const bool inb = (unsigned)xi < (unsigned)a.X && (unsigned)yi < (unsigned)a.Y &&  \
+                     (unsigned)zi < (unsigned)a.Z;                                     \
+    const size_t cbase = (((size_t)zi * a.Y + yi) * a.X + xi) * a.GC;                  \
+    BODY                                                                               \
+  }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.R) return;
+  const int S = a.S;
+
+  // ---- A13 sample_ray (nerf_head.py:32-55): normalise, march, contract, undo bda
+  float o[3], d[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = (a.rays_o[ray * 3 + i] - a.center[i]) / a.radius[i];
+  {
+    float nn = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nn += a.rays_d[ray * 3 + i] * a.rays_d[ray * 3 + i];
+    nn = sqrtf(nn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = a.rays_d[ray * 3 + i] / nn;
+  }
+  float px[RPASS], py[RPASS], pz[RPASS], tt[RPASS], dq[RPASS];
+  unsigned long long innerbits[RPASS], maskbits[RPASS];
+#pragma unroll
+  for (int p = 0; p < RPASS; ++p) {
+    const int s = p * 64 + lane;
+    const bool valid = s < S;
+    const float ts = a.t[valid ? s : S - 1];
+    float q0 = o[0] + d[0] * ts, q1 = o[1] + d[1] * ts, q2 = o[2] + d[2] * ts;
+    const float norm = sqrtf((q0 * q0 + q1 * q1) + q2 * q2);
+    const bool inner = norm <= 1.f;
+    if (!inner) {
+      const float sc = (1.f + a.bg_len) - a.bg_len / norm;
+      q0 = q0 / norm * sc; q1 = q1 / norm * sc; q2 = q2 / norm * sc;
+    }
+    float r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float acc = 0.f;
+      acc += a.bda[i * 3 + 0] * q0;
+      acc += a.bda[i * 3 + 1] * q1;
+      acc += a.bda[i * 3 + 2] * q2;
+      r[i] = acc;
+    }
+    px[p] = r[0]; py[p] = r[1]; pz[p] = r[2]; tt[p] = ts;
+    innerbits[p] = __ballot(valid && inner);
+  }
+  // distance to the previous sample (nerf_head.py:198): dq[s] = |p[s] - p[s-1]|, s >= 1
+#pragma unroll
+  for (int p = 0; p < RPASS; ++p) {
+    float ux = __shfl_up(px[p], 1, 64), uy = __shfl_up(py[p], 1, 64), uz = __shfl_up(pz[p], 1, 64);
+    // lane 0 pairs with lane 63 of the previous pass (wave-wide shuffles stay unconditional)
+    const float vx = p > 0 ? __shfl(px[p > 0 ? p - 1 : 0], 63, 64) : 0.f;
+    const float vy = p > 0 ? __shfl(py[p > 0 ? p - 1 : 0], 63, 64) : 0.f;
+    const float vz = p > 0 ? __shfl(pz[p > 0 ? p - 1 : 0], 63, 64) : 0.f;
+    if (lane == 0) { ux = vx; uy = vy; uz = vz; }
+    const float ex = px[p] - ux, ey = py[p] - uy, ez = pz[p] - uz;
+    dq[p] = sqrtf((ex * ex + ey * ey) + ez * ez);
+  }
+  // ---- A14 cumdist_thres (ub360_utils_kernel.cu:13-32): wave-uniform sequential scan
+  {
+    float cum = 0.f;
+#pragma unroll
+    for (int p = 0; p < RPASS; ++p) {
+      unsigned long long over_bits = 0ull;
+      const int lim = min(64, S - p * 64);
+      for (int l = (p == 0 ? 1 : 0); l < lim; ++l) {
+        const float dv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dq[p]), l));
+        cum += dv;
+        const bool over = cum > a.dist_thres;
+        cum *= (float)(!over);
+        over_bits |= (unsigned long long)over << l;
+      }
+      maskbits[p] = innerbits[p] | over_bits;      // mask[:,1:] |= cumdist (nerf_head.py:199)
+    }
+  }
+  // ---- A15/A16 density gather + raw2alpha on masked samples
+  float alpha[RPASS];
+  int n_mask = 0;
+#pragma unroll
+  for (int p = 0; p < RPASS; ++p) {
+    const bool m = (maskbits[p] >> lane) & 1ull;
+    n_mask += __popcll(maskbits[p]);
+    float al = 0.f;
+    if (m) {
+      const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
+      float sig = 0.f;
+      PW_FOR_CORNERS(t3, { if (inb) sig += a.grid[cbase + a.c_sigma] * wgt; })
+      const float e = expf(sig + a.act_shift);
+      al = 1.f - powf(1.f + e, -a.interval);
+    }
+    alpha[p] = al;
+  }
+  // ---- A17 alpha2weight (render_utils_kernel.cu:577-605) over samples with alpha > thres
+  float w[RPASS];
+#pragma unroll
+  for (int p = 0; p < RPASS; ++p) w[p] = 0.f;
+  float T_cum = 1.f;
+  int n_alpha = 0;
+  bool stopped = false;
+#pragma unroll
+  for (int p = 0; p < RPASS; ++p) {
+    const unsigned long long abits = __ballot(((maskbits[p] >> lane) & 1ull) && alpha[p] > a.fast_thres);
+    n_alpha += __popcll(abits);
+    unsigned long long rem = abits;
+    while (rem && !stopped) {
+      const int l = __builtin_ctzll(rem);
+      rem &= rem - 1;
+      const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha[p]), l));
+      const float wq = T_cum * al;
+      if (lane == l) w[p] = wq;
+      T_cum = (float)((double)T_cum * (1. - (double)al));
+      if ((double)T_cum < 1e-3) stopped = true;
+    }
+  }
+  // ---- A18 render_depth/semantic/color over samples with weight > thres
+  float acc_d = 0.f, acc_rgb[3] = {0.f, 0.f, 0.f};
+  float acc_sem[17];
+#pragma unroll
+  for (int k = 0; k < 17; ++k) acc_sem[k] = 0.f;
+  int n_w = 0;
+#pragma unroll
+  for (int p = 0; p < RPASS; ++p) {
+    const bool keep = w[p] > a.fast_thres;
+    n_w += __popcll(__ballot(keep));
+    if (a.out_weights && p * 64 + lane < S) a.out_weights[(size_t)ray * S + p * 64 + lane] = keep ? w[p] : 0.f;
+    if (a.out_mask && p * 64 + lane < S) a.out_mask[(size_t)ray * S + p * 64 + lane] = (maskbits[p] >> lane) & 1ull;
+    if (keep) {
+      const float sdist = 1.f - 1.f / (1.f + tt[p]);            // s = 1 - 1/(1+t) (nerf_head.py:256)
+      acc_d += w[p] * sdist;
+      const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
+      float sem[17], rgb[3];
+#pragma unroll
+      for (int k = 0; k < 17; ++k) sem[k] = 0.f;
+      rgb[0] = rgb[1] = rgb[2] = 0.f;
+      PW_FOR_CORNERS(t3, {
+        if (inb) {
+          const float* g = a.grid + cbase;
+          for (int k = 0; k < 17; ++k) sem[k] += g[a.c_sem + k] * wgt;
+          for (int k = 0; k < 3; ++k) rgb[k] += g[a.c_rgb + k] * wgt;
+        }
+      })
+#pragma unroll
+      for (int k = 0; k < 17; ++k) acc_sem[k] += w[p] * sem[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc_rgb[k] += w[p] * rgb[k];
+    }
+  }
+  acc_d = wave_sum(acc_d);
+#pragma unroll
+  for (int k = 0; k < 17; ++k) acc_sem[k] = wave_sum(acc_sem[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc_rgb[k] = wave_sum(acc_rgb[k]);
+  if (lane == 0) {
+    a.out_depth[ray] = (acc_d + 1e-7f) * a.depth_scale;         // (+1e-7) * radius (nerf_head.py:337-338)
+    a.out_last[ray] = T_cum;
+    if (a.out_counts) {
+      a.out_counts[ray * 3 + 0] = n_mask;
+      a.out_counts[ray * 3 + 1] = n_alpha;
+      a.out_counts[ray * 3 + 2] = n_w;
+    }
+  }
+  if (lane < 17 && lane < a.n_sem) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) v = (lane == k) ? acc_sem[k] : v;
+    a.out_sem[(size_t)ray * a.n_sem + lane] = v;
+  }
+  if (lane < 3) {
+    float v = lane == 0 ? acc_rgb[0] : (lane == 1 ? acc_rgb[1] : acc_rgb[2]);
+    a.out_rgb[(size_t)ray * 3 + lane] = v;
+  }
+}
+
+PW_API int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, const float* t,
+                          int n_samples, const float* grid, int X, int Y, int Z, int grid_channels,
+                          int c_sigma, int c_sem, int n_sem, int c_rgb,
+                          const float* consts_host /* 3 center, 3 radius, 9 bda, 3 xyz_min, 3 xyz_max,
+                          bg_len, act_shift, interval, dist_thres, fast_thres, depth_scale = 27 floats */,
+                          float* out_depth, float* out_sem, float* out_rgb, float* out_last,
+                          int32_t* out_counts, float* out_weights, uint8_t* out_mask, void* stream) {
+  if (n_rays == 0) return PW_OK;
+  PW_CHECK_ARG(rays_o && rays_d && t && grid && consts_host && out_depth && out_sem && out_rgb &&
+                   out_last,
+               "pw_render_rays: null pointer");
+  PW_CHECK_ARG(n_rays > 0 && n_samples > 1 && n_samples <= RPASS * 64,
+               "pw_render_rays: n_samples must be in [2, %d]", RPASS * 64);
+  PW_CHECK_ARG(X > 1 && Y > 1 && Z > 1 && grid_channels > 0, "pw_render_rays: bad grid");
+  PW_CHECK_ARG(n_sem == 17, "pw_render_rays: built for 17 semantic classes (got %d)", n_sem);
+  PW_CHECK_ARG(c_sigma >= 0 && c_sigma < grid_channels && c_sem >= 0 && c_sem + n_sem <= grid_channels &&
+                   c_rgb >= 0 && c_rgb + 3 <= grid_channels,
+               "pw_render_rays: channel offsets outside the packed grid");
+  RenderArgs a;
+  a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.grid = grid;
+  const float* c = consts_host;
+  for (int i = 0; i < 3; ++i) { a.center[i] = c[i]; a.radius[i] = c[3 + i]; a.xyz_min[i] = c[15 + i]; a.xyz_max[i] = c[18 + i]; }
+  for (int i = 0; i < 9; ++i) a.bda[i] = c[6 + i];
+  a.bg_len = c[21]; a.act_shift = c[22]; a.interval = c[23]; a.dist_thres = c[24]; a.fast_thres = c[25];
+  a.depth_scale = c[26];
+  a.R = n_rays; a.S = n_samples; a.X = X; a.Y = Y; a.Z = Z; a.GC = grid_channels;
+  a.c_sigma = c_sigma; a.c_sem = c_sem; a.n_sem = n_sem; a.c_rgb = c_rgb;
+  a.out_depth = out_depth; a.out_sem = out_sem; a.out_rgb = out_rgb; a.out_last = out_last;
+  a.out_counts = out_counts; a.out_weights = out_weights; a.out_mask = out_mask;
+  hipLaunchKernelGGL(k_render_rays, dim3((unsigned)pw_cdiv(n_rays, 4)), dim3(256), 0,
+                     pw_stream(stream), a);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

@@ -558,11 +558,30 @@ class PreWorld4DTraj(nn.Module):
         states = ops.forecast_steps(v_cl, B, w1p, w2p, c1p, fh[2].bias, n_steps)
         return states, ef
 
+    # ---- preworld_temporal_traj.py:231-236: density / semantic / color MLPs, fused
+    def attributes_cl(self, v_cl):
+        """v_cl (B,Z,Y,X,C) -> packed grid (B,Z,Y,X,24): [0:2] density_prob, [2:19] semantic,
+        [19:22] color.  `grid[..., 0]` is the reference's `density`."""
+        mods = (self.density_mlp, self.semantic_mlp, self.color_mlp)
+        params = [m[i].weight for m in mods for i in (0, 2)] + [m[i].bias for m in mods for i in (0, 2)]
+        if not hasattr(self, '_attr_cache'):
+            self._attr_cache = _PackedCache()
+        packed = self._attr_cache.get(params, lambda: ops.pack_attr_mlp(*mods))
+        return ops.attr_mlp(v_cl, packed, final_softplus=len(self.density_mlp) == 4)
+
+    # ---- preworld_temporal_traj.py:237-250: occupancy from density threshold + semantic argmax
+    def attribute_decode(self, grid):
+        dens = grid[..., 0]
+        sem = grid[..., 2:19].argmax(-1)
+        occ = torch.where(dens > self.test_threshold, sem, torch.full_like(sem, self.num_classes - 1))
+        return occ.to(torch.uint8)
+
     # ---- preworld_temporal_traj.py:212-370 (post-finetune branch) from lifted inputs
     @torch.no_grad()
     def simple_test_from_lift(self, frames, temporal_ego_states, n_steps=6, want_logits=False):
-        assert self.if_post_finetune, 'attribute-MLP decode (if_post_finetune=False) is not built yet'
         v0 = self.extract_voxel_feat_cl(frames)                       # (B,Z,Y,X,C)
+        if not self.if_post_finetune:
+            return self._simple_test_attributes(v0, temporal_ego_states, n_steps)
         res = {}
         feats = [v0]
         if n_steps > 0:
@@ -584,3 +603,166 @@ class PreWorld4DTraj(nn.Module):
             res['logits'] = logits_all
         res['voxel_feats'] = feats
         return res
+
+    # ---- preworld_temporal_traj.py:224-301: density/semantic-MLP decode (if_post_finetune=False).
+    # The reference names the future states 2s..7s in this branch (:294) and never emits 1s.
+    def _simple_test_attributes(self, v0, temporal_ego_states, n_steps):
+        feats = [v0]
+        if n_steps > 0:
+            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps)
+            feats += [states[k] for k in range(n_steps)]
+        res = {}
+        for k, f in enumerate(feats):
+            occ = self.attribute_decode(self.attributes_cl(f)).permute(0, 3, 2, 1)     # (B,X,Y,Z)
+            geo = torch.where(occ != self.num_classes - 1, torch.zeros_like(occ),
+                              torch.full_like(occ, self.num_classes - 1))
+            name = 0 if k == 0 else k + 1
+            res['semantic_occ_%ds' % name] = [occ[0]]
+            res['geo_occ_%ds' % name] = [geo[0]]
+        res['voxel_feats'] = feats
+        return res
+
+
+# =====================================================================================
+# volume-rendering head
+# =====================================================================================
+import numpy as _np
+
+nusc_class_frequencies = _np.array([1163161, 2309034, 188743, 2997643, 20317180, 852476, 243808,
+                                    2457947, 497017, 2731022, 7224789, 214411435, 5565043, 63191967,
+                                    76098082, 128860031, 141625221, 2307405309])
+
+
+def pack_attribute_grid(density, semantic, color):
+    """reference-layout attributes density (X,Y,Z), semantic (X,Y,Z,17), color (X,Y,Z,3) -> the
+    packed channels-last grid (Z,Y,X,24) pw_render_rays gathers from (sigma in channel 0)."""
+    X, Y, Z = density.shape
+    g = density.new_zeros(Z, Y, X, 24)
+    g[..., 0] = density.permute(2, 1, 0)
+    g[..., 2:19] = semantic.permute(2, 1, 0, 3)
+    g[..., 19:22] = color.permute(2, 1, 0, 3)
+    return g
+
+
+class NerfHead(nn.Module):
+    """Drop-in for mmdet3d/models/nerf/nerf_head.py:103-420 (same kwargs, same registered
+    buffers scene_center / scene_radius / xyz_min / xyz_max / act_shift, same loss keys).
+
+    The forward pass of render_one_scene + render_depth/semantic/color is one HIP kernel
+    (pw_render_rays, one wavefront per ray); the scalar losses on the (n_rays,) outputs are a
+    handful of torch reductions.  Forward/eval only in this round: gradients w.r.t. the
+    attribute grids are not built (ops.Raw2Alpha / ops.Alphas2Weights expose the reference's
+    autograd ops for composing one)."""
+
+    def __init__(self, point_cloud_range, voxel_size, scene_center=None, radius=39, step_size=0.5,
+                 use_depth_sup=True, balance_cls_weight=True, weight_depth=1.0, weight_semantic=1.0,
+                 weight_color=1.0, weight_entropy_last=0.01, weight_distortion=0.01, alpha_init=1e-6,
+                 fast_color_thres=1e-7):
+        super().__init__()
+        self.weight_entropy_last, self.weight_distortion = weight_entropy_last, weight_distortion
+        xyz_min = torch.Tensor(point_cloud_range[:3])
+        xyz_max = torch.Tensor(point_cloud_range[3:])
+        xyz_range = (xyz_max - xyz_min).float()
+        self.bg_len = (xyz_range[0] // 2 - radius) / radius          # 0-dim fp32 tensor (:131)
+        self.radius = radius
+        self.register_buffer('scene_center', (xyz_min + xyz_max) * 0.5)
+        self.register_buffer('scene_radius', torch.Tensor([radius, radius, radius]))
+        self.step_size, self.use_depth_sup = step_size, use_depth_sup
+        z_ = xyz_range[2] / xyz_range[0]
+        self.register_buffer('xyz_min', torch.Tensor([-1 - self.bg_len, -1 - self.bg_len, -z_]))
+        self.register_buffer('xyz_max', torch.Tensor([1 + self.bg_len, 1 + self.bg_len, z_]))
+        self.alpha_init = alpha_init
+        self.register_buffer('act_shift', torch.FloatTensor([_np.log(1 / (1 - alpha_init) - 1)]))
+        self.voxel_size = voxel_size / radius
+        self.world_size = torch.Tensor([200, 200, 16]).long()
+        self.world_len = self.world_size[0].item()
+        self.fast_color_thres = fast_color_thres
+        self.weight_depth, self.weight_semantic, self.weight_color = weight_depth, weight_semantic, weight_color
+        if balance_cls_weight:
+            self.class_weights = torch.from_numpy(1 / _np.log(nusc_class_frequencies[:17] + 0.001))
+        else:
+            self.class_weights = torch.ones(17) / 17
+        self._t = None
+
+    def t_table(self, device):
+        """nerf_head.py:35-43, with the same torch calls (N_inner=391, N_outer=26 -> 417)."""
+        if self._t is None or self._t.device != torch.device(device):
+            N_inner = int(2 / (2 + 2 * self.bg_len) * self.world_len / self.step_size) + 1
+            N_outer = N_inner // 15
+            b_inner = torch.linspace(0, 2, N_inner + 1)
+            b_outer = 2 / torch.linspace(1, 1 / 64, N_outer + 1)
+            t = torch.cat([(b_inner[1:] + b_inner[:-1]) * 0.5, (b_outer[1:] + b_outer[:-1]) * 0.5])
+            self._t = t.float().contiguous().to(device)
+        return self._t
+
+    def consts(self, bda, interval=0.5):
+        dist_thres = (2 + 2 * self.bg_len) / self.world_len * self.step_size * 0.95       # :197
+        vals = [float(v) for v in self.scene_center] + [float(v) for v in self.scene_radius] + \
+            [float(v) for v in bda.reshape(-1)] + [float(v) for v in self.xyz_min] + \
+            [float(v) for v in self.xyz_max] + \
+            [float(self.bg_len), float(self.act_shift[0]), float(interval), float(dist_thres),
+             float(self.fast_color_thres), float(self.radius)]
+        return vals
+
+    @torch.no_grad()
+    def render(self, grid, rays_o, rays_d, bda, want_debug=False):
+        """grid: packed (Z,Y,X,24) attribute grid; rays (R,3); bda (3,3)."""
+        return ops.render_rays(rays_o.float().contiguous(), rays_d.float().contiguous(),
+                               self.t_table(grid.device), grid, self.consts(bda.cpu()),
+                               want_debug=want_debug)
+
+    def compute_loss(self, out, target_depth, target_semantic, target_color, suffix=''):
+        """nerf_head.py:271-329 on the fused kernel's outputs."""
+        losses = {}
+        if self.use_depth_sup:
+            d = torch.log(out['depth'] + 1e-7) - torch.log(target_depth)
+            losses['loss_render_depth' + suffix] = \
+                torch.sqrt((d ** 2).mean() - 0.85 * (d.mean() ** 2)) * self.weight_depth
+        crit = nn.CrossEntropyLoss(weight=self.class_weights.type_as(out['semantic']), reduction='mean')
+        losses['loss_render_semantic' + suffix] = crit(out['semantic'], target_semantic.long()) * self.weight_semantic
+        losses['loss_render_color' + suffix] = \
+            torch.sum(torch.mean(torch.abs(out['color'] - target_color), dim=0)) * self.weight_color
+        if self.weight_entropy_last > 0:
+            p = out['alphainv_last'].clamp(1e-6, 1 - 1e-6)
+            losses['loss_sdf_entropy' + suffix] = self.weight_entropy_last * \
+                -(p * torch.log(p) + (1 - p) * torch.log(1 - p)).mean()
+        if self.weight_distortion > 0 and 'weights' in out:
+            w = out['weights']                                   # (R,S) dense, 0 where culled
+            t = self.t_table(w.device)
+            s = (1 - 1 / (1 + t))[None]
+            kept = w > 0
+            n_max = kept.sum().clamp_min(1)
+            rays_with = kept.any(1).nonzero()
+            n_rays = (rays_with.max() + 1) if rays_with.numel() else torch.ones((), device=w.device)
+            wm = w * s
+            w_pre = torch.cumsum(w, 1) - w
+            wm_pre = torch.cumsum(wm, 1) - wm
+            loss = ((1 / 3) * (1.0 / n_max) * w.pow(2)).sum() + (2 * w * (s * w_pre - wm_pre)).sum()
+            losses['loss_sdf_distortion' + suffix] = self.weight_distortion * loss / n_rays
+        return losses
+
+    def forward(self, density, semantic, color, if_pretrain=False, if_temporal=False,
+                dataset_type='Nuscenes', rays=None, bda=None, interval=0, **kwargs):
+        """Same signature as nerf_head.py:361-420.  density (B,X,Y,Z), semantic (B,X,Y,Z,17),
+        color (B,X,Y,Z,3), rays (B,R,16), bda (B,3,3) -> dict of scalar losses."""
+        assert dataset_type == 'Nuscenes'
+        if torch.is_grad_enabled() and (density.requires_grad or semantic.requires_grad):
+            raise NotImplementedError('NerfHead HIP path is forward-only in this build')
+        losses = {}
+        suffix = '_%ds' % int(interval) if if_temporal else ''
+        for b in range(rays.shape[0]):
+            gt_depth = rays[b, :, 2]
+            gt_depth[gt_depth > 52] = 0                          # in-place, like :379
+            mask = gt_depth > 0
+            grid = pack_attribute_grid(density[b].float(), semantic[b].float(), color[b].float())
+            out = ops.render_rays(rays[b, :, 4:7][mask].float().contiguous(),
+                                  rays[b, :, 7:10][mask].float().contiguous(),
+                                  self.t_table(grid.device), grid, self.consts(bda[b].cpu()),
+                                  want_debug=self.weight_distortion > 0)
+            single = self.compute_loss(out, gt_depth[mask], rays[b, :, 3][mask], rays[b, :, 13:16][mask],
+                                       suffix)
+            for k, v in single.items():
+                losses[k] = losses[k] + v if k in losses else v
+        for k in losses:
+            losses[k] = losses[k] / semantic.shape[0]
+        return losses

@@ -363,3 +363,179 @@ def softplus(x):
     y = torch.empty_like(x)
     _lib.call('pw_softplus', _chk(x, _f32, 'x'), _p(y), x.numel(), _stream())
     return y
+
+
+# ------------------------------------------------------------------------------ attribute MLPs
+def _row_of(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def _mfma_pack_indices(n_tiles):
+    """index helpers for the transposed MFMA chain (see pw_forecast.hip): for packed position
+    [t][q][lane][e] returns (tile-row i, k index row_of(4q+e, lane>>5))."""
+    import numpy as np
+    t, q, lane, e = np.meshgrid(np.arange(n_tiles), np.arange(4), np.arange(64), np.arange(4),
+                                indexing='ij')
+    i, h = lane & 31, lane >> 5
+    k = ((4 * q + e) & 3) + 8 * ((4 * q + e) >> 2) + 4 * h
+    return t, i, k
+
+
+def pack_attr_mlp(density_mlp, semantic_mlp, color_mlp):
+    """nn.Sequential(Linear(32,64), Softplus, Linear(64,n)[, Softplus]) x3 -> (w1p, w2p, b1p, b2)
+    in the operand order pw_attr_mlp consumes."""
+    import numpy as np
+    dev = density_mlp[0].weight.device
+    W1 = torch.cat([m[0].weight for m in (density_mlp, semantic_mlp, color_mlp)], 0).float()   # (192,32)
+    b1 = torch.cat([m[0].bias for m in (density_mlp, semantic_mlp, color_mlp)], 0).float()     # (192)
+    W2 = torch.zeros(32, 192, device=dev)
+    b2 = torch.zeros(32, device=dev)
+    row = 0
+    for blk, m in enumerate((density_mlp, semantic_mlp, color_mlp)):
+        n = m[2].weight.shape[0]
+        W2[row:row + n, blk * 64:(blk + 1) * 64] = m[2].weight.float()
+        b2[row:row + n] = m[2].bias.float()
+        row += n
+    assert row == 22
+    t, i, k = _mfma_pack_indices(6)
+    ti, ii, ki = [torch.from_numpy(a.reshape(-1)).to(dev) for a in (t, i, k)]
+    w1p = W1[ti * 32 + ii, ki].contiguous()                       # W1[t*32+i][k]
+    w2p = W2[ii, ti * 32 + ki].contiguous()                       # W2[i][t*32+k]
+    hh, tt, rr = np.meshgrid(np.arange(2), np.arange(6), np.arange(16), indexing='ij')
+    idx = tt * 32 + ((rr & 3) + 8 * (rr >> 2) + 4 * hh)
+    b1p = b1[torch.from_numpy(idx.reshape(-1)).to(dev)].contiguous()
+    return w1p, w2p, b1p, b2.contiguous()
+
+
+def attr_mlp(v_cl, packed, final_softplus=True, out=None):
+    """v_cl (..., 32) channels-last -> packed attribute grid (..., 24):
+    [0:2] density_prob, [2:19] semantic, [19:22] color (preworld_temporal_traj.py:231-236)."""
+    w1p, w2p, b1p, b2 = packed
+    n = v_cl.numel() // 32
+    if out is None:
+        out = torch.empty(tuple(v_cl.shape[:-1]) + (24,), device=v_cl.device, dtype=_f32)
+    _lib.call('pw_attr_mlp', _chk(v_cl, _f32, 'v'), n, _chk(w1p, _f32, 'w1p'), _chk(w2p, _f32, 'w2p'),
+              _chk(b1p, _f32, 'b1p'), _chk(b2, _f32, 'b2'), int(final_softplus), _chk(out, _f32, 'out'),
+              _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------ render ops
+_i64 = torch.int64
+
+
+def raw2alpha(density, shift, interval):
+    """render_utils_cuda.raw2alpha (render_utils.cpp:120-124) -> (exp, alpha)."""
+    d = density.contiguous()
+    e = torch.empty_like(d)
+    a = torch.empty_like(d)
+    _lib.call('pw_raw2alpha', _chk(d, _f32, 'density'), float(shift), float(interval), d.numel(),
+              _p(e), _p(a), _stream())
+    return e, a
+
+
+def raw2alpha_backward(exp, grad_back, interval):
+    g = torch.empty_like(exp)
+    _lib.call('pw_raw2alpha_backward', _chk(exp, _f32, 'exp'), _chk(grad_back.contiguous(), _f32, 'grad_back'),
+              float(interval), exp.numel(), _p(g), _stream())
+    return g
+
+
+def alpha2weight(alpha, ray_id, n_rays):
+    """render_utils_cuda.alpha2weight (render_utils.cpp:142-149) ->
+    (weight, T, alphainv_last, i_start, i_end)."""
+    a = alpha.contiguous()
+    n = a.numel()
+    dev = a.device
+    w = torch.empty(n, device=dev, dtype=_f32)
+    T = torch.empty(n, device=dev, dtype=_f32)
+    last = torch.empty(n_rays, device=dev, dtype=_f32)
+    i_s = torch.empty(n_rays, device=dev, dtype=_i64)
+    i_e = torch.empty(n_rays, device=dev, dtype=_i64)
+    _lib.call('pw_alpha2weight', _chk(a, _f32, 'alpha'), _chk(ray_id.contiguous(), _i64, 'ray_id'), n,
+              int(n_rays), _p(w), _p(T), _p(last), _p(i_s), _p(i_e), _stream())
+    return w, T, last, i_s, i_e
+
+
+def alpha2weight_backward(alpha, weight, T, alphainv_last, i_start, i_end, n_rays, grad_weights,
+                          grad_last):
+    g = torch.empty_like(alpha)
+    _lib.call('pw_alpha2weight_backward', _chk(alpha, _f32, 'alpha'), _chk(weight, _f32, 'weight'),
+              _chk(T, _f32, 'T'), _chk(alphainv_last, _f32, 'alphainv_last'), _chk(i_start, _i64, 'i_start'),
+              _chk(i_end, _i64, 'i_end'), int(n_rays), _chk(grad_weights.contiguous(), _f32, 'grad_weights'),
+              _chk(grad_last.contiguous(), _f32, 'grad_last'), alpha.numel(), _p(g), _stream())
+    return g
+
+
+def cumdist_thres(dist, thres):
+    """ub360_utils_cuda.cumdist_thres (ub360_utils.cpp:15-18): (R,S) float -> bool mask."""
+    d = dist.contiguous()
+    R, S = d.shape
+    m = torch.empty(R, S, device=d.device, dtype=torch.uint8)
+    _lib.call('pw_cumdist_thres', _chk(d, _f32, 'dist'), float(thres), R, S, _p(m), _stream())
+    return m.bool()
+
+
+class Raw2Alpha(torch.autograd.Function):
+    """Drop-in for mmdet3d/models/nerf/utils.py:26-50."""
+
+    @staticmethod
+    def forward(ctx, density, shift, interval):
+        exp, alpha = raw2alpha(density, shift, interval)
+        if density.requires_grad:
+            ctx.save_for_backward(exp)
+            ctx.interval = interval
+        return alpha
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_back):
+        exp = ctx.saved_tensors[0]
+        return raw2alpha_backward(exp, grad_back.contiguous(), ctx.interval), None, None
+
+
+class Alphas2Weights(torch.autograd.Function):
+    """Drop-in for mmdet3d/models/nerf/utils.py:52-68."""
+
+    @staticmethod
+    def forward(ctx, alpha, ray_id, N):
+        weights, T, alphainv_last, i_start, i_end = alpha2weight(alpha, ray_id, N)
+        if alpha.requires_grad:
+            ctx.save_for_backward(alpha, weights, T, alphainv_last, i_start, i_end)
+            ctx.n_rays = N
+        return weights, alphainv_last
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_weights, grad_last):
+        alpha, weights, T, alphainv_last, i_start, i_end = ctx.saved_tensors
+        grad = alpha2weight_backward(alpha, weights, T, alphainv_last, i_start, i_end, ctx.n_rays,
+                                     grad_weights, grad_last)
+        return grad, None, None
+
+
+def render_rays(rays_o, rays_d, t, grid, consts, c_sigma=0, c_sem=2, n_sem=17, c_rgb=19,
+                want_debug=False):
+    """Fused forward of NerfHead.render_one_scene + render_depth/semantic/color
+    (nerf_head.py:165-269,331-353).  grid: packed (Z,Y,X,GC) attribute grid.  consts: 27 floats
+    (see include/preworld_hip.h).  Returns dict(depth (R), semantic (R,17), color (R,3),
+    alphainv_last (R) [, counts (R,3), weights (R,S), mask (R,S)])."""
+    R, S = rays_o.shape[0], t.numel()
+    Z, Y, X, GC = grid.shape
+    dev = rays_o.device
+    depth = torch.empty(R, device=dev, dtype=_f32)
+    sem = torch.empty(R, n_sem, device=dev, dtype=_f32)
+    rgb = torch.empty(R, 3, device=dev, dtype=_f32)
+    last = torch.empty(R, device=dev, dtype=_f32)
+    counts = torch.empty(R, 3, device=dev, dtype=_i32) if want_debug else None
+    weights = torch.empty(R, S, device=dev, dtype=_f32) if want_debug else None
+    mask = torch.empty(R, S, device=dev, dtype=torch.uint8) if want_debug else None
+    ch = (ctypes.c_float * 27)(*[float(v) for v in consts])
+    _lib.call('pw_render_rays', _chk(rays_o.contiguous(), _f32, 'rays_o'),
+              _chk(rays_d.contiguous(), _f32, 'rays_d'), R, _chk(t, _f32, 't'), S,
+              _chk(grid, _f32, 'grid'), X, Y, Z, GC, c_sigma, c_sem, n_sem, c_rgb, ch, _p(depth),
+              _p(sem), _p(rgb), _p(last), _p(counts), _p(weights), _p(mask), _stream())
+    out = dict(depth=depth, semantic=sem, color=rgb, alphainv_last=last)
+    if want_debug:
+        out.update(counts=counts, weights=weights, mask=mask.bool())
+    return out

@@ -1,0 +1,189 @@
+"""GPU parity: volume-rendering head (reference-ABI ops + the fused one-wave-per-ray forward)
+and the fused attribute MLPs, against the CPU oracle and the golden vectors generated from the
+imported reference NerfHead."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from preworld_amd import modules as M
+from preworld_amd import ops
+from preworld_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _head():
+    return M.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4,
+                      scene_center=[0, 0, 2.2], radius=39, use_depth_sup=True).to(DEV)
+
+
+def test_reference_abi_ops_vs_oracle():
+    rs = np.random.RandomState(0)
+    dens = (rs.standard_normal(5000) * 6).astype(np.float32)
+    shift = float(np.log(1 / (1 - 1e-6) - 1))
+    e, a = ops.raw2alpha(T(dens), shift, 0.5)
+    oe, oa = O.raw2alpha(dens, shift, 0.5)
+    np.testing.assert_allclose(e.cpu().numpy(), oe, rtol=2e-6)
+    np.testing.assert_allclose(a.cpu().numpy(), oa, rtol=1e-5, atol=2e-7)
+    gb = rs.standard_normal(5000).astype(np.float32)
+    g = ops.raw2alpha_backward(e, T(gb), 0.5)
+    np.testing.assert_allclose(g.cpu().numpy(), O.raw2alpha_backward(oe, gb, 0.5), rtol=2e-5, atol=1e-12)
+    # alpha2weight on ragged segments incl. empty rays and an early-terminating ray
+    n_rays = 40
+    lens = rs.randint(0, 60, n_rays)
+    lens[3] = 0
+    ray_id = np.repeat(np.arange(n_rays), lens)
+    alpha = (rs.rand(ray_id.size) * 0.15).astype(np.float32)
+    alpha[ray_id == 5] = 0.9
+    w, Tt, last, i_s, i_e = ops.alpha2weight(T(alpha), T(ray_id), n_rays)
+    ow, oT, olast, ois, oie = O.alpha2weight(alpha, ray_id, n_rays)
+    np.testing.assert_array_equal(w.cpu().numpy(), ow)          # same op order, same double step
+    np.testing.assert_array_equal(Tt.cpu().numpy(), oT)
+    np.testing.assert_array_equal(last.cpu().numpy(), olast)
+    np.testing.assert_array_equal(i_s.cpu().numpy(), ois)
+    np.testing.assert_array_equal(i_e.cpu().numpy(), oie)
+    gw = rs.standard_normal(alpha.size).astype(np.float32)
+    gl = rs.standard_normal(n_rays).astype(np.float32)
+    g = ops.alpha2weight_backward(T(alpha), w, Tt, last, i_s, i_e, n_rays, T(gw), T(gl))
+    og = O.alpha2weight_backward(alpha, ow, oT, olast, ois, oie, n_rays, gw, gl)
+    np.testing.assert_allclose(g.cpu().numpy(), og, rtol=1e-6, atol=1e-7)
+    # autograd wrappers (same names as mmdet3d/models/nerf/utils.py)
+    at = T(alpha).requires_grad_()
+    ww, ll = ops.Alphas2Weights.apply(at, T(ray_id), n_rays)
+    ((ww * T(gw)).sum() + (ll * T(gl)).sum()).backward()
+    np.testing.assert_allclose(at.grad.cpu().numpy(), og, rtol=1e-6, atol=1e-7)
+    # cumdist_thres
+    dist = (rs.rand(17, 416) * 0.004).astype(np.float32)
+    m = ops.cumdist_thres(T(dist), 0.0048718)
+    np.testing.assert_array_equal(m.cpu().numpy(), O.cumdist_thres(dist, 0.0048718))
+    # empty inputs are fine
+    e0, a0 = ops.raw2alpha(torch.empty(0, device=DEV), shift, 0.5)
+    assert e0.numel() == 0
+    w0 = ops.alpha2weight(torch.empty(0, device=DEV), torch.empty(0, device=DEV, dtype=torch.int64), 3)
+    assert float(w0[2].sum()) == 3.0
+
+
+def _oracle_render(o, d, bda, density, semantic, color):
+    consts = O.NerfConsts()
+    res = O.render_one_scene(o, d, bda, density, semantic, color, consts)
+    depth, sem, col = O.render_outputs(res, consts)
+    return res, depth, sem, col
+
+
+@pytest.mark.parametrize('R', [64, 513])
+def test_fused_render_vs_oracle(R):
+    head = _head()
+    density, semantic, color = S.render_grids(31)
+    o, d = S.rays(32 + R, R)
+    bda = np.array([[0.98, 0.05, 0.0], [-0.05, 0.98, 0.0], [0.0, 0.0, 1.0]], np.float32)
+    grid = M.pack_attribute_grid(T(density), T(semantic), T(color))
+    out = head.render(grid, T(o), T(d), torch.from_numpy(bda), want_debug=True)
+    res, depth, sem, col = _oracle_render(o, d, bda, density, semantic, color)
+    # the three compactions: sample mask bit-exact, counts equal up to libm-last-bit flips
+    assert (out['mask'].cpu().numpy() == res['sample_mask']).mean() > 0.9999
+    n_kept = int(out['counts'][:, 2].sum())
+    assert abs(n_kept - len(res['weights'])) <= max(2, len(res['weights']) // 5000)
+    np.testing.assert_allclose(out['alphainv_last'].cpu().numpy(), res['alphainv_last'], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(out['depth'].cpu().numpy(), depth, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out['semantic'].cpu().numpy(), sem, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out['color'].cpu().numpy(), col, rtol=2e-4, atol=2e-4)
+    # dense weights == the oracle's compacted weights scattered back
+    dense = np.zeros((R, 417), np.float32)
+    dense[res['ray_id'], res['step_id']] = res['weights']
+    np.testing.assert_allclose(out['weights'].cpu().numpy(), dense, rtol=2e-4, atol=2e-7)
+
+
+def test_fused_render_golden(golden):
+    """against tensors produced by the imported reference NerfHead (tests/golden/render_small.npz)"""
+    g = golden('render_small.npz')
+    head = _head()
+    np.testing.assert_array_equal(head.t_table('cpu').numpy(), g['t'])
+    np.testing.assert_allclose(head.xyz_min.cpu().numpy(), g['xyz_min'], rtol=1e-6)
+    density, semantic, color = S.render_grids(int(g['seed_grid']))
+    o, d = S.rays(int(g['seed_rays']), int(g['R']))
+    grid = M.pack_attribute_grid(T(density), T(semantic), T(color))
+    out = head.render(grid, T(o), T(d), torch.from_numpy(g['bda']), want_debug=True)
+    assert (out['mask'].cpu().numpy()[:, :] == (g['inner_mask'] | out['mask'].cpu().numpy())).all()
+    np.testing.assert_allclose(out['alphainv_last'].cpu().numpy(), g['alphainv_last'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(out['depth'].cpu().numpy(), g['render_depth'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(out['semantic'].cpu().numpy(), g['render_semantic'], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(out['color'].cpu().numpy(), g['render_color'], rtol=1e-3, atol=1e-3)
+    w = out['weights'].cpu().numpy()
+    assert abs(int((w > 0).sum()) - len(g['weights'])) <= 2
+
+
+def test_render_edge_cases():
+    head = _head()
+    density, semantic, color = S.render_grids(5)
+    grid = M.pack_attribute_grid(T(density), T(semantic), T(color))
+    bda = torch.eye(3)
+    # zero rays
+    out = head.render(grid, torch.empty(0, 3, device=DEV), torch.empty(0, 3, device=DEV), bda)
+    assert out['depth'].numel() == 0
+    # a ray that never enters the grid (points straight up from above): sigma = 0 everywhere ->
+    # alpha = 1-(1+1e-6)^-0.5 ~ 5e-7 > 1e-7, so samples survive the first cull
+    o = T(np.array([[0.0, 0.0, 30.0]], np.float32))
+    d = T(np.array([[0.0, 0.0, 1.0]], np.float32))
+    out = head.render(grid, o, d, bda, want_debug=True)
+    assert int(out['counts'][0, 1]) > 0
+    assert float(out['alphainv_last'][0]) > 0.99
+    # opaque grid: the ray saturates and stops early (T < 1e-3)
+    g2 = grid.clone()
+    g2[..., 0] = 30.0
+    o, d = S.rays(9, 8)
+    out = head.render(g2, T(o), T(d), bda, want_debug=True)
+    assert float(out['alphainv_last'].max()) < 1e-3
+    assert int(out['counts'][:, 2].max()) <= 3
+
+
+def test_attr_mlp_vs_oracle_and_golden(golden):
+    g = golden('forecast_small.npz')
+    sd = S.synth_state_dict(int(g['seed_sd']))
+    from test_gpu_encoder import _load_net
+    net, _ = _load_net(int(g['seed_sd']))
+    v = np.random.RandomState(int(g['seed_v'])).standard_normal((1, 8, 8, 4, 32)).astype(np.float32)
+    with torch.no_grad():
+        grid = net.attributes_cl(T(v))
+    np.testing.assert_allclose(grid[..., 0:2].cpu().numpy(), g['density'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(grid[..., 2:19].cpu().numpy(), g['semantic'], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(grid[..., 19:22].cpu().numpy(), g['color'], rtol=2e-4, atol=2e-4)
+    assert float(grid[..., 22:].abs().max()) == 0.0
+    # ragged voxel count + threshold decode vs the oracle
+    v2 = np.random.RandomState(3).standard_normal((1, 3, 5, 7, 32)).astype(np.float32) * 3
+    with torch.no_grad():
+        grid2 = net.attributes_cl(T(v2))
+        occ = net.attribute_decode(grid2)
+    o_occ, o_dens, o_sem = O.attribute_decode(v2, sd)
+    np.testing.assert_allclose(grid2[..., 0].cpu().numpy(), o_dens, rtol=2e-4, atol=2e-5)
+    assert (occ.cpu().numpy() == o_occ).mean() > 0.995
+
+
+def test_nerf_head_losses_vs_oracle():
+    """NerfHead.forward (reference signature) -> loss dict, against the oracle's fp64 losses."""
+    head = _head()
+    density, semantic, color = S.render_grids(41)
+    R = 96
+    o, d = S.rays(42, R)
+    rs = np.random.RandomState(43)
+    rays = np.zeros((1, R, 16), np.float32)
+    rays[0, :, 2] = rs.uniform(1, 60, R)            # gt depth, some > 52 get dropped
+    rays[0, :, 3] = rs.randint(0, 17, R)
+    rays[0, :, 4:7] = o
+    rays[0, :, 7:10] = d
+    rays[0, :, 13:16] = rs.standard_normal((R, 3))
+    bda = np.eye(3, dtype=np.float32)[None]
+    with torch.no_grad():
+        losses = head(T(density)[None], T(semantic)[None], T(color)[None], rays=T(rays), bda=T(bda))
+    keep = (rays[0, :, 2] <= 52) & (rays[0, :, 2] > 0)
+    res, depth, sem, col = _oracle_render(o[keep], d[keep], bda[0], density, semantic, color)
+    cw = 1 / np.log(M.nusc_class_frequencies[:17] + 0.001)
+    ol = O.nerf_losses(res, depth, sem, col, rays[0, keep, 2], rays[0, keep, 3], rays[0, keep, 13:16], cw)
+    for k in ('loss_render_depth', 'loss_render_semantic', 'loss_render_color', 'loss_sdf_entropy',
+              'loss_sdf_distortion'):
+        assert abs(float(losses[k]) - ol[k]) <= 2e-3 * abs(ol[k]) + 1e-6, (k, float(losses[k]), ol[k])
