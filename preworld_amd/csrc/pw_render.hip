@@ -140,7 +140,8 @@ PW_API int pw_alpha2weight(const float* alpha, const int64_t* ray_id, int64_t n_
                            float* weight, float* T, float* alphainv_last, int64_t* i_start,
                            int64_t* i_end, void* stream) {
   PW_CHECK_ARG(n_pts >= 0 && n_rays >= 0, "pw_alpha2weight: bad sizes");
-  PW_CHECK_ARG(weight && T && alphainv_last && i_start && i_end, "pw_alpha2weight: null output");
+  PW_CHECK_ARG((n_pts == 0 || (weight && T)) && (n_rays == 0 || (alphainv_last && i_start && i_end)),
+               "pw_alpha2weight: null output");
   hipStream_t st = pw_stream(stream);
   int64_t m = n_pts > n_rays ? n_pts : n_rays;
   if (m == 0) return PW_OK;

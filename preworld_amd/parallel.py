@@ -1,0 +1,72 @@
+"""Multi-GPU modes for the hot path (one process per GPU, torch.distributed; backend 'nccl' is
+RCCL over xGMI on ROCm, 'gloo' in the CPU tests).
+
+* replicas (throughput mode, what bench.py measures): samples are independent, so each rank
+  runs its own sample stream; the data path has NO collective (the reference is plain DDP with
+  one sample per rank at test time, tools/dist_test.sh + apis/test.py:198-223).
+* state-sharded decode (latency mode for ONE sample, BASELINE.json configs[3]): every rank holds
+  the encoder output v0; rank r owns the output states {r, r+W, ...}.  State k is k applications
+  of the pointwise residual MLP (preworld_temporal_traj.py:335-342) followed by OccHead, so a
+  rank recomputes the cheap recursion locally up to its largest owned state and decodes only its
+  own states; ONE all_gather of uint8 grids (0.64 MB each) assembles the 7 states everywhere.
+* frame-sharded lift (the literal north_star wording): input frame f (key / adjacent) is lifted,
+  pooled and pre-processed on rank f % W and its (B,Z,Y,X,32) fp32 feature (81.92 MB) is
+  broadcast before cat + bev_encoder (bevdet_occ.py:266-267).  xGMI is point-to-point
+  (7 links x ~153 GB/s per GPU): a broadcast/all-gather of one 81.92 MB shard costs ~0.5 ms
+  direct vs ~3.7 ms around a ring, i.e. comparable to the ~1 ms of lift+pre_process it saves --
+  which is why replicas, not this mode, is the throughput mode.
+"""
+import torch
+import torch.distributed as dist
+
+
+def owned_states(n_states, rank, world):
+    """round-robin ownership: cheap states (few recursion steps) and expensive ones interleave"""
+    return list(range(rank, n_states, world))
+
+
+def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None):
+    """v0: encoder output on every rank.  forecast_fn(v0, k) -> state-k features (k >= 1 applications
+    of the recursion); decode_fn(features) -> uint8 occupancy grid.  Returns the list of all
+    n_states grids (identical on every rank)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = owned_states(n_states, rank, world)
+    local = {}
+    for k in mine:
+        feats = v0 if k == 0 else forecast_fn(v0, k)
+        local[k] = decode_fn(feats)
+    if world == 1:
+        return [local[k] for k in range(n_states)]
+    # pad every rank to the same number of slots so one all_gather moves everything
+    slots = (n_states + world - 1) // world
+    ref = next(iter(local.values())) if local else decode_fn(v0)
+    send = torch.zeros((slots,) + tuple(ref.shape), dtype=ref.dtype, device=ref.device)
+    for i, k in enumerate(mine):
+        send[i] = local[k]
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    out = [None] * n_states
+    for r in range(world):
+        for i, k in enumerate(owned_states(n_states, r, world)):
+            out[k] = recv[r][i]
+    return out
+
+
+def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None):
+    """frames: list of per-frame inputs (present on every rank); frame f is lifted by rank f % W
+    and broadcast.  Returns the list of lifted features on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    outs = []
+    for f, fr in enumerate(frames):
+        owner = f % world
+        if owner == rank:
+            buf = lift_fn(fr).contiguous()
+            assert tuple(buf.shape) == tuple(out_shape)
+        else:
+            buf = torch.empty(out_shape, dtype=dtype, device=device)
+        if world > 1:
+            dist.broadcast(buf, src=owner, group=group)
+        outs.append(buf)
+    return outs
