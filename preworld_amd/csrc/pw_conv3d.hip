@@ -27,6 +27,8 @@
 // conv1 and downsample (same input) run as ONE pass over the input with N = 2 x Cout.
 #include "pw_common.h"
 
+#include <stdlib.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -54,6 +56,7 @@ struct ConvArgs {
   int n1_start;           // first packed column that goes to y1
   int relu0, relu1;
   int tiles_d, tiles_h, tiles_w;
+  long long* probe;       // optional per-block phase timestamps (development aid) or null
 };
 
 // MFMA row (0..31) -> voxel of the 4x8 patch, chosen for conflict-free ds_read_b128 groups
@@ -77,6 +80,52 @@ __device__ __forceinline__ void store_out(const ConvArgs& a, int n, size_t vox, 
       a.y1[vox * a.cout1 + n1] = v;
     }
   }
+}
+
+// stage the 6x10x10 halo tile of one 32-channel chunk: global -> registers -> swizzled LDS.
+// All 19 loads are issued before the first LDS write; zero padding comes from the bounds test.
+__device__ __forceinline__ void stage_halo_chunk(const ConvArgs& a, float* lds, int b, int d0, int h0,
+                                                 int w0, int ch, int tid, long long* ts = nullptr) {
+  // Two waves share each SIMD and instruction issue is arbitrated by priority, then age: next to
+  // a partner that streams MFMAs this ~1000-instruction address/load/ds_write phase was measured
+  // at ~37 cycles per instruction (31k cycles, vs 1.4k actually waiting for the loads).  Run the
+  // non-MFMA phases at high priority; they are short, so the partner's MFMA stream barely moves.
+  __builtin_amdgcn_s_setprio(3);
+  float4 tmp[STAGE_ITERS];
+#pragma unroll
+  for (int k = 0; k < STAGE_ITERS; ++k) {
+    int it = tid + k * 256;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (it < STAGE_ITEMS) {
+      int vox = it >> 3, slot = it & 7;
+      int dd = vox / (TH * TW);
+      int rem = vox - dd * (TH * TW);
+      int hh = rem / TW, ww = rem - hh * TW;
+      int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + ww - 1;
+      if ((unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W) {
+        size_t g = ((((size_t)b * a.D + gd) * a.H + gh) * a.W + gw) * a.Cin + ch * KC + slot * 4;
+        v = *reinterpret_cast<const float4*>(a.x + g);
+      }
+    }
+    tmp[k] = v;
+  }
+  if (ts) { ts[0] = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[1] = __builtin_readcyclecounter(); }
+  if (ch > 0) __syncthreads();   // every wave finished reading the previous chunk
+#pragma unroll
+  for (int k = 0; k < STAGE_ITERS; ++k) {
+    int it = tid + k * 256;
+    if (it < STAGE_ITEMS) {
+      int vox = it >> 3, slot = it & 7;
+      int dd = vox / (TH * TW);
+      int rem = vox - dd * (TH * TW);
+      int hh = rem / TW, ww = rem - hh * TW;
+      int f = ((ww >> 1) & 3) | ((hh & 1) << 2);
+      *reinterpret_cast<float4*>(lds + ((vox << 3) + (slot ^ f)) * 4) = tmp[k];
+    }
+  }
+  if (ts) ts[2] = __builtin_readcyclecounter();
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
 }
 
 template <int NT>
@@ -156,41 +205,12 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_k3s1(ConvArgs a, OccTail tail
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const int nchunk = a.Cin / KC;
+  long long t_start = 0, t_staged = 0, t_taps = 0, t_s0 = 0, t_s1 = 0, t_s2 = 0;
+  if (a.probe) t_start = __builtin_readcyclecounter();
   for (int ch = 0; ch < nchunk; ++ch) {
-    // ---- stage the halo tile of this channel chunk: global -> registers -> LDS
-    float4 tmp[STAGE_ITERS];
-#pragma unroll
-    for (int k = 0; k < STAGE_ITERS; ++k) {
-      int it = tid + k * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < STAGE_ITEMS) {
-        int vox = it >> 3, slot = it & 7;
-        int dd = vox / (TH * TW);
-        int rem = vox - dd * (TH * TW);
-        int hh = rem / TW, ww = rem - hh * TW;
-        int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + ww - 1;
-        if ((unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H &&
-            (unsigned)gw < (unsigned)a.W) {
-          size_t g = ((((size_t)b * a.D + gd) * a.H + gh) * a.W + gw) * a.Cin + ch * KC + slot * 4;
-          v = *reinterpret_cast<const float4*>(a.x + g);
-        }
-      }
-      tmp[k] = v;
-    }
-    if (ch > 0) __syncthreads();   // every wave finished reading the previous chunk
-#pragma unroll
-    for (int k = 0; k < STAGE_ITERS; ++k) {
-      int it = tid + k * 256;
-      if (it < STAGE_ITEMS) {
-        int vox = it >> 3, slot = it & 7;
-        int dd = vox / (TH * TW);
-        int rem = vox - dd * (TH * TW);
-        int hh = rem / TW, ww = rem - hh * TW;
-        int f = ((ww >> 1) & 3) | ((hh & 1) << 2);
-        *reinterpret_cast<float4*>(lds + ((vox << 3) + (slot ^ f)) * 4) = tmp[k];
-      }
-    }
-    __syncthreads();
+    long long ts[3] = {0, 0, 0};
+    stage_halo_chunk(a, lds, b, d0, h0, w0, ch, tid, (a.probe && ch == 0) ? ts : nullptr);
+    if (a.probe && ch == 0) { t_staged = __builtin_readcyclecounter(); t_s0 = ts[0]; t_s1 = ts[1]; t_s2 = ts[2]; }
 
     // ---- 27 taps x 16 k-steps
     const float* wch = a.wpk + ((size_t)ch * 27 * ntiles_total + (size_t)ng * NT) * 1024 + lane * 16;
@@ -215,8 +235,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_k3s1(ConvArgs a, OccTail tail
     tap_mfma<NT>(lds, 26, wave, half, pr, pc, b0, acc);
   }
 
-  // ---- epilogue
+  // ---- epilogue (high issue priority, see stage_halo_chunk)
   const int od = d0 + wave;
+  if (a.probe) t_taps = __builtin_readcyclecounter();
+  __builtin_amdgcn_s_setprio(3);
   if constexpr (EPI == 0) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -235,6 +257,16 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_k3s1(ConvArgs a, OccTail tail
             store_out(a, n, vox, acc[mt][nt][r] * sc + bi);
           }
         }
+      }
+    }
+    if (a.probe) {
+      const long long t_issued = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long long t_drained = __builtin_readcyclecounter();
+      if (lane == 0) {
+        long long* p = a.probe + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        p[0] = t_start; p[1] = t_s0; p[2] = t_s1; p[3] = t_s2; p[4] = t_staged; p[5] = t_taps;
+        p[6] = t_issued; p[7] = t_drained;
       }
     }
   } else {
@@ -287,6 +319,129 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_k3s1(ConvArgs a, OccTail tail
       }
       tail.occ[vox] = (uint8_t)arg;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// OccHead on v_mfma_f32_16x16x4_f32: the head's 3x3x3 conv has only 16 output channels, which
+// would leave half of a 32-wide N tile empty; the 16x16x4 shape (same FLOP rate) has no waste.
+//   lane l: A[voxel = l&15][k = l>>4], B[k = l>>4][cout = l&15]; D: col l&15, rows (l>>4)*4 + reg.
+// A wave owns the 4 M-tiles (2x8 voxels each) of one d-slice of the 4x8x8 block tile; the four
+// accumulators are independent, which covers the 40-cycle dependent latency at 32-cycle issue.
+// K order inside a (chunk, tap): k-group g = l>>4 walks channels g*8 .. g*8+7 (2 x ds_read_b128,
+// 2 x global_load_dwordx4 of packed weights [chunk][tap][lane][8]).
+// ------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_b16(const float* w, float4 (&b)[2]) {
+  b[0] = *reinterpret_cast<const float4*>(w);
+  b[1] = *reinterpret_cast<const float4*>(w + 4);
+}
+
+__device__ __forceinline__ void tap_mfma16(const float* lds, int tap, int wave, int g, int i,
+                                           const float4 (&b)[2], f32x4 (&acc)[4]) {
+  const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+  float4 aq[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int hh = mt * 2 + (i >> 3) + kh, ww = (i & 7) + kw, dd = wave + kd;
+    const int vl = (dd * TH + hh) * TW + ww;
+    const int f = ((ww >> 1) & 3) | ((hh & 1) << 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      aq[mt][q] = *reinterpret_cast<const float4*>(lds + ((vl << 3) + ((g * 2 + q) ^ f)) * 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float bv[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const float av[4] = {aq[mt][q].x, aq[mt][q].y, aq[mt][q].z, aq[mt][q].w};
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[mt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_occ_head16(ConvArgs a, OccTail tail) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  int bid = blockIdx.x;
+  const int tw = bid % a.tiles_w; bid /= a.tiles_w;
+  const int th = bid % a.tiles_h; bid /= a.tiles_h;
+  const int td = bid % a.tiles_d;
+  const int b = bid / a.tiles_d;
+  const int d0 = td * BD, h0 = th * BH, w0 = tw * BW;
+  f32x4 acc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[mt][r] = 0.f;
+  const int nchunk = a.Cin / KC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    stage_halo_chunk(a, lds, b, d0, h0, w0, ch, tid);
+    const float* wch = a.wpk + (size_t)ch * 27 * 512 + lane * 8;
+    float4 b0[2], b1[2];
+    load_b16(wch, b0);
+#pragma unroll 1
+    for (int tap = 0; tap < 26; tap += 2) {
+      load_b16(wch + (size_t)(tap + 1) * 512, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      tap_mfma16(lds, tap, wave, g, i, b0, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b16(wch + (size_t)(tap + 2) * 512, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      tap_mfma16(lds, tap + 1, wave, g, i, b1, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    tap_mfma16(lds, 26, wave, g, i, b0, acc);
+  }
+  // ---- tail: BN+ReLU, transpose 64 voxels x 16 channels through LDS, per-voxel MLP + argmax
+  constexpr int MS = 17;
+  const int od = d0 + wave;
+  __builtin_amdgcn_s_setprio(3);
+  __syncthreads();
+  float* sm = lds + wave * (64 * MS);
+  {
+    const float sc = a.scale ? a.scale[i] : 1.f;
+    const float bi = a.bias ? a.bias[i] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = fmaxf(acc[mt][r] * sc + bi, 0.f);
+        sm[(mt * 16 + g * 4 + r) * MS + i] = v;
+      }
+  }
+  __syncthreads();
+  const int mt = lane >> 4, row = lane & 15;
+  const int oh = h0 + mt * 2 + (row >> 3), ow = w0 + (row & 7);
+  if (od < a.Do && oh < a.Ho && ow < a.Wo) {
+    const size_t vox = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+    float mid[16], hid[8];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mid[k] = sm[lane * MS + k];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s_ += mid[k] * tail.w1[o * 16 + k];
+      hid[o] = fmaxf(s_ * tail.s1[o] + tail.b1[o], 0.f);
+    }
+    float best = 0.f;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < 18; ++c) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) s_ += hid[o] * tail.w2[c * 8 + o];
+      if (tail.logits) tail.logits[vox * 18 + c] = s_;
+      if (c == 0 || s_ > best) { best = s_; arg = c; }
+    }
+    tail.occ[vox] = (uint8_t)arg;
   }
 }
 
@@ -398,7 +553,7 @@ __device__ __forceinline__ float trilerp_ac(const float* __restrict__ y, int b, 
   const float lh1 = fh - (float)h0, lh0 = 1.f - lh1;
   const float lw1 = fw - (float)w0, lw0 = 1.f - lw1;
   const float* p = y + (size_t)b * Dl * Hl * Wl * 32 + ch;
-#define YV(d, h, w) p[(((size_t)(d) * Hl + (h)) * Wl + (w)) * 32]
+#define YV(d, h, w) p[(unsigned)(((d) * Hl + (h)) * Wl + (w)) * 32u]
   const float v000 = YV(d0, h0, w0), v001 = YV(d0, h0, w1), v010 = YV(d0, h1, w0), v011 = YV(d0, h1, w1);
   const float v100 = YV(d1, h0, w0), v101 = YV(d1, h0, w1), v110 = YV(d1, h1, w0), v111 = YV(d1, h1, w1);
 #undef YV
@@ -447,10 +602,14 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
     const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
     const long long vox = m0 + row;
     if (vox < n_vox) {
-      int ow = (int)(vox % a.W); long long t = vox / a.W;
-      int oh = (int)(t % a.H); t /= a.H;
-      int od = (int)(t % a.D);
-      int b = (int)(t / a.D);
+      // 32-bit index math (host guarantees n_vox < 2^31): 64-bit div/mod dominated this kernel
+      const unsigned uv = (unsigned)vox;
+      const unsigned t1 = uv / (unsigned)a.W;
+      const int ow = (int)(uv - t1 * (unsigned)a.W);
+      const unsigned t2 = t1 / (unsigned)a.H;
+      const int oh = (int)(t1 - t2 * (unsigned)a.H);
+      const int b = (int)(t2 / (unsigned)a.D);
+      const int od = (int)(t2 - (unsigned)b * (unsigned)a.D);
       float v = acc[r];
       v += trilerp_ac(f.y16, b, f.D2, f.H2, f.W2, sd2, sh2, sw2, od, oh, ow, i);
       v += trilerp_ac(f.y32, b, f.D4, f.H4, f.W4, sd4, sh4, sw4, od, oh, ow, i);
@@ -473,6 +632,7 @@ PW_API int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, c
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin8; a.relu0 = relu; a.cout_total = 32; a.cout0 = 32;
   FpnArgs f = {y16, y32, D2, H2, W2, D4, H4, W4};
   const long long n = (long long)B * D * H * W;
+  PW_CHECK_ARG(n < (1ll << 31), "pw_fpn3d_fuse: more than 2^31 voxels");
   hipLaunchKernelGGL(k_fpn3d_fuse, dim3((unsigned)pw_cdiv(n, 128)), dim3(256), 0, pw_stream(stream),
                      a, f, n);
   PW_CHECK_LAUNCH();
@@ -517,12 +677,23 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   PW_CHECK_ARG(a.n1_start + cout1 <= cout_total || cout1 == 0, "pw_conv3d_ndhwc: cout split exceeds cout_total");
   hipStream_t st = pw_stream(stream);
   const int ntiles = cout_total / 32;
-  const int NT = (ntiles % 2 == 0) ? 2 : 1;
+  int NT = (ntiles % 2 == 0) ? 2 : 1;
+  if (ksize == 3 && stride == 1 && algo != 2 && NT == 2) {
+    // small grids: 2 blocks x 256 CUs = 512 resident slots; prefer twice as many half-size
+    // blocks when NT=2 cannot fill them (the 8x100x100 and 4x50x50 encoder stages)
+    long long nblk2 = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w * (ntiles / 2);
+    if (nblk2 < 512) NT = 1;
+  }
   const int ngroups = ntiles / NT;
   const long long n_out = (long long)B * a.Do * a.Ho * a.Wo;
   // algo: 0 = auto, 1 = force LDS-tiled (k3 s1 only), 2 = force gather
   const bool tiled = (ksize == 3 && stride == 1 && algo != 2);
   PW_CHECK_ARG(!(algo == 1 && !tiled), "pw_conv3d_ndhwc: algo=1 needs ksize 3 stride 1");
+  a.probe = nullptr;
+  {
+    const char* e = getenv("PW_CONV_PROBE");     // development aid: address of a device buffer
+    if (e) a.probe = (long long*)strtoull(e, nullptr, 0);
+  }
   if (tiled) {
     long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
     PW_CHECK_ARG(nblk < (1ll << 31), "pw_conv3d_ndhwc: grid too large");
@@ -558,7 +729,7 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
 PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, const float* bias,
                              const float* w1, const float* s1, const float* b1, const float* w2,
                              uint8_t* occ, float* logits, int B, int D, int H, int W, int Cin,
-                             int n_mid, int n_hid, int n_cls, void* stream) {
+                             int n_mid, int n_hid, int n_cls, int wpk_layout, void* stream) {
   PW_CHECK_ARG(x && wpk && w1 && s1 && b1 && w2 && occ, "pw_occ_head_fused: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cin % KC == 0, "pw_occ_head_fused: bad shape");
   if (n_mid != 16 || n_hid != 8 || n_cls != 18) {
@@ -572,12 +743,19 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
   a.cout_total = 32; a.cout0 = n_mid; a.relu0 = 1;
   a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
   OccTail t = {w1, s1, b1, w2, occ, logits, n_mid, n_hid, n_cls};
-  static int once = set_lds_limit(k_conv3d_k3s1<1, 1>);
-  if (once) return once;
   long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
-  PW_CHECK_ARG(nblk < (1ll << 31), "pw_occ_head_fused: grid too large");
-  hipLaunchKernelGGL((k_conv3d_k3s1<1, 1>), dim3((unsigned)nblk, 1), dim3(256), LDS_BYTES,
-                     pw_stream(stream), a, t);
+  if (wpk_layout == 16) {
+    static int once16 = set_lds_limit(k_occ_head16);
+    if (once16) return once16;
+    hipLaunchKernelGGL(k_occ_head16, dim3((unsigned)nblk, 1), dim3(256), LDS_BYTES, pw_stream(stream),
+                       a, t);
+  } else {
+    PW_CHECK_ARG(wpk_layout == 32, "pw_occ_head_fused: wpk_layout must be 16 or 32");
+    static int once = set_lds_limit(k_conv3d_k3s1<1, 1>);
+    if (once) return once;
+    hipLaunchKernelGGL((k_conv3d_k3s1<1, 1>), dim3((unsigned)nblk, 1), dim3(256), LDS_BYTES,
+                       pw_stream(stream), a, t);
+  }
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

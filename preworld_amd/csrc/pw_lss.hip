@@ -262,23 +262,25 @@ static int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_
 // ------------------------------------------------------------------------------------
 // stable segmented (counting) sort
 // ------------------------------------------------------------------------------------
+// histogram with RETURNING atomics: the old counter value is this point's arrival rank inside
+// its segment, so the scatter below needs no second round of atomics.
 __global__ void __launch_bounds__(256)
-k_hist(const int32_t* __restrict__ keys, int64_t n, int32_t* __restrict__ count) {
+k_hist(const int32_t* __restrict__ keys, int64_t n, int32_t* __restrict__ count,
+       int32_t* __restrict__ rank) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int k = keys[i];
-  if (k >= 0) atomicAdd(&count[k], 1);
+  if (k >= 0) rank[i] = atomicAdd(&count[k], 1);
 }
 
 __global__ void __launch_bounds__(256)
 k_scatter(const int32_t* __restrict__ keys, int64_t n, const int32_t* __restrict__ seg_start,
-          int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
+          const int32_t* __restrict__ rank, int32_t* __restrict__ tmp) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int k = keys[i];
   if (k < 0) return;
-  int pos = seg_start[k] + atomicAdd(&cursor[k], 1);
-  tmp[pos] = (int32_t)i;
+  tmp[seg_start[k] + rank[i]] = (int32_t)i;
 }
 
 // in-segment rank sort: the scatter order inside a segment is whatever the atomics gave;
@@ -306,7 +308,7 @@ k_ranksort(const int32_t* __restrict__ keys, const int32_t* __restrict__ seg_sta
 
 PW_API size_t pw_segment_sort_workspace_bytes(int64_t n, int64_t n_keys) {
   return pw_align_up((size_t)(n_keys + 1) * 4, 256)   // count
-         + pw_align_up((size_t)n_keys * 4, 256)       // cursor
+         + pw_align_up((size_t)n * 4, 256)            // arrival rank per point
          + pw_align_up((size_t)n * 4, 256)            // tmp
          + scan_ws_bytes(n_keys + 1);
 }
@@ -331,19 +333,18 @@ PW_API int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void*
   char* ws = (char*)workspace;
   int32_t* count = (int32_t*)ws;
   ws += pw_align_up((size_t)(n_keys + 1) * 4, 256);
-  int32_t* cursor = (int32_t*)ws;
-  ws += pw_align_up((size_t)n_keys * 4, 256);
+  int32_t* rank = (int32_t*)ws;
+  ws += pw_align_up((size_t)n * 4, 256);
   int32_t* tmp = (int32_t*)ws;
   ws += pw_align_up((size_t)n * 4, 256);
   int32_t* sums = (int32_t*)ws;
-  // count and cursor are adjacent: one memset
-  PW_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)((char*)tmp - (char*)count), st));
+  PW_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)(n_keys + 1) * 4, st));
   if (long_list) PW_CHECK_HIP(hipMemsetAsync(n_long, 0, sizeof(int32_t), st));
   unsigned nbk = (unsigned)pw_cdiv(n, 256);
-  hipLaunchKernelGGL(k_hist, dim3(nbk), dim3(256), 0, st, keys, n, count);
+  hipLaunchKernelGGL(k_hist, dim3(nbk), dim3(256), 0, st, keys, n, count, rank);
   int rc = scan_exclusive_i32(count, seg_start, n_keys + 1, sums, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_scatter, dim3(nbk), dim3(256), 0, st, keys, n, seg_start, cursor, tmp);
+  hipLaunchKernelGGL(k_scatter, dim3(nbk), dim3(256), 0, st, keys, n, seg_start, rank, tmp);
   hipLaunchKernelGGL(k_ranksort, dim3(nbk), dim3(256), 0, st, keys, seg_start, tmp,
                      seg_start + n_keys, order, aux_div, aux_mod, order_aux, long_threshold, long_list,
                      n_long);

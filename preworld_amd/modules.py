@@ -417,7 +417,7 @@ class OccHead(nn.Module):
             s0, b0 = ops.fold_bn(bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, bn0.eps)
             s1, b1 = ops.fold_bn(bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps)
             w0 = c0.weight
-            return (ops.pack_conv_weight(w0), ops.pack_conv_weight(w0.permute(0, 1, 4, 3, 2).contiguous()),
+            return (ops.pack_conv_weight16(w0), ops.pack_conv_weight16(w0.permute(0, 1, 4, 3, 2).contiguous()),
                     ops._pad32(s0, 1.0), ops._pad32(b0, 0.0),
                     c1.weight.reshape(c1.weight.shape[0], -1).float().contiguous(), s1, b1,
                     c2.weight.reshape(c2.weight.shape[0], -1).float().contiguous())

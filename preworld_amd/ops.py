@@ -312,6 +312,17 @@ def fpn3d_fuse(x8, wpk8, y16, y32, scale, bias, relu=True, out=None):
     return out
 
 
+def pack_conv_weight16(w):
+    """(16, Cin, 3,3,3) conv weight -> float[Cin/32][27][64][8] for the 16x16x4 MFMA OccHead
+    kernel: wpk[ch][tap][g*16+j][s] = w[j][ch*32+g*8+s][tap]."""
+    Cout, Cin = w.shape[:2]
+    if Cout != 16 or Cin % 32:
+        raise _lib.PreworldHipError('pack_conv_weight16 expects (16, 32k, 3,3,3)')
+    nch = Cin // 32
+    wp = w.reshape(16, nch, 4, 8, 27).permute(1, 4, 2, 0, 3).contiguous()    # (ch, tap, g, j, s)
+    return wp.view(nch, 27, 64, 8).float().contiguous()
+
+
 def occ_head_fused(x, wpk, scale, bias, w1, s1, b1, w2, want_logits=False, occ=None):
     """OccHead (occupancy_head.py:124-177) on channels-last x (B,D,H,W,32):
     returns uint8 argmax (B,D,H,W) and, if asked, logits (B,D,H,W,18)."""
@@ -321,7 +332,8 @@ def occ_head_fused(x, wpk, scale, bias, w1, s1, b1, w2, want_logits=False, occ=N
     logits = torch.empty(B, D, H, W, 18, device=x.device, dtype=_f32) if want_logits else None
     _lib.call('pw_occ_head_fused', _chk(x, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
               _chk(bias, _f32, 'bias'), _chk(w1, _f32, 'w1'), _chk(s1, _f32, 's1'), _chk(b1, _f32, 'b1'),
-              _chk(w2, _f32, 'w2'), _p(occ), _p(logits), B, D, H, W, Cin, 16, 8, 18, _stream())
+              _chk(w2, _f32, 'w2'), _p(occ), _p(logits), B, D, H, W, Cin, 16, 8, 18,
+              16 if wpk.shape[-1] == 8 else 32, _stream())
     return (occ, logits) if want_logits else occ
 
 

@@ -224,5 +224,4 @@ def test_softplus_accuracy():
     ref = torch.nn.functional.softplus(x.double().cpu())
     err = (y.double().cpu() - ref).abs()
     rel = err / ref.clamp_min(1e-30)
-    assert float(err.max()) < 3e-6
-    assert float(torch.minimum(err / 3e-7, rel / 2e-6).max()) <= 1.0   # abs 3e-7 or rel 2e-6
+    assert float(torch.minimum(err / 3e-7, rel / 1e-6).max()) <= 1.0   # abs 3e-7 or rel 1e-6

@@ -108,6 +108,9 @@ def bench_enc():
     w1 = torch.randn(8, 16, device=dev); s1 = torch.ones(8, device=dev); b1 = torch.zeros(8, device=dev)
     w2 = torch.randn(18, 8, device=dev); wp = w(16, 32)
     t = timeit(lambda: ops.occ_head_fused(x32, wp, sc, bi, w1, s1, b1, w2), iters=10)
+    res['occ_head_32x32x2_us'] = t
+    wp16 = ops.pack_conv_weight16(torch.randn(16, 32, 3, 3, 3, device=dev) * 0.05)
+    t = timeit(lambda: ops.occ_head_fused(x32, wp16, sc, bi, w1, s1, b1, w2), iters=10)
     res['occ_head_us'] = t; res['occ_head_TFLOPs_useful'] = flops(32, 16) / t / 1e6
     # forecast
     fw1 = torch.randn(128, 64, device=dev) * 0.1; fw2 = torch.randn(32, 128, device=dev) * 0.1
