@@ -56,7 +56,7 @@ struct ConvArgs {
   int n1_start;           // first packed column that goes to y1
   int relu0, relu1;
   int tiles_d, tiles_h, tiles_w;
-  long long* probe;       // optional per-block phase timestamps (development aid) or null
+  long long* probe;       // development aid: per-wave phase timestamps (PW_CONV_PROBE) or null
 };
 
 // MFMA row (0..31) -> voxel of the 4x8 patch, chosen for conflict-free ds_read_b128 groups
@@ -82,77 +82,167 @@ __device__ __forceinline__ void store_out(const ConvArgs& a, int n, size_t vox, 
   }
 }
 
-// stage the 6x10x10 halo tile of one 32-channel chunk: global -> registers -> swizzled LDS.
-// All 19 loads are issued before the first LDS write; zero padding comes from the bounds test.
-__device__ __forceinline__ void stage_halo_chunk(const ConvArgs& a, float* lds, int b, int d0, int h0,
-                                                 int w0, int ch, int tid, long long* ts = nullptr) {
-  // Two waves share each SIMD and instruction issue is arbitrated by priority, then age: next to
-  // a partner that streams MFMAs this ~1000-instruction address/load/ds_write phase was measured
-  // at ~37 cycles per instruction (31k cycles, vs 1.4k actually waiting for the loads).  Run the
-  // non-MFMA phases at high priority; they are short, so the partner's MFMA stream barely moves.
-  __builtin_amdgcn_s_setprio(3);
-  float4 tmp[STAGE_ITERS];
+// ------------------------------------------------------------------------------------
+// VALU budget.  On gfx950 the fp32-input MFMA executes on the SIMD's fp32 vector datapath:
+// every VALU instruction of ANY wave on the SIMD displaces matrix work (measured on the first
+// version of this kernel: 2.3k VALU instructions per wave -> 31 % of the MFMA issue slots idle;
+// phase timestamps showed the 19 staging loads taking 31k cycles just to ISSUE next to an
+// MFMA-streaming partner wave, s_setprio made no difference).  So everything around the MFMAs
+// is written to need (almost) no vector ALU:
+//   * staging walks the halo tile by ROWS that are wave-uniform (wave w takes rows w, w+4, ..):
+//     row decode, bounds tests and the 64-bit global address are scalar; a lane only adds a
+//     precomputed 32-bit offset (saddr-form global_load) and one LDS address add;
+//   * the 27 taps are fully unrolled and the swizzled LDS read addresses are precomputed per lane
+//     for the 6 (tap-row parity, kw) variants, so a tap's ds_read_b128 is base + immediate;
+//   * weights are read through a scalar base that the scalar ALU advances per tap;
+//   * the epilogue uses a scalar destination base + one 32-bit mad per element, and skips all
+//     bounds tests on interior tiles.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Buffer (SRD) addressing: descriptor + scalar byte offset + 32-bit lane offset -> the address
+// arithmetic of every load/store is scalar; no 64-bit VALU adds (see "VALU budget" above).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(rsrc_t r, unsigned voff, unsigned soff) {
+  // NB: keep `auto` -- converting the builtin's vector to an ext_vector_type makes hipcc (ROCm 7.2)
+  // load only the first dword
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                     __uint_as_float(v[3]));
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(rsrc_t r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+// WD = number of 4-deep d-groups per block: WD=1 -> 4 waves, tile 4x8x8, 76.8 KB LDS, 2 blocks/CU;
+// WD=2 -> 8 waves, tile 8x8x8, 128 KB LDS, ONE block per CU.  Measured with per-phase timestamps:
+// next to a wave that streams fp32 MFMAs, every VGPR-reading instruction of the partner wave
+// (VALU, VMEM, DS) is starved -- the 32-store epilogue takes 3k cycles alone but 51k beside an
+// MFMA stream, staging 12k vs 60k.  With two independent blocks per CU the waves sharing a SIMD
+// drift into anti-phase and the non-MFMA phases crawl; with one 8-wave block the block's own
+// barriers keep both waves of every SIMD in the SAME phase: staging and epilogue run at full
+// speed, and during the taps the two waves hide each other's LDS/weight-load latency.
+template <int WD> struct TileGeom {
+  static constexpr int BDt = 4 * WD, TDt = BDt + 2, ROWS = TDt * TH, NW = 4 * WD;
+  static constexpr int ROWS_PER_WAVE = (ROWS + NW - 1) / NW;      // 15 (WD=1) / 13 (WD=2)
+  static constexpr int LDS = TDt * TH * TW * KC * 4;              // 76800 / 128000 bytes
+};
+
+// per-lane constants of the staging pattern: a halo row is 10 voxels x 8 slots = 80 float4;
+// pass 0 covers voxels 0..7 (64 lanes), pass 1 voxels 8..9 (lanes 0..15)
+struct StageLane {
+  unsigned goff[2];        // global BYTE offset inside a row: (ww*Cin + slot*4)*4
+  unsigned loff[2][2];     // LDS byte offset inside a row, [hh parity][pass], swizzle applied
+  bool wok[2];             // w0-1+ww inside [0,W)
+};
+
+__device__ __forceinline__ StageLane stage_lane_setup(const ConvArgs& a, int w0, int lane) {
+  StageLane s;
 #pragma unroll
-  for (int k = 0; k < STAGE_ITERS; ++k) {
-    int it = tid + k * 256;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (it < STAGE_ITEMS) {
-      int vox = it >> 3, slot = it & 7;
-      int dd = vox / (TH * TW);
-      int rem = vox - dd * (TH * TW);
-      int hh = rem / TW, ww = rem - hh * TW;
-      int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + ww - 1;
-      if ((unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W) {
-        size_t g = ((((size_t)b * a.D + gd) * a.H + gh) * a.W + gw) * a.Cin + ch * KC + slot * 4;
-        v = *reinterpret_cast<const float4*>(a.x + g);
+  for (int ps = 0; ps < 2; ++ps) {
+    const int ww = ps * 8 + (lane >> 3), slot = lane & 7;
+    // offsets are relative to voxel max(w0-1, 0) of the row: buffer soffset/voffset are UNSIGNED,
+    // so the "-1 voxel" of the halo cannot be expressed as a negative scalar offset at w0 = 0
+    // (there lane ww = 0 is masked by wok and its wrapped offset is never used)
+    s.goff[ps] = (unsigned)((ww - (w0 == 0 ? 1 : 0)) * a.Cin + slot * 4) * 4u;      // bytes
+    s.wok[ps] = (unsigned)(w0 - 1 + ww) < (unsigned)a.W && (ps == 0 || lane < 16);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int f = ((ww >> 1) & 3) | (par << 2);
+      s.loff[par][ps] = (unsigned)((ww * 8 + (slot ^ f)) * 16);
+    }
+  }
+  return s;
+}
+
+// stage the 6x10x10 halo tile of one 32-channel chunk: global -> registers -> swizzled LDS
+template <int WD, int KB0>
+__device__ __forceinline__ void stage_halo_chunk(const ConvArgs& a, rsrc_t xr, float* lds,
+                                                 const StageLane& sl, int b, int d0, int h0, int w0,
+                                                 int ch, int wave, int lane) {
+  using G = TileGeom<WD>;
+  char* ldsb = reinterpret_cast<char*>(lds);
+  if (ch > 0) __syncthreads();   // every wave finished reading the previous chunk
+  // KB0 rows per batch (all loads of a batch are issued before its LDS writes): 8 rows = 64 VGPRs
+  // for the NT=1 kernels, 4 rows where the 2 x 32-wide accumulators leave fewer registers
+  constexpr int NBATCH = (G::ROWS_PER_WAVE + KB0 - 1) / KB0;
+#pragma unroll
+  for (int batch = 0; batch < NBATCH; ++batch) {
+    const int k0 = batch * KB0, k1 = (batch + 1) * KB0 < G::ROWS_PER_WAVE ? (batch + 1) * KB0 : G::ROWS_PER_WAVE;
+    float4 tmp[KB0][2];
+#pragma unroll
+    for (int k = k0; k < k1; ++k) {
+      const int row = wave + G::NW * k;                 // wave-uniform (wave comes from readfirstlane)
+      const int dd = row / TH, hh = row - dd * TH;
+      const int gd = d0 + dd - 1, gh = h0 + hh - 1;
+      const bool rok = row < G::ROWS && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H;
+      // scalar byte offset of voxel max(w0-1, 0) of this row (see stage_lane_setup)
+      const unsigned soff = (unsigned)((((((long long)b * a.D + gd) * a.H + gh) * a.W + (w0 > 0 ? w0 - 1 : 0)) * a.Cin + ch * KC) * 4);
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rok && sl.wok[ps]) v = buf_load4(xr, sl.goff[ps], soff);
+        tmp[k - k0][ps] = v;
       }
     }
-    tmp[k] = v;
-  }
-  if (ts) { ts[0] = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[1] = __builtin_readcyclecounter(); }
-  if (ch > 0) __syncthreads();   // every wave finished reading the previous chunk
 #pragma unroll
-  for (int k = 0; k < STAGE_ITERS; ++k) {
-    int it = tid + k * 256;
-    if (it < STAGE_ITEMS) {
-      int vox = it >> 3, slot = it & 7;
-      int dd = vox / (TH * TW);
-      int rem = vox - dd * (TH * TW);
-      int hh = rem / TW, ww = rem - hh * TW;
-      int f = ((ww >> 1) & 3) | ((hh & 1) << 2);
-      *reinterpret_cast<float4*>(lds + ((vox << 3) + (slot ^ f)) * 4) = tmp[k];
+    for (int k = k0; k < k1; ++k) {
+      const int row = wave + G::NW * k;
+      const int dd = row / TH, hh = row - dd * TH;
+      const unsigned rofs = (unsigned)row * (TW * 128);
+      if (row < G::ROWS) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const unsigned lo = (hh & 1) ? sl.loff[1][ps] : sl.loff[0][ps];
+          if (ps == 0 || lane < 16)
+            *reinterpret_cast<float4*>(ldsb + rofs + lo) = tmp[k - k0][ps];
+        }
+      }
     }
   }
-  if (ts) ts[2] = __builtin_readcyclecounter();
   __syncthreads();
-  __builtin_amdgcn_s_setprio(0);
 }
 
 template <int NT>
-__device__ __forceinline__ void load_b(const float* w, float4 (&b)[NT][4]) {
+__device__ __forceinline__ void load_b(rsrc_t wr, unsigned wsoff, unsigned lane_off, float4 (&b)[NT][4]) {
+  // wsoff: wave-uniform byte offset of this (chunk, tap, N-group); lane_off = lane*64 bytes
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b[nt][q] = *reinterpret_cast<const float4*>(w + nt * 1024 + q * 4);
+    for (int q = 0; q < 4; ++q) b[nt][q] = buf_load4(wr, lane_off + (unsigned)(q * 16), wsoff + (unsigned)(nt * 4096));
 }
 
-// one tap: 2 M-tiles x NT N-tiles x 16 k-steps of v_mfma_f32_32x32x2_f32
-template <int NT>
-__device__ __forceinline__ void tap_mfma(const float* lds, int tap, int wave, int half, int pr,
-                                         int pc, const float4 (&b)[NT][4], f32x16 (&acc)[2][NT]) {
-  const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+// one tap: 2 M-tiles x NT N-tiles x 16 k-steps of v_mfma_f32_32x32x2_f32.
+// aaddr[khp][kw][q]: precomputed swizzled LDS byte address of this lane's voxel for tap-row
+// parity khp and column shift kw; the rest of the tap offset is a compile-time immediate.
+template <int NT, int TAP>
+__device__ __forceinline__ void tap_mfma(const float* lds, const unsigned (&aaddr)[2][3][4],
+                                         const float4 (&b)[NT][4], f32x16 (&acc)[2][NT]) {
+  constexpr int kd = TAP / 9, kh = (TAP / 3) % 3, kw = TAP % 3;
+  const char* ldsb = reinterpret_cast<const char*>(lds);
+  // all 8 A reads of the tap go out first (pinned by the sched_barrier): the LDS latency is then
+  // paid once per tap under the previous tap's trailing MFMAs instead of before every 4 MFMAs
+  float4 aq[2][4];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    const int hh = mt * 4 + pr + kh, ww = pc + kw, dd = wave + kd;
-    const int vl = (dd * TH + hh) * TW + ww;
-    const int f = ((ww >> 1) & 3) | ((hh & 1) << 2);
-    float4 aq[4];
+    const unsigned imm = (unsigned)(((kd * TH + mt * 4 + kh) * TW) * 128);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      aq[q] = *reinterpret_cast<const float4*>(lds + ((vl << 3) + ((half * 4 + q) ^ f)) * 4);
+      aq[mt][q] = *reinterpret_cast<const float4*>(ldsb + (aaddr[kh & 1][kw][q] + imm));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float av[4] = {aq[q].x, aq[q].y, aq[q].z, aq[q].w};
+      const float av[4] = {aq[mt][q].x, aq[mt][q].y, aq[mt][q].z, aq[mt][q].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -165,36 +255,74 @@ __device__ __forceinline__ void tap_mfma(const float* lds, int tap, int wave, in
   }
 }
 
+// taps TAP, TAP+1 with the weight ping-pong; recursion unrolls all 27 taps at compile time
+template <int NT, int TAP>
+__device__ __forceinline__ void tap_pair(const float* lds, const unsigned (&aaddr)[2][3][4],
+                                         rsrc_t wr, unsigned wsoff, unsigned lane_off, unsigned wstride,
+                                         float4 (&b0)[NT][4], float4 (&b1)[NT][4],
+                                         f32x16 (&acc)[2][NT]) {
+  if constexpr (TAP + 1 < 27) {
+    load_b<NT>(wr, wsoff + (unsigned)(TAP + 1) * wstride, lane_off, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    tap_mfma<NT, TAP>(lds, aaddr, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b<NT>(wr, wsoff + (unsigned)(TAP + 2) * wstride, lane_off, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    tap_mfma<NT, TAP + 1>(lds, aaddr, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    tap_pair<NT, TAP + 2>(lds, aaddr, wr, wsoff, lane_off, wstride, b0, b1, acc);
+  } else {
+    tap_mfma<NT, TAP>(lds, aaddr, b0, acc);
+  }
+}
+
+// (pr, pc) patch position of accumulator register r for lane half h -- see patch_of_row
+__device__ __forceinline__ constexpr int acc_patch(int r, int h) {
+  const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+  const int g = i >> 2;
+  const int set = (0x96 >> g) & 1;
+  return set * 16 + (g >> 1) * 4 + (i & 3);
+}
+
 // ------------------------------------------------------------------------------------
 // 3x3x3, stride 1, pad 1, LDS halo tile
 // ------------------------------------------------------------------------------------
-// Fused OccHead tail (mmdet3d/models/heads/occupancy_head.py:92-99,124-161): after the 3x3x3
-// conv + BN + ReLU (16 mid channels) each voxel runs 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18 and
-// argmax -> uint8 inside the conv epilogue; the 46 MB logits tensor is only written on request.
-struct OccTail {
-  const float* w1;      // [8][16]  occ_pred_conv.0.weight
-  const float* s1;      // [8]      folded BN scale
-  const float* b1;      // [8]      folded BN bias
-  const float* w2;      // [18][8]  occ_pred_conv.3.weight
-  uint8_t* occ;         // [B*D*H*W] argmax class
-  float* logits;        // [B*D*H*W][18] or null
-  int n_mid, n_hid, n_cls;
-};
-
-template <int NT, int EPI>
-__global__ void __launch_bounds__(256, 2) k_conv3d_k3s1(ConvArgs a, OccTail tail) {
+template <int NT, int WD>
+__global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
   const int half = lane >> 5, i = lane & 31;
+  const int ng = blockIdx.y;
+  const int pj = patch_of_row(i), pr = pj >> 3, pc = pj & 7;
+  const int ntiles_total = a.cout_total >> 5;
+
+  // swizzled LDS read addresses (bytes) of this lane's patch voxel, 6 variants x 4 slots
+  unsigned aaddr[2][3][4];
+#pragma unroll
+  for (int khp = 0; khp < 2; ++khp)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ww = pc + kw;
+      const int f = ((ww >> 1) & 3) | (((pr + khp) & 1) << 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        aaddr[khp][kw][q] = (unsigned)((((wave * TH + pr) * TW + ww) * 8 + ((half * 4 + q) ^ f)) * 16);
+    }
+  const unsigned lane_off = (unsigned)lane * 64u;
+  const unsigned wstride = (unsigned)ntiles_total * 4096u;           // bytes per tap
+  const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
+  const rsrc_t wr = make_rsrc(a.wpk, (unsigned)((size_t)(a.Cin / KC) * 27 * ntiles_total * 4096));
+
+  // (A persistent tile loop and a one-block-per-CU 8-wave variant were both measured: neither
+  // moved the needle -- the remaining gap of the NT=1 kernel is the exposed halo-load latency.)
   int bid = blockIdx.x;
   const int tw = bid % a.tiles_w; bid /= a.tiles_w;
   const int th = bid % a.tiles_h; bid /= a.tiles_h;
   const int td = bid % a.tiles_d;
   const int b = bid / a.tiles_d;
-  const int d0 = td * BD, h0 = th * BH, w0 = tw * BW;
-  const int ng = blockIdx.y;
-  const int pj = patch_of_row(i), pr = pj >> 3, pc = pj & 7;
-  const int ntiles_total = a.cout_total >> 5;
+  const int d0 = td * (BD * WD), h0 = th * BH, w0 = tw * BW;
+  const StageLane sl = stage_lane_setup(a, w0, lane);
 
   f32x16 acc[2][NT];
 #pragma unroll
@@ -205,120 +333,92 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_k3s1(ConvArgs a, OccTail tail
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const int nchunk = a.Cin / KC;
-  long long t_start = 0, t_staged = 0, t_taps = 0, t_s0 = 0, t_s1 = 0, t_s2 = 0;
-  if (a.probe) t_start = __builtin_readcyclecounter();
+  long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (a.probe) ts0 = __builtin_readcyclecounter();
   for (int ch = 0; ch < nchunk; ++ch) {
-    long long ts[3] = {0, 0, 0};
-    stage_halo_chunk(a, lds, b, d0, h0, w0, ch, tid, (a.probe && ch == 0) ? ts : nullptr);
-    if (a.probe && ch == 0) { t_staged = __builtin_readcyclecounter(); t_s0 = ts[0]; t_s1 = ts[1]; t_s2 = ts[2]; }
-
-    // ---- 27 taps x 16 k-steps
-    const float* wch = a.wpk + ((size_t)ch * 27 * ntiles_total + (size_t)ng * NT) * 1024 + lane * 16;
-    // weights are double-buffered in registers (ping-pong, taps two at a time) so that the
-    // loads of tap t+1 stay in flight under the 32*NT MFMAs of tap t
-    const size_t wstride = (size_t)ntiles_total * 1024;
+    // first tap's weights go out before the halo loads so they are not queued behind them
+    const unsigned wsoff = (unsigned)((ch * 27 * ntiles_total + ng * NT) * 4096);
     float4 b0[NT][4], b1[NT][4];
-    load_b<NT>(wch, b0);
-#pragma unroll 1
-    for (int tap = 0; tap < 26; tap += 2) {
-      // sched_barrier pins "issue next tap's loads, THEN compute": the waitcnt pass can then
-      // use a counted vmcnt that leaves the 4*NT prefetch loads in flight under the MFMAs
-      load_b<NT>(wch + (size_t)(tap + 1) * wstride, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      tap_mfma<NT>(lds, tap, wave, half, pr, pc, b0, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      load_b<NT>(wch + (size_t)(tap + 2) * wstride, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      tap_mfma<NT>(lds, tap + 1, wave, half, pr, pc, b1, acc);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    tap_mfma<NT>(lds, 26, wave, half, pr, pc, b0, acc);
+    load_b<NT>(wr, wsoff, lane_off, b0);
+    stage_halo_chunk<WD, 8>(a, xr, lds, sl, b, d0, h0, w0, ch, wave, lane);
+    if (a.probe && ch == 0) ts1 = __builtin_readcyclecounter();
+    tap_pair<NT, 0>(lds, aaddr, wr, wsoff, lane_off, wstride, b0, b1, acc);
   }
+  if (a.probe) ts2 = __builtin_readcyclecounter();
 
-  // ---- epilogue (high issue priority, see stage_halo_chunk)
+  // ---- epilogue: y = acc*scale + bias (+residual) (ReLU).  Destination, residual and the
+  // M-tile origin are scalar (buffer descriptor + soffset); a lane adds one 32-bit offset per
+  // element.  Interior tiles with full 32-column N-tiles take a branch-free path: all residual
+  // loads first, then the math, then the stores.
   const int od = d0 + wave;
-  if (a.probe) t_taps = __builtin_readcyclecounter();
-  __builtin_amdgcn_s_setprio(3);
-  if constexpr (EPI == 0) {
+  if (od < a.Do) {
+  const bool interior = h0 + BH <= a.Ho && w0 + BW <= a.Wo;
+  const unsigned out_vox = (unsigned)((size_t)a.B * a.Do * a.Ho * a.Wo);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = (ng * NT + nt) * 32 + i;
-      const float sc = a.scale ? a.scale[n] : 1.f;
-      const float bi = a.bias ? a.bias[n] : 0.f;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n0 = (ng * NT + nt) * 32;               // first packed column of this N-tile (uniform)
+    const int n = n0 + i;
+    const bool to_y0 = n0 < a.cout0;
+    float* dst = to_y0 ? a.y0 : a.y1;
+    if (dst == nullptr) continue;
+    const int stride = to_y0 ? a.cout0 : a.cout1;
+    const int col0 = to_y0 ? n0 : n0 - a.n1_start;    // uniform
+    if (col0 < 0 || col0 >= stride) continue;
+    const bool fullcols = col0 + 32 <= stride;
+    const float lo = (to_y0 ? a.relu0 : a.relu1) ? 0.f : -3.402823466e38f;
+    const bool has_res = to_y0 && a.residual != nullptr;
+    const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)stride * 4u);
+    const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)stride * 4u);
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float bi = a.bias ? a.bias[n] : 0.f;
+    const unsigned lanecol = (unsigned)(col0 + i) * 4u;
+    // Accumulator register r = 4g+e of lane half h sits at patch (row pr(g,h), column pc0(g,h)+e):
+    // one per-lane byte offset per group g; the +e column step and the M-tile origin are scalar
+    // (buffer soffset), so no per-element address VALU at all.
+    unsigned goff[4];
+    int gpr[4], gpc[4];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int p0 = acc_patch(4 * g4, 0), p1 = acc_patch(4 * g4, 1);
+      gpr[g4] = half ? (p1 >> 3) : (p0 >> 3);
+      gpc[g4] = half ? (p1 & 7) : (p0 & 7);
+      goff[g4] = (unsigned)((gpr[g4] * a.Wo + gpc[g4]) * stride) * 4u + lanecol;
+    }
+    const unsigned estep = (unsigned)stride * 4u;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      // byte offset of patch position (0,0) of this M-tile: uniform
+      const unsigned soff = (unsigned)((((((long long)b * a.Do + od) * a.Ho + (h0 + mt * 4)) * a.Wo + w0) * stride) * 4);
+      if (interior && fullcols) {
+        float rv[16];
+        if (has_res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = buf_load1(rr, goff[r >> 2], soff + (unsigned)(r & 3) * estep);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int pjr = patch_of_row(row);
-          const int oh = h0 + mt * 4 + (pjr >> 3), ow = w0 + (pjr & 7);
-          if (od < a.Do && oh < a.Ho && ow < a.Wo) {
-            size_t vox = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-            store_out(a, n, vox, acc[mt][nt][r] * sc + bi);
+          float v = acc[mt][nt][r] * sc + bi;
+          if (has_res) v += rv[r];
+          buf_store1(yr, goff[r >> 2], soff + (unsigned)(r & 3) * estep, fmaxf(v, lo));
+        }
+      } else {
+        const bool colok = col0 + i < stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (colok && (h0 + mt * 4 + gpr[r >> 2] < a.Ho) && (w0 + gpc[r >> 2] + (r & 3) < a.Wo)) {
+            float v = acc[mt][nt][r] * sc + bi;
+            const unsigned so = soff + (unsigned)(r & 3) * estep;
+            if (has_res) v += buf_load1(rr, goff[r >> 2], so);
+            buf_store1(yr, goff[r >> 2], so, fmaxf(v, lo));
           }
         }
       }
     }
-    if (a.probe) {
-      const long long t_issued = __builtin_readcyclecounter();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const long long t_drained = __builtin_readcyclecounter();
-      if (lane == 0) {
-        long long* p = a.probe + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
-        p[0] = t_start; p[1] = t_s0; p[2] = t_s1; p[3] = t_s2; p[4] = t_staged; p[5] = t_taps;
-        p[6] = t_issued; p[7] = t_drained;
-      }
-    }
-  } else {
-    // transpose the wave's 64 voxels x 16 mid channels through LDS (reusing the halo tile),
-    // then one lane per voxel runs the tiny MLP + argmax.
-    static_assert(EPI == 0 || NT == 1, "OccHead tail expects a single N-tile");
-    constexpr int MS = 17;                         // padded row stride (bank spread)
-    __syncthreads();                               // all waves are done with the halo tile
-    float* sm = lds + wave * (64 * MS);
-    {
-      const float sc = a.scale ? a.scale[i] : 1.f;
-      const float bi = a.bias ? a.bias[i] : 0.f;
-      if (i < tail.n_mid) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[mt][0][r] * sc + bi;
-            if (a.relu0) v = fmaxf(v, 0.f);
-            sm[(mt * 32 + row) * MS + i] = v;
-          }
-      }
-    }
-    __syncthreads();
-    const int mt = lane >> 5, row = lane & 31;
-    const int pjr = patch_of_row(row);
-    const int oh = h0 + mt * 4 + (pjr >> 3), ow = w0 + (pjr & 7);
-    if (od < a.Do && oh < a.Ho && ow < a.Wo) {
-      const size_t vox = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-      float mid[16], hid[8];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) mid[k] = sm[lane * MS + k];
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        float s_ = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s_ += mid[k] * tail.w1[o * 16 + k];
-        hid[o] = fmaxf(s_ * tail.s1[o] + tail.b1[o], 0.f);
-      }
-      float best = 0.f;
-      int arg = 0;
-#pragma unroll
-      for (int c = 0; c < 18; ++c) {
-        float s_ = 0.f;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) s_ += hid[o] * tail.w2[c * 8 + o];
-        if (tail.logits) tail.logits[vox * 18 + c] = s_;
-        if (c == 0 || s_ > best) { best = s_; arg = c; }
-      }
-      tail.occ[vox] = (uint8_t)arg;
-    }
+  }
+  }   // od < Do
+  if (a.probe && lane == 0) {
+    long long* p = a.probe + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (4 * WD) + wave) * 4;
+    p[0] = ts0; p[1] = ts1; p[2] = ts2; p[3] = __builtin_readcyclecounter();
   }
 }
 
@@ -330,27 +430,41 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_k3s1(ConvArgs a, OccTail tail
 // accumulators are independent, which covers the 40-cycle dependent latency at 32-cycle issue.
 // K order inside a (chunk, tap): k-group g = l>>4 walks channels g*8 .. g*8+7 (2 x ds_read_b128,
 // 2 x global_load_dwordx4 of packed weights [chunk][tap][lane][8]).
+// Fused tail (mmdet3d/models/heads/occupancy_head.py:92-99,124-161): after conv + BN + ReLU each
+// voxel runs 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18 and argmax -> uint8 inside the epilogue; the
+// 46 MB logits tensor is only written on request.
 // ------------------------------------------------------------------------------------
+struct OccTail {
+  const float* w1;      // [8][16]  occ_pred_conv.0.weight
+  const float* s1;      // [8]      folded BN scale
+  const float* b1;      // [8]      folded BN bias
+  const float* w2;      // [18][8]  occ_pred_conv.3.weight
+  uint8_t* occ;         // [B*D*H*W] argmax class
+  float* logits;        // [B*D*H*W][18] or null
+  int n_mid, n_hid, n_cls;
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void load_b16(const float* w, float4 (&b)[2]) {
-  b[0] = *reinterpret_cast<const float4*>(w);
-  b[1] = *reinterpret_cast<const float4*>(w + 4);
+__device__ __forceinline__ void load_b16(rsrc_t wr, unsigned wsoff, unsigned lane_off, float4 (&b)[2]) {
+  b[0] = buf_load4(wr, lane_off, wsoff);
+  b[1] = buf_load4(wr, lane_off + 16u, wsoff);
 }
 
-__device__ __forceinline__ void tap_mfma16(const float* lds, int tap, int wave, int g, int i,
+template <int TAP>
+__device__ __forceinline__ void tap_mfma16(const float* lds, const unsigned (&aaddr)[2][3][2],
                                            const float4 (&b)[2], f32x4 (&acc)[4]) {
-  const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+  constexpr int kd = TAP / 9, kh = (TAP / 3) % 3, kw = TAP % 3;
+  const char* ldsb = reinterpret_cast<const char*>(lds);
   float4 aq[4][2];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int hh = mt * 2 + (i >> 3) + kh, ww = (i & 7) + kw, dd = wave + kd;
-    const int vl = (dd * TH + hh) * TW + ww;
-    const int f = ((ww >> 1) & 3) | ((hh & 1) << 2);
+    const unsigned imm = (unsigned)(((kd * TH + mt * 2 + kh) * TW) * 128);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      aq[mt][q] = *reinterpret_cast<const float4*>(lds + ((vl << 3) + ((g * 2 + q) ^ f)) * 4);
+      aq[mt][q] = *reinterpret_cast<const float4*>(ldsb + (aaddr[kh & 1][kw][q] + imm));
   }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const float bv[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
@@ -365,16 +479,52 @@ __device__ __forceinline__ void tap_mfma16(const float* lds, int tap, int wave, 
   }
 }
 
-__global__ void __launch_bounds__(256, 2) k_occ_head16(ConvArgs a, OccTail tail) {
+template <int TAP>
+__device__ __forceinline__ void tap_pair16(const float* lds, const unsigned (&aaddr)[2][3][2],
+                                           rsrc_t wr, unsigned wsoff, unsigned lane_off,
+                                           float4 (&b0)[2], float4 (&b1)[2], f32x4 (&acc)[4]) {
+  if constexpr (TAP + 1 < 27) {
+    load_b16(wr, wsoff + (unsigned)(TAP + 1) * 2048u, lane_off, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    tap_mfma16<TAP>(lds, aaddr, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b16(wr, wsoff + (unsigned)(TAP + 2) * 2048u, lane_off, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    tap_mfma16<TAP + 1>(lds, aaddr, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    tap_pair16<TAP + 2>(lds, aaddr, wr, wsoff, lane_off, b0, b1, acc);
+  } else {
+    tap_mfma16<TAP>(lds, aaddr, b0, acc);
+  }
+}
+
+template <int WD>
+__global__ void __launch_bounds__(256 * WD, 2) k_occ_head16(ConvArgs a, OccTail tail) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
   int bid = blockIdx.x;
   const int tw = bid % a.tiles_w; bid /= a.tiles_w;
   const int th = bid % a.tiles_h; bid /= a.tiles_h;
   const int td = bid % a.tiles_d;
   const int b = bid / a.tiles_d;
-  const int d0 = td * BD, h0 = th * BH, w0 = tw * BW;
+  const int d0 = td * (BD * WD), h0 = th * BH, w0 = tw * BW;
+  unsigned aaddr[2][3][2];
+#pragma unroll
+  for (int khp = 0; khp < 2; ++khp)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ww = (i & 7) + kw, hr = i >> 3;
+      const int f = ((ww >> 1) & 3) | (((hr + khp) & 1) << 2);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        aaddr[khp][kw][q] = (unsigned)((((wave * TH + hr) * TW + ww) * 8 + ((g * 2 + q) ^ f)) * 16);
+    }
+  const StageLane sl = stage_lane_setup(a, w0, lane);
+  const unsigned lane_off = (unsigned)lane * 32u;
+  const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
+  const rsrc_t wr = make_rsrc(a.wpk, (unsigned)((size_t)(a.Cin / KC) * 27 * 2048));
   f32x4 acc[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -382,27 +532,15 @@ __global__ void __launch_bounds__(256, 2) k_occ_head16(ConvArgs a, OccTail tail)
     for (int r = 0; r < 4; ++r) acc[mt][r] = 0.f;
   const int nchunk = a.Cin / KC;
   for (int ch = 0; ch < nchunk; ++ch) {
-    stage_halo_chunk(a, lds, b, d0, h0, w0, ch, tid);
-    const float* wch = a.wpk + (size_t)ch * 27 * 512 + lane * 8;
+    const unsigned wsoff = (unsigned)(ch * 27 * 2048);
     float4 b0[2], b1[2];
-    load_b16(wch, b0);
-#pragma unroll 1
-    for (int tap = 0; tap < 26; tap += 2) {
-      load_b16(wch + (size_t)(tap + 1) * 512, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      tap_mfma16(lds, tap, wave, g, i, b0, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      load_b16(wch + (size_t)(tap + 2) * 512, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      tap_mfma16(lds, tap + 1, wave, g, i, b1, acc);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    tap_mfma16(lds, 26, wave, g, i, b0, acc);
+    load_b16(wr, wsoff, lane_off, b0);
+    stage_halo_chunk<WD, 8>(a, xr, lds, sl, b, d0, h0, w0, ch, wave, lane);
+    tap_pair16<0>(lds, aaddr, wr, wsoff, lane_off, b0, b1, acc);
   }
   // ---- tail: BN+ReLU, transpose 64 voxels x 16 channels through LDS, per-voxel MLP + argmax
   constexpr int MS = 17;
   const int od = d0 + wave;
-  __builtin_amdgcn_s_setprio(3);
   __syncthreads();
   float* sm = lds + wave * (64 * MS);
   {
@@ -643,10 +781,25 @@ PW_API int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, c
 // host entry
 // ------------------------------------------------------------------------------------
 template <typename K>
-static int set_lds_limit(K kernel) {
+static int set_lds_limit(K kernel, int bytes) {
   PW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   return PW_OK;
+}
+
+// 8-wave blocks (WD=2) when the grid has enough 8x8x8 tiles to fill the 256 CUs more than once;
+// 4-wave blocks otherwise (small encoder stages).  PW_CONV_WD=1|2 forces a variant (A/B runs).
+static int choose_wd(int B, int Do, int Ho, int Wo, int ngroups) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("PW_CONV_WD");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 1 || forced == 2) return forced;
+  // measured equal within noise on the 16x200x200 grid (325 vs 326 us for 32->32); the 4-wave
+  // variant is the default because it needs less LDS per block and tiles small grids better
+  (void)B; (void)Do; (void)Ho; (void)Wo; (void)ngroups;
+  return 1;
 }
 
 PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const float* bias,
@@ -675,6 +828,9 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   a.tiles_d = (a.Do + BD - 1) / BD; a.tiles_h = (a.Ho + BH - 1) / BH; a.tiles_w = (a.Wo + BW - 1) / BW;
   PW_CHECK_ARG(!(cout1 > 0 && !y1), "pw_conv3d_ndhwc: cout1 > 0 needs y1");
   PW_CHECK_ARG(a.n1_start + cout1 <= cout_total || cout1 == 0, "pw_conv3d_ndhwc: cout split exceeds cout_total");
+  PW_CHECK_ARG((size_t)B * D * H * W * Cin * 4 < (1ull << 32) &&
+                   (size_t)B * a.Do * a.Ho * a.Wo * (cout0 > cout1 ? cout0 : cout1) * 4 < (1ull << 32),
+               "pw_conv3d_ndhwc: tensors must be < 4 GiB (32-bit buffer addressing)");
   hipStream_t st = pw_stream(stream);
   const int ntiles = cout_total / 32;
   int NT = (ntiles % 2 == 0) ? 2 : 1;
@@ -690,24 +846,24 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   const bool tiled = (ksize == 3 && stride == 1 && algo != 2);
   PW_CHECK_ARG(!(algo == 1 && !tiled), "pw_conv3d_ndhwc: algo=1 needs ksize 3 stride 1");
   a.probe = nullptr;
-  {
-    const char* e = getenv("PW_CONV_PROBE");     // development aid: address of a device buffer
-    if (e) a.probe = (long long*)strtoull(e, nullptr, 0);
-  }
+  if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
   if (tiled) {
+    const int WD = choose_wd(B, a.Do, a.Ho, a.Wo, ngroups);
+    a.tiles_d = (a.Do + BD * WD - 1) / (BD * WD);
     long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
     PW_CHECK_ARG(nblk < (1ll << 31), "pw_conv3d_ndhwc: grid too large");
     dim3 grid((unsigned)nblk, (unsigned)ngroups);
-    OccTail none = {};
-    if (NT == 2) {
-      static int once = set_lds_limit(k_conv3d_k3s1<2, 0>);
-      if (once) return once;
-      hipLaunchKernelGGL((k_conv3d_k3s1<2, 0>), grid, dim3(256), LDS_BYTES, st, a, none);
-    } else {
-      static int once = set_lds_limit(k_conv3d_k3s1<1, 0>);
-      if (once) return once;
-      hipLaunchKernelGGL((k_conv3d_k3s1<1, 0>), grid, dim3(256), LDS_BYTES, st, a, none);
-    }
+#define PW_LAUNCH_TILED(NTv, WDv)                                                              \
+  do {                                                                                         \
+    static int once = set_lds_limit(k_conv3d_k3s1<NTv, WDv>, TileGeom<WDv>::LDS);               \
+    if (once) return once;                                                                     \
+    hipLaunchKernelGGL((k_conv3d_k3s1<NTv, WDv>), grid, dim3(256 * WDv), TileGeom<WDv>::LDS, st, a); \
+  } while (0)
+    if (NT == 2 && WD == 2) PW_LAUNCH_TILED(2, 2);
+    else if (NT == 2) PW_LAUNCH_TILED(2, 1);
+    else if (WD == 2) PW_LAUNCH_TILED(1, 2);
+    else PW_LAUNCH_TILED(1, 1);
+#undef PW_LAUNCH_TILED
   } else {
     dim3 grid((unsigned)pw_cdiv(n_out, 128), (unsigned)ngroups);
 #define PW_GATHER(NTv, KSv, STv) \
@@ -744,16 +900,19 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
   a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
   OccTail t = {w1, s1, b1, w2, occ, logits, n_mid, n_hid, n_cls};
   long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
-  if (wpk_layout == 16) {
-    static int once16 = set_lds_limit(k_occ_head16);
-    if (once16) return once16;
-    hipLaunchKernelGGL(k_occ_head16, dim3((unsigned)nblk, 1), dim3(256), LDS_BYTES, pw_stream(stream),
-                       a, t);
-  } else {
-    PW_CHECK_ARG(wpk_layout == 32, "pw_occ_head_fused: wpk_layout must be 16 or 32");
-    static int once = set_lds_limit(k_conv3d_k3s1<1, 1>);
+  PW_CHECK_ARG(wpk_layout == 16, "pw_occ_head_fused: wpk_layout must be 16 (the 16x16x4 MFMA packing)");
+  const int WD = choose_wd(B, D, H, W, 1);
+  a.tiles_d = (D + BD * WD - 1) / (BD * WD);
+  nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
+  if (WD == 2) {
+    static int once = set_lds_limit(k_occ_head16<2>, TileGeom<2>::LDS);
     if (once) return once;
-    hipLaunchKernelGGL((k_conv3d_k3s1<1, 1>), dim3((unsigned)nblk, 1), dim3(256), LDS_BYTES,
+    hipLaunchKernelGGL(k_occ_head16<2>, dim3((unsigned)nblk, 1), dim3(512), TileGeom<2>::LDS,
+                       pw_stream(stream), a, t);
+  } else {
+    static int once = set_lds_limit(k_occ_head16<1>, TileGeom<1>::LDS);
+    if (once) return once;
+    hipLaunchKernelGGL(k_occ_head16<1>, dim3((unsigned)nblk, 1), dim3(256), TileGeom<1>::LDS,
                        pw_stream(stream), a, t);
   }
   PW_CHECK_LAUNCH();

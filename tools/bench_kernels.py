@@ -106,9 +106,7 @@ def bench_enc():
     res['fpn_fuse_us'] = t; res['fpn_fuse_GBps'] = 164e6 / t / 1e3
     # occ head
     w1 = torch.randn(8, 16, device=dev); s1 = torch.ones(8, device=dev); b1 = torch.zeros(8, device=dev)
-    w2 = torch.randn(18, 8, device=dev); wp = w(16, 32)
-    t = timeit(lambda: ops.occ_head_fused(x32, wp, sc, bi, w1, s1, b1, w2), iters=10)
-    res['occ_head_32x32x2_us'] = t
+    w2 = torch.randn(18, 8, device=dev)
     wp16 = ops.pack_conv_weight16(torch.randn(16, 32, 3, 3, 3, device=dev) * 0.05)
     t = timeit(lambda: ops.occ_head_fused(x32, wp16, sc, bi, w1, s1, b1, w2), iters=10)
     res['occ_head_us'] = t; res['occ_head_TFLOPs_useful'] = flops(32, 16) / t / 1e6
