@@ -226,6 +226,12 @@ int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, const f
 int pw_attr_mlp(const float* v0, int64_t n_vox, const float* w1p, const float* w2p,
                 const float* b1p, const float* b2, int final_softplus, float* out, void* stream);
 
+/* A22  confusion matrix of the occupancy metric (mmdet3d/datasets/occ_metrics.py:82-105):
+ * hist[n_cl*gt + pred] += 1 over voxels with gt < n_cl (and mask != 0 when mask is given).
+ * pred/gt/mask uint8[n]; hist int64[n_cl*n_cl] ACCUMULATES (zero it for a fresh metric). */
+int pw_confusion_hist(const uint8_t* pred, const uint8_t* gt, const uint8_t* mask, int64_t n,
+                      int n_cl, int64_t* hist, void* stream);
+
 /* nn.Softplus(beta=1, threshold=20) elementwise (the activation inside fusion_head and the
  * attribute MLPs, preworld_temporal_traj.py:81-132), same device function as the fused kernels. */
 int pw_softplus(const float* x, float* y, int64_t n, void* stream);

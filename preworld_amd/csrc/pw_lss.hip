@@ -731,3 +731,39 @@ PW_API int pw_bev_pool_v2_backward(const float* out_grad, float* depth_grad, flo
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// A22  occupancy confusion matrix (mmdet3d/datasets/occ_metrics.py:82-105: bincount(n_cl*gt+pred)
+// over voxels with gt < n_cl, optionally restricted to mask_camera / mask_lidar).  Integer work:
+// per-wave privatised LDS histograms, one global atomic per (bin, block).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_confusion_hist(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ gt,
+                 const uint8_t* __restrict__ mask, int64_t n, int n_cl,
+                 unsigned long long* __restrict__ hist) {
+  extern __shared__ unsigned int lh[];
+  const int nb = n_cl * n_cl;
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) lh[k] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (mask && !mask[i]) continue;
+    const int g = gt[i], p = pred[i];
+    if (g < n_cl && p < n_cl) atomicAdd(&lh[g * n_cl + p], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nb; k += blockDim.x)
+    if (lh[k]) atomicAdd(&hist[k], (unsigned long long)lh[k]);
+}
+
+PW_API int pw_confusion_hist(const uint8_t* pred, const uint8_t* gt, const uint8_t* mask, int64_t n,
+                             int n_cl, int64_t* hist, void* stream) {
+  PW_CHECK_ARG(pred && gt && hist && n >= 0 && n_cl > 0 && n_cl <= 64, "pw_confusion_hist: bad arguments");
+  if (n == 0) return PW_OK;
+  int64_t want = pw_cdiv(n, 256 * 16);
+  unsigned nb = (unsigned)(want < 1024 ? (want < 1 ? 1 : want) : 1024);
+  hipLaunchKernelGGL(k_confusion_hist, dim3(nb), dim3(256), (size_t)n_cl * n_cl * 4, pw_stream(stream),
+                     pred, gt, mask, n, n_cl, reinterpret_cast<unsigned long long*>(hist));
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

@@ -504,6 +504,42 @@ class PreWorld4DTraj(nn.Module):
                                          nn.Linear(out_dim * 4, out_dim))
         self._fc_cache = _PackedCache()
 
+    # ---- bevdet_occ.py:88-139 (BEVStereo4DOCC.prepare_inputs): split the stacked inputs into
+    # frames and express every sweep's sensor pose in the KEY frame's ego system (fp64 algebra)
+    def prepare_inputs(self, inputs, stereo=False, num_frame=None, temporal_frame=None,
+                       extra_ref_frames=1):
+        """inputs = (imgs (B, N*T, C, H, W) camera-major/frame-minor, sensor2egos (B, T*N, 4, 4)
+        frame-major, ego2globals, intrins (B,T*N,3,3), post_rots, post_trans (B,T*N,3), bda).
+        Returns (imgs[T], sensor2keyegos[T], ego2globals[T], intrins[T], post_rots[T],
+        post_trans[T], bda, curr2adjsensor) exactly like the reference."""
+        num_frame = num_frame or (self.num_adj + 1 + (extra_ref_frames if stereo else 0))
+        temporal_frame = temporal_frame or (num_frame - extra_ref_frames if stereo else num_frame)
+        B, N, C, H, W = inputs[0].shape
+        N = N // num_frame
+        imgs = inputs[0].view(B, N, num_frame, C, H, W)
+        imgs = [t.squeeze(2) for t in torch.split(imgs, 1, 2)]
+        sensor2egos, ego2globals, intrins, post_rots, post_trans, bda = inputs[1:7]
+        sensor2egos = sensor2egos.view(B, num_frame, N, 4, 4)
+        ego2globals = ego2globals.view(B, num_frame, N, 4, 4)
+        keyego2global = ego2globals[:, 0, 0, ...].unsqueeze(1).unsqueeze(1)
+        global2keyego = torch.inverse(keyego2global.double())
+        sensor2keyegos = (global2keyego @ ego2globals.double() @ sensor2egos.double()).float()
+        curr2adjsensor = None
+        if stereo:
+            s_curr = sensor2egos[:, :temporal_frame, ...].double()
+            e_curr = ego2globals[:, :temporal_frame, ...].double()
+            s_adj = sensor2egos[:, 1:temporal_frame + 1, ...].double()
+            e_adj = ego2globals[:, 1:temporal_frame + 1, ...].double()
+            c2a = (torch.inverse(e_adj @ s_adj) @ e_curr @ s_curr).float()
+            curr2adjsensor = [p.squeeze(1) for p in torch.split(c2a, 1, 1)]
+            curr2adjsensor.extend([None for _ in range(extra_ref_frames)])
+            assert len(curr2adjsensor) == num_frame
+        extra = [sensor2keyegos, ego2globals, intrins.view(B, num_frame, N, 3, 3),
+                 post_rots.view(B, num_frame, N, 3, 3), post_trans.view(B, num_frame, N, 3)]
+        extra = [[p.squeeze(1) for p in torch.split(t, 1, 1)] for t in extra]
+        sensor2keyegos, ego2globals, intrins, post_rots, post_trans = extra
+        return imgs, sensor2keyegos, ego2globals, intrins, post_rots, post_trans, bda, curr2adjsensor
+
     # ---- bevdet.py:52-58
     def bev_encoder_cl(self, x_cl):
         return self.img_bev_encoder_neck.forward_cl(self.img_bev_encoder_backbone.forward_cl(x_cl))

@@ -551,3 +551,15 @@ def render_rays(rays_o, rays_d, t, grid, consts, c_sigma=0, c_sem=2, n_sem=17, c
     if want_debug:
         out.update(counts=counts, weights=weights, mask=mask.bool())
     return out
+
+
+def confusion_hist(pred, gt, mask, n_cl, hist):
+    """hist (n_cl,n_cl) int64 += bincount(n_cl*gt + pred) over (masked) voxels -- occ_metrics.py:82-105."""
+    p = pred.contiguous().view(-1)
+    g = gt.contiguous().view(-1)
+    m = mask.contiguous().view(-1).to(torch.uint8) if mask is not None else None
+    if p.dtype != torch.uint8 or g.dtype != torch.uint8:
+        raise _lib.PreworldHipError('pred/gt must be uint8')
+    _lib.call('pw_confusion_hist', _chk(p, torch.uint8, 'pred'), _chk(g, torch.uint8, 'gt'), _p(m),
+              p.numel(), int(n_cl), _chk(hist, _i64, 'hist'), _stream())
+    return hist

@@ -187,3 +187,31 @@ def test_nerf_head_losses_vs_oracle():
     for k in ('loss_render_depth', 'loss_render_semantic', 'loss_render_color', 'loss_sdf_entropy',
               'loss_sdf_distortion'):
         assert abs(float(losses[k]) - ol[k]) <= 2e-3 * abs(ol[k]) + 1e-6, (k, float(losses[k]), ol[k])
+
+
+def test_metric_miou_golden_and_oracle(golden):
+    """A22: GPU confusion matrix is bit-identical to the reference's Metric_mIoU histogram."""
+    from preworld_amd.metrics import Metric_mIoU, Metric_mIoU_Temporal
+    g = golden('metric_miou.npz')
+    m = Metric_mIoU(num_classes=18, use_image_mask=True, device=DEV)
+    for p, gt, k in zip(g['pred'], g['gt'], g['mask']):
+        m.add_batch(p, gt, None, k)
+    np.testing.assert_array_equal(m.hist, g['hist'])
+    _, iu, cnt, miou = m.count_miou()
+    assert miou == float(g['miou']) and cnt == 3
+    np.testing.assert_allclose(iu, g['iou'], rtol=1e-12)
+    # full-size random labels incl. 255 (ignored) vs the oracle's histogram; no mask
+    rs = np.random.RandomState(0)
+    gt = rs.randint(0, 18, (200, 200, 16)).astype(np.uint8)
+    gt[rs.rand(200, 200, 16) < 0.05] = 255
+    pred = rs.randint(0, 18, (200, 200, 16)).astype(np.uint8)
+    m2 = Metric_mIoU(num_classes=18, device=DEV)
+    m2.add_batch(T(pred), T(gt), None, None)
+    o = O.MetricMIoU(num_classes=18)
+    o.add_batch(pred, gt)
+    np.testing.assert_array_equal(m2.hist.astype(np.int64), o.hist)
+    # temporal indexing: gt idx 4 is scored against stacked state 2
+    mt = Metric_mIoU_Temporal(device=DEV)
+    stack = np.stack([pred, gt, gt, pred])
+    mt.add_batch(stack, gt, None, None, 4)
+    assert mt.metrics[4].count_miou()[3] == 100.0

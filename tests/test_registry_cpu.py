@@ -85,3 +85,41 @@ def test_modules_refuse_cpu_tensors():
     m = M.CustomResNet3D(numC_input=32, num_layer=[1], num_channels=[32], stride=[1]).eval()
     with pytest.raises(Exception):
         m(torch.zeros(1, 32, 4, 8, 8))
+
+
+def test_prepare_inputs_pose_algebra():
+    """A21: bevdet_occ.py:88-139 -- sweep poses expressed in the key ego frame (fp64), frame split
+    orders (images camera-major/frame-minor, poses frame-major)."""
+    import numpy as np
+    net = M.PreWorld4DTraj(
+        img_view_transformer=dict(grid_config=S.GRID_CONFIG_FULL, input_size=S.INPUT_SIZE,
+                                  in_channels=512, out_channels=32, collapse_z=False, downsample=16),
+        img_bev_encoder_backbone=dict(numC_input=64, num_layer=[1], num_channels=[32], stride=[1]),
+        img_bev_encoder_neck=dict(in_channels=224, out_channels=32))
+    B, N, T = 1, 6, 3
+    rs = np.random.RandomState(0)
+
+    def rand_pose(n):
+        P = np.tile(np.eye(4), (n, 1, 1))
+        for k in range(n):
+            q, _ = np.linalg.qr(rs.standard_normal((3, 3)))
+            P[k, :3, :3] = q * np.sign(np.linalg.det(q))
+            P[k, :3, 3] = rs.standard_normal(3) * 10
+        return P
+    s2e = rand_pose(T * N)[None]
+    e2g = rand_pose(T * N)[None]
+    imgs = torch.arange(B * N * T).float().view(B, N * T, 1, 1, 1).expand(B, N * T, 3, 2, 2)
+    inputs = (imgs, torch.from_numpy(s2e).float(), torch.from_numpy(e2g).float(),
+              torch.rand(B, T * N, 3, 3), torch.rand(B, T * N, 3, 3), torch.rand(B, T * N, 3),
+              torch.eye(3)[None])
+    out = net.prepare_inputs(inputs, stereo=True, num_frame=T, temporal_frame=2, extra_ref_frames=1)
+    im, s2k, e2gs, K, pr, pt, bda, c2a = out
+    assert len(im) == T and im[1].shape == (B, N, 3, 2, 2)
+    # image (camera n, frame t) sits at stacked index n*T + t
+    assert float(im[2][0, 4, 0, 0, 0]) == 4 * T + 2
+    ref = np.linalg.inv(e2g[0, 0]) @ e2g[0].reshape(T, N, 4, 4) @ s2e[0].reshape(T, N, 4, 4)
+    np.testing.assert_allclose(torch.stack(s2k, 1)[0].numpy(), ref, rtol=1e-4, atol=1e-4)
+    a, c = e2g[0].reshape(T, N, 4, 4), s2e[0].reshape(T, N, 4, 4)
+    ref_c2a = np.linalg.inv(a[1] @ c[1]) @ a[0] @ c[0]
+    np.testing.assert_allclose(c2a[0][0].numpy(), ref_c2a, rtol=1e-4, atol=1e-4)
+    assert c2a[2] is None and len(c2a) == T
