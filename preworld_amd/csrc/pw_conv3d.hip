@@ -36,9 +36,6 @@ constexpr int BD = 4, BH = 8, BW = 8;
 constexpr int TD = BD + 2, TH = BH + 2, TW = BW + 2;
 constexpr int TV = TD * TH * TW;                 // 600 halo voxels
 constexpr int KC = 32;                           // input channels per LDS chunk
-constexpr int LDS_BYTES = TV * KC * 4;           // 76800
-constexpr int STAGE_ITEMS = TV * (KC / 4);       // float4 items per chunk (4800)
-constexpr int STAGE_ITERS = (STAGE_ITEMS + 255) / 256;
 }  // namespace
 
 struct ConvArgs {
@@ -423,6 +420,383 @@ __global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// 3x3x3 stride 1, PERSISTENT + DMA-PIPELINED variant (the default for large grids).
+//
+// Measured on gfx950 (tools/probes/mfma_shadow.hip): nothing is free next to fp32 MFMAs.  Every
+// ds_read_b128 / buffer_load_dwordx4 a SIMD issues costs ~15 ticks of matrix-pipe time and a VALU
+// instruction ~3-6, whether it comes from the MFMA wave or from a sibling; and instructions of a
+// sibling wave only issue when the MFMA wave stalls, so the tile-per-block kernel above runs its
+// halo staging and its MFMA phases back to back (~15-20 % of the time not on the matrix pipe).
+// Hence:
+//   * the halo is staged by `buffer_load_dword(x4) ... lds`: the load unit writes LDS directly --
+//     no data VGPRs, no ds_write, 2 instructions per halo row instead of ~10 -- and the MFMA wave
+//     itself issues them, one halo row of the NEXT stage per tap;
+//   * one 4-wave block per CU, persistent over a contiguous, XCD-local range of work items
+//     (tile x N-group); LDS = two 76.8 KB halo buffers, stage s computes from buffer s&1 while
+//     the DMA for stage s+1 fills the other; ONE barrier per stage;
+//   * a wave owns 2 M-tiles x NT N-tiles (weights are reused across the M-tiles, A fragments
+//     across the N-tiles: 0.375 / 0.25 operand loads per MFMA for NT = 1 / 2); A fragments of
+//     tap t+1 and weights of tap t+2 are requested before the MFMAs of tap t;
+//   * the XOR swizzle moves to the global side: the DMA writes lane L's bytes at LDS row base +
+//     16 L (4 L for the dword form), so lane (ww, slot') fetches channel slot slot' ^ f(ww, hh)
+//     of voxel ww -- the lanes of a voxel still cover its whole 128-byte line;
+//   * a halo row is 8 + 2 voxels: one dwordx4 DMA (64 lanes x 16 B) and one dword DMA
+//     (64 lanes x 4 B), every lane active, no EXEC games, no branches inside a tap;
+//   * out-of-volume halo voxels (and "no next stage"): the lane's buffer offset is forced out of
+//     range, the load unit returns 0 and the zero lands in LDS (tools/probes/dma_probe.hip).
+// ------------------------------------------------------------------------------------
+struct PipeArgs {
+  unsigned m_ng, m_tw, m_th, m_td;   // floor(2^32 / d) + 1 for exact x / d by mulhi (x * d < 2^32)
+  int ngroups, n_items;
+};
+
+typedef __attribute__((address_space(3))) char* lds3_t;
+
+__device__ __forceinline__ int udiv_magic(int x, int d, unsigned magic) {
+  return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
+}
+
+struct PipeTile { int b, d0, h0, w0, ng; };
+
+__device__ __forceinline__ PipeTile pipe_decode(const ConvArgs& a, const PipeArgs& p, int item) {
+  PipeTile t;
+  int tile = udiv_magic(item, p.ngroups, p.m_ng);
+  t.ng = item - tile * p.ngroups;
+  int q = udiv_magic(tile, a.tiles_w, p.m_tw);
+  t.w0 = (tile - q * a.tiles_w) * BW; tile = q;
+  q = udiv_magic(tile, a.tiles_h, p.m_th);
+  t.h0 = (tile - q * a.tiles_h) * BH; tile = q;
+  q = udiv_magic(tile, a.tiles_d, p.m_td);
+  t.d0 = (tile - q * a.tiles_d) * BD;
+  t.b = q;
+  return t;
+}
+
+constexpr unsigned PIPE_OOB = 0xfffffff0u;     // voffset beyond any num_records -> load returns 0
+constexpr int PIPE_BUF_BYTES = TV * KC * 4;     // 76800
+constexpr int PIPE_ROWS_PER_WAVE = TD * TH / 4; // 15 halo rows per wave and stage
+
+struct PipeDma {                                 // what the DMA of one stage needs
+  unsigned voff[2][2];                           // [halo-row parity][pass] lane offset or PIPE_OOB
+  int b, d0, h0, wbase, ch;                      // scalars
+  unsigned ldsbuf;                               // byte offset of the destination buffer
+  bool live;                                     // false: no next stage, every lane goes OOB
+};
+
+// lane offsets for a tile column position w0 (see stage_lane_setup for the w0 == 0 shift);
+// pass 0 = voxels 0..7 as 16-byte slots, pass 1 = voxels 8..9 as dwords
+__device__ __forceinline__ void pipe_lane_offsets(const ConvArgs& a, int w0, int lane, unsigned (&voff)[2][2]) {
+  const int shift = w0 == 0 ? 1 : 0;
+  {
+    const int ww = lane >> 3, slot = lane & 7;
+    const bool wok = (unsigned)(w0 - 1 + ww) < (unsigned)a.W;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int f = ((ww >> 1) & 3) | (par << 2);
+      voff[par][0] = wok ? (unsigned)((ww - shift) * a.Cin + (slot ^ f) * 4) * 4u : PIPE_OOB;
+    }
+  }
+  {
+    const int ww = 8 + (lane >> 5), dw = lane & 31, slot = dw >> 2;
+    const bool wok = (unsigned)(w0 - 1 + ww) < (unsigned)a.W;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int f = ((ww >> 1) & 3) | (par << 2);
+      voff[par][1] = wok ? (unsigned)((ww - shift) * a.Cin + (slot ^ f) * 4 + (dw & 3)) * 4u : PIPE_OOB;
+    }
+  }
+}
+
+// halo row `wave + 4 K` of the stage described by dm: two DMA instructions (8 + 2 voxels)
+template <int K>
+__device__ __forceinline__ void pipe_dma_row(const ConvArgs& a, rsrc_t xr, lds3_t lds3, const PipeDma& dm,
+                                             int wave) {
+  const int row = wave + 4 * K;                    // wave-uniform, < 60
+  const int dd = row / TH, hh = row - dd * TH;
+  const int gd = dm.d0 + dd - 1, gh = dm.h0 + hh - 1;
+  const bool rok = dm.live && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H;
+  const unsigned soff = rok ? (unsigned)(((((dm.b * a.D + gd) * a.H + gh) * a.W + dm.wbase) * a.Cin + dm.ch * KC) * 4) : 0u;
+  const unsigned v0 = rok ? ((hh & 1) ? dm.voff[1][0] : dm.voff[0][0]) : PIPE_OOB;
+  const unsigned v1 = rok ? ((hh & 1) ? dm.voff[1][1] : dm.voff[0][1]) : PIPE_OOB;
+  lds3_t dst = lds3 + (dm.ldsbuf + (unsigned)row * (TW * 128));
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, v0, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst + 1024, 4, v1, soff, 0, 0);
+}
+
+template <int NT>
+struct PipeCtx {
+  lds3_t lds3;
+  rsrc_t xr, wr;
+  unsigned lane_off, wstride;
+  unsigned wsoff;              // this stage's (chunk, N-group) weight base
+  unsigned wsoff_next;         // next stage's
+  bool has_next;
+  PipeDma dm;                  // next stage's DMA description
+  int wave, lane;
+  long long* tap_probe;
+};
+
+template <int TAP>
+__device__ __forceinline__ void pipe_read_a_tap(lds3_t lds3, const unsigned (&aaddr)[2][3][4], float4 (&aq)[2][4]) {
+  constexpr int kd = TAP / 9, kh = (TAP / 3) % 3, kw = TAP % 3;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    constexpr unsigned imm0 = (unsigned)(((kd * TH + kh) * TW) * 128);
+    const unsigned imm = imm0 + (unsigned)(mt * 4 * TW * 128);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v4f v = *reinterpret_cast<const __attribute__((address_space(3))) v4f*>(lds3 + aaddr[kh & 1][kw][q] + imm);
+      aq[mt][q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void pipe_mfma(const float4 (&aq)[2][4], const float4 (&b)[NT][4], f32x16 (&acc)[2][NT]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float av[4] = {aq[mt][q].x, aq[mt][q].y, aq[mt][q].z, aq[mt][q].w};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float bv[4] = {b[nt][q].x, b[nt][q].y, b[nt][q].z, b[nt][q].w};
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// Tap TAP computes from (ac, b0).  Before its MFMAs it requests the weights of tap TAP+2 (-> b2),
+// one halo row of the next stage (taps 1..15) and the A fragments of tap TAP+1 (-> an).
+// vmcnt is an in-order counter: waiting for the weights of tap t also waits for every load issued
+// before them, so the DMA rows go out AFTER a weight request and the weights run two taps ahead --
+// a DMA row then has two taps (~1.7 us) to land before anything has to wait for it.
+// 27 taps rotate the three weight buffers back to their starting roles; after tap 26 b0/b1 hold
+// taps 0/1 of the NEXT stage.
+template <int NT, int TAP>
+__device__ __forceinline__ void pipe_step(const ConvArgs& a, const PipeCtx<NT>& c, const unsigned (&aaddr)[2][3][4],
+                                          float4 (&ac)[2][4], float4 (&an)[2][4], float4 (&b0)[NT][4],
+                                          float4 (&b1)[NT][4], float4 (&b2)[NT][4], f32x16 (&acc)[2][NT]) {
+  if (c.tap_probe) {                       // development aid: cycle counter at every tap of one stage
+    if (c.lane == 0) c.tap_probe[c.wave * 27 + TAP] = __builtin_readcyclecounter();
+  }
+  if constexpr (TAP + 2 < 27) {
+    load_b<NT>(c.wr, c.wsoff + (unsigned)(TAP + 2) * c.wstride, c.lane_off, b2);
+  } else {
+    // past the last item this re-reads a valid (unused) weight block: no branch in the tap
+    load_b<NT>(c.wr, c.wsoff_next + (unsigned)(TAP + 2 - 27) * c.wstride, c.lane_off, b2);
+  }
+  if constexpr (TAP >= 1 && TAP <= PIPE_ROWS_PER_WAVE) pipe_dma_row<TAP - 1>(a, c.xr, c.lds3, c.dm, c.wave);
+  if constexpr (TAP < 26) pipe_read_a_tap<TAP + 1>(c.lds3, aaddr, an);
+  __builtin_amdgcn_sched_barrier(0);
+  pipe_mfma<NT>(ac, b0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TAP < 26) pipe_step<NT, TAP + 1>(a, c, aaddr, an, ac, b1, b2, b0, acc);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1) k_conv3d_k3s1_pipe(ConvArgs a, PipeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);                  // = d-slice of the tile
+  const int half = lane >> 5, i = lane & 31;
+  const int pj = patch_of_row(i), pr = pj >> 3, pc = pj & 7;
+  const int ntiles_total = a.cout_total >> 5;
+  const int nchunk = a.Cin / KC;
+
+  // work items of this block: XCD x (workgroups are dealt round-robin to the 8 XCDs) owns a
+  // contiguous eighth of the items, so neighbouring tiles (shared halos, same weights) meet in
+  // one L2; inside the XCD the blocks stride over that range
+  const int nslots = (int)gridDim.x >> 3;
+  const int per = (p.n_items + 7) >> 3;
+  const int it_end = min(((int)blockIdx.x & 7) * per + per, p.n_items);
+  int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (item >= it_end) return;
+
+  unsigned aaddr0[2][3][4];
+#pragma unroll
+  for (int khp = 0; khp < 2; ++khp)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ww = pc + kw;
+      const int f = ((ww >> 1) & 3) | (((pr + khp) & 1) << 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        aaddr0[khp][kw][q] = (unsigned)((((wave * TH + pr) * TW + ww) * 8 + ((half * 4 + q) ^ f)) * 16);
+    }
+
+  PipeCtx<NT> c;
+  c.lds3 = (lds3_t)lds;
+  c.xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
+  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 27 * ntiles_total * 4096));
+  c.lane_off = (unsigned)lane * 64u;
+  c.wstride = (unsigned)ntiles_total * 4096u;
+  c.wave = wave; c.lane = lane;
+
+  PipeTile t = pipe_decode(a, p, item);
+  int ch = 0;
+  float4 a0[2][4], a1[2][4], b0[NT][4], b1[NT][4], b2[NT][4];
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // prologue: the first stage's halo goes out in one burst
+  {
+    PipeDma dm;
+    pipe_lane_offsets(a, t.w0, lane, dm.voff);
+    dm.b = t.b; dm.d0 = t.d0; dm.h0 = t.h0; dm.wbase = t.w0 > 0 ? t.w0 - 1 : 0; dm.ch = 0; dm.ldsbuf = 0;
+    dm.live = true;
+    load_b<NT>(c.wr, (unsigned)((t.ng * NT) * 4096), c.lane_off, b0);
+    load_b<NT>(c.wr, (unsigned)((t.ng * NT) * 4096) + c.wstride, c.lane_off, b1);
+    pipe_dma_row<0>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<1>(a, c.xr, c.lds3, dm, wave);
+    pipe_dma_row<2>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<3>(a, c.xr, c.lds3, dm, wave);
+    pipe_dma_row<4>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<5>(a, c.xr, c.lds3, dm, wave);
+    pipe_dma_row<6>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<7>(a, c.xr, c.lds3, dm, wave);
+    pipe_dma_row<8>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<9>(a, c.xr, c.lds3, dm, wave);
+    pipe_dma_row<10>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<11>(a, c.xr, c.lds3, dm, wave);
+    pipe_dma_row<12>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<13>(a, c.xr, c.lds3, dm, wave);
+    pipe_dma_row<14>(a, c.xr, c.lds3, dm, wave);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+
+  for (int stage = 0;; ++stage) {
+    const unsigned bufoff = (stage & 1) ? (unsigned)PIPE_BUF_BYTES : 0u;
+    unsigned aaddr[2][3][4];
+#pragma unroll
+    for (int khp = 0; khp < 2; ++khp)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          aaddr[khp][kw][q] = aaddr0[khp][kw][q] + bufoff;
+          // opaque: keep ONE address register per variant and the tap offset as the ds_read
+          // immediate (the compiler otherwise re-adds buffer + tap offset per read: 8 VALU per tap)
+          asm volatile("" : "+v"(aaddr[khp][kw][q]));
+        }
+    long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (a.probe) ts0 = __builtin_readcyclecounter();
+    pipe_read_a_tap<0>(c.lds3, aaddr, a0);
+    // folded-BN scale/bias of this lane's output column: requested now, used in the epilogue
+    // (all waves of the block reach the epilogue together, nothing would hide the latency there)
+    float sc_r[NT], bi_r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (t.ng * NT + nt) * 32 + i;
+      sc_r[nt] = a.scale ? a.scale[n] : 1.f;
+      bi_r[nt] = a.bias ? a.bias[n] : 0.f;
+    }
+
+    // next stage: next chunk of this tile, else chunk 0 of the block's next item
+    PipeTile tn = t;
+    int chn = ch + 1, itemn = item;
+    if (chn == nchunk) { chn = 0; itemn = item + nslots; }
+    c.has_next = itemn < it_end;
+    if (c.has_next && chn == 0) tn = pipe_decode(a, p, itemn);
+    if (!c.has_next) chn = 0;
+    c.wsoff = (unsigned)((ch * 27 * ntiles_total + t.ng * NT) * 4096);
+    c.wsoff_next = (unsigned)((chn * 27 * ntiles_total + tn.ng * NT) * 4096);
+    pipe_lane_offsets(a, tn.w0, lane, c.dm.voff);
+    c.dm.b = tn.b; c.dm.d0 = tn.d0; c.dm.h0 = tn.h0; c.dm.wbase = tn.w0 > 0 ? tn.w0 - 1 : 0;
+    c.dm.ch = chn; c.dm.ldsbuf = (unsigned)PIPE_BUF_BYTES - bufoff; c.dm.live = c.has_next;
+    c.tap_probe = (a.probe && blockIdx.x == 17 && stage == 3) ? a.probe + 256 * 8 * 16 * 4 : nullptr;
+
+    pipe_step<NT, 0>(a, c, aaddr, a0, a1, b0, b1, b2, acc);
+    if (a.probe) ts1 = __builtin_readcyclecounter();
+
+    __builtin_amdgcn_s_waitcnt(0);     // my DMA rows of the next stage have landed
+    __syncthreads();                   // everyone's have; everyone is done with this buffer
+    if (a.probe) ts2 = __builtin_readcyclecounter();
+
+    if (ch == nchunk - 1) {
+      // ---- epilogue: y = acc*scale + bias (+residual) (ReLU), see k_conv3d_k3s1
+      const int od = t.d0 + wave;
+      if (od < a.Do) {
+        const bool interior = t.h0 + BH <= a.Ho && t.w0 + BW <= a.Wo;
+        const unsigned out_vox = (unsigned)((size_t)a.B * a.Do * a.Ho * a.Wo);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n0 = (t.ng * NT + nt) * 32;
+          const bool to_y0 = n0 < a.cout0;
+          float* dst = to_y0 ? a.y0 : a.y1;
+          if (dst == nullptr) continue;
+          const int stride = to_y0 ? a.cout0 : a.cout1;
+          const int col0 = to_y0 ? n0 : n0 - a.n1_start;
+          if (col0 < 0 || col0 >= stride) continue;
+          const bool fullcols = col0 + 32 <= stride;
+          const float lo = (to_y0 ? a.relu0 : a.relu1) ? 0.f : -3.402823466e38f;
+          const bool has_res = to_y0 && a.residual != nullptr;
+          const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)stride * 4u);
+          const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)stride * 4u);
+          const float sc = sc_r[nt];
+          const float bi = bi_r[nt];
+          const unsigned lanecol = (unsigned)(col0 + i) * 4u;
+          unsigned goff[4];
+          int gpr[4], gpc[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int p0 = acc_patch(4 * g4, 0), p1 = acc_patch(4 * g4, 1);
+            gpr[g4] = half ? (p1 >> 3) : (p0 >> 3);
+            gpc[g4] = half ? (p1 & 7) : (p0 & 7);
+            goff[g4] = (unsigned)((gpr[g4] * a.Wo + gpc[g4]) * stride) * 4u + lanecol;
+          }
+          const unsigned estep = (unsigned)stride * 4u;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const unsigned soff = (unsigned)(((((t.b * a.Do + od) * a.Ho + (t.h0 + mt * 4)) * a.Wo + t.w0) * stride) * 4);
+            if (interior && fullcols) {
+              float rv[16];
+              if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = buf_load1(rr, goff[r >> 2], soff + (unsigned)(r & 3) * estep);
+              }
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float v = acc[mt][nt][r] * sc + bi;
+                if (has_res) v += rv[r];
+                buf_store1(yr, goff[r >> 2], soff + (unsigned)(r & 3) * estep, fmaxf(v, lo));
+              }
+            } else {
+              const bool colok = col0 + i < stride;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                if (colok && (t.h0 + mt * 4 + gpr[r >> 2] < a.Ho) && (t.w0 + gpc[r >> 2] + (r & 3) < a.Wo)) {
+                  float v = acc[mt][nt][r] * sc + bi;
+                  const unsigned so = soff + (unsigned)(r & 3) * estep;
+                  if (has_res) v += buf_load1(rr, goff[r >> 2], so);
+                  buf_store1(yr, goff[r >> 2], so, fmaxf(v, lo));
+                }
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    }
+    if (a.probe && lane == 0 && stage < 16) {   // {stage start, taps done, barrier passed, epilogue done}
+      long long* pp = a.probe + (((size_t)blockIdx.x * 8 + wave) * 16 + stage) * 4;
+      pp[0] = ts0; pp[1] = ts1; pp[2] = ts2; pp[3] = __builtin_readcyclecounter();
+    }
+    if (!c.has_next) break;
+    t = tn; ch = chn; item = itemn;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // OccHead on v_mfma_f32_16x16x4_f32: the head's 3x3x3 conv has only 16 output channels, which
 // would leave half of a 32-wide N tile empty; the 16x16x4 shape (same FLOP rate) has no waste.
 //   lane l: A[voxel = l&15][k = l>>4], B[k = l>>4][cout = l&15]; D: col l&15, rows (l>>4)*4 + reg.
@@ -787,6 +1161,35 @@ static int set_lds_limit(K kernel, int bytes) {
   return PW_OK;
 }
 
+// exact x / d by one mulhi for x * d < 2^32 (tile counts): floor(2^32 / d) + 1
+static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
+
+static int pw_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n < 8) n = 256;
+  }
+  return n;
+}
+
+// Persistent DMA-pipelined kernel: PW_CONV_PIPE=0|1 forces it off/on.  Sustained (8 s loops, clocks
+// settled at 2.39 GHz) on the 16x200x200 grid: 32->32 278 us vs 281 us tile-per-block, 32->64 536 vs
+// 521 us, 64->64 1049 vs 1012 us -- both designs sit on the same ceiling (operand loads cost matrix-pipe
+// time, see the kernel comment), so it is only the default where it wins: one N-tile per wave (NT = 1)
+// on grids with several items per CU.
+static bool use_pipe(long long n_items, int NT) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("PW_CONV_PIPE");
+    forced = e ? (atoi(e) ? 1 : 0) : 2;
+  }
+  if (forced != 2) return forced == 1 && n_items < (1ll << 20);
+  return NT == 1 && n_items >= 1024 && n_items < (1ll << 20);
+}
+
 // 8-wave blocks (WD=2) when the grid has enough 8x8x8 tiles to fill the 256 CUs more than once;
 // 4-wave blocks otherwise (small encoder stages).  PW_CONV_WD=1|2 forces a variant (A/B runs).
 static int choose_wd(int B, int Do, int Ho, int Wo, int ngroups) {
@@ -847,7 +1250,24 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   PW_CHECK_ARG(!(algo == 1 && !tiled), "pw_conv3d_ndhwc: algo=1 needs ksize 3 stride 1");
   a.probe = nullptr;
   if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
-  if (tiled) {
+  if (tiled && use_pipe((long long)B * a.tiles_d * a.tiles_h * a.tiles_w * ngroups, NT)) {
+    PipeArgs p;
+    p.ngroups = ngroups;
+    p.n_items = (int)((long long)B * a.tiles_d * a.tiles_h * a.tiles_w * ngroups);
+    p.m_ng = magic_of(ngroups); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h);
+    p.m_td = magic_of(a.tiles_d);
+    const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
+    constexpr int PLDS = 2 * PIPE_BUF_BYTES;
+    if (NT == 2) {
+      static int once = set_lds_limit(k_conv3d_k3s1_pipe<2>, PLDS);
+      if (once) return once;
+      hipLaunchKernelGGL((k_conv3d_k3s1_pipe<2>), dim3(nb), dim3(256), PLDS, st, a, p);
+    } else {
+      static int once = set_lds_limit(k_conv3d_k3s1_pipe<1>, PLDS);
+      if (once) return once;
+      hipLaunchKernelGGL((k_conv3d_k3s1_pipe<1>), dim3(nb), dim3(256), PLDS, st, a, p);
+    }
+  } else if (tiled) {
     const int WD = choose_wd(B, a.Do, a.Ho, a.Wo, ngroups);
     a.tiles_d = (a.Do + BD * WD - 1) / (BD * WD);
     long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;

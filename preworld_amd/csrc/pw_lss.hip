@@ -264,46 +264,126 @@ static int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_
 // ------------------------------------------------------------------------------------
 // histogram with RETURNING atomics: the old counter value is this point's arrival rank inside
 // its segment, so the scatter below needs no second round of atomics.
+// Device-scope atomics execute below the per-XCD L2 on this part and sustain only ~19 G ops/s
+// (measured: 0.88 M distinct-address atomics = 59 us, and hot addresses serialise on top), so the
+// kernel is bound by how many it issues.  Consecutive lanes are consecutive pixels of one depth
+// bin and therefore fall into the same voxel in runs (hundreds of lanes near the camera, ~2 at
+// mid range, 1 far away): each run of equal keys inside a wave is served by ONE atomicAdd of the
+// run length issued by its first lane; the other lanes take base + offset in the run.
 __global__ void __launch_bounds__(256)
 k_hist(const int32_t* __restrict__ keys, int64_t n, int32_t* __restrict__ count,
        int32_t* __restrict__ rank) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int k = keys[i];
-  if (k >= 0) rank[i] = atomicAdd(&count[k], 1);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int k = i < n ? keys[i] : -1;
+  const int kprev = __shfl_up(k, 1, 64);
+  const unsigned long long heads = __ballot(lane == 0 || k != kprev);
+  const unsigned long long upto = heads & (~0ull >> (63 - lane));           // heads at lanes <= mine
+  const int start = 63 - __builtin_clzll(upto);
+  const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+  const int end = above ? __builtin_ctzll(above) : 64;
+  int base = 0;
+  if (k >= 0 && lane == start) base = atomicAdd(&count[k], end - start);
+  base = __shfl(base, start, 64);
+  if (k >= 0) rank[i] = base + lane - start;
 }
 
+// scatter by (segment start + arrival rank); the first arrival of a long segment registers it
 __global__ void __launch_bounds__(256)
 k_scatter(const int32_t* __restrict__ keys, int64_t n, const int32_t* __restrict__ seg_start,
-          const int32_t* __restrict__ rank, int32_t* __restrict__ tmp) {
+          const int32_t* __restrict__ rank, int32_t* __restrict__ tmp, int long_threshold,
+          int32_t* __restrict__ long_list, int32_t* __restrict__ n_long) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int k = keys[i];
   if (k < 0) return;
-  tmp[seg_start[k] + rank[i]] = (int32_t)i;
+  const int s = seg_start[k], r = rank[i];
+  tmp[s + r] = (int32_t)i;
+  if (long_list && r == 0 && seg_start[k + 1] - s > long_threshold) long_list[atomicAdd(n_long, 1)] = k;
 }
 
 // in-segment rank sort: the scatter order inside a segment is whatever the atomics gave;
-// ids are distinct, so final position = number of smaller ids in the segment.
-// Optional by-products for the pooling kernel:
-//   order_aux[pos] = (id / aux_div) * aux_mod + id % aux_mod   (LSS: the feat-pixel index,
-//                    view_transformer.py:219-224, so pooling does no integer division)
-//   long_list      = keys whose segment is longer than long_threshold (handled by whole waves)
+// ids are distinct, so final position = number of smaller ids in the segment.  One thread per
+// point for segments up to SORT_LONG entries (<= SORT_LONG loop trips); longer segments are
+// sorted by whole blocks through LDS (k_sort_long).
+// Optional by-product: order_aux[pos] = (id / aux_div) * aux_mod + id % aux_mod (LSS: the
+// feat-pixel index, view_transformer.py:219-224, so pooling does no integer division).
+constexpr int SORT_LONG = 64;
+constexpr int SORT_LDS_MAX = 4096;          // ids per LDS pass of k_sort_long (16 KB)
+
+__device__ __forceinline__ void emit_sorted(int32_t* order, int32_t* order_aux, int pos, int id,
+                                            int aux_div, int aux_mod) {
+  order[pos] = id;
+  if (order_aux) order_aux[pos] = (id / aux_div) * aux_mod + id % aux_mod;
+}
+
 __global__ void __launch_bounds__(256)
 k_ranksort(const int32_t* __restrict__ keys, const int32_t* __restrict__ seg_start,
            const int32_t* __restrict__ tmp, const int32_t* __restrict__ kept_ptr,
            int32_t* __restrict__ order, int aux_div, int aux_mod, int32_t* __restrict__ order_aux,
-           int long_threshold, int32_t* __restrict__ long_list, int32_t* __restrict__ n_long) {
+           int long_sorted_elsewhere) {
   int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= *kept_ptr) return;
   int id = tmp[pos];
   int k = keys[id];
   int s = seg_start[k], e = seg_start[k + 1];
+  if (long_sorted_elsewhere && e - s > SORT_LONG) return;
   int r = 0;
   for (int j = s; j < e; ++j) r += tmp[j] < id;
-  order[s + r] = id;
-  if (order_aux) order_aux[s + r] = (id / aux_div) * aux_mod + id % aux_mod;
-  if (long_list && pos == s && e - s > long_threshold) long_list[atomicAdd(n_long, 1)] = k;
+  emit_sorted(order, order_aux, s + r, id, aux_div, aux_mod);
+}
+
+// long segments: one block per segment, ids staged in LDS, rank = #smaller ids (LDS broadcast
+// reads, no global traffic in the O(n^2) part).  Segments beyond SORT_LDS_MAX ids are processed
+// in LDS-sized passes (rank accumulates over passes).
+__device__ __forceinline__ int count_smaller_lds(const int32_t* ids, int m16, int id) {
+  const int4* ids4 = reinterpret_cast<const int4*>(ids);
+  int r = 0;
+  for (int j = 0; j < m16 / 4; j += 4) {                  // 4 x ds_read_b128 (broadcast) per trip
+    const int4 a = ids4[j], b = ids4[j + 1], c = ids4[j + 2], d = ids4[j + 3];
+    r += (a.x < id) + (a.y < id) + (a.z < id) + (a.w < id);
+    r += (b.x < id) + (b.y < id) + (b.z < id) + (b.w < id);
+    r += (c.x < id) + (c.y < id) + (c.z < id) + (c.w < id);
+    r += (d.x < id) + (d.y < id) + (d.z < id) + (d.w < id);
+  }
+  return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_long(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ tmp,
+            const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
+            int32_t* __restrict__ order, int aux_div, int aux_mod, int32_t* __restrict__ order_aux) {
+  extern __shared__ __attribute__((aligned(16))) int32_t ids[];
+  const int nl = *n_long;
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+    const int k = long_list[li];
+    const int s = seg_start[k], n = seg_start[k + 1] - s;
+    if (n <= SORT_LDS_MAX) {                              // the segment fits: stage once
+      const int m16 = (n + 15) & ~15;                     // padded with INT_MAX: never "smaller"
+      for (int j = threadIdx.x; j < m16; j += blockDim.x) ids[j] = j < n ? tmp[s + j] : 0x7fffffff;
+      __syncthreads();
+      for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int id = ids[t];
+        emit_sorted(order, order_aux, s + count_smaller_lds(ids, m16, id), id, aux_div, aux_mod);
+      }
+    } else {
+      for (int t0 = 0; t0 < n; t0 += blockDim.x) {        // elements owned by this block's threads
+        const int t = t0 + threadIdx.x;
+        const int id = t < n ? tmp[s + t] : 0;
+        int r = 0;
+        for (int p0 = 0; p0 < n; p0 += SORT_LDS_MAX) {    // LDS passes over the segment
+          const int m = min(SORT_LDS_MAX, n - p0);
+          const int m16 = (m + 15) & ~15;
+          __syncthreads();
+          for (int j = threadIdx.x; j < m16; j += blockDim.x) ids[j] = j < m ? tmp[s + p0 + j] : 0x7fffffff;
+          __syncthreads();
+          if (t < n) r += count_smaller_lds(ids, m16, id);
+        }
+        if (t < n) emit_sorted(order, order_aux, s + r, id, aux_div, aux_mod);
+      }
+    }
+    __syncthreads();
+  }
 }
 
 PW_API size_t pw_segment_sort_workspace_bytes(int64_t n, int64_t n_keys) {
@@ -344,10 +424,15 @@ PW_API int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void*
   hipLaunchKernelGGL(k_hist, dim3(nbk), dim3(256), 0, st, keys, n, count, rank);
   int rc = scan_exclusive_i32(count, seg_start, n_keys + 1, sums, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_scatter, dim3(nbk), dim3(256), 0, st, keys, n, seg_start, rank, tmp);
+  hipLaunchKernelGGL(k_scatter, dim3(nbk), dim3(256), 0, st, keys, n, seg_start, rank, tmp,
+                     long_threshold, long_list, n_long);
+  // with a long list (threshold must be SORT_LONG) the long segments go to the LDS block sort
+  const int split = (long_list && long_threshold == SORT_LONG) ? 1 : 0;
   hipLaunchKernelGGL(k_ranksort, dim3(nbk), dim3(256), 0, st, keys, seg_start, tmp,
-                     seg_start + n_keys, order, aux_div, aux_mod, order_aux, long_threshold, long_list,
-                     n_long);
+                     seg_start + n_keys, order, aux_div, aux_mod, order_aux, split);
+  if (split)
+    hipLaunchKernelGGL(k_sort_long, dim3(1024), dim3(256), SORT_LDS_MAX * 4, st, seg_start, tmp,
+                       long_list, n_long, order, aux_div, aux_mod, order_aux);
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
@@ -435,7 +520,7 @@ __device__ __forceinline__ void fma4_nc(float4& acc, const float4& f, float d) {
 // hold up to ~1300 points) are taken by whole waves in the first LONG_BLOCKS blocks, which
 // start first and run under the bulk sweep: 64 (pixel, depth) pairs are fetched in one
 // coalesced go, then broadcast lane by lane so the sum keeps its sequential point order.
-constexpr int LONG_BLOCKS = 64;     // x 4 waves
+constexpr int LONG_BLOCKS = 128;    // x 4 waves
 
 template <int LPV>
 __global__ void __launch_bounds__(256)
@@ -448,55 +533,123 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
   const int sub = lane % LPV;
   const int long_blocks = long_list ? LONG_BLOCKS : 0;
   if ((int)blockIdx.x < long_blocks) {
+    // Long segments: one wave per segment, 64 points per batch.  Lane L owns point base+L (its
+    // pixel index and depth); lane group g gathers the feature rows of points u*8+g (u = 0..7,
+    // 8 different rows per load instruction, 64 rows in flight), then every lane walks the 64
+    // points IN ORDER, pulling its 4 channels of point p from lane (p%8)*8+sub with a ds_bpermute:
+    // the data movement is parallel, the sum order stays the oracle's.
     const int nl = *n_long;
+    const int grp = lane / LPV;
+    constexpr int GROUPS = 64 / LPV;
+    constexpr int NU = LPV < 16 ? LPV : 16;             // gathers in flight per lane
+    constexpr int PB = NU * GROUPS;                     // points per batch (64 for LPV <= 16)
     for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < nl; li += LONG_BLOCKS * 4) {
       const int64_t v = long_list[li];
       const int s = seg_start[v], e = seg_start[v + 1];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int base = s; base < e; base += 64) {
-        const int n = min(64, e - base);
-        const int idx = base + min(lane, n - 1);
-        const int my_pf = order_feat[idx];
-        const float my_d = depth[order[idx]];
-        for (int k0 = 0; k0 < n; k0 += POOL_UNROLL) {
-          float d[POOL_UNROLL];
-          float4 f[POOL_UNROLL];
+      int idx = s + min(lane, e - s - 1);
+      int my_pf = order_feat[idx];
+      float my_d = depth[order[idx]];
+      for (int base = s; base < e; base += PB) {
+        const int n = min(PB, e - base);
+        float4 f[NU];
 #pragma unroll
-          for (int u = 0; u < POOL_UNROLL; ++u) {          // 8 independent gathers in flight
-            const int kk = min(k0 + u, n - 1);             // wave-uniform lane select
-            const int pf = __builtin_amdgcn_readlane(my_pf, kk);
-            d[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_d), kk));
-            f[u] = feat[(int64_t)pf * LPV + sub];
+        for (int u = 0; u < NU; ++u) {
+          const int q = u * GROUPS + grp;
+          const int pf = __shfl(my_pf, q, 64);
+          f[u] = q < n ? feat[(int64_t)pf * LPV + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float cur_d = my_d;
+        if (base + PB < e) {                               // next batch's ids while this one sums
+          idx = base + PB + min(lane, e - base - PB - 1);
+          my_pf = order_feat[idx];
+          my_d = depth[order[idx]];
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+          for (int g = 0; g < GROUPS; ++g) {
+            const int pidx = u * GROUPS + g;                // compile-time
+            if (pidx < n) {                                // wave-uniform
+              const int src = g * LPV + sub;
+              float4 fv;
+              fv.x = __shfl(f[u].x, src, 64);
+              fv.y = __shfl(f[u].y, src, 64);
+              fv.z = __shfl(f[u].z, src, 64);
+              fv.w = __shfl(f[u].w, src, 64);
+              const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_d), pidx));
+              fma4_nc(acc, fv, d);
+            }
           }
-#pragma unroll
-          for (int u = 0; u < POOL_UNROLL; ++u)
-            if (k0 + u < n) fma4_nc(acc, f[u], d[u]);
         }
       }
-      if (lane < LPV) out[v * LPV + sub] = acc;     // every LPV-group holds the same sums
+      if (lane < LPV) out[v * LPV + sub] = acc;     // every lane group holds the same sums
     }
     return;
   }
+  // Dense sweep, software-pipelined over the voxels of one lane group.  A voxel costs a chain of
+  // dependent loads (segment bounds -> point ids -> depth / feature row); run back to back that
+  // chain (~3 memory latencies) times ~10 voxels per group was the whole kernel time.  Here the
+  // bounds and the first LPV point ids of voxel v+stride are requested while voxel v gathers, so
+  // one memory latency per voxel stays exposed.  Lane `sub` holds the (pixel, point id) pair of
+  // point s+sub (one coalesced load per array per group instead of LPV clamped ones); pairs are
+  // broadcast inside the lane group and only points that exist gather their feature row.
+  // The sum order is still point order, one non-contracted multiply-add at a time (bit-exact).
   const int64_t gid = (int64_t)(blockIdx.x - long_blocks) * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)(gridDim.x - long_blocks) * blockDim.x / LPV;
-  for (int64_t v = gid / LPV; v < n_voxels; v += stride) {
-    const int s = seg_start[v], e = seg_start[v + 1];
-    if (long_list && e - s > long_threshold) continue;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = s; i < e; i += POOL_UNROLL) {
-      float d[POOL_UNROLL];
-      float4 f[POOL_UNROLL];
-#pragma unroll
-      for (int u = 0; u < POOL_UNROLL; ++u) {
-        const int j = min(i + u, e - 1);
-        d[u] = depth[order[j]];
-        f[u] = feat[(int64_t)order_feat[j] * LPV + sub];
-      }
-#pragma unroll
-      for (int u = 0; u < POOL_UNROLL; ++u)
-        if (i + u < e) fma4_nc(acc, f[u], d[u]);
+  const int gbase = lane - sub;                     // first lane of this voxel's lane group
+  int64_t v = gid / LPV;
+  int s = 0, e = 0, my_pf = 0, my_o = 0;
+  if (v < n_voxels) {
+    s = seg_start[v];
+    e = seg_start[v + 1];
+    if (e > s) {
+      const int j = min(s + sub, e - 1);
+      my_pf = order_feat[j];
+      my_o = order[j];
     }
-    out[v * LPV + sub] = acc;
+  }
+  while (v < n_voxels) {
+    const int64_t vn = v + stride;
+    int sn = 0, en = 0;
+    if (vn < n_voxels) { sn = seg_start[vn]; en = seg_start[vn + 1]; }
+    const bool skip = long_list && e - s > long_threshold;   // summed by the long-segment blocks
+    const int cnt = skip ? 0 : min(LPV, e - s);
+    const float my_d = cnt > 0 ? depth[my_o] : 0.f;
+    float4 f[LPV];
+#pragma unroll
+    for (int u = 0; u < LPV; ++u) {
+      const int pf = __shfl(my_pf, gbase + u, 64);
+      f[u] = u < cnt ? feat[(int64_t)pf * LPV + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int n_pf = 0, n_o = 0;
+    if (en > sn) {
+      const int j = min(sn + sub, en - 1);
+      n_pf = order_feat[j];
+      n_o = order[j];
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < LPV; ++u) {
+      const float d = __shfl(my_d, gbase + u, 64);
+      if (u < cnt) fma4_nc(acc, f[u], d);
+    }
+    if (!skip) {
+      for (int i = s + LPV; i < e; i += LPV) {             // points LPV.. of a medium segment
+        const int j = min(i + sub, e - 1);
+        const int r_pf = order_feat[j];
+        const float r_d = depth[order[j]];
+        const int rc = min(LPV, e - i);
+#pragma unroll
+        for (int u = 0; u < LPV; ++u) {
+          const int pf = __shfl(r_pf, gbase + u, 64);
+          const float d = __shfl(r_d, gbase + u, 64);
+          if (u < rc) fma4_nc(acc, feat[(int64_t)pf * LPV + sub], d);
+        }
+      }
+      out[v * LPV + sub] = acc;
+    }
+    v = vn; s = sn; e = en; my_pf = n_pf; my_o = n_o;
   }
 }
 
