@@ -123,10 +123,12 @@ class KernelProbe:
             ks = kw.get('ksize', 3)
             st = kw.get('stride', 1)
             nv = B * (D // st) * (H // st) * (W // st)
-            cout = kw.get('cout0', nt * 32) + kw.get('cout1', 0)
+            cout = (kw.get('cout0') or nt * 32) + (kw.get('cout1') or 0)
             tiled = ks == 3 and st == 1 and kw.get('algo', 0) != 2
-            label = ('conv3d_k3s1_mfma<NT=%d>' % (2 if nt % 2 == 0 else 1)) if tiled else \
-                'conv3d_gather_mfma<k%d,s%d>' % (ks, st)
+            # one label per (kernel family, grid, channels): the library picks the tile/N-group variant
+            # per grid size, and small grids fill the 256 CUs less well than the full-resolution ones
+            label = '%s %dx%dx%d %d->%d' % ('conv3d_k3s1_mfma' if tiled else 'conv3d_gather_mfma<k%d,s%d>' % (ks, st),
+                                           D, H, W, Cin, cout)
             byts = 4.0 * (x.numel() + nv * cout + wpk.numel())
             return label, 2.0 * nv * taps * Cin * cout, byts
         if name == 'occ_head_fused':
@@ -245,8 +247,19 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
         label, a = dom
         tf = a['flops'] / (a['ms'] * 1e-3) / 1e12
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this
+        # process, so the figure comes from the committed rocprofv3 --pmc passes (same kernel, same
+        # shape; profiles/r01_pmc_hbm_traffic.md says how it was collected and corrected)
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(pmc):
+            ent = json.load(open(pmc)).get(label)
+            if ent:
+                traffic = int(ent['fetch_bytes'] + ent['write_bytes'])
         roofline = dict(bound='mfma', kernel=label, achieved=round(tf, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit='TFLOP/s', frac=round(tf / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        unit='TFLOP/s', frac=round(tf / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                        traffic_unit='bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
+                        algorithmic_bytes=int(a['bytes'] / a['launches']),
                         avg_launch_us=round(a['ms'] * 1e3 / a['launches'], 2),
                         launches_per_step=a['launches'] // 3,
                         all_kernels={k: dict(us_per_step=round(v['ms'] * 1e3 / 3, 1),

@@ -281,6 +281,16 @@ __device__ __forceinline__ constexpr int acc_patch(int r, int h) {
   return set * 16 + (g >> 1) * 4 + (i & 3);
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2).  Remap the linear
+// block id so that XCD x works on a CONTIGUOUS range of tiles: neighbouring tiles share halo
+// voxels, and with the plain order every halo line was fetched into several L2s (PMC FETCH_SIZE:
+// 2.1x the input tensor per launch; 1.4x with contiguous ranges).
+__device__ __forceinline__ int xcd_contiguous(int bid, int nblk) {
+  const int x = bid & 7, idx = bid >> 3;
+  const int q = nblk >> 3, r = nblk & 7;
+  return x * q + min(x, r) + idx;
+}
+
 // ------------------------------------------------------------------------------------
 // 3x3x3, stride 1, pad 1, LDS halo tile
 // ------------------------------------------------------------------------------------
@@ -313,7 +323,7 @@ __global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
 
   // (A persistent tile loop and a one-block-per-CU 8-wave variant were both measured: neither
   // moved the needle -- the remaining gap of the NT=1 kernel is the exposed halo-load latency.)
-  int bid = blockIdx.x;
+  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
   const int tw = bid % a.tiles_w; bid /= a.tiles_w;
   const int th = bid % a.tiles_h; bid /= a.tiles_h;
   const int td = bid % a.tiles_d;
@@ -878,7 +888,7 @@ __global__ void __launch_bounds__(256 * WD, 2) k_occ_head16(ConvArgs a, OccTail 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
-  int bid = blockIdx.x;
+  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
   const int tw = bid % a.tiles_w; bid /= a.tiles_w;
   const int th = bid % a.tiles_h; bid /= a.tiles_h;
   const int td = bid % a.tiles_d;
@@ -1175,11 +1185,12 @@ static int pw_num_cus() {
   return n;
 }
 
-// Persistent DMA-pipelined kernel: PW_CONV_PIPE=0|1 forces it off/on.  Sustained (8 s loops, clocks
-// settled at 2.39 GHz) on the 16x200x200 grid: 32->32 278 us vs 281 us tile-per-block, 32->64 536 vs
-// 521 us, 64->64 1049 vs 1012 us -- both designs sit on the same ceiling (operand loads cost matrix-pipe
-// time, see the kernel comment), so it is only the default where it wins: one N-tile per wave (NT = 1)
-// on grids with several items per CU.
+// Persistent DMA-pipelined kernel: PW_CONV_PIPE=0|1 forces it off/on.  Sustained timings (1 s loops,
+// clocks settled at 2.39 GHz, tools/bench_layers.py), tile-per-block vs pipelined:
+//   16x200x200 32->32  277.9 / 278.4 us    32->64  518.3 / 537.6    64->64 1002.8 / 1049.3
+//   8x100x100  64->64  180.4 / 165.6 us    64->128 308.0 / 319.5    4x50x50 128->128 110.8 / 110.4
+// Both designs sit on the same ceiling (operand loads cost matrix-pipe time, see the kernel comment);
+// the pipelined one wins where a wave owns a single N-tile and the grid gives every CU 2+ items.
 static bool use_pipe(long long n_items, int NT) {
   static int forced = -1;
   if (forced < 0) {
@@ -1187,7 +1198,7 @@ static bool use_pipe(long long n_items, int NT) {
     forced = e ? (atoi(e) ? 1 : 0) : 2;
   }
   if (forced != 2) return forced == 1 && n_items < (1ll << 20);
-  return NT == 1 && n_items >= 1024 && n_items < (1ll << 20);
+  return NT == 1 && n_items >= 512 && n_items < (1ll << 20);
 }
 
 // 8-wave blocks (WD=2) when the grid has enough 8x8x8 tiles to fill the 256 CUs more than once;
