@@ -129,7 +129,7 @@ int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_
  *   residual    same layout as y0 or NULL (added before ReLU; BasicBlock3D.forward resnet.py:120-123)
  *   y0 (B,Do,Ho,Wo,cout0) gets packed columns [0,cout0); y1 (B,Do,Ho,Wo,cout1) gets columns
  *   [roundup32(cout0), +cout1) or is NULL -- lets conv1 and downsample of a BasicBlock3D share
- *   one pass over x.  ksize in {1,3} (pad = ksize/2), stride in {1,2}.
+ *   one pass over x.  ksize in {1,2,3} (pad = (ksize-1)/2; ksize 2 needs stride 2), stride in {1,2}.
  *   algo: 0 auto, 1 LDS-tiled kernel (k3 s1), 2 gather kernel. */
 int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const float* bias,
                     const float* residual, float* y0, float* y1, int B, int D, int H, int W,
@@ -235,6 +235,18 @@ int pw_confusion_hist(const uint8_t* pred, const uint8_t* gt, const uint8_t* mas
 /* nn.Softplus(beta=1, threshold=20) elementwise (the activation inside fusion_head and the
  * attribute MLPs, preworld_temporal_traj.py:81-132), same device function as the fused kernels. */
 int pw_softplus(const float* x, float* y, int64_t n, void* stream);
+
+/* A20  trajectory branch, train-time only (preworld_temporal_traj.py:464-470).
+ * pw_global_avgpool_ndhwc: nn.AdaptiveAvgPool3d((1,1,1)) at the end of DownScaleModule3DCustom
+ * (mmdet3d/models/heads/occupancy_head.py:180-200): x (B, n_vox, C) channels-last -> y (B, C),
+ * sequential voxel order per channel.  The three Conv3d(k=2, s=2, bias) in front of it are
+ * pw_conv3d_ndhwc with ksize=2, stride=2.
+ * pw_linear_act: one nn.Linear (+activation) of ego_fusion_head / traj_head
+ * (preworld_temporal_traj.py:136-150): y[r][o] = act(b[o] + sum_k x[r][k] * w[o][k]), w row-major
+ * (out, in) as in the state dict; act 0 none, 1 ReLU, 2 Softplus(beta=1, threshold=20). */
+int pw_global_avgpool_ndhwc(const float* x, int B, int64_t n_vox, int C, float* y, void* stream);
+int pw_linear_act(const float* x, const float* w, const float* b, float* y, int rows, int n_in,
+                  int n_out, int act, void* stream);
 
 #ifdef __cplusplus
 }

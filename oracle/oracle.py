@@ -326,6 +326,33 @@ def forecast_step(v, e, sd, prefix='fusion_head'):
     return out
 
 
+def downscale_module(fused_xyzc, sd, prefix='downscale'):
+    """A20  DownScaleModule3DCustom, mmdet3d/models/heads/occupancy_head.py:180-200:
+    (B,X,Y,Z,C) -> permute to (B,C,X,Y,Z) -> 3x Conv3d(k=2,s=2,bias) -> AdaptiveAvgPool3d(1) -> (B,4C).
+    Also returns the three conv outputs (B,C',X',Y',Z')."""
+    x = np.ascontiguousarray(np.transpose(_f32(fused_xyzc), (0, 4, 1, 2, 3)))
+    levels = []
+    for k in ('downscale1', 'downscale2', 'downscale3'):
+        x = conv3d(x, sd['%s.%s.weight' % (prefix, k)], sd['%s.%s.bias' % (prefix, k)], stride=2, pad=0)
+        levels.append(x)
+    B, C = x.shape[:2]
+    pooled = x.reshape(B, C, -1).sum(axis=2, dtype=np.float32) / np.float32(x[0, 0].size)
+    return pooled.astype(np.float32), levels
+
+
+def traj_branch(fused_xyzc, ego_feat, sd):
+    """A20  preworld_temporal_traj.py:457-470: down = downscale(fused); h = ego_fusion_head(cat(identity,
+    down)); fused_ego = identity + h; pred_traj = traj_head(fused_ego)."""
+    down, _ = downscale_module(fused_xyzc, sd)
+    h = np.concatenate([_f32(ego_feat), down], axis=-1)
+    for i in (0, 2, 4):
+        h = linear(h, sd['ego_fusion_head.%d.weight' % i], sd['ego_fusion_head.%d.bias' % i], 2)
+    res = linear(h, sd['ego_fusion_head.6.weight'], sd['ego_fusion_head.6.bias'], 0)
+    fused_ego = _f32(ego_feat) + res
+    t = linear(fused_ego, sd['traj_head.0.weight'], sd['traj_head.0.bias'], 2)
+    return linear(t, sd['traj_head.2.weight'], sd['traj_head.2.bias'], 0), fused_ego
+
+
 def argmax_u8(x):
     x = _f32(x)
     C = x.shape[-1]

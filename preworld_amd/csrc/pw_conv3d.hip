@@ -981,7 +981,7 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
   const int ng = blockIdx.y;
   const int ntiles_total = a.cout_total >> 5;
   constexpr int TAPS = KS * KS * KS;
-  constexpr int PAD = KS / 2;
+  constexpr int PAD = (KS - 1) / 2;       // k3: 1, k2 (stride-2 patchify, A20): 0, k1: 0
   long long m = m0 + i;
   const bool mvalid = m < n_out_vox;
   if (!mvalid) m = n_out_vox - 1;
@@ -1225,11 +1225,12 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   PW_CHECK_ARG(Cin > 0 && Cin % KC == 0, "pw_conv3d_ndhwc: Cin must be a multiple of 32 (got %d)", Cin);
   PW_CHECK_ARG(cout_total > 0 && cout_total % 32 == 0, "pw_conv3d_ndhwc: cout_total must be a multiple of 32");
   PW_CHECK_ARG(cout0 > 0 && cout0 <= cout_total && cout1 >= 0, "pw_conv3d_ndhwc: bad cout split");
-  PW_CHECK_ARG(ksize == 1 || ksize == 3, "pw_conv3d_ndhwc: kernel size must be 1 or 3");
+  PW_CHECK_ARG(ksize >= 1 && ksize <= 3, "pw_conv3d_ndhwc: kernel size must be 1, 2 or 3");
+  PW_CHECK_ARG(!(ksize == 2 && stride != 2), "pw_conv3d_ndhwc: 2x2x2 is built for stride 2 only");
   PW_CHECK_ARG(stride == 1 || stride == 2, "pw_conv3d_ndhwc: stride must be 1 or 2");
   PW_CHECK_ARG(!(ksize == 1 && stride != 1), "pw_conv3d_ndhwc: 1x1x1 stride 2 unsupported");
   PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)wpk) & 15) == 0, "pw_conv3d_ndhwc: x/wpk must be 16-B aligned");
-  const int pad = ksize / 2;
+  const int pad = (ksize - 1) / 2;
   ConvArgs a;
   a.x = x; a.wpk = wpk; a.scale = scale; a.bias = bias; a.residual = residual; a.y0 = y0; a.y1 = y1;
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin;
@@ -1301,6 +1302,8 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv>), grid, dim3(256), 0, st, a, n_out)
     if (ksize == 1) {
       if (NT == 2) PW_GATHER(2, 1, 1); else PW_GATHER(1, 1, 1);
+    } else if (ksize == 2) {
+      if (NT == 2) PW_GATHER(2, 2, 2); else PW_GATHER(1, 2, 2);
     } else if (stride == 1) {
       if (NT == 2) PW_GATHER(2, 3, 1); else PW_GATHER(1, 3, 1);
     } else {

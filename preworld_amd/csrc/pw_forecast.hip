@@ -352,3 +352,48 @@ PW_API int pw_softplus(const float* x, float* y, int64_t n, void* stream) {
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// A20  trajectory branch helpers (train-time only, tiny): global average pool + dense layers
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_global_avgpool(const float* __restrict__ x, int64_t n_vox, int C, float* __restrict__ y) {
+  // block = one sample; thread = one channel (coalesced over channels), voxels in order
+  const float* xb = x + (size_t)blockIdx.x * n_vox * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int64_t v = 0; v < n_vox; ++v) s += xb[v * C + c];
+    y[(size_t)blockIdx.x * C + c] = s / (float)n_vox;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_linear_act(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+             float* __restrict__ y, int n_in, int n_out, int act) {
+  const float* xr = x + (size_t)blockIdx.x * n_in;
+  for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
+    float acc = b ? b[o] : 0.f;
+    const float* wo = w + (size_t)o * n_in;
+    for (int k = 0; k < n_in; ++k) acc += xr[k] * wo[k];
+    if (act == 1) acc = fmaxf(acc, 0.f);
+    else if (act == 2) acc = softplus_t20(acc);
+    y[(size_t)blockIdx.x * n_out + o] = acc;
+  }
+}
+
+PW_API int pw_global_avgpool_ndhwc(const float* x, int B, int64_t n_vox, int C, float* y, void* stream) {
+  PW_CHECK_ARG(x && y && B > 0 && n_vox > 0 && C > 0, "pw_global_avgpool_ndhwc: bad arguments");
+  hipLaunchKernelGGL(k_global_avgpool, dim3((unsigned)B), dim3(256), 0, pw_stream(stream), x, n_vox, C, y);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_linear_act(const float* x, const float* w, const float* b, float* y, int rows, int n_in,
+                         int n_out, int act, void* stream) {
+  PW_CHECK_ARG(x && w && y && rows > 0 && n_in > 0 && n_out > 0, "pw_linear_act: bad arguments");
+  PW_CHECK_ARG(act >= 0 && act <= 2, "pw_linear_act: act must be 0 (none), 1 (ReLU) or 2 (Softplus)");
+  hipLaunchKernelGGL(k_linear_act, dim3((unsigned)rows), dim3(256), 0, pw_stream(stream), x, w, b, y, n_in,
+                     n_out, act);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

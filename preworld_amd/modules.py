@@ -444,6 +444,42 @@ class OccHead(nn.Module):
 # =====================================================================================
 # detector-level composition of the hot path
 # =====================================================================================
+class DownScaleModule3DCustom(nn.Module):
+    """mmdet3d/models/heads/occupancy_head.py:180-200: three Conv3d(k=2, s=2, bias) 32->64->128->128
+    and a global average pool.  The reference runs them on (B,C,X,Y,Z); here the feature map
+    stays channels-last (B,Z,Y,X,C), so the 2x2x2 taps are permuted (kx,ky,kz)->(kz,ky,kx) when the
+    weights are packed."""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        self.in_dim = in_dim
+        self.downscale1 = nn.Conv3d(in_dim, in_dim * 2, 2, stride=2)
+        self.downscale2 = nn.Conv3d(in_dim * 2, in_dim * 4, 2, stride=2)
+        self.downscale3 = nn.Conv3d(in_dim * 4, in_dim * 4, 2, stride=2)
+        self._cache = _PackedCache()
+
+    def _packed(self):
+        convs = (self.downscale1, self.downscale2, self.downscale3)
+        params = [c.weight for c in convs]
+        return self._cache.get(params, lambda: [ops.pack_conv_weight(c.weight.permute(0, 1, 4, 3, 2).contiguous())
+                                                for c in convs])
+
+    def forward_cl(self, v_cl, want_levels=False):
+        """v_cl (B,Z,Y,X,C) -> (B, 4*in_dim)."""
+        x = v_cl
+        levels = []
+        for conv, wpk in zip((self.downscale1, self.downscale2, self.downscale3), self._packed()):
+            x = ops.conv3d_ndhwc(x, wpk, bias=conv.bias, ksize=2, stride=2)
+            levels.append(x)
+        out = ops.global_avgpool_ndhwc(x)
+        return (out, levels) if want_levels else out
+
+    def forward(self, feats):
+        """reference layout: feats (B, X, Y, Z, C) -> (B, 1, 1, 1, 4*in_dim)."""
+        v_cl = feats.permute(0, 3, 2, 1, 4).contiguous()
+        return self.forward_cl(v_cl).view(feats.shape[0], 1, 1, 1, -1)
+
+
 class PreWorld4DTraj(nn.Module):
     """Hot-path half of mmdet3d/models/detectors/preworld_temporal_traj.py:26-370 (and of its
     base classes bevdet_occ.py:167-269, bevdet.py:52-58): everything downstream of the
@@ -502,7 +538,29 @@ class PreWorld4DTraj(nn.Module):
                                        nn.ReLU(inplace=True), nn.Linear(256, out_dim))
         self.fusion_head = nn.Sequential(nn.Linear(out_dim * 2, out_dim * 4), nn.Softplus(),
                                          nn.Linear(out_dim * 4, out_dim))
+        # A20 trajectory branch (train-time only, preworld_temporal_traj.py:134-150)
+        self.downscale = DownScaleModule3DCustom(in_dim=out_dim)
+        self.ego_fusion_head = nn.Sequential(nn.Linear(out_dim * 5, out_dim * 8), nn.Softplus(),
+                                             nn.Linear(out_dim * 8, out_dim * 4), nn.Softplus(),
+                                             nn.Linear(out_dim * 4, out_dim * 2), nn.Softplus(),
+                                             nn.Linear(out_dim * 2, out_dim))
+        self.traj_head = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                       nn.Linear(out_dim * 2, 2))
         self._fc_cache = _PackedCache()
+
+    # ---- preworld_temporal_traj.py:457-470: ego-feature update + 2-D waypoint from one fused state
+    def traj_branch_cl(self, fused_cl, ego_feat):
+        """fused_cl (B,Z,Y,X,C) = v + fusion_head([v, e]); ego_feat (B,C) = plan_head(ego) ("identity").
+        Returns (pred_traj (B,2), fused_ego_feats (B,C))."""
+        down = self.downscale.forward_cl(fused_cl)                          # (B, 4C)
+        h = torch.cat([ego_feat, down], dim=-1).contiguous()                # (B, 5C)
+        efh, th = self.ego_fusion_head, self.traj_head
+        for i in (0, 2, 4):
+            h = ops.linear_act(h, efh[i].weight.contiguous(), efh[i].bias, 'softplus')
+        res = ops.linear_act(h, efh[6].weight.contiguous(), efh[6].bias)
+        fused_ego = ego_feat + res
+        t = ops.linear_act(fused_ego.contiguous(), th[0].weight.contiguous(), th[0].bias, 'softplus')
+        return ops.linear_act(t, th[2].weight.contiguous(), th[2].bias), fused_ego
 
     # ---- bevdet_occ.py:88-139 (BEVStereo4DOCC.prepare_inputs): split the stacked inputs into
     # frames and express every sweep's sensor pose in the KEY frame's ego system (fp64 algebra)

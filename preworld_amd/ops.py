@@ -280,7 +280,7 @@ def conv3d_ndhwc(x, wpk, scale=None, bias=None, residual=None, cout0=None, cout1
     cout_total = nt * 32
     if cout0 is None:
         cout0 = cout_total
-    pad = ksize // 2
+    pad = (ksize - 1) // 2
     Do = (D + 2 * pad - ksize) // stride + 1
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (W + 2 * pad - ksize) // stride + 1
@@ -374,6 +374,31 @@ def forecast_steps(v0, n_samples, w1p, w2p, c1p, fusion_b2, n_steps, states=None
 def softplus(x):
     y = torch.empty_like(x)
     _lib.call('pw_softplus', _chk(x, _f32, 'x'), _p(y), x.numel(), _stream())
+    return y
+
+
+# ------------------------------------------------------------------------------ A20 trajectory branch
+def global_avgpool_ndhwc(x):
+    """x (B, ..., C) channels-last -> (B, C): nn.AdaptiveAvgPool3d((1,1,1)) of
+    DownScaleModule3DCustom (occupancy_head.py:187,198)."""
+    B, C = x.shape[0], x.shape[-1]
+    n_vox = x.numel() // (B * C)
+    y = torch.empty(B, C, device=x.device, dtype=_f32)
+    _lib.call('pw_global_avgpool_ndhwc', _chk(x, _f32, 'x'), B, n_vox, C, _p(y), _stream())
+    return y
+
+
+_ACT = {None: 0, 'none': 0, 'relu': 1, 'softplus': 2}
+
+
+def linear_act(x, weight, bias=None, act=None):
+    """nn.Linear (+ReLU / Softplus) on a few rows: x (rows, in), weight (out, in) as stored."""
+    rows, n_in = x.shape
+    n_out = weight.shape[0]
+    y = torch.empty(rows, n_out, device=x.device, dtype=_f32)
+    _lib.call('pw_linear_act', _chk(x, _f32, 'x'), _chk(weight, _f32, 'weight'),
+              _p(bias.contiguous()) if bias is not None else None, _p(y), rows, n_in, n_out, _ACT[act],
+              _stream())
     return y
 
 

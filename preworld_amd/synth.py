@@ -118,6 +118,20 @@ def synth_state_dict(seed=0, out_dim=32, num_classes=18):
     _linear(rs, sd, 'plan_head.4', 256, out_dim)
     _linear(rs, sd, 'fusion_head.0', out_dim * 2, out_dim * 4)
     _linear(rs, sd, 'fusion_head.2', out_dim * 4, out_dim)
+    # A20 trajectory branch -- appended LAST so the random stream of every earlier key (and the
+    # fixtures generated from it) is unchanged
+    for name, ci, co in (('downscale.downscale1', out_dim, out_dim * 2),
+                         ('downscale.downscale2', out_dim * 2, out_dim * 4),
+                         ('downscale.downscale3', out_dim * 4, out_dim * 4)):
+        bound = 1.0 / np.sqrt(ci * 8)
+        sd[name + '.weight'] = rs.uniform(-bound, bound, (co, ci, 2, 2, 2)).astype(np.float32)
+        sd[name + '.bias'] = rs.uniform(-bound, bound, (co,)).astype(np.float32)
+    _linear(rs, sd, 'ego_fusion_head.0', out_dim * 5, out_dim * 8)
+    _linear(rs, sd, 'ego_fusion_head.2', out_dim * 8, out_dim * 4)
+    _linear(rs, sd, 'ego_fusion_head.4', out_dim * 4, out_dim * 2)
+    _linear(rs, sd, 'ego_fusion_head.6', out_dim * 2, out_dim)
+    _linear(rs, sd, 'traj_head.0', out_dim, out_dim * 2)
+    _linear(rs, sd, 'traj_head.2', out_dim * 2, 2)
     return sd
 
 

@@ -175,6 +175,40 @@ def test_forecast_golden(golden):
         np.testing.assert_allclose(states[k].cpu().numpy(), g['states'][k + 1], **TOL)
 
 
+def test_traj_branch_golden(golden):
+    """A20 through the C ABI (2x2x2 stride-2 convs on the MFMA gather kernel, global average pool,
+    dense layers) against the imported reference module's outputs and the oracle's levels."""
+    g = golden('traj_small.npz')
+    net, sd = _load_net(int(g['seed_sd']))
+    fused = np.random.RandomState(int(g['seed_v'])).standard_normal((1, 16, 16, 8, 32)).astype(np.float32)
+    fused_cl = T(np.ascontiguousarray(fused.transpose(0, 3, 2, 1, 4)))           # (B,Z,Y,X,C)
+    with torch.no_grad():
+        down, levels = net.downscale.forward_cl(fused_cl, want_levels=True)
+        ref_out = net.downscale(T(fused))                                        # reference layout API
+        traj, fused_ego = net.traj_branch_cl(fused_cl, T(g['identity']))
+    _, olev = O.downscale_module(fused, sd)
+    for got, want in zip(levels, olev):                                          # (B,Z,Y,X,C) vs (B,C,X,Y,Z)
+        np.testing.assert_allclose(got.cpu().numpy().transpose(0, 4, 3, 2, 1), want, **TOL)
+    np.testing.assert_allclose(down.cpu().numpy(), g['down'], rtol=2e-4, atol=2e-5)
+    assert ref_out.shape == (1, 1, 1, 1, 128)
+    np.testing.assert_allclose(ref_out.view(1, 128).cpu().numpy(), g['down'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(fused_ego.cpu().numpy(), g['fused_ego'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(traj.cpu().numpy(), g['traj'], rtol=2e-4, atol=2e-5)
+
+
+def test_traj_branch_odd_sizes():
+    """grid extents that are not multiples of 8 (floor division at every level), two samples."""
+    net, sd = _load_net(5)
+    rs = np.random.RandomState(3)
+    fused = rs.standard_normal((2, 18, 10, 9, 32)).astype(np.float32)             # (B,X,Y,Z,C)
+    ego_feat = rs.standard_normal((2, 32)).astype(np.float32)
+    with torch.no_grad():
+        traj, fused_ego = net.traj_branch_cl(T(np.ascontiguousarray(fused.transpose(0, 3, 2, 1, 4))), T(ego_feat))
+    otraj, oego = O.traj_branch(fused, ego_feat, sd)
+    np.testing.assert_allclose(fused_ego.cpu().numpy(), oego, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(traj.cpu().numpy(), otraj, rtol=2e-4, atol=2e-5)
+
+
 def test_forecast_ragged_and_batched():
     """voxel counts that are not a multiple of 32, two samples with different ego states."""
     net, sd = _load_net(5)

@@ -164,6 +164,22 @@ def test_forecast_small(golden):
     np.testing.assert_allclose(sem, g['semantic'], rtol=1e-4, atol=1e-4)
 
 
+def test_traj_branch_small(golden):
+    """A20: DownScaleModule3DCustom (imported reference module) + ego_fusion_head + traj_head."""
+    g = golden('traj_small.npz')
+    sd = S.synth_state_dict(int(g['seed_sd']))
+    fused = np.random.RandomState(int(g['seed_v'])).standard_normal((1, 16, 16, 8, 32)).astype(np.float32)
+    ego = S.ego_state(int(g['seed_ego']))
+    identity = O.plan_head(ego.reshape(1, 21), sd)
+    np.testing.assert_allclose(identity, g['identity'], rtol=1e-4, atol=1e-5)
+    down, levels = O.downscale_module(fused, sd)
+    assert [l.shape for l in levels] == [(1, 64, 8, 8, 4), (1, 128, 4, 4, 2), (1, 128, 2, 2, 1)]
+    np.testing.assert_allclose(down, g['down'], rtol=1e-4, atol=1e-5)
+    traj, fused_ego = O.traj_branch(fused, identity, sd)
+    np.testing.assert_allclose(fused_ego, g['fused_ego'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(traj, g['traj'], rtol=1e-4, atol=1e-5)
+
+
 # ----------------------------------------------------------------------------- render
 def test_render_small(golden):
     g = golden('render_small.npz')

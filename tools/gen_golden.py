@@ -405,6 +405,34 @@ def gen_forecast():
          density=d.numpy(), semantic=s.numpy(), color=c.numpy())
 
 
+def gen_traj(occ):
+    """G9 (A20): trajectory branch -- the reference's DownScaleModule3DCustom
+    (occupancy_head.py:180-200) imported as is; ego_fusion_head / traj_head are nn.Sequential
+    stacks with the reference's shapes (preworld_temporal_traj.py:136-150), driven as :457-470."""
+    sd = S.synth_state_dict(11)
+    down = occ.DownScaleModule3DCustom(in_dim=32)
+    efh = nn.Sequential(nn.Linear(160, 256), nn.Softplus(), nn.Linear(256, 128), nn.Softplus(),
+                        nn.Linear(128, 64), nn.Softplus(), nn.Linear(64, 32))
+    th = nn.Sequential(nn.Linear(32, 64), nn.Softplus(), nn.Linear(64, 2))
+    plan = nn.Sequential(nn.Linear(21, 256), nn.ReLU(inplace=True), nn.Linear(256, 256),
+                         nn.ReLU(inplace=True), nn.Linear(256, 32))
+    with torch.no_grad():
+        load_sd(down, sd, 'downscale.')
+        load_sd(efh, sd, 'ego_fusion_head.')
+        load_sd(th, sd, 'traj_head.')
+        load_sd(plan, sd, 'plan_head.')
+        rs = np.random.RandomState(15)
+        fused = torch.from_numpy(rs.standard_normal((1, 16, 16, 8, 32)).astype(np.float32))   # (B,X,Y,Z,C)
+        ego = torch.from_numpy(S.ego_state(14))
+        identity = plan(ego.reshape(1, 21))
+        d = down(fused).squeeze(1).squeeze(1).squeeze(1)
+        res_ego = efh(torch.cat([identity, d], dim=-1))
+        fused_ego = identity + res_ego
+        traj = th(fused_ego)
+    save('traj_small.npz', seed_sd=np.int64(11), seed_v=np.int64(15), seed_ego=np.int64(14),
+         identity=identity.numpy(), down=d.numpy(), fused_ego=fused_ego.numpy(), traj=traj.numpy())
+
+
 def gen_render(nh):
     """G7: NerfHead.sample_ray / render_one_scene / render_* through the reference Python."""
     head = nh.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4,
@@ -484,6 +512,7 @@ def main():
     gen_geometry(vtm)
     gen_conv_stack(res, fpn, occ)
     gen_forecast()
+    gen_traj(occ)
     gen_render(nh)
     gen_metric(om)
 
