@@ -62,6 +62,10 @@ def lib():
         raise PreworldHipError(
             'libpreworld_hip.so is missing (%s). Build it with `python -m preworld_amd.build` '
             '(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.' % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64; if this library were loaded before it, the
+    # process would hold two HIP runtimes and calls through this one would see no device
+    # ("no ROCm-capable device is detected" -- hit by build() followed by smoke() in one process)
+    import torch  # noqa: F401
     l = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (restype, argtypes, _) in _protos.items():

@@ -1,0 +1,84 @@
+"""Row H of SURVEY.md 8a: what replaces tools/test_temporal.py + mmdet3d/apis/test.py for the hot
+path -- build the detector from a restated config dict, load a state dict by the reference's key
+names, feed lifted inputs, collect `semantic_occ_{k}s`, stack states 0/2/4/6
+(mmdet3d/apis/test.py:218-223) and score them with Metric_mIoU_Temporal
+(mmdet3d/datasets/occ_metrics.py:413-594).  GPU only: every op goes through libpreworld_hip.so."""
+import numpy as np
+import torch
+
+from . import metrics, modules, synth
+
+
+def model_cfg(grid_config=None, with_prev=True, if_post_finetune=True):
+    """The `model = dict(...)` section of configs/preworld/*.py restricted to the hot path
+    (bevstereo-occ.py:62-131), as a plain dict."""
+    gc = grid_config or synth.GRID_CONFIG_FULL
+    sx = int(round((gc['x'][1] - gc['x'][0]) / gc['x'][2]))
+    sy = int(round((gc['y'][1] - gc['y'][0]) / gc['y'][2]))
+    sz = int(round((gc['z'][1] - gc['z'][0]) / gc['z'][2]))
+    return dict(
+        type='PreWorld4DTraj',
+        img_view_transformer=dict(type='LSSViewTransformerBEVStereo', grid_config=gc,
+                                  input_size=synth.INPUT_SIZE, in_channels=512, out_channels=32, sid=False,
+                                  collapse_z=False, loss_depth_weight=0.05,
+                                  depthnet_cfg=dict(use_dcn=False, aspp_mid_channels=96, stereo=True, bias=5.0),
+                                  downsample=16),
+        img_bev_encoder_backbone=dict(type='CustomResNet3D', numC_input=64, num_layer=[1, 2, 4], with_cp=False,
+                                      num_channels=[32, 64, 128], stride=[1, 2, 2], backbone_output_ids=[0, 1, 2]),
+        img_bev_encoder_neck=dict(type='LSSFPN3D', in_channels=224, out_channels=32),
+        pre_process=dict(type='CustomResNet3D', numC_input=32, with_cp=False, num_layer=[1], num_channels=[32],
+                         stride=[1], backbone_output_ids=[0]),
+        occupancy_head=dict(type='OccHead', with_cp=False, use_deblock=False,
+                            norm_cfg=dict(type='SyncBN', requires_grad=True), soft_weights=True,
+                            final_occ_size=[sx, sy, sz], empty_idx=17, num_level=1, in_channels=[32],
+                            out_channel=18, point_cloud_range=[gc['x'][0], gc['y'][0], gc['z'][0],
+                                                               gc['x'][1], gc['y'][1], gc['z'][1]]),
+        if_post_finetune=if_post_finetune, with_prev=with_prev)
+
+
+def build_model(cfg, state_dict, device='cuda:0'):
+    """cfg: model_cfg(...) (or the reference's own model dict); state_dict: numpy or torch tensors under
+    the reference's key names.  Hot-path keys must all be present; DepthNet/backbone keys are ignored."""
+    cfg = dict(cfg)
+    cfg.pop('type', None)
+    net = modules.PreWorld4DTraj(**cfg)
+    sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in state_dict.items()}
+    missing, _ = net.load_state_dict(sd, strict=False)
+    bad = [k for k in missing if 'depth_net' not in k and 'num_batches_tracked' not in k]
+    if bad:
+        raise KeyError('state dict lacks hot-path keys: %s' % bad[:8])
+    return net.to(device).eval()
+
+
+def lifted_frames(seed, grid_cams, device='cuda:0', n_frames=2):
+    """Synthetic (depth, context, camera) inputs of SURVEY.md 8d for `n_frames` frames (key first)."""
+    def T(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    frames = []
+    for f in range(n_frames):
+        rig = synth.synthetic_rig(grid_cams, dx=-2.5 * f)
+        depth, feat = synth.lift_inputs(seed * 16 + f, N=grid_cams)
+        frames.append(dict(depth=T(depth).view(grid_cams, 88, 32, 88), tran_feat=T(feat).view(grid_cams, 32, 32, 88),
+                           sensor2keyego=T(rig['sensor2ego']), intrin=T(rig['intrin']),
+                           post_rot=T(rig['post_rot']), post_tran=T(rig['post_tran']), bda=T(rig['bda'])))
+    return frames
+
+
+def stack_states(result, horizons=(0, 2, 4, 6)):
+    """apis/test.py:218-223: [np.stack([semantic_occ_0s, _2s, _4s, _6s])] of sample 0."""
+    return np.stack([result['semantic_occ_%ds' % h][0].cpu().numpy() for h in horizons], axis=0)
+
+
+@torch.no_grad()
+def evaluate(net, samples, device='cuda:0', use_image_mask=True):
+    """samples: iterable of dict(frames, ego, gt {horizon: (X,Y,Z) uint8}, mask_camera (X,Y,Z) bool).
+    Returns (Metric_mIoU_Temporal.count_miou() dict, list of stacked predictions)."""
+    metric = metrics.Metric_mIoU_Temporal(num_classes=18, use_image_mask=use_image_mask, device=device)
+    stacks = []
+    for s in samples:
+        res = net.simple_test_from_lift(s['frames'], s['ego'], n_steps=6)
+        st = stack_states(res)
+        stacks.append(st)
+        for h, gt in s['gt'].items():
+            metric.add_batch(st, gt, None, s.get('mask_camera'), h)
+    return metric.count_miou(), stacks
