@@ -212,12 +212,19 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
     dist = None
+    n_dev = torch.cuda.device_count()
+    # one rank per GPU over RCCL.  Fewer GPUs than ranks only happens when the launch contract is
+    # exercised on a 1-GPU development box: ranks then share a device and rendezvous over gloo
+    # (RCCL refuses two ranks on one GPU); the timing of such a run means nothing.
+    oversubscribed = world > n_dev
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = 'cuda:%d' % dev_index
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # 'nccl' == RCCL on ROCm
-    torch.cuda.set_device(local_rank)
-    dev = 'cuda:%d' % local_rank
+        dist.init_process_group('gloo' if oversubscribed else 'nccl',       # 'nccl' == RCCL on ROCm
+                                rank=rank, world_size=world)
 
     n_frames, n_steps_fc = (2, 6) if args.config == 'C3' else (1, 0)
     net, sd = build_net(dev, with_prev=args.config == 'C3')
@@ -302,7 +309,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device='cpu' if oversubscribed else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -334,7 +341,8 @@ def main():
                 'C2: single frame (with_prev=False), 6 cams, 200x200x16, 1 state',
                 'states_per_sample': n_states,
                 'launch': 'hipGraph replay' if graph is not None else 'eager',
-                'parallelism': 'replicas x%d (independent samples, no data-path collective)' % world,
+                'parallelism': 'replicas x%d (independent samples, no data-path collective)%s' % (
+                    world, ' -- OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else ''),
                 'excluded': 'image backbone + DepthNet (stay on PyTorch, SURVEY 8a)',
             },
             'roofline': roofline,
