@@ -120,6 +120,45 @@ def bench_enc():
     return res
 
 
+def bench_render():
+    """C5: attribute MLPs on the full grid + the fused ray march,
+    (ii) the reference shape 38 400 rays x 417 samples and (i) 3 072 rays x 96 uniform samples."""
+    from preworld_amd import modules as M, synth as S
+    dev = 'cuda:0'
+    res = {}
+    sd = S.synth_state_dict(0)
+    mods = []
+    for name, nout in (('density_mlp', 2), ('semantic_mlp', 17), ('color_mlp', 3)):
+        m = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.Softplus(), torch.nn.Linear(64, nout))
+        m.load_state_dict({k[len(name) + 1:]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(name + '.')})
+        mods.append(m.to(dev))
+    packed = ops.pack_attr_mlp(*mods)
+    v = torch.randn(1, 16, 200, 200, 32, device=dev)
+    grid = ops.attr_mlp(v, packed, final_softplus=False)
+    t = timeit(lambda: ops.attr_mlp(v, packed, final_softplus=False, out=grid), iters=10)
+    res['attr_mlp_us'] = t
+    res['attr_mlp_TFLOPs'] = 640000 * 2.0 * (32 * 192 + 192 * 24) / t / 1e6
+    res['attr_mlp_GBps'] = 640000 * (32 + 24) * 4 / t / 1e3
+    head = M.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4, scene_center=[0, 0, 2.2],
+                      radius=39).to(dev)
+    bda = torch.eye(3)
+    g = grid[0].contiguous()
+    g[..., 0] = torch.rand(16, 200, 200, device=dev) * 4 - 2            # sigma logits around the act shift
+    for label, R, tt in (('ii_38400x417', 38400, head.t_table(dev)),
+                         ('i_3072x96', 3072, torch.linspace(0, 2, 97, device=dev)[:-1] + 1.0 / 96)):
+        o, d = S.rays(5, R)
+        o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        fn = lambda: ops.render_rays(o, d, tt.contiguous(), g, head.consts(bda))
+        fn()
+        t = timeit(fn, iters=10)
+        npts = R * tt.numel()
+        res['render_%s_us' % label] = t
+        res['render_%s_Mpts_per_s' % label] = npts / t
+        res['render_%s_gather_GBps' % label] = npts * 8 * 96 / t / 1e3     # cache-level corner rows
+        res['render_%s_hbm_alg_GBps' % label] = (g.numel() * 4 + R * 25 * 4) / t / 1e3
+    return res
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--what', default='lss')
@@ -129,4 +168,6 @@ if __name__ == '__main__':
         out['lss'] = bench_lss()
     if 'enc' in a.what:
         out['enc'] = bench_enc()
+    if 'render' in a.what:
+        out['render'] = bench_render()
     print(json.dumps(out, indent=1))
