@@ -248,6 +248,17 @@ int pw_global_avgpool_ndhwc(const float* x, int B, int64_t n_vox, int C, float* 
 int pw_linear_act(const float* x, const float* w, const float* b, float* y, int rows, int n_in,
                   int n_out, int act, void* stream);
 
+/* SURVEY 8f row 1 (first half): the DepthNet tail, mmdet3d/models/necks/view_transformer.py:797-801:
+ *   depth_digit = x[:, :D]; tran_feat = x[:, D:D+C]; depth = depth_digit.softmax(dim=1)
+ * plus the (B,N,H,W,C) re-layout bev_pool_v2 makes of tran_feat (view_transformer.py:189), in one
+ * pass over the DepthNet output.
+ *   x         float[BN][D + C (+ rest)][HW]  DepthNet output, channel stride HW; x_channels = its channel count
+ *   depth     float[BN][D][HW]               softmax over D per pixel (max-subtracted, like ATen)
+ *   feat_cl   float[BN][HW][C]               context features, channels-last (what pooling gathers)
+ * C must be a multiple of 4. */
+int pw_depthnet_tail(const float* x, int BN, int x_channels, int D, int C, int HW, float* depth,
+                     float* feat_cl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

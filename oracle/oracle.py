@@ -200,6 +200,21 @@ def lss_view_transform(depth, tran_feat, sensor2ego, cam2imgs, post_rots, post_t
     return bev_pool_v2(depth, feat, rd, rf, rb, (B, size[2], size[1], size[0], C), st, ln)
 
 
+def depthnet_tail(x, D, C):
+    """view_transformer.py:797-801: depth = x[:, :D].softmax(dim=1), tran_feat = x[:, D:D+C];
+    the context is returned channels-last (BN,H,W,C) as bev_pool_v2 makes it (:189)."""
+    x = _f32(x)
+    z = x[:, :D]
+    m = z.max(axis=1, keepdims=True)
+    e = np.exp(z - m, dtype=np.float32)
+    s = np.zeros_like(m)
+    for d in range(D):                       # sequential fp32 sum, the order a scalar loop uses
+        s[:, 0] += e[:, d]
+    depth = (e / s).astype(np.float32)
+    feat = np.ascontiguousarray(x[:, D:D + C].transpose(0, 2, 3, 1))
+    return depth, feat
+
+
 # --------------------------------------------------------------------------- conv stack
 def conv3d(x, w, bias=None, stride=1, pad=1):
     x = _f32(x)

@@ -920,3 +920,65 @@ PW_API int pw_confusion_hist(const uint8_t* pred, const uint8_t* gt, const uint8
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// DepthNet tail (view_transformer.py:797-801 + :189): softmax over the D depth logits of each
+// pixel and the channels-last copy of the context features, one thread per pixel.  Reads are
+// coalesced over pixels (channel stride HW), the softmax keeps its D values in registers between
+// the max / exp-sum / normalise sweeps when D <= 96 (one read of the logits), the context row
+// leaves as float4 stores.  HBM: (D + C) * 4 B read and written per pixel.
+// ------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ void __launch_bounds__(256)
+k_depthnet_tail(const float* __restrict__ x, int x_channels, int D, int C, int HW,
+                float* __restrict__ depth, float4* __restrict__ feat_cl) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bn = blockIdx.y;
+  if (pix >= HW) return;
+  const float* xp = x + ((size_t)bn * x_channels) * HW + pix;
+  float* dp = depth + ((size_t)bn * D) * HW + pix;
+  if (DMAX > 0) {
+    float v[DMAX > 0 ? DMAX : 1];
+    float m = -3.402823466e38f;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+      v[d] = d < D ? xp[(size_t)d * HW] : -3.402823466e38f;
+      m = fmaxf(m, v[d]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+      v[d] = d < D ? expf(v[d] - m) : 0.f;
+      sum += v[d];
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < D) dp[(size_t)d * HW] = v[d] / sum;
+  } else {
+    float m = -3.402823466e38f;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, xp[(size_t)d * HW]);
+    float sum = 0.f;
+    for (int d = 0; d < D; ++d) sum += expf(xp[(size_t)d * HW] - m);
+    for (int d = 0; d < D; ++d) dp[(size_t)d * HW] = expf(xp[(size_t)d * HW] - m) / sum;
+  }
+  const float* cp = xp + (size_t)D * HW;
+  float4* fo = feat_cl + ((size_t)bn * HW + pix) * (C / 4);
+  for (int c = 0; c < C; c += 4)
+    fo[c / 4] = make_float4(cp[(size_t)c * HW], cp[(size_t)(c + 1) * HW], cp[(size_t)(c + 2) * HW],
+                            cp[(size_t)(c + 3) * HW]);
+}
+
+PW_API int pw_depthnet_tail(const float* x, int BN, int x_channels, int D, int C, int HW, float* depth,
+                            float* feat_cl, void* stream) {
+  PW_CHECK_ARG(x && depth && feat_cl, "pw_depthnet_tail: null pointer");
+  PW_CHECK_ARG(BN > 0 && D > 0 && C > 0 && HW > 0 && x_channels >= D + C, "pw_depthnet_tail: bad shape");
+  PW_CHECK_ARG(C % 4 == 0 && ((uintptr_t)feat_cl & 15) == 0, "pw_depthnet_tail: C must be a multiple of 4, feat_cl 16-B aligned");
+  dim3 grid((unsigned)pw_cdiv(HW, 256), (unsigned)BN);
+  hipStream_t st = pw_stream(stream);
+  if (D <= 96)
+    hipLaunchKernelGGL(k_depthnet_tail<96>, grid, dim3(256), 0, st, x, x_channels, D, C, HW, depth, (float4*)feat_cl);
+  else
+    hipLaunchKernelGGL(k_depthnet_tail<0>, grid, dim3(256), 0, st, x, x_channels, D, C, HW, depth, (float4*)feat_cl);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

@@ -121,7 +121,10 @@ class LSSViewTransformer(nn.Module):
         else:
             vs = self._sort(input[1], input[3], input[4], input[5], input[6])
         seg_start, order, n_vox = vs.seg_start, vs.order, vs.n_keys
-        feat = tran_feat.view(B, N, self.out_channels, H, W).permute(0, 1, 3, 4, 2).contiguous().float()
+        if getattr(tran_feat, '_pw_channels_last', False):        # already (B*N,H,W,C) from ops.depthnet_tail
+            feat = tran_feat.view(B, N, H, W, self.out_channels)
+        else:
+            feat = tran_feat.view(B, N, self.out_channels, H, W).permute(0, 1, 3, 4, 2).contiguous().float()
         dep = depth.view(B, N, self.D, H, W).contiguous().float()
         if (dep.requires_grad or feat.requires_grad) and torch.is_grad_enabled():
             rb, rd, rf, st, ln = ops.lss_ranks(seg_start, order, n_vox, self.D, H * W)
@@ -148,10 +151,16 @@ class LSSViewTransformer(nn.Module):
         B, N, C, H, W = x.shape
         x = x.view(B * N, C, H, W)
         x = self.depth_net(x)
-        depth_digit = x[:, :self.D, ...]
-        tran_feat = x[:, self.D:self.D + self.out_channels, ...]
-        depth = depth_digit.softmax(dim=1)
+        depth, tran_feat = self.depthnet_tail(x)
         return self.view_transform(input, depth, tran_feat)
+
+    def depthnet_tail(self, x):
+        """view_transformer.py:797-801: split the DepthNet output, softmax the depth logits; the
+        context comes back channels-last (what the pooling gathers), tagged so that
+        view_transform_core skips its permute copy."""
+        depth, feat = ops.depthnet_tail(x.float().contiguous(), self.D, self.out_channels)
+        feat._pw_channels_last = True
+        return depth, feat
 
     def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda):
         return None

@@ -377,6 +377,17 @@ def softplus(x):
     return y
 
 
+# ------------------------------------------------------------------------------ DepthNet tail
+def depthnet_tail(x, D, C):
+    """x (BN, >=D+C, H, W) DepthNet output -> (depth (BN,D,H,W) softmaxed over D,
+    feat_cl (BN,H,W,C) channels-last context) -- view_transformer.py:797-801 and :189 in one pass."""
+    BN, XC, H, W = x.shape
+    depth = torch.empty(BN, D, H, W, device=x.device, dtype=_f32)
+    feat = torch.empty(BN, H, W, C, device=x.device, dtype=_f32)
+    _lib.call('pw_depthnet_tail', _chk(x, _f32, 'x'), BN, XC, D, C, H * W, _p(depth), _p(feat), _stream())
+    return depth, feat
+
+
 # ------------------------------------------------------------------------------ A20 trajectory branch
 def global_avgpool_ndhwc(x):
     """x (B, ..., C) channels-last -> (B, C): nn.AdaptiveAvgPool3d((1,1,1)) of

@@ -181,6 +181,41 @@ def test_full_size_properties(golden):
     assert bad.mean() < 0.01
 
 
+def test_depthnet_tail_softmax_and_layout():
+    """view_transformer.py:797-801 (+ :189): softmax over the depth logits and the channels-last
+    context copy, against the oracle and torch's own softmax; then LSSViewTransformer.forward with
+    an identity DepthNet must equal view_transform on the separately prepared tensors."""
+    from preworld_amd import modules as M
+    rs = np.random.RandomState(9)
+    x = (rs.standard_normal((6, 120, 32, 88)) * 3).astype(np.float32)
+    x[0, :88, 0, 0] = 50.0 * rs.standard_normal(88)            # a peaked pixel (max subtraction matters)
+    depth, feat = ops.depthnet_tail(T(x), 88, 32)
+    od, of = O.depthnet_tail(x, 88, 32)
+    np.testing.assert_allclose(depth.cpu().numpy(), od, rtol=2e-6, atol=1e-9)
+    np.testing.assert_array_equal(feat.cpu().numpy(), of)
+    td = torch.from_numpy(x[:, :88]).softmax(dim=1).numpy()
+    np.testing.assert_allclose(depth.cpu().numpy(), td, rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(depth.sum(1).cpu().numpy(), 1.0, rtol=1e-5)
+    # D > 96 takes the streaming variant, ragged pixel count
+    x2 = rs.standard_normal((2, 140, 5, 7)).astype(np.float32)
+    d2, f2 = ops.depthnet_tail(T(x2), 100, 40)
+    od2, of2 = O.depthnet_tail(x2, 100, 40)
+    np.testing.assert_allclose(d2.cpu().numpy(), od2, rtol=2e-6, atol=1e-9)
+    np.testing.assert_array_equal(f2.cpu().numpy(), of2)
+    # module level
+    rig = S.synthetic_rig(6)
+    vt = M.LSSViewTransformer(grid_config=S.GRID_CONFIG_FULL, input_size=S.INPUT_SIZE, downsample=S.DOWNSAMPLE,
+                              in_channels=120, out_channels=32, collapse_z=False).to(DEV)
+    vt.depth_net = torch.nn.Identity()
+    inp = [T(x).view(1, 6, 120, 32, 88), T(rig['sensor2ego']), None] + \
+        [T(rig[k]) for k in ('intrin', 'post_rot', 'post_tran', 'bda')]
+    with torch.no_grad():
+        bev, dep = vt(inp)
+        bev2, _ = vt.view_transform(inp, T(td), T(np.ascontiguousarray(x[:, 88:120])))
+    np.testing.assert_allclose(bev.cpu().numpy(), bev2.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert dep.shape == (6, 88, 32, 88)
+
+
 def test_edge_cases():
     lower, interval, size = O.grid_infos(S.GRID_CONFIG_FULL)
     # nothing inside the grid -> five Nones like view_transformer.py:237-238

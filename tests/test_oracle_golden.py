@@ -164,6 +164,17 @@ def test_forecast_small(golden):
     np.testing.assert_allclose(sem, g['semantic'], rtol=1e-4, atol=1e-4)
 
 
+def test_depthnet_tail_matches_torch_softmax():
+    """oracle restatement of view_transformer.py:797-801 against torch's softmax (the reference call)."""
+    import torch
+    rs = np.random.RandomState(9)
+    x = (rs.standard_normal((3, 120, 8, 11)) * 3).astype(np.float32)
+    depth, feat = O.depthnet_tail(x, 88, 32)
+    want = torch.from_numpy(x[:, :88]).softmax(dim=1).numpy()
+    np.testing.assert_allclose(depth, want, rtol=3e-6, atol=1e-9)
+    np.testing.assert_array_equal(feat, x[:, 88:120].transpose(0, 2, 3, 1))
+
+
 def test_traj_branch_small(golden):
     """A20: DownScaleModule3DCustom (imported reference module) + ego_fusion_head + traj_head."""
     g = golden('traj_small.npz')
