@@ -148,14 +148,15 @@ int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const fl
  * use_deblock=False): conv3x3x3 Cin->16 + BN + ReLU, 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18,
  * argmax -> uint8, in one kernel.  x (B,D,H,W,Cin); scale/bias float[>=16] (folded BN of
  * occ_convs.0.1); w1 [8][16], s1/b1 [8] (folded BN of occ_pred_conv.1), w2 [18][8]; occ
- * uint8[B*D*H*W]; logits float[B*D*H*W][18] or NULL.
+ * uint8[B*D*H*W]; logits float[B*D*H*W][18] or NULL; geo uint8[B*D*H*W] or NULL receives the
+ * reference's geo_occ (preworld_temporal_traj.py:313-319): 0 where occ != empty_idx, n_cls-1 elsewhere.
  * wpk_layout 16: wpk = float[Cin/32][27][64][8], wpk[ch][tap][g*16+j][s] = w[j][ch*32+g*8+s][tap]
  *   (v_mfma_f32_16x16x4_f32 kernel, no padded output columns -- the fast path);
- * wpk_layout 32: wpk as for pw_conv3d_ndhwc with the 16 couts padded to 32 (32x32x2 kernel). */
+ * (only layout 16 is built). */
 int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, const float* bias,
                       const float* w1, const float* s1, const float* b1, const float* w2,
-                      uint8_t* occ, float* logits, int B, int D, int H, int W, int Cin, int n_mid,
-                      int n_hid, int n_cls, int wpk_layout, void* stream);
+                      uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H,
+                      int W, int Cin, int n_mid, int n_hid, int n_cls, int wpk_layout, void* stream);
 
 /* A10  state-conditioned forecast (mmdet3d/models/detectors/preworld_temporal_traj.py:329-368).
  * pw_forecast_pack: fusion_head.{0,2}.weight ([128][64], [32][128]) -> per-lane MFMA operand

@@ -825,6 +825,8 @@ struct OccTail {
   const float* w2;      // [18][8]  occ_pred_conv.3.weight
   uint8_t* occ;         // [B*D*H*W] argmax class
   float* logits;        // [B*D*H*W][18] or null
+  uint8_t* geo;         // [B*D*H*W] geo_occ or null
+  int empty_idx;
   int n_mid, n_hid, n_cls;
 };
 
@@ -964,6 +966,7 @@ __global__ void __launch_bounds__(256 * WD, 2) k_occ_head16(ConvArgs a, OccTail 
       if (c == 0 || s_ > best) { best = s_; arg = c; }
     }
     tail.occ[vox] = (uint8_t)arg;
+    if (tail.geo) tail.geo[vox] = arg != tail.empty_idx ? (uint8_t)0 : (uint8_t)(tail.n_cls - 1);
   }
 }
 
@@ -1318,8 +1321,9 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
 // A11  fused OccHead: conv3x3x3 (Cin->16, BN, ReLU) + 1x1x1 16->8 (BN, ReLU) + 1x1x1 8->18 + argmax
 PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, const float* bias,
                              const float* w1, const float* s1, const float* b1, const float* w2,
-                             uint8_t* occ, float* logits, int B, int D, int H, int W, int Cin,
-                             int n_mid, int n_hid, int n_cls, int wpk_layout, void* stream) {
+                             uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D,
+                             int H, int W, int Cin, int n_mid, int n_hid, int n_cls, int wpk_layout,
+                             void* stream) {
   PW_CHECK_ARG(x && wpk && w1 && s1 && b1 && w2 && occ, "pw_occ_head_fused: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cin % KC == 0, "pw_occ_head_fused: bad shape");
   if (n_mid != 16 || n_hid != 8 || n_cls != 18) {
@@ -1332,7 +1336,7 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Do = D; a.Ho = H; a.Wo = W;
   a.cout_total = 32; a.cout0 = n_mid; a.relu0 = 1;
   a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
-  OccTail t = {w1, s1, b1, w2, occ, logits, n_mid, n_hid, n_cls};
+  OccTail t = {w1, s1, b1, w2, occ, logits, geo, empty_idx, n_mid, n_hid, n_cls};
   long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
   PW_CHECK_ARG(wpk_layout == 16, "pw_occ_head_fused: wpk_layout must be 16 (the 16x16x4 MFMA packing)");
   const int WD = choose_wd(B, D, H, W, 1);

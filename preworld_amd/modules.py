@@ -433,7 +433,7 @@ class OccHead(nn.Module):
         wpk, wpk_t, s0, b0, w1, s1, b1, w2 = self._cache.get(params, build)
         return (wpk_t if transposed else wpk), s0, b0, w1, s1, b1, w2
 
-    def decode_cl(self, x_cl, want_logits=False, transposed=False):
+    def decode_cl(self, x_cl, want_logits=False, transposed=False, want_geo=False):
         """x_cl (B,D,H,W,C) channels-last -> uint8 argmax (B,D,H,W) [, logits (B,D,H,W,18)].
         The reference feeds (1,C,X,Y,Z), i.e. kernel axes (kD,kH,kW) <-> (X,Y,Z).  With
         transposed=True, x_cl is the encoder's native (B,Z,Y,X,C) buffer and the kernel taps are
@@ -442,7 +442,8 @@ class OccHead(nn.Module):
         if self.training:
             raise NotImplementedError('OccHead HIP path is eval-only')
         wpk, s0, b0, w1, s1, b1, w2 = self._folded(transposed)
-        return ops.occ_head_fused(x_cl, wpk, s0, b0, w1, s1, b1, w2, want_logits=want_logits)
+        return ops.occ_head_fused(x_cl, wpk, s0, b0, w1, s1, b1, w2, want_logits=want_logits,
+                                  want_geo=want_geo, empty_idx=self.empty_idx)
 
     def forward(self, voxel_feats, **kwargs):
         assert type(voxel_feats) is list and len(voxel_feats) == self.num_level
@@ -692,13 +693,12 @@ class PreWorld4DTraj(nn.Module):
             feats += [states[k] for k in range(n_steps)]
         logits_all = []
         for k, f in enumerate(feats):
-            out = self.occupancy_head.decode_cl(f, want_logits=want_logits, transposed=True)
-            occ = out[0] if want_logits else out
+            out = self.occupancy_head.decode_cl(f, want_logits=want_logits, transposed=True, want_geo=True)
+            occ, geo = out[0], out[-1]                                 # geo_occ from the same kernel (:313-319)
             if want_logits:
                 logits_all.append(out[1])
             occ_xyz = occ.permute(0, 3, 2, 1)                          # (B,X,Y,Z) view
-            geo = torch.where(occ_xyz != self.empty_idx, torch.zeros_like(occ_xyz),
-                              torch.full_like(occ_xyz, self.num_classes - 1))
+            geo = geo.permute(0, 3, 2, 1)
             # the reference indexes batch element 0 (:306) and names states 0s..6s (:361)
             res['semantic_occ_%ds' % k] = [occ_xyz[0]]
             res['geo_occ_%ds' % k] = [geo[0]]

@@ -60,6 +60,19 @@ def test_mini_split_states_and_miou_match_oracle():
     assert abs(miou['avg_future'] - round(float(np.mean([want[2], want[4], want[6]])), 2)) <= 0.05
 
 
+def test_geo_occ_comes_from_the_same_kernel():
+    """preworld_temporal_traj.py:313-319: geo_occ = 0 where the argmax is not the empty class, 17 elsewhere."""
+    sd = S.synth_state_dict(0)
+    net = harness.build_model(harness.model_cfg(GC), sd, DEV)
+    with torch.no_grad():
+        res = net.simple_test_from_lift(harness.lifted_frames(3, 1, DEV), torch.from_numpy(S.ego_state(3)).to(DEV), n_steps=2)
+    for k in range(3):
+        occ = res['semantic_occ_%ds' % k][0].cpu().numpy()
+        geo = res['geo_occ_%ds' % k][0].cpu().numpy()
+        assert geo.dtype == np.uint8 and geo.shape == occ.shape
+        np.testing.assert_array_equal(geo, np.where(occ != 17, 0, 17).astype(np.uint8))
+
+
 def test_build_model_rejects_incomplete_state_dict():
     sd = S.synth_state_dict(0)
     sd.pop('final_conv.conv.weight')
