@@ -129,12 +129,15 @@ int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_
  *   residual    same layout as y0 or NULL (added before ReLU; BasicBlock3D.forward resnet.py:120-123)
  *   y0 (B,Do,Ho,Wo,cout0) gets packed columns [0,cout0); y1 (B,Do,Ho,Wo,cout1) gets columns
  *   [roundup32(cout0), +cout1) or is NULL -- lets conv1 and downsample of a BasicBlock3D share
- *   one pass over x.  ksize in {1,2,3} (pad = (ksize-1)/2; ksize 2 needs stride 2), stride in {1,2}.
+ *   one pass over x.  ld_y0 / ld_y1: floats between consecutive voxels of y0 (and residual) / y1;
+ *   0 = dense (cout0 / cout1); larger when the output is a channel slice of a wider channels-last
+ *   buffer (the [adjacent, key] concat of bevdet_occ.py:266 is produced in place this way).
+ *   ksize in {1,2,3} (pad = (ksize-1)/2; ksize 2 needs stride 2), stride in {1,2}.
  *   algo: 0 auto, 1 LDS-tiled kernel (k3 s1), 2 gather kernel. */
 int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const float* bias,
                     const float* residual, float* y0, float* y1, int B, int D, int H, int W,
-                    int Cin, int cout_total, int cout0, int cout1, int ksize, int stride,
-                    int relu0, int relu1, int algo, void* stream);
+                    int Cin, int cout_total, int cout0, int cout1, int ld_y0, int ld_y1, int ksize,
+                    int stride, int relu0, int relu1, int algo, void* stream);
 
 /* A8  LSSFPN3D fused (mmdet3d/models/necks/lss_fpn.py:132-148): out = ReLU(BN(W8 x8 +
  * up2(y16) + up4(y32))) where y16/y32 are the 1x1x1 conv already applied at 1/2 and 1/4

@@ -50,6 +50,8 @@ struct ConvArgs {
   int Do, Ho, Wo;         // output dims
   int cout_total;         // multiple of 32
   int cout0, cout1;       // real channel counts of y0 / y1
+  int ld0, ld1;           // row stride (floats per voxel) of y0 (and residual) / y1: >= cout, a channel
+                          // slice of a wider channels-last buffer when larger (no concat copy)
   int n1_start;           // first packed column that goes to y1
   int relu0, relu1;
   int tiles_d, tiles_h, tiles_w;
@@ -66,7 +68,7 @@ __device__ __forceinline__ int patch_of_row(int i) {
 __device__ __forceinline__ void store_out(const ConvArgs& a, int n, size_t vox, float v) {
   // n = packed output column
   if (n < a.cout0) {
-    size_t o = vox * a.cout0 + n;
+    size_t o = vox * a.ld0 + n;
     if (a.residual) v += a.residual[o];
     if (a.relu0) v = fmaxf(v, 0.f);
     a.y0[o] = v;
@@ -74,7 +76,7 @@ __device__ __forceinline__ void store_out(const ConvArgs& a, int n, size_t vox, 
     int n1 = n - a.n1_start;
     if (a.y1 && n1 >= 0 && n1 < a.cout1) {
       if (a.relu1) v = fmaxf(v, 0.f);
-      a.y1[vox * a.cout1 + n1] = v;
+      a.y1[vox * a.ld1 + n1] = v;
     }
   }
 }
@@ -368,14 +370,15 @@ __global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
     const bool to_y0 = n0 < a.cout0;
     float* dst = to_y0 ? a.y0 : a.y1;
     if (dst == nullptr) continue;
-    const int stride = to_y0 ? a.cout0 : a.cout1;
+    const int stride = to_y0 ? a.cout0 : a.cout1;      // valid columns
+    const int ld = to_y0 ? a.ld0 : a.ld1;              // row stride
     const int col0 = to_y0 ? n0 : n0 - a.n1_start;    // uniform
     if (col0 < 0 || col0 >= stride) continue;
     const bool fullcols = col0 + 32 <= stride;
     const float lo = (to_y0 ? a.relu0 : a.relu1) ? 0.f : -3.402823466e38f;
     const bool has_res = to_y0 && a.residual != nullptr;
-    const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)stride * 4u);
-    const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)stride * 4u);
+    const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)ld * 4u);
+    const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)ld * 4u);
     const float sc = a.scale ? a.scale[n] : 1.f;
     const float bi = a.bias ? a.bias[n] : 0.f;
     const unsigned lanecol = (unsigned)(col0 + i) * 4u;
@@ -389,13 +392,13 @@ __global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
       const int p0 = acc_patch(4 * g4, 0), p1 = acc_patch(4 * g4, 1);
       gpr[g4] = half ? (p1 >> 3) : (p0 >> 3);
       gpc[g4] = half ? (p1 & 7) : (p0 & 7);
-      goff[g4] = (unsigned)((gpr[g4] * a.Wo + gpc[g4]) * stride) * 4u + lanecol;
+      goff[g4] = (unsigned)((gpr[g4] * a.Wo + gpc[g4]) * ld) * 4u + lanecol;
     }
-    const unsigned estep = (unsigned)stride * 4u;
+    const unsigned estep = (unsigned)ld * 4u;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       // byte offset of patch position (0,0) of this M-tile: uniform
-      const unsigned soff = (unsigned)((((((long long)b * a.Do + od) * a.Ho + (h0 + mt * 4)) * a.Wo + w0) * stride) * 4);
+      const unsigned soff = (unsigned)((((((long long)b * a.Do + od) * a.Ho + (h0 + mt * 4)) * a.Wo + w0) * ld) * 4);
       if (interior && fullcols) {
         float rv[16];
         if (has_res) {
@@ -739,14 +742,15 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_k3s1_pipe(ConvArgs a, PipeArg
           const bool to_y0 = n0 < a.cout0;
           float* dst = to_y0 ? a.y0 : a.y1;
           if (dst == nullptr) continue;
-          const int stride = to_y0 ? a.cout0 : a.cout1;
+          const int stride = to_y0 ? a.cout0 : a.cout1;      // valid columns
+    const int ld = to_y0 ? a.ld0 : a.ld1;              // row stride
           const int col0 = to_y0 ? n0 : n0 - a.n1_start;
           if (col0 < 0 || col0 >= stride) continue;
           const bool fullcols = col0 + 32 <= stride;
           const float lo = (to_y0 ? a.relu0 : a.relu1) ? 0.f : -3.402823466e38f;
           const bool has_res = to_y0 && a.residual != nullptr;
-          const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)stride * 4u);
-          const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)stride * 4u);
+          const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)ld * 4u);
+          const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)ld * 4u);
           const float sc = sc_r[nt];
           const float bi = bi_r[nt];
           const unsigned lanecol = (unsigned)(col0 + i) * 4u;
@@ -757,12 +761,12 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_k3s1_pipe(ConvArgs a, PipeArg
             const int p0 = acc_patch(4 * g4, 0), p1 = acc_patch(4 * g4, 1);
             gpr[g4] = half ? (p1 >> 3) : (p0 >> 3);
             gpc[g4] = half ? (p1 & 7) : (p0 & 7);
-            goff[g4] = (unsigned)((gpr[g4] * a.Wo + gpc[g4]) * stride) * 4u + lanecol;
+            goff[g4] = (unsigned)((gpr[g4] * a.Wo + gpc[g4]) * ld) * 4u + lanecol;
           }
-          const unsigned estep = (unsigned)stride * 4u;
+          const unsigned estep = (unsigned)ld * 4u;
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
-            const unsigned soff = (unsigned)(((((t.b * a.Do + od) * a.Ho + (t.h0 + mt * 4)) * a.Wo + t.w0) * stride) * 4);
+            const unsigned soff = (unsigned)(((((t.b * a.Do + od) * a.Ho + (t.h0 + mt * 4)) * a.Wo + t.w0) * ld) * 4);
             if (interior && fullcols) {
               float rv[16];
               if (has_res) {
@@ -1154,7 +1158,7 @@ PW_API int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, c
   PW_CHECK_ARG(D2 > 0 && H2 > 0 && W2 > 0 && D4 > 0 && H4 > 0 && W4 > 0, "pw_fpn3d_fuse: bad level shape");
   ConvArgs a = {};
   a.x = x8; a.wpk = wpk8; a.scale = scale; a.bias = bias; a.y0 = out;
-  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin8; a.relu0 = relu; a.cout_total = 32; a.cout0 = 32;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin8; a.relu0 = relu; a.cout_total = 32; a.cout0 = 32; a.ld0 = 32;
   FpnArgs f = {y16, y32, D2, H2, W2, D4, H4, W4};
   const long long n = (long long)B * D * H * W;
   PW_CHECK_ARG(n < (1ll << 31), "pw_fpn3d_fuse: more than 2^31 voxels");
@@ -1195,11 +1199,8 @@ static int pw_num_cus() {
 // Both designs sit on the same ceiling (operand loads cost matrix-pipe time, see the kernel comment);
 // the pipelined one wins where a wave owns a single N-tile and the grid gives every CU 2+ items.
 static bool use_pipe(long long n_items, int NT) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("PW_CONV_PIPE");
-    forced = e ? (atoi(e) ? 1 : 0) : 2;
-  }
+  const char* e = getenv("PW_CONV_PIPE");            // read per call: tests flip it inside one process
+  const int forced = e ? (atoi(e) ? 1 : 0) : 2;
   if (forced != 2) return forced == 1 && n_items < (1ll << 20);
   return NT == 1 && n_items >= 512 && n_items < (1ll << 20);
 }
@@ -1221,8 +1222,8 @@ static int choose_wd(int B, int Do, int Ho, int Wo, int ngroups) {
 
 PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const float* bias,
                            const float* residual, float* y0, float* y1, int B, int D, int H, int W,
-                           int Cin, int cout_total, int cout0, int cout1, int ksize, int stride,
-                           int relu0, int relu1, int algo, void* stream) {
+                           int Cin, int cout_total, int cout0, int cout1, int ld_y0, int ld_y1, int ksize,
+                           int stride, int relu0, int relu1, int algo, void* stream) {
   PW_CHECK_ARG(x && wpk && y0, "pw_conv3d_ndhwc: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "pw_conv3d_ndhwc: bad shape");
   PW_CHECK_ARG(Cin > 0 && Cin % KC == 0, "pw_conv3d_ndhwc: Cin must be a multiple of 32 (got %d)", Cin);
@@ -1241,13 +1242,15 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   a.Ho = (H + 2 * pad - ksize) / stride + 1;
   a.Wo = (W + 2 * pad - ksize) / stride + 1;
   a.cout_total = cout_total; a.cout0 = cout0; a.cout1 = cout1;
+  a.ld0 = ld_y0 > 0 ? ld_y0 : cout0; a.ld1 = ld_y1 > 0 ? ld_y1 : cout1;
+  PW_CHECK_ARG(a.ld0 >= cout0 && a.ld1 >= cout1, "pw_conv3d_ndhwc: ld_y0/ld_y1 must be >= the channel counts");
   a.n1_start = (cout0 + 31) / 32 * 32;
   a.relu0 = relu0; a.relu1 = relu1;
   a.tiles_d = (a.Do + BD - 1) / BD; a.tiles_h = (a.Ho + BH - 1) / BH; a.tiles_w = (a.Wo + BW - 1) / BW;
   PW_CHECK_ARG(!(cout1 > 0 && !y1), "pw_conv3d_ndhwc: cout1 > 0 needs y1");
   PW_CHECK_ARG(a.n1_start + cout1 <= cout_total || cout1 == 0, "pw_conv3d_ndhwc: cout split exceeds cout_total");
   PW_CHECK_ARG((size_t)B * D * H * W * Cin * 4 < (1ull << 32) &&
-                   (size_t)B * a.Do * a.Ho * a.Wo * (cout0 > cout1 ? cout0 : cout1) * 4 < (1ull << 32),
+                   (size_t)B * a.Do * a.Ho * a.Wo * (a.ld0 > a.ld1 ? a.ld0 : a.ld1) * 4 < (1ull << 32),
                "pw_conv3d_ndhwc: tensors must be < 4 GiB (32-bit buffer addressing)");
   hipStream_t st = pw_stream(stream);
   const int ntiles = cout_total / 32;

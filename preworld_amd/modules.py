@@ -271,7 +271,9 @@ class BasicBlock3D(nn.Module):
         self.downsample = downsample
         self._cache = _PackedCache()
 
-    def forward_cl(self, x):
+    def forward_cl(self, x, out=None):
+        """out: optional destination (a channel slice of a wider channels-last buffer is fine); the
+        downsample branch is then written there first and conv2 adds onto it in place."""
         c1, c2, ds = self.conv1, self.conv2, self.downsample
         c1._check_eval()
         if ds is not None:
@@ -286,13 +288,16 @@ class BasicBlock3D(nn.Module):
             wpk, sc, bi = self._cache.get(params, build)
             y, identity = ops.conv3d_ndhwc(x, wpk, sc, bi, cout0=c1.out_channels,
                                            cout1=ds.out_channels, ksize=3, stride=c1.stride,
-                                           relu0=True, relu1=False)
+                                           relu0=True, relu1=False, out1=out)
         else:
             identity = x
             y = c1.forward_cl(x)
         w2, s2, b2 = c2.folded()
+        if out is not None and ds is None:
+            out.copy_(identity)
+            identity = out
         return ops.conv3d_ndhwc(y, w2, s2, b2, residual=identity, cout0=c2.out_channels, ksize=3,
-                                stride=1, relu0=True)
+                                stride=1, relu0=True, out0=out)
 
     def forward(self, x):
         return from_channels_last_3d(self.forward_cl(to_channels_last_3d(x)))
@@ -323,11 +328,14 @@ class CustomResNet3D(nn.Module):
         self.layers = nn.Sequential(*layers)
         self.with_cp = with_cp
 
-    def forward_cl(self, x):
+    def forward_cl(self, x, out_last=None):
+        """out_last: optional destination of the LAST block's output (see BasicBlock3D.forward_cl)."""
         feats = []
+        n_layers = len(self.layers)
         for lid, layer in enumerate(self.layers):
-            for blk in layer:
-                x = blk.forward_cl(x)
+            for bid, blk in enumerate(layer):
+                last = out_last is not None and lid == n_layers - 1 and bid == len(layer) - 1
+                x = blk.forward_cl(x, out=out_last) if last else blk.forward_cl(x)
             if lid in self.backbone_output_ids:
                 feats.append(x)
         return feats
@@ -613,7 +621,7 @@ class PreWorld4DTraj(nn.Module):
         return self.img_bev_encoder_neck.forward_cl(self.img_bev_encoder_backbone.forward_cl(x_cl))
 
     # ---- bevdet_occ.py:141-165 minus the image encoder / DepthNet
-    def lift_frame_cl(self, depth, tran_feat, sensor2keyego, intrin, post_rot, post_tran, bda):
+    def lift_frame_cl(self, depth, tran_feat, sensor2keyego, intrin, post_rot, post_tran, bda, out=None):
         vt = self.img_view_transformer
         B, N = sensor2keyego.shape[:2]
         H, W = depth.shape[-2:]
@@ -626,19 +634,31 @@ class PreWorld4DTraj(nn.Module):
             vt.collapse_z = keep
         x = to_channels_last_3d(bev)
         if self.pre_process:
-            x = self.pre_process_net.forward_cl(x)[0]
+            x = self.pre_process_net.forward_cl(x, out_last=out)[0]
+        elif out is not None:
+            out.copy_(x)
+            x = out
         return x
 
     # ---- bevdet_occ.py:167-269 (frame loop, [adj, key] concat, with_prev=False -> zeros)
     def extract_voxel_feat_cl(self, frames):
         """frames: list ordered [key, adj, ...] of dicts(depth, tran_feat, sensor2keyego, intrin,
         post_rot, post_tran, bda).  Returns final_conv output, channels-last (B,Z,Y,X,out_dim)."""
-        key = self.lift_frame_cl(**frames[0])
-        if self.with_prev and len(frames) > 1:
-            adj = [self.lift_frame_cl(**f) for f in frames[1:1 + self.num_adj]]
-        else:
-            adj = [torch.zeros_like(key) for _ in range(self.num_adj)]
-        x = torch.cat(adj[::-1] + [key], dim=-1)          # channel order [adjacent, key] (:266)
+        # channel order [adjacent ..., key] (bevdet_occ.py:266): every frame's pre_process output is
+        # written straight into its channel slice of ONE buffer (row stride n*C), no torch.cat copy
+        f0 = frames[0]
+        B = f0['sensor2keyego'].shape[0]
+        _, _, size = self.img_view_transformer._grid()
+        C = self.img_view_transformer.out_channels
+        n = self.num_adj + 1
+        x = torch.empty(B, size[2], size[1], size[0], n * C, device=f0['depth'].device, dtype=torch.float32)
+        self.lift_frame_cl(out=x[..., (n - 1) * C:], **f0)
+        for j in range(self.num_adj):                      # adjacent frame j+1 sits left of frame j
+            sl = x[..., (n - 2 - j) * C:(n - 1 - j) * C]
+            if self.with_prev and len(frames) > 1 + j:
+                self.lift_frame_cl(out=sl, **frames[1 + j])
+            else:
+                sl.zero_()
         x = self.bev_encoder_cl(x)
         return self.final_conv.forward_cl(x)              # conv + bias + ReLU (preworld.py:72-79)
 

@@ -271,10 +271,26 @@ def _pad32(v, fill):
     return out
 
 
+def _row_stride(t, shape, name):
+    """t must be (B,Do,Ho,Wo,c) laid out as a channel slice of a dense channels-last buffer:
+    strides (Do*Ho*Wo*ld, Ho*Wo*ld, Wo*ld, ld, 1).  Returns ld."""
+    if not t.is_cuda or t.dtype != _f32 or tuple(t.shape) != tuple(shape):
+        raise _lib.PreworldHipError('%s must be a float32 device tensor of shape %s' % (name, tuple(shape)))
+    B, Do, Ho, Wo, c = shape
+    ld = t.stride(3)
+    want = (Do * Ho * Wo * ld, Ho * Wo * ld, Wo * ld, ld, 1)
+    ok = ld >= c and all(t.stride(i) == want[i] or t.shape[i] == 1 for i in range(5))
+    if not ok:
+        raise _lib.PreworldHipError('%s must be dense or a channel slice of a dense channels-last buffer' % name)
+    return ld
+
+
 def conv3d_ndhwc(x, wpk, scale=None, bias=None, residual=None, cout0=None, cout1=0, ksize=3,
                  stride=1, relu0=False, relu1=False, algo=0, out0=None, out1=None):
     """x (B,D,H,W,Cin) channels-last -> y0 (B,Do,Ho,Wo,cout0) [, y1 (B,Do,Ho,Wo,cout1)].
-    scale/bias: per packed column (length cout_total, see include/preworld_hip.h)."""
+    scale/bias: per packed column (length cout_total, see include/preworld_hip.h).
+    out0 / out1 may be channel slices of a wider channels-last buffer (e.g. buf[..., 32:64]); a
+    residual then has to share out0's layout (it may BE out0: each element is read, then written)."""
     B, D, H, W, Cin = x.shape
     nch, taps, nt = wpk.shape[:3]
     cout_total = nt * 32
@@ -285,9 +301,13 @@ def conv3d_ndhwc(x, wpk, scale=None, bias=None, residual=None, cout0=None, cout1
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (W + 2 * pad - ksize) // stride + 1
     y0 = out0 if out0 is not None else torch.empty(B, Do, Ho, Wo, cout0, device=x.device, dtype=_f32)
-    y1 = None
+    ld0 = _row_stride(y0, (B, Do, Ho, Wo, cout0), 'y0')
+    y1, ld1 = None, 0
     if cout1:
         y1 = out1 if out1 is not None else torch.empty(B, Do, Ho, Wo, cout1, device=x.device, dtype=_f32)
+        ld1 = _row_stride(y1, (B, Do, Ho, Wo, cout1), 'y1')
+    if residual is not None and _row_stride(residual, (B, Do, Ho, Wo, cout0), 'residual') != ld0:
+        raise _lib.PreworldHipError('residual must have the same row stride as y0')
     if scale is not None and scale.numel() != cout_total:
         raise _lib.PreworldHipError('scale must have cout_total=%d entries' % cout_total)
     if bias is not None and bias.numel() != cout_total:
@@ -295,7 +315,7 @@ def conv3d_ndhwc(x, wpk, scale=None, bias=None, residual=None, cout0=None, cout1
     if nch * 32 != Cin or taps != ksize ** 3:
         raise _lib.PreworldHipError('packed weight does not match Cin/ksize')
     _lib.call('pw_conv3d_ndhwc', _chk(x, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _p(scale), _p(bias),
-              _p(residual), _chk(y0, _f32, 'y0'), _p(y1), B, D, H, W, Cin, cout_total, cout0, cout1,
+              _p(residual), _p(y0), _p(y1), B, D, H, W, Cin, cout_total, cout0, cout1, ld0, ld1,
               ksize, stride, int(relu0), int(relu1), algo, _stream())
     return (y0, y1) if cout1 else y0
 

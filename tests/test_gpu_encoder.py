@@ -79,6 +79,46 @@ def test_conv3d_two_outputs_share_input():
     np.testing.assert_allclose(ncdhw(y1), O.conv3d(x, wb), **TOL)
 
 
+@pytest.mark.parametrize('shape', [(1, 16, 40, 48), (2, 5, 9, 11)])
+def test_conv3d_outputs_into_channel_slices(shape):
+    """ld_y0 / ld_y1: y0 (with an in-place residual) and y1 written into channel slices of wider
+    channels-last buffers must equal the dense results, on the tiled, pipelined and gather kernels,
+    and must not touch the other channels."""
+    import os
+    B, D, H, W = shape
+    rs = np.random.RandomState(21)
+    x = T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32))
+    w = [torch.from_numpy(rs.standard_normal((32, 32, 3, 3, 3)).astype(np.float32) * 0.05).to(DEV) for _ in range(2)]
+    wpk2 = ops.pack_conv_weights_concat(w)
+    sc = T(rs.uniform(0.5, 1.5, 64).astype(np.float32)); bi = T(rs.standard_normal(64).astype(np.float32))
+    res = T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32))
+    for algo, pipe in ((1, '0'), (1, '1'), (2, '0')):
+        os.environ['PW_CONV_PIPE'] = pipe
+        try:
+            d0, d1 = ops.conv3d_ndhwc(x, wpk2, sc, bi, cout0=32, cout1=32, ksize=3, relu0=True, algo=algo)
+            buf = torch.full((B, D, H, W, 96), 7.0, device=DEV)
+            s0, s1 = ops.conv3d_ndhwc(x, wpk2, sc, bi, cout0=32, cout1=32, ksize=3, relu0=True, algo=algo,
+                                      out0=buf[..., 0:32], out1=buf[..., 64:96])
+            assert s0.data_ptr() == buf.data_ptr()
+            np.testing.assert_array_equal(buf[..., 0:32].cpu().numpy(), d0.cpu().numpy())
+            np.testing.assert_array_equal(buf[..., 64:96].cpu().numpy(), d1.cpu().numpy())
+            assert bool((buf[..., 32:64] == 7.0).all())
+            # residual in place: slice holds the residual, conv adds onto it
+            wp1 = ops.pack_conv_weight(w[0])
+            dense = ops.conv3d_ndhwc(x, wp1, sc[:32].contiguous(), bi[:32].contiguous(), residual=res, ksize=3,
+                                     relu0=True, algo=algo)
+            buf2 = torch.full((B, D, H, W, 64), -3.0, device=DEV)
+            buf2[..., 32:64] = res
+            ops.conv3d_ndhwc(x, wp1, sc[:32].contiguous(), bi[:32].contiguous(), residual=buf2[..., 32:64], ksize=3,
+                             relu0=True, algo=algo, out0=buf2[..., 32:64])
+            np.testing.assert_array_equal(buf2[..., 32:64].cpu().numpy(), dense.cpu().numpy())
+            assert bool((buf2[..., 0:32] == -3.0).all())
+        finally:
+            os.environ.pop('PW_CONV_PIPE', None)
+    with pytest.raises(Exception):
+        ops.conv3d_ndhwc(x, wp1, residual=res, ksize=3, out0=buf2[..., 32:64])      # residual stride != y0 stride
+
+
 def test_conv3d_bad_arguments_raise():
     x = torch.zeros(1, 4, 8, 8, 24, device=DEV)
     with pytest.raises(Exception):
