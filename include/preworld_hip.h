@@ -263,6 +263,24 @@ int pw_linear_act(const float* x, const float* w, const float* b, float* y, int 
 int pw_depthnet_tail(const float* x, int BN, int x_channels, int D, int C, int HW, float* depth,
                      float* feat_cl, void* stream);
 
+/* ray table + weighted-ray-sampling weights of the pre-train dataloader
+ * (mmdet3d/datasets/ray.py:34-119), on the GPU.
+ * pw_pts2ray (ray.py:34-55, one camera): for pixel p = coor[i] (x, y):
+ *   dirs = ((x+0.5-K02)/K00, (y+0.5-K12)/K11, 1); rays_d = c2w[:3,:3] . dirs; rays_o = c2w[:3,3];
+ *   viewdirs = rays_d/|rays_d|;  rays[i] = {x, y, depth, seg, rays_o[3], rays_d[3], viewdirs[3], img[3]}
+ *   coor float[n][2], depth/seg float[n], img float[n][3], c2w float[16] (row-major 4x4, device),
+ *   K float[9] (device), rays float[n][16].
+ * pw_class_count (ray.py:94-97): counts[c] += #(rays[:,3] == c), c < n_cls; counts int64[n_cls] accumulates.
+ * pw_wrs_weights (ray.py:99-112): weight = balance_weight[class] * (frame_id == 0 ? 1 : (class in
+ *   dynamic_class ? weight_dyn : weight_adj)); rays float[n][16], balance_weight float[n_cls],
+ *   dynamic_class int32[n_dyn], weights float[n]. */
+int pw_pts2ray(const float* coor, const float* depth, const float* seg, const float* img,
+               const float* c2w, const float* K, int64_t n, float* rays, void* stream);
+int pw_class_count(const float* rays, int64_t n, int n_cls, int64_t* counts, void* stream);
+int pw_wrs_weights(const float* rays, int64_t n, int frame_id, const float* balance_weight, int n_cls,
+                   const int32_t* dynamic_class, int n_dyn, float weight_adj, float weight_dyn,
+                   float* weights, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

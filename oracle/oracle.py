@@ -666,6 +666,39 @@ class MetricMIoU:
         return round(float(np.nanmean(iu[:self.num_classes - 1])) * 100, 2), iu
 
 
+# --------------------------------------------------------------------------- ray table + WRS weights
+def pts2ray(coor, label_depth, label_seg, label_img, c2w, K):
+    """mmdet3d/datasets/ray.py:34-55: get_rays(x+0.5, y+0.5, K, c2w, inverse_y=True) + the (n,16) row."""
+    coor, c2w, K = _f32(coor), _f32(c2w), _f32(K)
+    i, j = coor[:, 0] + np.float32(0.5), coor[:, 1] + np.float32(0.5)
+    dirs = np.stack([(i - K[0, 2]) / K[0, 0], (j - K[1, 2]) / K[1, 1], np.ones_like(i)], -1).astype(np.float32)
+    prod = dirs[:, None, :] * c2w[None, :3, :3]
+    rays_d = ((prod[..., 0] + prod[..., 1]) + prod[..., 2]).astype(np.float32)
+    rays_o = np.broadcast_to(c2w[:3, 3], rays_d.shape)
+    sq = rays_d * rays_d
+    nrm = np.sqrt((sq[:, 0] + sq[:, 1]) + sq[:, 2]).astype(np.float32)
+    view = rays_d / nrm[:, None]
+    return np.concatenate([coor, _f32(label_depth)[:, None], _f32(label_seg)[:, None], rays_o, rays_d, view,
+                           _f32(label_img)], axis=1).astype(np.float32)
+
+
+def wrs_weights(rays_list, ids, dynamic_class, balance_weight=None, weight_adj=0.3, weight_dyn=0.0):
+    """ray.py:88-114: (balance_weight, concatenated weights)."""
+    if balance_weight is None:
+        classes = np.concatenate([r[:, 3] for r in rays_list])
+        class_nums = np.array([(classes == c).sum() for c in range(17)], np.float32)
+        with np.errstate(divide='ignore'):
+            balance_weight = np.exp(np.float32(0.005) * (class_nums.max() / class_nums - np.float32(1))).astype(np.float32)
+    out = []
+    for r, fid in zip(rays_list, ids):
+        wt = np.full(r.shape[0], 1.0 if fid == 0 else weight_adj, np.float32)
+        if fid != 0:
+            dyn = np.isin(r[:, 3], np.asarray(dynamic_class, np.float32))
+            wt[dyn] = weight_dyn
+        out.append(_f32(balance_weight)[r[:, 3].astype(np.int64)] * wt)
+    return _f32(balance_weight), np.concatenate(out).astype(np.float32)
+
+
 # --------------------------------------------------------------------------- synthetic rig
 def synthetic_rig(n_cams=6, dx=0.0, dtype=np.float32):
     """SURVEY.md 8d analytic 6-camera rig (nuScenes-like). Returns dict of (1,N,...) arrays."""

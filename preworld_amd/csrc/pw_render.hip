@@ -483,3 +483,91 @@ PW_API int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, 
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Ray table + WRS weights of the pre-train dataloader (mmdet3d/datasets/ray.py:34-119).
+// One thread per labelled pixel; the 64-byte ray row leaves as four float4 stores.
+// (This file is compiled with -ffp-contract=off: products and sums round like the torch ops.)
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_pts2ray(const float* __restrict__ coor, const float* __restrict__ depth, const float* __restrict__ seg,
+          const float* __restrict__ img, const float* __restrict__ c2w, const float* __restrict__ K,
+          int64_t n, float4* __restrict__ rays) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = coor[i * 2], y = coor[i * 2 + 1];
+  const float d0 = ((x + 0.5f) - K[2]) / K[0];
+  const float d1 = ((y + 0.5f) - K[5]) / K[4];
+  const float d2 = 1.f;
+  float rd[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) rd[k] = (d0 * c2w[k * 4 + 0] + d1 * c2w[k * 4 + 1]) + d2 * c2w[k * 4 + 2];
+  const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+  rays[i * 4 + 0] = make_float4(x, y, depth[i], seg[i]);
+  rays[i * 4 + 1] = make_float4(c2w[3], c2w[7], c2w[11], rd[0]);
+  rays[i * 4 + 2] = make_float4(rd[1], rd[2], rd[0] / nrm, rd[1] / nrm);
+  rays[i * 4 + 3] = make_float4(rd[2] / nrm, img[i * 3], img[i * 3 + 1], img[i * 3 + 2]);
+}
+
+__global__ void __launch_bounds__(256)
+k_class_count(const float* __restrict__ rays, int64_t n, int n_cls, unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int local[64];
+  if (threadIdx.x < 64) local[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float c = rays[i * 16 + 3];
+    const int ci = (int)c;
+    if (ci >= 0 && ci < n_cls && (float)ci == c) atomicAdd(&local[ci], 1u);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_cls && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)local[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256)
+k_wrs_weights(const float* __restrict__ rays, int64_t n, int frame_id, const float* __restrict__ bw, int n_cls,
+              const int32_t* __restrict__ dyn, int n_dyn, float w_adj, float w_dyn, float* __restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float c = rays[i * 16 + 3];
+  float wt = 1.f;
+  if (frame_id != 0) {
+    wt = w_adj;
+    for (int k = 0; k < n_dyn; ++k)
+      if ((float)dyn[k] == c) wt = w_dyn;
+  }
+  const int ci = min(max((int)c, 0), n_cls - 1);          // .long() truncation (ray.py:108)
+  w[i] = bw[ci] * wt;
+}
+
+PW_API int pw_pts2ray(const float* coor, const float* depth, const float* seg, const float* img,
+                      const float* c2w, const float* K, int64_t n, float* rays, void* stream) {
+  if (n == 0) return PW_OK;
+  PW_CHECK_ARG(coor && depth && seg && img && c2w && K && rays && n > 0, "pw_pts2ray: bad arguments");
+  PW_CHECK_ARG(((uintptr_t)rays & 15) == 0, "pw_pts2ray: rays must be 16-B aligned");
+  hipLaunchKernelGGL(k_pts2ray, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0, pw_stream(stream), coor, depth,
+                     seg, img, c2w, K, n, (float4*)rays);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_class_count(const float* rays, int64_t n, int n_cls, int64_t* counts, void* stream) {
+  if (n == 0) return PW_OK;
+  PW_CHECK_ARG(rays && counts && n > 0 && n_cls > 0 && n_cls <= 64, "pw_class_count: bad arguments (n_cls <= 64)");
+  int64_t want = pw_cdiv(n, 256);
+  hipLaunchKernelGGL(k_class_count, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, pw_stream(stream),
+                     rays, n, n_cls, (unsigned long long*)counts);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_wrs_weights(const float* rays, int64_t n, int frame_id, const float* balance_weight, int n_cls,
+                          const int32_t* dynamic_class, int n_dyn, float weight_adj, float weight_dyn,
+                          float* weights, void* stream) {
+  if (n == 0) return PW_OK;
+  PW_CHECK_ARG(rays && balance_weight && weights && n > 0 && n_cls > 0 && (n_dyn == 0 || dynamic_class),
+               "pw_wrs_weights: bad arguments");
+  hipLaunchKernelGGL(k_wrs_weights, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0, pw_stream(stream), rays, n,
+                     frame_id, balance_weight, n_cls, dynamic_class, n_dyn, weight_adj, weight_dyn, weights);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

@@ -401,6 +401,39 @@ def softplus(x):
     return y
 
 
+# ------------------------------------------------------------------------------ ray table + WRS weights
+def pts2ray(coor, label_depth, label_seg, label_img, c2w, cam_intrinsic):
+    """mmdet3d/datasets/ray.py:47-55 (one camera): (n,16) rows
+    {x, y, depth, seg, rays_o[3], rays_d[3], viewdirs[3], rgb[3]}."""
+    n = coor.shape[0]
+    rays = torch.empty(n, 16, device=coor.device, dtype=_f32)
+    _lib.call('pw_pts2ray', _chk(coor.float().contiguous(), _f32, 'coor'),
+              _chk(label_depth.float().contiguous(), _f32, 'label_depth'),
+              _chk(label_seg.float().contiguous(), _f32, 'label_seg'),
+              _chk(label_img.float().contiguous(), _f32, 'label_img'),
+              _chk(c2w.float().contiguous(), _f32, 'c2w'), _chk(cam_intrinsic.float().contiguous(), _f32, 'K'),
+              n, _p(rays), _stream())
+    return rays
+
+
+def class_count(rays, n_cls=17, counts=None):
+    if counts is None:
+        counts = torch.zeros(n_cls, device=rays.device, dtype=torch.int64)
+    _lib.call('pw_class_count', _chk(rays, _f32, 'rays'), rays.shape[0], n_cls, _p(counts), _stream())
+    return counts
+
+
+def wrs_weights(rays, frame_id, balance_weight, dynamic_class, weight_adj=0.3, weight_dyn=0.0):
+    """ray.py:99-112 for one camera's rays of frame `frame_id`."""
+    n = rays.shape[0]
+    w = torch.empty(n, device=rays.device, dtype=_f32)
+    dyn = dynamic_class.to(device=rays.device, dtype=_i32).contiguous()
+    _lib.call('pw_wrs_weights', _chk(rays, _f32, 'rays'), n, int(frame_id),
+              _chk(balance_weight.float().contiguous(), _f32, 'balance_weight'), balance_weight.numel(),
+              _p(dyn), dyn.numel(), float(weight_adj), float(weight_dyn), _p(w), _stream())
+    return w
+
+
 # ------------------------------------------------------------------------------ DepthNet tail
 def depthnet_tail(x, D, C):
     """x (BN, >=D+C, H, W) DepthNet output -> (depth (BN,D,H,W) softmaxed over D,

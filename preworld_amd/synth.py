@@ -158,3 +158,20 @@ def rays(seed, R, n_cams=6):
     d = rs.standard_normal((R, 3)).astype(np.float32)
     d[:, 2] *= 0.15
     return o, d
+
+
+def ray_label_inputs(seed, n_cams=4, n_pts=(300, 257, 64, 1)):
+    """Seeded labelled pixels per camera for the ray-table rows (mmdet3d/datasets/ray.py):
+    lists of coor (n,2) pixel xy, depth (n), seg (n) class ids as float, rgb (n,3), c2w (4,4), K (3,3)."""
+    rs = np.random.RandomState(seed)
+    rig = synthetic_rig(6)
+    coors, depths, segs, imgs, c2ws, Ks = [], [], [], [], [], []
+    for c in range(n_cams):
+        n = n_pts[c]
+        coors.append(np.stack([rs.randint(0, 1600, n), rs.randint(0, 900, n)], 1).astype(np.float32))
+        depths.append(rs.uniform(1, 52, n).astype(np.float32))
+        segs.append(rs.randint(0, 17, n).astype(np.float32))
+        imgs.append(rs.standard_normal((n, 3)).astype(np.float32))
+        c2ws.append(rig['sensor2ego'][0, c].astype(np.float32))
+        Ks.append(rig['intrin'][0, c].astype(np.float32))
+    return coors, depths, segs, imgs, c2ws, Ks

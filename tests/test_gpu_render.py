@@ -215,3 +215,30 @@ def test_metric_miou_golden_and_oracle(golden):
     stack = np.stack([pred, gt, gt, pred])
     mt.add_batch(stack, gt, None, None, 4)
     assert mt.metrics[4].count_miou()[3] == 100.0
+
+
+def test_ray_table_and_wrs_weights_gpu(golden):
+    """SURVEY 8f row 3 through the C ABI: (R,16) ray rows and WRS weights vs the reference's outputs
+    (tests/golden/rays_small.npz) and the oracle; the multinomial draw returns distinct indices that
+    follow the weights (zero-weight rays are never drawn)."""
+    from preworld_amd import rays as R
+    g = golden('rays_small.npz')
+    coors, depths, segs, imgs, c2ws, Ks = [[T(a) for a in l] for l in S.ray_label_inputs(int(g['seed']))]
+    time_ids = {0: [0, 1], 1: [2, 3]}
+    dyn = torch.tensor([0, 1, 3, 4, 5, 7, 9, 10])
+    table = R.generate_rays(coors, depths, segs, imgs, c2ws, Ks, time_ids=time_ids, dynamic_class=dyn, use_wrs=False)
+    np.testing.assert_allclose(table.cpu().numpy(), g['table'], rtol=2e-6, atol=1e-6)
+    np.testing.assert_array_equal(table[:, :4].cpu().numpy(), g['table'][:, :4])       # labels copied verbatim
+    rays, w, sel = R.generate_rays(coors, depths, segs, imgs, c2ws, Ks, max_ray_nums=100, time_ids=time_ids,
+                                   dynamic_class=dyn, return_weights=True)
+    np.testing.assert_allclose(w.cpu().numpy(), g['weights_batch'], rtol=1e-5)
+    assert rays.shape == (100, 16) and len(set(sel.cpu().tolist())) == 100
+    assert bool((w[sel] > 0).all())
+    _, w2, _ = R.generate_rays(coors, depths, segs, imgs, c2ws, Ks, max_ray_nums=100, time_ids=time_ids,
+                               dynamic_class=dyn, balance_weight=T(g['balance_weight']), weight_adj=0.25,
+                               weight_dyn=0.1, return_weights=True)
+    np.testing.assert_allclose(w2.cpu().numpy(), g['weights_given'], rtol=1e-6)
+    # empty camera
+    e = ops.pts2ray(T(np.zeros((0, 2), np.float32)), T(np.zeros(0, np.float32)), T(np.zeros(0, np.float32)),
+                    T(np.zeros((0, 3), np.float32)), c2ws[0], Ks[0])
+    assert e.shape == (0, 16)

@@ -191,6 +191,21 @@ def test_traj_branch_small(golden):
     np.testing.assert_allclose(traj, g['traj'], rtol=1e-4, atol=1e-5)
 
 
+def test_ray_table_and_wrs_weights(golden):
+    """oracle restatement of mmdet3d/datasets/ray.py against the reference's outputs."""
+    g = golden('rays_small.npz')
+    coors, depths, segs, imgs, c2ws, Ks = S.ray_label_inputs(int(g['seed']))
+    rays = [O.pts2ray(coors[i], depths[i], segs[i], imgs[i], c2ws[i], Ks[i]) for i in range(4)]
+    table = np.concatenate(rays)
+    assert table.shape == g['table'].shape
+    np.testing.assert_allclose(table, g['table'], rtol=2e-6, atol=1e-6)
+    dyn = [0, 1, 3, 4, 5, 7, 9, 10]
+    _, w = O.wrs_weights(rays, [0, 0, 1, 1], dyn)
+    np.testing.assert_allclose(w, g['weights_batch'], rtol=1e-5)
+    _, w2 = O.wrs_weights(rays, [0, 0, 1, 1], dyn, balance_weight=g['balance_weight'], weight_adj=0.25, weight_dyn=0.1)
+    np.testing.assert_allclose(w2, g['weights_given'], rtol=1e-6)
+
+
 # ----------------------------------------------------------------------------- render
 def test_render_small(golden):
     g = golden('render_small.npz')

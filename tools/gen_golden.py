@@ -433,6 +433,35 @@ def gen_traj(occ):
          identity=identity.numpy(), down=d.numpy(), fused_ego=fused_ego.numpy(), traj=traj.numpy())
 
 
+def gen_rays():
+    """G10: mmdet3d/datasets/ray.py generate_rays -- the table with use_wrs=False
+    and the WRS weights captured from the sampler the reference constructs (ray.py:116)."""
+    ray = load_ref('ref_ray', 'mmdet3d/datasets/ray.py')
+    coors, depths, segs, imgs, c2ws, Ks = [[torch.from_numpy(a) for a in l] for l in S.ray_label_inputs(31)]
+    time_ids = {0: [0, 1], 1: [2, 3]}
+    dyn = torch.tensor([0, 1, 3, 4, 5, 7, 9, 10])
+    table = ray.generate_rays(coors, depths, segs, imgs, c2ws, Ks, max_ray_nums=0, time_ids=time_ids,
+                              dynamic_class=dyn, use_wrs=False)
+    captured = {}
+
+    class Capture:
+        def __init__(self, weights, num_samples, replacement):
+            captured['w'] = weights.clone()
+            self.n = num_samples
+
+        def __iter__(self):
+            return iter(range(self.n))
+    ray.WeightedRandomSampler = Capture
+    ray.generate_rays(coors, depths, segs, imgs, c2ws, Ks, max_ray_nums=100, time_ids=time_ids,
+                      dynamic_class=dyn, balance_weight=None, weight_adj=0.3, weight_dyn=0.0, use_wrs=True)
+    w_batch = captured['w'].numpy()
+    bw = torch.exp(0.005 * (torch.arange(1, 18).float().max() / torch.arange(1, 18).float() - 1))
+    ray.generate_rays(coors, depths, segs, imgs, c2ws, Ks, max_ray_nums=100, time_ids=time_ids,
+                      dynamic_class=dyn, balance_weight=bw, weight_adj=0.25, weight_dyn=0.1, use_wrs=True)
+    save('rays_small.npz', seed=np.int64(31), table=table.numpy(), weights_batch=w_batch,
+         balance_weight=bw.numpy(), weights_given=captured['w'].numpy())
+
+
 def gen_render(nh):
     """G7: NerfHead.sample_ray / render_one_scene / render_* through the reference Python."""
     head = nh.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4,
@@ -513,6 +542,7 @@ def main():
     gen_conv_stack(res, fpn, occ)
     gen_forecast()
     gen_traj(occ)
+    gen_rays()
     gen_render(nh)
     gen_metric(om)
 
