@@ -975,70 +975,143 @@ __global__ void __launch_bounds__(256 * WD, 2) k_occ_head16(ConvArgs a, OccTail 
 }
 
 // ------------------------------------------------------------------------------------
-// generic gather kernel: KS in {1,3}, STRIDE in {1,2}; A fragments straight from global/L2.
+// generic gather kernel: KS in {1,2,3}, STRIDE in {1,2}; A fragments straight from global/L2.
 // One M-tile = 32 consecutive output voxels (linear index) per wave; used for the stride-2
-// convs, the 1x1x1 convs and as the any-shape fallback.
+// convs, the 1x1x1 convs, the 2x2x2 patchify convs (A20) and as the any-shape fallback.
+//
+// Branch-free and software-pipelined: a lane keeps ONE byte offset (its reference input voxel,
+// always inside the volume); the tap displacement and the channel chunk move the scalar buffer
+// base, the per-axis bounds tests are 3 x KS lane masks computed once, and a tap that falls
+// outside the volume swaps the offset for an out-of-range one (the load unit returns 0).  With no
+// branch around the loads, A and weights of tap t+1 are requested before the MFMAs of tap t.
+// (First version: `if (inb)` around the A loads + 64-bit address math per tap: every tap paid an
+// exposed L2 round trip -- 196 us for the 32->128 stride-2 layer.)
 // ------------------------------------------------------------------------------------
-template <int NT, int KS, int STRIDE>
+constexpr unsigned GATHER_OOB = 0xfffffff0u;
+
+template <int KS, int MT>
+struct GatherCtx {
+  const float* xbase;          // a.x (scalar)
+  unsigned voff[MT];           // byte offset of this lane's reference voxel (+ its 64-byte half) per M-tile
+  bool vd[MT][KS], vh[MT][KS], vw[MT][KS];  // per lane: tap plane/row/column inside the volume (lane masks in SGPRs)
+  int H, W, Cin;
+  rsrc_t wr;
+  unsigned lane_off, wstride;
+};
+
+template <int NT, int KS, int MT, int TAP>
+__device__ __forceinline__ void gather_load(const GatherCtx<KS, MT>& c, int ch, unsigned wsoff,
+                                            float4 (&aq)[MT][4], float4 (&bq)[NT][4]) {
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int kd = TAP / (KS * KS), kh = (TAP / KS) % KS, kw = TAP % KS;
+  // scalar: element displacement of this tap relative to the reference tap (PAD,PAD,PAD), plus the chunk
+  const long long delta = ((long long)((kd - PAD) * c.H + (kh - PAD)) * c.W + (kw - PAD)) * c.Cin + ch * KC;
+  const rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.xbase + delta), 0, 0xffffffe0u, 0x00020000);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const unsigned v = (c.vd[mt][kd] && c.vh[mt][kh] && c.vw[mt][kw]) ? c.voff[mt] : GATHER_OOB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aq[mt][q] = buf_load4(xr, v, (unsigned)(q * 16));
+  }
+  load_b<NT>(c.wr, wsoff + (unsigned)TAP * c.wstride, c.lane_off, bq);
+}
+
+template <int NT, int MT>
+__device__ __forceinline__ void gather_mfma(const float4 (&aq)[MT][4], const float4 (&bq)[NT][4], f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float av[4] = {aq[mt][q].x, aq[mt][q].y, aq[mt][q].z, aq[mt][q].w};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float bv[4] = {bq[nt][q].x, bq[nt][q].y, bq[nt][q].z, bq[nt][q].w};
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[mt][nt], 0, 0, 0);
+        }
+      }
+  }
+}
+
+// tap TAP computes from (ac, bc) while (an, bn) receive tap TAP+1 (or tap 0 of the next chunk)
+template <int NT, int KS, int MT, int TAP>
+__device__ __forceinline__ void gather_step(const GatherCtx<KS, MT>& c, int ch, bool more_chunks, unsigned wsoff,
+                                            unsigned wsoff_next, float4 (&ac)[MT][4], float4 (&bc)[NT][4],
+                                            float4 (&an)[MT][4], float4 (&bn)[NT][4], f32x16 (&acc)[MT][NT]) {
+  constexpr int TAPS = KS * KS * KS;
+  if constexpr (TAP + 1 < TAPS) {
+    gather_load<NT, KS, MT, TAP + 1>(c, ch, wsoff, an, bn);
+  } else {
+    if (more_chunks) gather_load<NT, KS, MT, 0>(c, ch + 1, wsoff_next, an, bn);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  gather_mfma<NT, MT>(ac, bc, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TAP + 1 < TAPS)
+    gather_step<NT, KS, MT, TAP + 1>(c, ch, more_chunks, wsoff, wsoff_next, an, bn, ac, bc, acc);
+}
+
+// MT = M-tiles (32 output voxels each) per wave (default 1, see the dispatch)
+template <int NT, int KS, int STRIDE, int MT>
 __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_out_vox) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, i = lane & 31;
-  const long long m0 = ((long long)blockIdx.x * 4 + wave) * 32;
+  const long long m0 = ((long long)blockIdx.x * 4 + wave) * (32 * MT);
   if (m0 >= n_out_vox) return;
   const int ng = blockIdx.y;
   const int ntiles_total = a.cout_total >> 5;
   constexpr int TAPS = KS * KS * KS;
   constexpr int PAD = (KS - 1) / 2;       // k3: 1, k2 (stride-2 patchify, A20): 0, k1: 0
-  long long m = m0 + i;
-  const bool mvalid = m < n_out_vox;
-  if (!mvalid) m = n_out_vox - 1;
-  int ow = (int)(m % a.Wo); long long t = m / a.Wo;
-  int oh = (int)(t % a.Ho); t /= a.Ho;
-  int od = (int)(t % a.Do);
-  int b = (int)(t / a.Do);
 
-  f32x16 acc[NT];
+  GatherCtx<KS, MT> c;
+  c.xbase = a.x; c.H = a.H; c.W = a.W; c.Cin = a.Cin;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int mt = 0; mt < MT; ++mt) {
+    long long m = m0 + mt * 32 + i;
+    const bool mvalid = m < n_out_vox;
+    if (!mvalid) m = n_out_vox - 1;
+    const int ow = (int)(m % a.Wo); long long t = m / a.Wo;
+    const int oh = (int)(t % a.Ho); t /= a.Ho;
+    const int od = (int)(t % a.Do);
+    const int b = (int)(t / a.Do);
+    // reference tap (PAD,PAD,PAD) = input voxel (od*S, oh*S, ow*S): always inside the volume
+    c.voff[mt] = (unsigned)((((((long long)b * a.D + od * STRIDE) * a.H + oh * STRIDE) * a.W + ow * STRIDE) * a.Cin + half * 16) * 4);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-
+    for (int k = 0; k < KS; ++k) {
+      c.vd[mt][k] = mvalid && (unsigned)(od * STRIDE - PAD + k) < (unsigned)a.D;
+      c.vh[mt][k] = (unsigned)(oh * STRIDE - PAD + k) < (unsigned)a.H;
+      c.vw[mt][k] = (unsigned)(ow * STRIDE - PAD + k) < (unsigned)a.W;
+    }
+  }
   const int nchunk = a.Cin / KC;
+  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * TAPS * ntiles_total * 4096));
+  c.lane_off = (unsigned)lane * 64u;
+  c.wstride = (unsigned)ntiles_total * 4096u;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  float4 a0[MT][4], a1[MT][4], b0[NT][4], b1[NT][4];
+  gather_load<NT, KS, MT, 0>(c, 0, (unsigned)((ng * NT) * 4096), a0, b0);
   for (int ch = 0; ch < nchunk; ++ch) {
-    const float* wch = a.wpk + ((size_t)ch * TAPS * ntiles_total + (size_t)ng * NT) * 1024 + lane * 16;
+    const unsigned wsoff = (unsigned)((ch * TAPS * ntiles_total + ng * NT) * 4096);
+    const unsigned wsoff_next = (unsigned)(((ch + 1) * TAPS * ntiles_total + ng * NT) * 4096);
+    gather_step<NT, KS, MT, 0>(c, ch, ch + 1 < nchunk, wsoff, wsoff_next, a0, b0, a1, b1, acc);
+    if constexpr (TAPS & 1) {             // an odd tap count leaves the next chunk's tap 0 in (a1, b1)
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
-      const int id = od * STRIDE - PAD + kd, ih = oh * STRIDE - PAD + kh, iw = ow * STRIDE - PAD + kw;
-      const bool inb = mvalid && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H &&
-                       (unsigned)iw < (unsigned)a.W;
-      float4 aq[4];
-      if (inb) {
-        const float* src = a.x + ((((size_t)b * a.D + id) * a.H + ih) * a.W + iw) * a.Cin + ch * KC + half * 16;
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) aq[q] = *reinterpret_cast<const float4*>(src + q * 4);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) aq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      const float* wt = wch + (size_t)tap * ntiles_total * 1024;
-      float4 bq[NT][4];
+        for (int q = 0; q < 4; ++q) a0[mt][q] = a1[mt][q];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          bq[nt][q] = *reinterpret_cast<const float4*>(wt + nt * 1024 + q * 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float av[4] = {aq[q].x, aq[q].y, aq[q].z, aq[q].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float bv[4] = {bq[nt][q].x, bq[nt][q].y, bq[nt][q].z, bq[nt][q].w};
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[nt], 0, 0, 0);
-          }
-      }
+        for (int q = 0; q < 4; ++q) b0[nt][q] = b1[nt][q];
     }
   }
 #pragma unroll
@@ -1047,11 +1120,13 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
     const float sc = a.scale ? a.scale[n] : 1.f;
     const float bi = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const long long vox = m0 + row;
-      if (vox < n_out_vox) store_out(a, n, (size_t)vox, acc[nt][r] * sc + bi);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const long long vox = m0 + mt * 32 + row;
+        if (vox < n_out_vox) store_out(a, n, (size_t)vox, acc[mt][nt][r] * sc + bi);
+      }
   }
 }
 
@@ -1303,9 +1378,16 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
     else PW_LAUNCH_TILED(1, 1);
 #undef PW_LAUNCH_TILED
   } else {
-    dim3 grid((unsigned)pw_cdiv(n_out, 128), (unsigned)ngroups);
-#define PW_GATHER(NTv, KSv, STv) \
-  hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv>), grid, dim3(256), 0, st, a, n_out)
+    // M-tiles per wave: 2 halves the weight loads per MFMA but measured slower (32->128 stride 2:
+    // 199 us vs 180 us -- fewer waves to hide the L2 gather latency); PW_GATHER_MT=2 selects it
+    const char* mte = getenv("PW_GATHER_MT");
+    const int MT = (mte && atoi(mte) == 2) ? 2 : 1;
+    dim3 grid((unsigned)pw_cdiv(n_out, 128 * MT), (unsigned)ngroups);
+#define PW_GATHER(NTv, KSv, STv)                                                                           \
+  do {                                                                                                     \
+    if (MT == 2) hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 2>), grid, dim3(256), 0, st, a, n_out); \
+    else hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1>), grid, dim3(256), 0, st, a, n_out);         \
+  } while (0)
     if (ksize == 1) {
       if (NT == 2) PW_GATHER(2, 1, 1); else PW_GATHER(1, 1, 1);
     } else if (ksize == 2) {
