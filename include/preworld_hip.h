@@ -133,7 +133,8 @@ int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_
  *   0 = dense (cout0 / cout1); larger when the output is a channel slice of a wider channels-last
  *   buffer (the [adjacent, key] concat of bevdet_occ.py:266 is produced in place this way).
  *   ksize in {1,2,3} (pad = (ksize-1)/2; ksize 2 needs stride 2), stride in {1,2}.
- *   algo: 0 auto, 1 LDS-tiled kernel (k3 s1), 2 gather kernel. */
+ *   algo: 0 auto, 1 LDS-tiled kernel (k3 s1), 2 gather kernel, 3 gather kernel with the input-channel
+ *   chunks split over the 4 waves of a block and summed in LDS in a fixed order (small grids). */
 int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const float* bias,
                     const float* residual, float* y0, float* y1, int B, int D, int H, int W,
                     int Cin, int cout_total, int cout0, int cout1, int ld_y0, int ld_y1, int ksize,

@@ -1235,58 +1235,40 @@ __device__ __forceinline__ void gather_mfma(const float4 (&aq)[MT][4], const flo
 
 // tap TAP computes from (ac, bc) while (an, bn) receive tap TAP+1 (or tap 0 of the next chunk)
 template <int NT, int KS, int MT, int TAP>
-__device__ __forceinline__ void gather_step(const GatherCtx<KS, MT>& c, int ch, bool more_chunks, unsigned wsoff,
+__device__ __forceinline__ void gather_step(const GatherCtx<KS, MT>& c, int ch, int ch_step, bool more_chunks, unsigned wsoff,
                                             unsigned wsoff_next, float4 (&ac)[MT][4], float4 (&bc)[NT][4],
                                             float4 (&an)[MT][4], float4 (&bn)[NT][4], f32x16 (&acc)[MT][NT]) {
   constexpr int TAPS = KS * KS * KS;
   if constexpr (TAP + 1 < TAPS) {
     gather_load<NT, KS, MT, TAP + 1>(c, ch, wsoff, an, bn);
   } else {
-    if (more_chunks) gather_load<NT, KS, MT, 0>(c, ch + 1, wsoff_next, an, bn);
+    if (more_chunks) gather_load<NT, KS, MT, 0>(c, ch + ch_step, wsoff_next, an, bn);
   }
   __builtin_amdgcn_sched_barrier(0);
   gather_mfma<NT, MT>(ac, bc, acc);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (TAP + 1 < TAPS)
-    gather_step<NT, KS, MT, TAP + 1>(c, ch, more_chunks, wsoff, wsoff_next, an, bn, ac, bc, acc);
+    gather_step<NT, KS, MT, TAP + 1>(c, ch, ch_step, more_chunks, wsoff, wsoff_next, an, bn, ac, bc, acc);
 }
 
 // MT = M-tiles (32 output voxels each) per wave (default 1, see the dispatch)
+// ksplit (1, 2 or 4): the block's 4 waves are 4/ksplit M-groups x ksplit partitions of the input-channel
+// chunks (wave w: M-group w / ksplit, chunks w % ksplit, + ksplit, ...).  The partial accumulators
+// meet in LDS and partition 0 adds them in a fixed order (deterministic) before the epilogue.  Small
+// grids need this: with one (M-tile, N-group) per wave the 4x50x50 stage has ~1.2 waves of 1728-3456
+// MFMAs per SIMD, i.e. the slowest SIMD does 2 of them; split by 4 it is ~5 waves of 432.
 template <int NT, int KS, int STRIDE, int MT>
-__global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_out_vox) {
+__global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_out_vox, int ksplit) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, i = lane & 31;
-  const long long m0 = ((long long)blockIdx.x * 4 + wave) * (32 * MT);
-  if (m0 >= n_out_vox) return;
+  const int mslot = wave / ksplit, kpart = wave - mslot * ksplit;
+  const long long m0 = ((long long)blockIdx.x * (4 / ksplit) + mslot) * (32 * MT);
+  const bool active = m0 < n_out_vox;                 // wave-uniform; inactive waves still meet the barriers
   const int ng = blockIdx.y;
   const int ntiles_total = a.cout_total >> 5;
   constexpr int TAPS = KS * KS * KS;
   constexpr int PAD = (KS - 1) / 2;       // k3: 1, k2 (stride-2 patchify, A20): 0, k1: 0
-
-  GatherCtx<KS, MT> c;
-  c.xbase = a.x; c.H = a.H; c.W = a.W; c.Cin = a.Cin;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    long long m = m0 + mt * 32 + i;
-    const bool mvalid = m < n_out_vox;
-    if (!mvalid) m = n_out_vox - 1;
-    const int ow = (int)(m % a.Wo); long long t = m / a.Wo;
-    const int oh = (int)(t % a.Ho); t /= a.Ho;
-    const int od = (int)(t % a.Do);
-    const int b = (int)(t / a.Do);
-    // reference tap (PAD,PAD,PAD) = input voxel (od*S, oh*S, ow*S): always inside the volume
-    c.voff[mt] = (unsigned)((((((long long)b * a.D + od * STRIDE) * a.H + oh * STRIDE) * a.W + ow * STRIDE) * a.Cin + half * 16) * 4);
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      c.vd[mt][k] = mvalid && (unsigned)(od * STRIDE - PAD + k) < (unsigned)a.D;
-      c.vh[mt][k] = (unsigned)(oh * STRIDE - PAD + k) < (unsigned)a.H;
-      c.vw[mt][k] = (unsigned)(ow * STRIDE - PAD + k) < (unsigned)a.W;
-    }
-  }
-  const int nchunk = a.Cin / KC;
-  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * TAPS * ntiles_total * 4096));
-  c.lane_off = (unsigned)lane * 64u;
-  c.wstride = (unsigned)ntiles_total * 4096u;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -1296,23 +1278,75 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  float4 a0[MT][4], a1[MT][4], b0[NT][4], b1[NT][4];
-  gather_load<NT, KS, MT, 0>(c, 0, (unsigned)((ng * NT) * 4096), a0, b0);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const unsigned wsoff = (unsigned)((ch * TAPS * ntiles_total + ng * NT) * 4096);
-    const unsigned wsoff_next = (unsigned)(((ch + 1) * TAPS * ntiles_total + ng * NT) * 4096);
-    gather_step<NT, KS, MT, 0>(c, ch, ch + 1 < nchunk, wsoff, wsoff_next, a0, b0, a1, b1, acc);
-    if constexpr (TAPS & 1) {             // an odd tap count leaves the next chunk's tap 0 in (a1, b1)
+  if (active) {
+    GatherCtx<KS, MT> c;
+    c.xbase = a.x; c.H = a.H; c.W = a.W; c.Cin = a.Cin;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      long long m = m0 + mt * 32 + i;
+      const bool mvalid = m < n_out_vox;
+      if (!mvalid) m = n_out_vox - 1;
+      const int ow = (int)(m % a.Wo); long long t = m / a.Wo;
+      const int oh = (int)(t % a.Ho); t /= a.Ho;
+      const int od = (int)(t % a.Do);
+      const int b = (int)(t / a.Do);
+      // reference tap (PAD,PAD,PAD) = input voxel (od*S, oh*S, ow*S): always inside the volume
+      c.voff[mt] = (unsigned)((((((long long)b * a.D + od * STRIDE) * a.H + oh * STRIDE) * a.W + ow * STRIDE) * a.Cin + half * 16) * 4);
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        c.vd[mt][k] = mvalid && (unsigned)(od * STRIDE - PAD + k) < (unsigned)a.D;
+        c.vh[mt][k] = (unsigned)(oh * STRIDE - PAD + k) < (unsigned)a.H;
+        c.vw[mt][k] = (unsigned)(ow * STRIDE - PAD + k) < (unsigned)a.W;
+      }
+    }
+    const int nchunk = a.Cin / KC;
+    c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * TAPS * ntiles_total * 4096));
+    c.lane_off = (unsigned)lane * 64u;
+    c.wstride = (unsigned)ntiles_total * 4096u;
+
+    float4 a0[MT][4], a1[MT][4], b0[NT][4], b1[NT][4];
+    if (kpart < nchunk)
+      gather_load<NT, KS, MT, 0>(c, kpart, (unsigned)((kpart * TAPS * ntiles_total + ng * NT) * 4096), a0, b0);
+    for (int ch = kpart; ch < nchunk; ch += ksplit) {
+      const unsigned wsoff = (unsigned)((ch * TAPS * ntiles_total + ng * NT) * 4096);
+      const unsigned wsoff_next = (unsigned)(((ch + ksplit) * TAPS * ntiles_total + ng * NT) * 4096);
+      gather_step<NT, KS, MT, 0>(c, ch, ksplit, ch + ksplit < nchunk, wsoff, wsoff_next, a0, b0, a1, b1, acc);
+      if constexpr (TAPS & 1) {             // an odd tap count leaves the next chunk's tap 0 in (a1, b1)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a0[mt][q] = a1[mt][q];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) b0[nt][q] = b1[nt][q];
+      }
+    }
+  }
+  if (ksplit > 1) {
+    // partial sums of partitions 1.. -> LDS [slot][mt][nt][r][lane]; partition 0 adds them in order
+    if (kpart > 0) {
+      float* dst = red + (size_t)((mslot * (ksplit - 1) + (kpart - 1)) * MT * NT) * 1024 + lane;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a0[mt][q] = a1[mt][q];
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+          for (int r = 0; r < 16; ++r) dst[((mt * NT + nt) * 16 + r) * 64] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (kpart > 0) return;
+    for (int pp = 1; pp < ksplit; ++pp) {
+      const float* src = red + (size_t)((mslot * (ksplit - 1) + (pp - 1)) * MT * NT) * 1024 + lane;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b0[nt][q] = b1[nt][q];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] += src[((mt * NT + nt) * 16 + r) * 64];
     }
   }
+  if (!active) return;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (ng * NT + nt) * 32 + i;
@@ -1535,10 +1569,20 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
     long long nblk2 = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w * (ntiles / 2);
     if (nblk2 < 512) NT = 1;
   }
+  if (const char* e = getenv("PW_CONV_NT")) {          // experiments only
+    const int f = atoi(e);
+    if ((f == 1 || f == 2) && ntiles % f == 0) NT = f;
+  }
   const int ngroups = ntiles / NT;
   const long long n_out = (long long)B * a.Do * a.Ho * a.Wo;
-  // algo: 0 = auto, 1 = force LDS-tiled (k3 s1 only), 2 = force gather
-  const bool tiled = (ksize == 3 && stride == 1 && algo != 2);
+  // algo: 0 = auto, 1 = force LDS-tiled (k3 s1 only), 2 = force gather, 3 = gather with the input
+  // channels split over the 4 waves of a block (small grids, see k_conv3d_gather)
+  // auto: a grid with fewer (tile, N-group) items than CUs and >= 4 input chunks (the 4x50x50 128->128
+  // stage: 196 items) runs ~5 % faster on the channel-split gather kernel (106 vs 112 us)
+  if (algo == 0 && ksize == 3 && stride == 1 && NT == 1 && (Cin / KC) % 4 == 0 &&
+      (long long)B * a.tiles_d * a.tiles_h * a.tiles_w * ngroups < pw_num_cus())
+    algo = 3;
+  const bool tiled = (ksize == 3 && stride == 1 && algo != 2 && algo != 3);
   PW_CHECK_ARG(!(algo == 1 && !tiled), "pw_conv3d_ndhwc: algo=1 needs ksize 3 stride 1");
   a.probe = nullptr;
   if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
@@ -1581,11 +1625,20 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
     // 199 us vs 180 us -- fewer waves to hide the L2 gather latency); PW_GATHER_MT=2 selects it
     const char* mte = getenv("PW_GATHER_MT");
     const int MT = (mte && atoi(mte) == 2) ? 2 : 1;
-    dim3 grid((unsigned)pw_cdiv(n_out, 128 * MT), (unsigned)ngroups);
-#define PW_GATHER(NTv, KSv, STv)                                                                           \
-  do {                                                                                                     \
-    if (MT == 2) hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 2>), grid, dim3(256), 0, st, a, n_out); \
-    else hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1>), grid, dim3(256), 0, st, a, n_out);         \
+    const int nchunk = Cin / KC;
+    int ksplit = 1;
+    if (algo == 3) ksplit = (nchunk % 4 == 0) ? 4 : (nchunk % 2 == 0 ? 2 : 1);
+    if (const char* e = getenv("PW_GATHER_KSPLIT")) {
+      const int f = atoi(e);
+      if ((f == 1 || f == 2 || f == 4) && nchunk % f == 0) ksplit = f;
+    }
+    const int mgroups = 4 / ksplit;                     // M-groups (32*MT voxels each) per block
+    dim3 grid((unsigned)pw_cdiv(n_out, 32 * MT * mgroups), (unsigned)ngroups);
+    const size_t red_bytes = ksplit > 1 ? (size_t)mgroups * (ksplit - 1) * MT * NT * 4096 : 0;
+#define PW_GATHER(NTv, KSv, STv)                                                                                   \
+  do {                                                                                                             \
+    if (MT == 2) hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 2>), grid, dim3(256), red_bytes, st, a, n_out, ksplit); \
+    else hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1>), grid, dim3(256), red_bytes, st, a, n_out, ksplit);         \
   } while (0)
     if (ksize == 1) {
       if (NT == 2) PW_GATHER(2, 1, 1); else PW_GATHER(1, 1, 1);

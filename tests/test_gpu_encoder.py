@@ -119,6 +119,24 @@ def test_conv3d_outputs_into_channel_slices(shape):
         ops.conv3d_ndhwc(x, wp1, residual=res, ksize=3, out0=buf2[..., 32:64])      # residual stride != y0 stride
 
 
+@pytest.mark.parametrize('shape', [(1, 4, 50, 50, 128, 128, 1), (2, 3, 7, 9, 64, 32, 1), (1, 8, 20, 22, 64, 96, 2),
+                                   (1, 5, 6, 7, 32, 32, 1)])
+def test_conv3d_channel_split_gather(shape):
+    """algo=3: input-channel chunks split over the waves of a block, partial sums reduced in LDS in
+    a fixed order -- equal to the plain gather kernel up to fp32 summation order, and deterministic."""
+    B, D, H, W, ci, co, st = shape
+    rs = np.random.RandomState(4)
+    x = T(rs.standard_normal((B, D, H, W, ci)).astype(np.float32))
+    wpk = ops.pack_conv_weight(torch.from_numpy(rs.standard_normal((co, ci, 3, 3, 3)).astype(np.float32) * 0.05).to(DEV))
+    sc = T(rs.uniform(0.5, 1.5, wpk.shape[2] * 32).astype(np.float32))
+    bi = T(rs.standard_normal(wpk.shape[2] * 32).astype(np.float32))
+    ref = ops.conv3d_ndhwc(x, wpk, sc, bi, cout0=co, ksize=3, stride=st, relu0=True, algo=2)
+    y1 = ops.conv3d_ndhwc(x, wpk, sc, bi, cout0=co, ksize=3, stride=st, relu0=True, algo=3)
+    y2 = ops.conv3d_ndhwc(x, wpk, sc, bi, cout0=co, ksize=3, stride=st, relu0=True, algo=3)
+    np.testing.assert_allclose(y1.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(y1.cpu().numpy(), y2.cpu().numpy())
+
+
 def test_conv3d_bad_arguments_raise():
     x = torch.zeros(1, 4, 8, 8, 24, device=DEV)
     with pytest.raises(Exception):

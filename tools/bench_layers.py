@@ -26,7 +26,7 @@ for (D, H, W, ci, co, ks, st) in SHAPES:
         continue
     x = torch.randn(1, D, H, W, ci, device=dev)
     w = ops.pack_conv_weight(torch.randn(co, ci, ks, ks, ks, device=dev) * 0.05)
-    fn = lambda: ops.conv3d_ndhwc(x, w, ksize=ks, stride=st)
+    fn = lambda: ops.conv3d_ndhwc(x, w, ksize=ks, stride=st, algo=int(os.environ.get('ALGO', 0)))
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
