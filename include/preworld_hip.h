@@ -282,6 +282,39 @@ int pw_wrs_weights(const float* rays, int64_t n, int frame_id, const float* bala
                    const int32_t* dynamic_class, int n_dyn, float weight_adj, float weight_dyn,
                    float* weights, void* stream);
 
+/* voxel-grid training losses of mmdet3d/models/detectors/loss.py -- CE_ssc_loss
+ * (:20-29, class-weighted cross entropy, ignore_index), sem_scal_loss (:32-80) and geo_scal_loss
+ * (:83-113) as used by loss_voxel (preworld_temporal_traj.py:176-199) -- forward statistics in one
+ * pass over the logits and the gradient w.r.t. the logits in a second pass.
+ *   logits   float, element (b, c, x, y, z) at b*sb + c*sc + x*sx + y*sy + z*sz (any layout: the
+ *            reference's (B,C,X,Y,Z) tensor or a channels-last buffer viewed that way)
+ *   target   uint8[B][X][Y][Z] (255 = ignore), cam_mask uint8[B][X][Y][Z] or NULL
+ *   n_cls <= 32 classes, class_weights float[n_cls] (CE), empty_idx = geo_scal's non_empty_idx
+ * pw_voxel_loss_stats ACCUMULATES into stats (double[PW_VOXEL_LOSS_NSTATS], zero it first):
+ *   [0] sum_{t!=ignore} w_t * (-log p_t)   [1] sum_{t!=ignore} w_t
+ *   [2] N = #(t != ignore & cam)           [3+i] S_p[i] = sum_M p_i   [35+i] S_t[i] = #_M (t == i)
+ *   [67+i] S_pt[i] = sum_M p_i [t == i]    (M = the N voxels)
+ *   [99] I = sum nt*(1-p_e)  [100] sum (1-p_e)  [101] sum nt  [102] sum (1-nt)*p_e  [103] sum (1-nt)
+ *        with nt = (t != empty_idx) & cam over ALL voxels (geo_scal_loss :93-110)
+ * pw_voxel_loss_grad: grad_logits (same strides as logits) = d(loss)/d(logits) where
+ *   d(loss)/d(p_i(v)) = [v in M] * (ga[i] + gb[i]*[t(v) == i]) + [i == empty_idx] * (gc0 + gc1*nt(v)),
+ *   plus the cross-entropy part ce_scale * w_t * (p - onehot(t)) for t != ignore; the softmax Jacobian
+ *   is applied in the kernel.  coef = float[2*32 + 3] = {ga[32], gb[32], gc0, gc1, ce_scale} (device).
+ * pw_voxel_loss_finish: losses float[3] = {CE, sem_scal, geo_scal} from the sums (loss.py:58-80,104-113).
+ * pw_voxel_loss_coef: coef for pw_voxel_loss_grad from the sums and the upstream gradients
+ *   grad_losses float[3] (device) of the three losses. */
+#define PW_VOXEL_LOSS_NSTATS 104
+int pw_voxel_loss_stats(const float* logits, const uint8_t* target, const uint8_t* cam_mask,
+                        const float* class_weights, int B, int n_cls, int X, int Y, int Z, int64_t sb,
+                        int64_t sc, int64_t sx, int64_t sy, int64_t sz, int ignore_index, int empty_idx,
+                        double* stats, void* stream);
+int pw_voxel_loss_grad(const float* logits, const uint8_t* target, const uint8_t* cam_mask,
+                       const float* class_weights, const float* coef, int B, int n_cls, int X, int Y,
+                       int Z, int64_t sb, int64_t sc, int64_t sx, int64_t sy, int64_t sz,
+                       int ignore_index, int empty_idx, float* grad_logits, void* stream);
+int pw_voxel_loss_finish(const double* stats, int n_cls, float* losses, void* stream);
+int pw_voxel_loss_coef(const double* stats, int n_cls, const float* grad_losses, float* coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -666,6 +666,52 @@ class MetricMIoU:
         return round(float(np.nanmean(iu[:self.num_classes - 1])) * 100, 2), iu
 
 
+# --------------------------------------------------------------------------- voxel-grid training losses
+def _bce1(x):
+    with np.errstate(divide='ignore'):
+        return -np.maximum(np.log(np.float64(x)), -100.0)
+
+
+def voxel_losses(pred, target, class_weights=None, ignore_index=255, empty_idx=17, camera_mask=None):
+    """mmdet3d/models/detectors/loss.py:20-113 restated (CE_ssc_loss, sem_scal_loss, geo_scal_loss);
+    pred (B,C,X,Y,Z) logits, target (B,X,Y,Z) ints.  Sums in float64 (the reference sums fp32 tensors;
+    the difference is inside the stated tolerance)."""
+    z = np.asarray(pred, np.float64)
+    B, C = z.shape[:2]
+    m = z.max(axis=1, keepdims=True)
+    e = np.exp(z - m)
+    p = e / e.sum(axis=1, keepdims=True)
+    t = np.asarray(target).astype(np.int64)
+    cam = np.ones_like(t, bool) if camera_mask is None else np.asarray(camera_mask).astype(bool)
+    w = np.ones(C) if class_weights is None else np.asarray(class_weights, np.float64)
+    valid = t != ignore_index
+    logp = np.log(p)
+    tt = np.where(valid, t, 0)
+    lp_t = np.take_along_axis(logp, tt[:, None], axis=1)[:, 0]
+    ce = (w[tt] * -lp_t)[valid].sum() / w[tt][valid].sum()
+    M = valid & cam
+    loss, count = 0.0, 0
+    for i in range(C):
+        pi = p[:, i][M]
+        ct = (t[M] == i).astype(np.float64)
+        if ct.sum() > 0:
+            count += 1
+            nom = (pi * ct).sum()
+            lc = 0.0
+            if pi.sum() > 0:
+                lc += _bce1(nom / pi.sum())
+            lc += _bce1(nom / ct.sum())
+            if (1 - ct).sum() > 0:
+                lc += _bce1(((1 - pi) * (1 - ct)).sum() / (1 - ct).sum())
+            loss += lc
+    sem = loss / count
+    pe = p[:, empty_idx]
+    nt = ((t != empty_idx) & cam).astype(np.float64)
+    inter = (nt * (1 - pe)).sum()
+    geo = _bce1(inter / (1 - pe).sum()) + _bce1(inter / nt.sum()) + _bce1(((1 - nt) * pe).sum() / (1 - nt).sum())
+    return float(ce), float(sem), float(geo)
+
+
 # --------------------------------------------------------------------------- ray table + WRS weights
 def pts2ray(coor, label_depth, label_seg, label_img, c2w, K):
     """mmdet3d/datasets/ray.py:34-55: get_rays(x+0.5, y+0.5, K, c2w, inverse_y=True) + the (n,16) row."""

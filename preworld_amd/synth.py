@@ -175,3 +175,14 @@ def ray_label_inputs(seed, n_cams=4, n_pts=(300, 257, 64, 1)):
         c2ws.append(rig['sensor2ego'][0, c].astype(np.float32))
         Ks.append(rig['intrin'][0, c].astype(np.float32))
     return coors, depths, segs, imgs, c2ws, Ks
+
+
+def voxel_loss_inputs(seed, shape=(2, 18, 10, 12, 6)):
+    rs = np.random.RandomState(seed)
+    B, C, X, Y, Z = shape
+    pred = (rs.standard_normal(shape) * 2).astype(np.float32)
+    target = rs.randint(0, 18, (B, X, Y, Z)).astype(np.int64)
+    target[rs.rand(B, X, Y, Z) < 0.1] = 255
+    target[rs.rand(B, X, Y, Z) < 0.4] = 17
+    cam = rs.rand(B, X, Y, Z) < 0.8
+    return pred, target, cam

@@ -206,6 +206,17 @@ def test_ray_table_and_wrs_weights(golden):
     np.testing.assert_allclose(w2, g['weights_given'], rtol=1e-6)
 
 
+def test_voxel_losses(golden):
+    """oracle restatement of loss.py (CE / sem_scal / geo_scal) vs the reference's values."""
+    g = golden('voxel_losses.npz')
+    pred, target, cam = S.voxel_loss_inputs(int(g['seed']))
+    for tag, cm in (('cam', cam), ('nocam', None)):
+        ce, sem, geo = O.voxel_losses(pred, target, g['class_weights'], 255, 17, cm)
+        np.testing.assert_allclose(ce, float(g['ce_' + tag]), rtol=2e-5)
+        np.testing.assert_allclose(sem, float(g['sem_' + tag]), rtol=2e-5)
+        np.testing.assert_allclose(geo, float(g['geo_' + tag]), rtol=2e-5)
+
+
 # ----------------------------------------------------------------------------- render
 def test_render_small(golden):
     g = golden('render_small.npz')

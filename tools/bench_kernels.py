@@ -159,6 +159,34 @@ def bench_render():
     return res
 
 
+def bench_loss():
+    """CE + sem_scal + geo_scal forward (one pass) and backward (one pass) on
+    (1,18,200,200,16) logits; algorithmic HBM bytes = logits read (46 MB) [+ gradient written]."""
+    from preworld_amd import losses as L
+    dev = 'cuda:0'
+    res = {}
+    pred = torch.randn(1, 18, 200, 200, 16, device=dev, requires_grad=True)
+    target = torch.randint(0, 18, (1, 200, 200, 16), device=dev)
+    cam = torch.rand(1, 200, 200, 16, device=dev) < 0.8
+    cw = torch.rand(18, device=dev) + 0.1
+
+    def fwd():
+        return L.voxel_losses(pred, target, cw, 255, 17, cam)
+
+    def fwd_bwd():
+        pred.grad = None
+        ce, sem, geo = fwd()
+        (ce + sem + geo).backward()
+    with torch.no_grad():
+        t = timeit(fwd, iters=10)
+    res['loss_fwd_us'] = t
+    res['loss_fwd_GBps'] = (pred.numel() * 4 + 2 * 640000) / t / 1e3
+    t2 = timeit(fwd_bwd, iters=10)
+    res['loss_fwd_bwd_us'] = t2
+    res['loss_bwd_GBps'] = (2 * pred.numel() * 4 + 2 * 640000) / max(t2 - t, 1e-3) / 1e3
+    return res
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--what', default='lss')
@@ -170,4 +198,6 @@ if __name__ == '__main__':
         out['enc'] = bench_enc()
     if 'render' in a.what:
         out['render'] = bench_render()
+    if 'loss' in a.what:
+        out['loss'] = bench_loss()
     print(json.dumps(out, indent=1))

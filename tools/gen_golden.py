@@ -462,6 +462,28 @@ def gen_rays():
          balance_weight=bw.numpy(), weights_given=captured['w'].numpy())
 
 
+def gen_losses():
+    """G11: mmdet3d/models/detectors/loss.py CE_ssc_loss / sem_scal_loss /
+    geo_scal_loss values and their autograd gradients w.r.t. the logits."""
+    ls = load_ref('ref_loss', 'mmdet3d/models/detectors/loss.py')
+    pred_np, target_np, cam_np = S.voxel_loss_inputs(41)
+    cw = torch.cat([torch.from_numpy(1 / np.log(np.array([1163161, 2309034, 188743, 2997643, 20317180, 852476,
+                    243808, 2457947, 497017, 2731022, 7224789, 214411435, 5565043, 63191967, 76098082,
+                    128860031, 141625221], np.float64) + 0.001)).float(), torch.tensor([0.])])
+    out = {}
+    for tag, cam in (('cam', torch.from_numpy(cam_np)), ('nocam', None)):
+        pred = torch.from_numpy(pred_np).clone().requires_grad_()
+        target = torch.from_numpy(target_np)
+        ce = ls.CE_ssc_loss(pred, target, cw, 255)
+        sem = ls.sem_scal_loss(pred, target, 255, camera_mask=cam)
+        geo = ls.geo_scal_loss(pred, target, 255, non_empty_idx=17, camera_mask=cam)
+        total = 1.0 * ce + 0.7 * sem + 1.3 * geo
+        total.backward()
+        out['ce_' + tag], out['sem_' + tag], out['geo_' + tag] = ce.item(), sem.item(), geo.item()
+        out['grad_' + tag] = pred.grad.numpy().copy()
+    save('voxel_losses.npz', seed=np.int64(41), class_weights=cw.numpy(), **{k: np.asarray(v) for k, v in out.items()})
+
+
 def gen_render(nh):
     """G7: NerfHead.sample_ray / render_one_scene / render_* through the reference Python."""
     head = nh.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4,
@@ -543,6 +565,7 @@ def main():
     gen_forecast()
     gen_traj(occ)
     gen_rays()
+    gen_losses()
     gen_render(nh)
     gen_metric(om)
 
