@@ -264,6 +264,22 @@ int pw_linear_act(const float* x, const float* w, const float* b, float* y, int 
 int pw_depthnet_tail(const float* x, int BN, int x_channels, int D, int C, int HW, float* depth,
                      float* feat_cl, void* stream);
 
+/* SURVEY 8f row 1 (second half): the DepthNet's stereo cost volume,
+ * mmdet3d/models/necks/view_transformer.py:546-604 (gen_grid + calculate_cost_volumn), one kernel.
+ *   prev, curr  stereo features of the previous / current frame, element (bn, c, y, x) at
+ *               bn*s_bn + c*s_c + y*s_y + x*s_x (NCHW or channels_last storage; channels_last is the
+ *               fast path), C % 4 == 0 channels, H x W = the cv_frustum's height x width
+ *   ds[D], xs[W], ys[H]  the separable cv_frustum (depth bins; pixel coordinates in the wi x hi input image)
+ *   inv_post_rot, combine (= k2s_sensor[:3,:3] @ inv(intrins)), trans (= k2s_sensor[:3,3]): from
+ *               pw_lss_camera_matrices(k2s_sensor, intrins, post_rots); post_trans [BN][3], intrins, post_rots [BN][9]
+ *   out         float[BN][D][H][W] = softmax_D( -(sum_c |curr - warp(prev)| + bias * [warp outside]) ) */
+int pw_stereo_cost_volume(const float* prev, const float* curr, int BN, int C, int H, int W,
+                          int64_t s_bn, int64_t s_c, int64_t s_y, int64_t s_x, const float* ds, int D,
+                          const float* xs, const float* ys, const float* inv_post_rot,
+                          const float* post_trans, const float* combine, const float* trans,
+                          const float* intrins, const float* post_rots, float wi, float hi, float bias,
+                          float* out, void* stream);
+
 /* ray table + weighted-ray-sampling weights of the pre-train dataloader
  * (mmdet3d/datasets/ray.py:34-119), on the GPU.
  * pw_pts2ray (ray.py:34-55, one camera): for pixel p = coor[i] (x, y):

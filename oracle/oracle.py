@@ -666,6 +666,70 @@ class MetricMIoU:
         return round(float(np.nanmean(iu[:self.num_classes - 1])) * 100, 2), iu
 
 
+# --------------------------------------------------------------------------- stereo cost volume
+def stereo_cost_volume(prev, curr, frustum, k2s_sensor, intrins, post_rots, post_trans, bias=0.0):
+    """mmdet3d/models/necks/view_transformer.py:546-604 restated in numpy (float32 steps).
+    prev/curr (BN,C,H,W); frustum (D,H,W,3); k2s (B,N,4,4); intrins/post_rots (B,N,3,3); post_trans (B,N,3)."""
+    f32 = np.float32
+    prev, curr = _f32(prev), _f32(curr)
+    BN, C, H, W = curr.shape
+    D = frustum.shape[0]
+    hi, wi = H * 4, W * 4
+    k2s = _f32(k2s_sensor).reshape(BN, 4, 4)
+    K = _f32(intrins).reshape(BN, 3, 3)
+    pr = _f32(post_rots).reshape(BN, 3, 3)
+    pt = _f32(post_trans).reshape(BN, 3)
+    ipr, comb, tr = camera_matrices(k2s[None], K[None], pr[None])
+    ipr, comb, tr = ipr.reshape(BN, 3, 3), comb.reshape(BN, 3, 3), tr.reshape(BN, 3)
+    out = np.empty((BN, D, H, W), f32)
+
+    def mv(m, v):                                  # (3,3) x (...,3), left-to-right fp32 sums
+        return np.stack([(m[r, 0] * v[..., 0] + m[r, 1] * v[..., 1]) + m[r, 2] * v[..., 2] for r in range(3)], -1).astype(f32)
+    for bn in range(BN):
+        p = (_f32(frustum) - pt[bn]).astype(f32)
+        q = mv(ipr[bn], p)
+        r = np.stack([q[..., 0] * q[..., 2], q[..., 1] * q[..., 2], q[..., 2]], -1).astype(f32)
+        q = (mv(comb[bn], r) + tr[bn]).astype(f32)
+        neg = q[..., 2] < f32(1e-3)
+        r = mv(K[bn], q)
+        u, v = r[..., 0] / r[..., 2], r[..., 1] / r[..., 2]
+        x = ((pr[bn, 0, 0] * u + pr[bn, 0, 1] * v) + pt[bn, 0]).astype(f32)
+        y = ((pr[bn, 1, 0] * u + pr[bn, 1, 1] * v) + pt[bn, 1]).astype(f32)
+        px = (x / f32(wi - 1.0) * f32(2.0) - f32(1.0)).astype(f32)
+        py = (y / f32(hi - 1.0) * f32(2.0) - f32(1.0)).astype(f32)
+        px[neg] = -2
+        py[neg] = -2
+        ix = ((px + f32(1)) / f32(2) * f32(W - 1)).astype(f32)
+        iy = ((py + f32(1)) / f32(2) * f32(H - 1)).astype(f32)
+        x0, y0 = np.floor(ix), np.floor(iy)
+        tx1, tx0 = ix - x0, (x0 + 1) - ix
+        ty1, ty0 = iy - y0, (y0 + 1) - iy
+        x0i = np.clip(x0, -2, W).astype(np.int64)
+        y0i = np.clip(y0, -2, H).astype(np.int64)
+        cost = np.zeros((D, H, W), f32)
+        last0 = None
+        for c0 in range(0, C, 4):
+            grp = np.zeros((D, H, W), f32)
+            for k in range(4):
+                img = prev[bn, c0 + k]
+                acc = np.zeros((D, H, W), f32)
+                for (dx, dy, wgt) in ((0, 0, tx0 * ty0), (1, 0, tx1 * ty0), (0, 1, tx0 * ty1), (1, 1, tx1 * ty1)):
+                    xi, yi = x0i + dx, y0i + dy
+                    ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+                    val = img[np.clip(yi, 0, H - 1), np.clip(xi, 0, W - 1)]
+                    acc = np.where(ok, acc + val * wgt.astype(f32), acc).astype(f32)
+                if k == 0:
+                    last0 = acc
+                grp = (grp + np.abs(curr[bn, c0 + k][None] - acc)).astype(f32)
+            cost = (cost + grp).astype(f32)
+        if bias != 0:
+            cost = np.where(last0 == 0, cost + f32(bias), cost).astype(f32)
+        z = -cost
+        e = np.exp(z - z.max(axis=0, keepdims=True), dtype=f32)
+        out[bn] = e / e.sum(axis=0, keepdims=True)
+    return out
+
+
 # --------------------------------------------------------------------------- voxel-grid training losses
 def _bce1(x):
     with np.errstate(divide='ignore'):

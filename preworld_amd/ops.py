@@ -445,6 +445,30 @@ def depthnet_tail(x, D, C):
     return depth, feat
 
 
+def stereo_cost_volume(prev, curr, frustum, k2s_sensor, intrins, post_rots, post_trans, bias=0.0):
+    """DepthNet.calculate_cost_volumn (view_transformer.py:546-604).  prev/curr (B*N, C, H, W) stereo
+    features (any strides; torch.channels_last storage is the fast path), frustum (D,H,W,3) the
+    cv_frustum, k2s_sensor (B,N,4,4), intrins/post_rots (B,N,3,3), post_trans (B,N,3).
+    Returns the softmaxed cost volume (B*N, D, H, W)."""
+    BN, C, H, W = curr.shape
+    D = frustum.shape[0]
+    if tuple(frustum.shape[1:3]) != (H, W) or tuple(prev.shape) != tuple(curr.shape) or prev.stride() != curr.stride():
+        raise _lib.PreworldHipError('stereo_cost_volume: prev/curr/frustum shapes or strides disagree')
+    dev = curr.device
+    ds = frustum[:, 0, 0, 2].contiguous().float()
+    xs = frustum[0, 0, :, 0].contiguous().float()
+    ys = frustum[0, :, 0, 1].contiguous().float()
+    ipr, comb, tr = lss_camera_matrices(k2s_sensor, intrins, post_rots)
+    out = torch.empty(BN, D, H, W, device=dev, dtype=_f32)
+    sbn, sc, sy, sx = curr.stride()
+    _lib.call('pw_stereo_cost_volume', _p(prev), _p(curr), BN, C, H, W, sbn, sc, sy, sx, _p(ds), D, _p(xs), _p(ys),
+              _p(ipr), _chk(post_trans.reshape(BN, 3).float().contiguous(), _f32, 'post_trans'), _p(comb), _p(tr),
+              _chk(intrins.reshape(BN, 9).float().contiguous(), _f32, 'intrins'),
+              _chk(post_rots.reshape(BN, 9).float().contiguous(), _f32, 'post_rots'),
+              float(4 * W), float(4 * H), float(bias), _p(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------ A20 trajectory branch
 def global_avgpool_ndhwc(x):
     """x (B, ..., C) channels-last -> (B, C): nn.AdaptiveAvgPool3d((1,1,1)) of

@@ -186,3 +186,29 @@ def voxel_loss_inputs(seed, shape=(2, 18, 10, 12, 6)):
     target[rs.rand(B, X, Y, Z) < 0.4] = 17
     cam = rs.rand(B, X, Y, Z) < 0.8
     return pred, target, cam
+
+
+def stereo_inputs(seed, C=8, H=6, W=11, D=12, n_cams=2):
+    """Seeded inputs of the DepthNet cost volume (view_transformer.py:546-604) at a reduced size:
+    prev/curr stereo features (n_cams, C, H, W); a pinhole camera sized for the (4H x 4W) input image
+    with a mild image augmentation; k2s_sensor (1,n,4,4) = a small ego motion; the cv_frustum
+    (D,H,W,3) built like create_frustum(downsample=4) (view_transformer.py:84-112)."""
+    rs = np.random.RandomState(seed)
+    hi, wi = 4 * H, 4 * W
+    prev = rs.standard_normal((n_cams, C, H, W)).astype(np.float32)
+    curr = rs.standard_normal((n_cams, C, H, W)).astype(np.float32)
+    K = np.tile(np.array([[0.9 * wi, 0, wi / 2.0], [0, 0.9 * wi, hi / 2.0], [0, 0, 1]], np.float32), (1, n_cams, 1, 1))
+    post_rot = np.tile(np.eye(3, dtype=np.float32), (1, n_cams, 1, 1))
+    post_tran = np.zeros((1, n_cams, 3), np.float32)
+    k2s = np.tile(np.eye(4, dtype=np.float32), (1, n_cams, 1, 1))
+    for c in range(n_cams):
+        post_rot[0, c, 0, 0] = post_rot[0, c, 1, 1] = 0.95 + 0.03 * c
+        post_tran[0, c, :2] = (1.5 - c, -0.7 * (c + 1))
+        ang = 0.03 * (c + 1)
+        k2s[0, c, :3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+        k2s[0, c, :3, 3] = np.array([0.15 * (c + 1), 0.03, -0.8 - 0.4 * c], np.float32)
+    d = (1.0 + 2.0 * np.arange(D)).astype(np.float32)
+    x = np.linspace(0, wi - 1, W, dtype=np.float32)
+    y = np.linspace(0, hi - 1, H, dtype=np.float32)
+    frustum = np.stack(np.broadcast_arrays(x[None, None, :], y[None, :, None], d[:, None, None]), -1).astype(np.float32)
+    return prev, curr, k2s, K, post_rot, post_tran, np.ascontiguousarray(frustum)

@@ -216,6 +216,29 @@ def test_depthnet_tail_softmax_and_layout():
     assert dep.shape == (6, 88, 32, 88)
 
 
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_stereo_cost_volume(golden, channels_last):
+    """SURVEY 8f row 1 through the C ABI: the DepthNet cost volume in one kernel vs the reference's own
+    output (tests/golden/stereo_small.npz) and the oracle, NCHW and channels_last feature storage."""
+    g = golden('stereo_small.npz')
+    prev, curr, k2s, K, pr, pt, fr = S.stereo_inputs(int(g['seed']))
+    tp, tc = T(prev), T(curr)
+    if channels_last:
+        tp, tc = tp.contiguous(memory_format=torch.channels_last), tc.contiguous(memory_format=torch.channels_last)
+    for bias in (0.0, 5.0):
+        cv = ops.stereo_cost_volume(tp, tc, T(fr), T(k2s), T(K), T(pr), T(pt), bias=bias)
+        np.testing.assert_allclose(cv.cpu().numpy(), g['cv_bias%d' % int(bias)], rtol=2e-4, atol=5e-6)
+    # ragged width (W not a multiple of the 8-pixel block), more channels, vs the oracle
+    prev, curr, k2s, K, pr, pt, fr = S.stereo_inputs(5, C=16, H=5, W=13, D=20, n_cams=3)
+    tp, tc = T(prev), T(curr)
+    if channels_last:
+        tp, tc = tp.contiguous(memory_format=torch.channels_last), tc.contiguous(memory_format=torch.channels_last)
+    cv = ops.stereo_cost_volume(tp, tc, T(fr), T(k2s), T(K), T(pr), T(pt), bias=5.0)
+    want = O.stereo_cost_volume(prev, curr, fr, k2s, K, pr, pt, bias=5.0)
+    np.testing.assert_allclose(cv.cpu().numpy(), want, rtol=2e-4, atol=5e-6)
+    np.testing.assert_allclose(cv.sum(1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
 def test_edge_cases():
     lower, interval, size = O.grid_infos(S.GRID_CONFIG_FULL)
     # nothing inside the grid -> five Nones like view_transformer.py:237-238

@@ -206,6 +206,17 @@ def test_ray_table_and_wrs_weights(golden):
     np.testing.assert_allclose(w2, g['weights_given'], rtol=1e-6)
 
 
+def test_stereo_cost_volume(golden):
+    """oracle restatement of DepthNet.gen_grid + calculate_cost_volumn vs the reference."""
+    g = golden('stereo_small.npz')
+    prev, curr, k2s, K, pr, pt, fr = S.stereo_inputs(int(g['seed']))
+    for bias in (0.0, 5.0):
+        cv = O.stereo_cost_volume(prev, curr, fr, k2s, K, pr, pt, bias=bias)
+        np.testing.assert_allclose(cv, g['cv_bias%d' % int(bias)], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(cv.sum(1), 1.0, rtol=1e-5)
+    assert np.abs(g['cv_bias0'] - g['cv_bias5']).max() > 1e-3        # the bias branch is exercised
+
+
 def test_voxel_losses(golden):
     """oracle restatement of loss.py (CE / sem_scal / geo_scal) vs the reference's values."""
     g = golden('voxel_losses.npz')

@@ -159,6 +159,34 @@ def bench_render():
     return res
 
 
+def bench_stereo():
+    """DepthNet cost volume at the reference shape (6 cams, 128 channels, 128x352, D=88)."""
+    dev = 'cuda:0'
+    res = {}
+    rig = S.synthetic_rig(6)
+    BN, C, H, W, D = 6, 128, 128, 352, 88
+    prev = torch.randn(BN, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    curr = torch.randn(BN, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    d = torch.arange(1.0, 45.0, 0.5, device=dev)
+    x = torch.linspace(0, 1408 - 1, W, device=dev)
+    y = torch.linspace(0, 512 - 1, H, device=dev)
+    fr = torch.stack([x.view(1, 1, W).expand(D, H, W), y.view(1, H, 1).expand(D, H, W), d.view(D, 1, 1).expand(D, H, W)], -1).contiguous()
+    k2s = torch.eye(4, device=dev).repeat(1, 6, 1, 1)
+    k2s[0, :, 2, 3] = -2.5
+    args = (fr, k2s) + tuple(torch.from_numpy(np.ascontiguousarray(rig[k])).to(dev) for k in ('intrin', 'post_rot', 'post_tran'))
+    fn = lambda: ops.stereo_cost_volume(prev, curr, *args, bias=5.0)
+    fn()
+    t = timeit(fn, iters=5)
+    npts = BN * D * H * W
+    res['stereo_cv_us'] = t
+    res['stereo_cv_Gpts_per_s'] = npts / t / 1e3
+    res['stereo_cv_gather_GBps'] = npts * 4 * C * 4 / t / 1e3        # 4 corners x C floats per point (cache level)
+    res['stereo_cv_hbm_alg_GBps'] = (2 * prev.numel() * 4 + npts * 4) / t / 1e3
+    t2 = timeit(lambda: ops.stereo_cost_volume(prev.contiguous(), curr.contiguous(), *args, bias=5.0), iters=2)
+    res['stereo_cv_nchw_us'] = t2
+    return res
+
+
 def bench_loss():
     """CE + sem_scal + geo_scal forward (one pass) and backward (one pass) on
     (1,18,200,200,16) logits; algorithmic HBM bytes = logits read (46 MB) [+ gradient written]."""
@@ -200,4 +228,6 @@ if __name__ == '__main__':
         out['render'] = bench_render()
     if 'loss' in a.what:
         out['loss'] = bench_loss()
+    if 'stereo' in a.what:
+        out['stereo'] = bench_stereo()
     print(json.dumps(out, indent=1))

@@ -462,6 +462,21 @@ def gen_rays():
          balance_weight=bw.numpy(), weights_given=captured['w'].numpy())
 
 
+def gen_stereo(vtm):
+    """G12: DepthNet.gen_grid + calculate_cost_volumn (view_transformer.py:546-604)
+    called as plain functions (the DepthNet constructor needs mmcv; the two methods only read self.bias)."""
+    prev, curr, k2s, K, pr, pt, frustum = [torch.from_numpy(a) for a in S.stereo_inputs(51)]
+    outs = {}
+    for bias in (0.0, 5.0):
+        me = types.SimpleNamespace(bias=bias)
+        me.gen_grid = lambda *a, **k: vtm.DepthNet.gen_grid(me, *a, **k)
+        metas = dict(k2s_sensor=k2s, intrins=K, post_rots=pr, post_trans=pt, frustum=frustum,
+                     cv_feat_list=[prev, curr])
+        with torch.no_grad():
+            outs['cv_bias%d' % int(bias)] = vtm.DepthNet.calculate_cost_volumn(me, metas).numpy()
+    save('stereo_small.npz', seed=np.int64(51), **outs)
+
+
 def gen_losses():
     """G11: mmdet3d/models/detectors/loss.py CE_ssc_loss / sem_scal_loss /
     geo_scal_loss values and their autograd gradients w.r.t. the logits."""
@@ -566,6 +581,7 @@ def main():
     gen_traj(occ)
     gen_rays()
     gen_losses()
+    gen_stereo(vtm)
     gen_render(nh)
     gen_metric(om)
 
