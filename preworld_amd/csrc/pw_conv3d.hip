@@ -56,6 +56,7 @@ struct ConvArgs {
   int relu0, relu1;
   int tiles_d, tiles_h, tiles_w;
   long long* probe;       // development aid: per-wave phase timestamps (PW_CONV_PROBE) or null
+  int dma_stage;          // tile-per-block kernels: stage the halo with buffer_load ... lds
 };
 
 // MFMA row (0..31) -> voxel of the 4x8 patch, chosen for conflict-free ds_read_b128 groups
@@ -293,6 +294,79 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int nblk) {
   return x * q + min(x, r) + idx;
 }
 
+// ---- halo staging by `buffer_load ... lds` (shared by the tile-per-block and the persistent kernels)
+typedef __attribute__((address_space(3))) char* lds3_t;
+constexpr unsigned PIPE_OOB = 0xfffffff0u;     // voffset beyond any num_records -> load returns 0
+constexpr int PIPE_BUF_BYTES = TV * KC * 4;     // 76800
+constexpr int PIPE_ROWS_PER_WAVE = TD * TH / 4; // 15 halo rows per wave and stage
+
+struct PipeDma {                                 // what the DMA of one stage needs
+  unsigned voff[2][2];                           // [halo-row parity][pass] lane offset or PIPE_OOB
+  int b, d0, h0, wbase, ch;                      // scalars
+  unsigned ldsbuf;                               // byte offset of the destination buffer
+  bool live;                                     // false: no next stage, every lane goes OOB
+};
+
+// lane offsets for a tile column position w0 (see stage_lane_setup for the w0 == 0 shift);
+// pass 0 = voxels 0..7 as 16-byte slots, pass 1 = voxels 8..9 as dwords
+__device__ __forceinline__ void pipe_lane_offsets(const ConvArgs& a, int w0, int lane, unsigned (&voff)[2][2]) {
+  const int shift = w0 == 0 ? 1 : 0;
+  {
+    const int ww = lane >> 3, slot = lane & 7;
+    const bool wok = (unsigned)(w0 - 1 + ww) < (unsigned)a.W;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int f = ((ww >> 1) & 3) | (par << 2);
+      voff[par][0] = wok ? (unsigned)((ww - shift) * a.Cin + (slot ^ f) * 4) * 4u : PIPE_OOB;
+    }
+  }
+  {
+    const int ww = 8 + (lane >> 5), dw = lane & 31, slot = dw >> 2;
+    const bool wok = (unsigned)(w0 - 1 + ww) < (unsigned)a.W;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int f = ((ww >> 1) & 3) | (par << 2);
+      voff[par][1] = wok ? (unsigned)((ww - shift) * a.Cin + (slot ^ f) * 4 + (dw & 3)) * 4u : PIPE_OOB;
+    }
+  }
+}
+
+// halo row `wave + 4 K` of the stage described by dm: two DMA instructions (8 + 2 voxels)
+template <int K>
+__device__ __forceinline__ void pipe_dma_row(const ConvArgs& a, rsrc_t xr, lds3_t lds3, const PipeDma& dm,
+                                             int wave) {
+  const int row = wave + 4 * K;                    // wave-uniform, < 60
+  const int dd = row / TH, hh = row - dd * TH;
+  const int gd = dm.d0 + dd - 1, gh = dm.h0 + hh - 1;
+  const bool rok = dm.live && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H;
+  const unsigned soff = rok ? (unsigned)(((((dm.b * a.D + gd) * a.H + gh) * a.W + dm.wbase) * a.Cin + dm.ch * KC) * 4) : 0u;
+  const unsigned v0 = rok ? ((hh & 1) ? dm.voff[1][0] : dm.voff[0][0]) : PIPE_OOB;
+  const unsigned v1 = rok ? ((hh & 1) ? dm.voff[1][1] : dm.voff[0][1]) : PIPE_OOB;
+  lds3_t dst = lds3 + (dm.ldsbuf + (unsigned)row * (TW * 128));
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, v0, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst + 1024, 4, v1, soff, 0, 0);
+}
+
+
+// tile-per-block kernels: the whole halo of one chunk as 30 DMA instructions per wave instead of the
+// ~100-instruction global -> VGPR -> swizzled ds_write sequence (which crawls next to an MFMA-streaming
+// sibling block, section "VALU budget")
+__device__ __forceinline__ void stage_halo_chunk_dma(const ConvArgs& a, rsrc_t xr, float* lds, int b, int d0,
+                                                     int h0, int w0, int ch, int wave, int lane) {
+  if (ch > 0) __syncthreads();   // every wave finished reading the previous chunk
+  PipeDma dm;
+  pipe_lane_offsets(a, w0, lane, dm.voff);
+  dm.b = b; dm.d0 = d0; dm.h0 = h0; dm.wbase = w0 > 0 ? w0 - 1 : 0; dm.ch = ch; dm.ldsbuf = 0; dm.live = true;
+  const lds3_t lds3 = (lds3_t)lds;
+  pipe_dma_row<0>(a, xr, lds3, dm, wave); pipe_dma_row<1>(a, xr, lds3, dm, wave); pipe_dma_row<2>(a, xr, lds3, dm, wave);
+  pipe_dma_row<3>(a, xr, lds3, dm, wave); pipe_dma_row<4>(a, xr, lds3, dm, wave); pipe_dma_row<5>(a, xr, lds3, dm, wave);
+  pipe_dma_row<6>(a, xr, lds3, dm, wave); pipe_dma_row<7>(a, xr, lds3, dm, wave); pipe_dma_row<8>(a, xr, lds3, dm, wave);
+  pipe_dma_row<9>(a, xr, lds3, dm, wave); pipe_dma_row<10>(a, xr, lds3, dm, wave); pipe_dma_row<11>(a, xr, lds3, dm, wave);
+  pipe_dma_row<12>(a, xr, lds3, dm, wave); pipe_dma_row<13>(a, xr, lds3, dm, wave); pipe_dma_row<14>(a, xr, lds3, dm, wave);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------
 // 3x3x3, stride 1, pad 1, LDS halo tile
 // ------------------------------------------------------------------------------------
@@ -349,7 +423,8 @@ __global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
     const unsigned wsoff = (unsigned)((ch * 27 * ntiles_total + ng * NT) * 4096);
     float4 b0[NT][4], b1[NT][4];
     load_b<NT>(wr, wsoff, lane_off, b0);
-    stage_halo_chunk<WD, 8>(a, xr, lds, sl, b, d0, h0, w0, ch, wave, lane);
+    if (WD == 1 && a.dma_stage) stage_halo_chunk_dma(a, xr, lds, b, d0, h0, w0, ch, wave, lane);
+    else stage_halo_chunk<WD, 8>(a, xr, lds, sl, b, d0, h0, w0, ch, wave, lane);
     if (a.probe && ch == 0) ts1 = __builtin_readcyclecounter();
     tap_pair<NT, 0>(lds, aaddr, wr, wsoff, lane_off, wstride, b0, b1, acc);
   }
@@ -463,7 +538,6 @@ struct PipeArgs {
   int ngroups, n_items;
 };
 
-typedef __attribute__((address_space(3))) char* lds3_t;
 
 __device__ __forceinline__ int udiv_magic(int x, int d, unsigned magic) {
   return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
@@ -483,57 +557,6 @@ __device__ __forceinline__ PipeTile pipe_decode(const ConvArgs& a, const PipeArg
   t.d0 = (tile - q * a.tiles_d) * BD;
   t.b = q;
   return t;
-}
-
-constexpr unsigned PIPE_OOB = 0xfffffff0u;     // voffset beyond any num_records -> load returns 0
-constexpr int PIPE_BUF_BYTES = TV * KC * 4;     // 76800
-constexpr int PIPE_ROWS_PER_WAVE = TD * TH / 4; // 15 halo rows per wave and stage
-
-struct PipeDma {                                 // what the DMA of one stage needs
-  unsigned voff[2][2];                           // [halo-row parity][pass] lane offset or PIPE_OOB
-  int b, d0, h0, wbase, ch;                      // scalars
-  unsigned ldsbuf;                               // byte offset of the destination buffer
-  bool live;                                     // false: no next stage, every lane goes OOB
-};
-
-// lane offsets for a tile column position w0 (see stage_lane_setup for the w0 == 0 shift);
-// pass 0 = voxels 0..7 as 16-byte slots, pass 1 = voxels 8..9 as dwords
-__device__ __forceinline__ void pipe_lane_offsets(const ConvArgs& a, int w0, int lane, unsigned (&voff)[2][2]) {
-  const int shift = w0 == 0 ? 1 : 0;
-  {
-    const int ww = lane >> 3, slot = lane & 7;
-    const bool wok = (unsigned)(w0 - 1 + ww) < (unsigned)a.W;
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int f = ((ww >> 1) & 3) | (par << 2);
-      voff[par][0] = wok ? (unsigned)((ww - shift) * a.Cin + (slot ^ f) * 4) * 4u : PIPE_OOB;
-    }
-  }
-  {
-    const int ww = 8 + (lane >> 5), dw = lane & 31, slot = dw >> 2;
-    const bool wok = (unsigned)(w0 - 1 + ww) < (unsigned)a.W;
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int f = ((ww >> 1) & 3) | (par << 2);
-      voff[par][1] = wok ? (unsigned)((ww - shift) * a.Cin + (slot ^ f) * 4 + (dw & 3)) * 4u : PIPE_OOB;
-    }
-  }
-}
-
-// halo row `wave + 4 K` of the stage described by dm: two DMA instructions (8 + 2 voxels)
-template <int K>
-__device__ __forceinline__ void pipe_dma_row(const ConvArgs& a, rsrc_t xr, lds3_t lds3, const PipeDma& dm,
-                                             int wave) {
-  const int row = wave + 4 * K;                    // wave-uniform, < 60
-  const int dd = row / TH, hh = row - dd * TH;
-  const int gd = dm.d0 + dd - 1, gh = dm.h0 + hh - 1;
-  const bool rok = dm.live && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H;
-  const unsigned soff = rok ? (unsigned)(((((dm.b * a.D + gd) * a.H + gh) * a.W + dm.wbase) * a.Cin + dm.ch * KC) * 4) : 0u;
-  const unsigned v0 = rok ? ((hh & 1) ? dm.voff[1][0] : dm.voff[0][0]) : PIPE_OOB;
-  const unsigned v1 = rok ? ((hh & 1) ? dm.voff[1][1] : dm.voff[0][1]) : PIPE_OOB;
-  lds3_t dst = lds3 + (dm.ldsbuf + (unsigned)row * (TW * 128));
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, v0, soff, 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst + 1024, 4, v1, soff, 0, 0);
 }
 
 template <int NT>
@@ -925,7 +948,8 @@ __global__ void __launch_bounds__(256 * WD, 2) k_occ_head16(ConvArgs a, OccTail 
     const unsigned wsoff = (unsigned)(ch * 27 * 2048);
     float4 b0[2], b1[2];
     load_b16(wr, wsoff, lane_off, b0);
-    stage_halo_chunk<WD, 8>(a, xr, lds, sl, b, d0, h0, w0, ch, wave, lane);
+    if (WD == 1 && a.dma_stage) stage_halo_chunk_dma(a, xr, lds, b, d0, h0, w0, ch, wave, lane);
+    else stage_halo_chunk<WD, 8>(a, xr, lds, sl, b, d0, h0, w0, ch, wave, lane);
     tap_pair16<0>(lds, aaddr, wr, wsoff, lane_off, b0, b1, acc);
   }
   // ---- tail: BN+ReLU, transpose 64 voxels x 16 channels through LDS, per-voxel MLP + argmax
@@ -1486,6 +1510,13 @@ static int set_lds_limit(K kernel, int bytes) {
   return PW_OK;
 }
 
+// halo staging of the tile-per-block kernels by buffer_load ... lds: on by default (A/B on one box, C3 step:
+// 7.125 ms with the VGPR staging, 7.056 ms with DMA); PW_CONV_DMA_STAGE=0 selects the VGPR path
+static int dma_stage_default() {
+  const char* e = getenv("PW_CONV_DMA_STAGE");
+  return e ? (atoi(e) ? 1 : 0) : 1;
+}
+
 // exact x / d by one mulhi for x * d < 2^32 (tile counts): floor(2^32 / d) + 1
 static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 
@@ -1586,6 +1617,7 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   PW_CHECK_ARG(!(algo == 1 && !tiled), "pw_conv3d_ndhwc: algo=1 needs ksize 3 stride 1");
   a.probe = nullptr;
   if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
+  a.dma_stage = dma_stage_default();
   if (tiled && use_pipe((long long)B * a.tiles_d * a.tiles_h * a.tiles_w * ngroups, NT)) {
     PipeArgs p;
     p.ngroups = ngroups;
@@ -1674,6 +1706,7 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
   a.cout_total = 32; a.cout0 = n_mid; a.relu0 = 1;
   a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
   OccTail t = {w1, s1, b1, w2, occ, logits, geo, empty_idx, n_mid, n_hid, n_cls};
+  a.dma_stage = dma_stage_default();
   long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
   PW_CHECK_ARG(wpk_layout == 16, "pw_occ_head_fused: wpk_layout must be 16 (the 16x16x4 MFMA packing)");
   // persistent DMA-pipelined variant: opt-in with PW_OCC_PIPE=1.  Measured at 16x200x200: 176 us vs
