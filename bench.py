@@ -277,16 +277,9 @@ def main():
 
     graph = None
     if not args.no_graph:
-        g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            step()                                   # side-stream warmup required before capture
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g):
-            out = step()
-        graph = g
+        from preworld_amd.pipeline import CapturedSample
+        graph = CapturedSample(net, frames, ego, n_steps=n_steps_fc)     # hipGraph over static buffers
+        out = graph.out
         run = graph.replay
     else:
         def run():

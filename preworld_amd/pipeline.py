@@ -1,9 +1,49 @@
-"""Composition of the hot path for bench.py / smoke(): synthetic inputs in HBM -> LSS voxel
-pooling -> voxel encoder -> forecast decode -> occupancy heads.  Mirrors the call order of
-PreWorld4DTraj.simple_test (mmdet3d/models/detectors/preworld_temporal_traj.py:212-370)."""
+"""Serving-side composition of the hot path: synthetic or real lifted inputs in HBM -> LSS voxel
+pooling -> voxel encoder -> forecast decode -> occupancy heads, mirroring the call order of
+PreWorld4DTraj.simple_test (mmdet3d/models/detectors/preworld_temporal_traj.py:212-370).
+
+`CapturedSample` records one sample's ~60 kernel launches into a hipGraph (torch.cuda.CUDAGraph) over
+static input/output buffers: a replay has no launch gaps (kernel time == wall time in
+profiles/r01_bench_kernel_stats_v4.md) and no per-launch host work, which is what the C3 step needs
+once the kernels themselves run in 10-1000 us."""
 import numpy as np
 import torch
 
 
 def to_dev(a, dev='cuda:0'):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+class CapturedSample:
+    """net: modules.PreWorld4DTraj (eval).  frames / ego: example inputs defining the shapes (list of
+    dicts as for simple_test_from_lift, (B,1,21) ego states).  run(frames, ego) copies new inputs into
+    the static buffers, replays the graph and returns the (static) result dict: consume or clone the
+    outputs before the next run()."""
+
+    def __init__(self, net, frames, ego, n_steps=6):
+        self.net, self.n_steps = net, n_steps
+        self.frames = [{k: v.clone() for k, v in f.items()} for f in frames]
+        self.ego = ego.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():        # warm-up off the capture stream: fills the packed-weight
+            self._step()                                       # caches and sets the kernels' LDS attributes
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = self._step()
+
+    def _step(self):
+        return self.net.simple_test_from_lift(self.frames, self.ego, n_steps=self.n_steps)
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+    def run(self, frames, ego):
+        for dst, src in zip(self.frames, frames):
+            for k, v in src.items():
+                dst[k].copy_(v, non_blocking=True)
+        self.ego.copy_(ego, non_blocking=True)
+        return self.replay()

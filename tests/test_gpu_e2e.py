@@ -73,6 +73,27 @@ def test_geo_occ_comes_from_the_same_kernel():
         np.testing.assert_array_equal(geo, np.where(occ != 17, 0, 17).astype(np.uint8))
 
 
+def test_captured_sample_replays_like_eager():
+    """pipeline.CapturedSample: a hipGraph replay with new inputs copied into the static buffers gives
+    exactly the eager results (all kernels are deterministic)."""
+    from preworld_amd.pipeline import CapturedSample
+    sd = S.synth_state_dict(0)
+    net = harness.build_model(harness.model_cfg(GC), sd, DEV)
+    f1, e1 = harness.lifted_frames(1, 1, DEV), torch.from_numpy(S.ego_state(1)).to(DEV)
+    f2, e2 = harness.lifted_frames(2, 1, DEV), torch.from_numpy(S.ego_state(2)).to(DEV)
+    cap = CapturedSample(net, f1, e1, n_steps=6)
+    with torch.no_grad():
+        want2 = {k: v[0].clone() for k, v in net.simple_test_from_lift(f2, e2, n_steps=6).items() if k.startswith('semantic_occ')}
+        want1 = {k: v[0].clone() for k, v in net.simple_test_from_lift(f1, e1, n_steps=6).items() if k.startswith('semantic_occ')}
+    got2 = {k: v[0].clone() for k, v in cap.run(f2, e2).items() if k.startswith('semantic_occ')}
+    got1 = {k: v[0].clone() for k, v in cap.run(f1, e1).items() if k.startswith('semantic_occ')}
+    assert len(got1) == 7
+    for k in want1:
+        assert torch.equal(got1[k], want1[k]), k
+        assert torch.equal(got2[k], want2[k]), k
+    assert any(not torch.equal(got1[k], got2[k]) for k in got1)
+
+
 def test_build_model_rejects_incomplete_state_dict():
     sd = S.synth_state_dict(0)
     sd.pop('final_conv.conv.weight')
