@@ -201,6 +201,8 @@ def main():
     ap.add_argument('--settle-s', type=float, default=1.0,
                     help='untimed run-in before the W warm-up steps: the GPU needs a few hundred ms of load to leave '
                          'its idle clock state (measured: 304 us vs 278 us for the same conv launch)')
+    ap.add_argument('--in-flight', type=int, default=2,
+                    help='independent samples in flight per GPU (one hipGraph + HIP stream each); 1 = strictly serial')
     ap.add_argument('--config', default='C3', choices=['C3', 'C2'])
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -276,27 +278,49 @@ def main():
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])})
 
     graph = None
+    latency_ms = None
     if not args.no_graph:
         from preworld_amd.pipeline import CapturedSample
-        graph = CapturedSample(net, frames, ego, n_steps=n_steps_fc)     # hipGraph over static buffers
+        # M independent samples in flight, each a hipGraph over its own static buffers on its own HIP
+        # stream: while one sample sits in a stage that cannot fill 256 CUs (the 8x100x100 / 4x50x50
+        # encoder levels, the last partial wave of tiles of every launch, the latency-bound sort), the other
+        # one's kernels take the idle CUs.  A step is still one sample; steps alternate between the streams.
+        M = max(1, args.in_flight)
+        caps = [CapturedSample(net, *make_inputs(dev, seed=rank * 8 + k, n_frames=n_frames), n_steps=n_steps_fc)
+                for k in range(M)]
+        streams = [torch.cuda.Stream() for _ in range(M)]
+        graph = caps[0]
         out = graph.out
-        run = graph.replay
+
+        def run_steps(n):
+            for i in range(n):
+                with torch.cuda.stream(streams[i % M]):
+                    caps[i % M].replay()
     else:
-        def run():
-            step()
+        M = 1
+
+        def run_steps(n):
+            for _ in range(n):
+                step()
 
     t_settle = time.perf_counter() + args.settle_s
     while time.perf_counter() < t_settle:
-        run()
+        run_steps(M)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        run()
+    if graph is not None and M > 1 and rank == 0:        # single-sample latency, reported next to the throughput
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            caps[0].replay()
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - t0) / 20 * 1e3
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -333,7 +357,9 @@ def main():
                 if args.config == 'C3' else
                 'C2: single frame (with_prev=False), 6 cams, 200x200x16, 1 state',
                 'states_per_sample': n_states,
-                'launch': 'hipGraph replay' if graph is not None else 'eager',
+                'launch': ('hipGraph replay, %d independent sample(s) in flight on %d HIP stream(s)' % (M, M))
+                if graph is not None else 'eager',
+                'single_sample_latency_ms': round(latency_ms, 4) if latency_ms else None,
                 'parallelism': 'replicas x%d (independent samples, no data-path collective)%s' % (
                     world, ' -- OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else ''),
                 'excluded': 'image backbone + DepthNet (stay on PyTorch, SURVEY 8a)',
