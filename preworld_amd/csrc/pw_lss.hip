@@ -386,6 +386,14 @@ k_sort_long(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ t
   }
 }
 
+// zero-fill by a kernel, not hipMemsetAsync: a hipGraph that contains memset nodes faulted on replay
+// ("write access to a read-only page") as soon as the process had allocated new device memory after
+// the capture (ROCm 7.2; reproduced with this function alone, gone with the kernel)
+__global__ void __launch_bounds__(256) k_zero_i32(int32_t* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 PW_API size_t pw_segment_sort_workspace_bytes(int64_t n, int64_t n_keys) {
   return pw_align_up((size_t)(n_keys + 1) * 4, 256)   // count
          + pw_align_up((size_t)n * 4, 256)            // arrival rank per point
@@ -418,8 +426,8 @@ PW_API int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void*
   int32_t* tmp = (int32_t*)ws;
   ws += pw_align_up((size_t)n * 4, 256);
   int32_t* sums = (int32_t*)ws;
-  PW_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)(n_keys + 1) * 4, st));
-  if (long_list) PW_CHECK_HIP(hipMemsetAsync(n_long, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)pw_cdiv(n_keys + 1, 256)), dim3(256), 0, st, count, n_keys + 1);
+  if (long_list) hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(256), 0, st, n_long, (int64_t)1);
   unsigned nbk = (unsigned)pw_cdiv(n, 256);
   hipLaunchKernelGGL(k_hist, dim3(nbk), dim3(256), 0, st, keys, n, count, rank);
   int rc = scan_exclusive_i32(count, seg_start, n_keys + 1, sums, st);

@@ -106,6 +106,11 @@ k_cumdist_thres(const float* __restrict__ dist, float thres, int n_rays, int n_p
   }
 }
 
+__global__ void __launch_bounds__(256) k_zero_f32(float* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 PW_API int pw_raw2alpha(const float* density, float shift, float interval, int64_t n, float* exp_d,
                         float* alpha, void* stream) {
   if (n == 0) return PW_OK;
@@ -169,7 +174,7 @@ PW_API int pw_alpha2weight_backward(const float* alpha, const float* weight, con
                    grad_last && grad,
                "pw_alpha2weight_backward: null pointer");
   hipStream_t st = pw_stream(stream);
-  PW_CHECK_HIP(hipMemsetAsync(grad, 0, (size_t)n_pts * 4, st));
+  hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)pw_cdiv(n_pts, 256)), dim3(256), 0, st, grad, (int64_t)n_pts);   // not hipMemsetAsync: see pw_lss.hip k_zero_i32
   if (n_rays > 0)
     hipLaunchKernelGGL(k_alpha2weight_bwd, dim3((unsigned)pw_cdiv(n_rays, 256)), dim3(256), 0, st,
                        alpha, weight, T, alphainv_last, i_start, i_end, n_rays, grad_weights,
