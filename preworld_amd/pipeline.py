@@ -4,7 +4,7 @@ PreWorld4DTraj.simple_test (mmdet3d/models/detectors/preworld_temporal_traj.py:2
 
 `CapturedSample` records one sample's ~60 kernel launches into a hipGraph (torch.cuda.CUDAGraph) over
 static input/output buffers: a replay has no launch gaps (kernel time == wall time in
-profiles/r01_bench_kernel_stats_v4.md) and no per-launch host work, which is what the C3 step needs
+profiles/r01_bench_kernel_stats_v5.md) and no per-launch host work, which is what the C3 step needs
 once the kernels themselves run in 10-1000 us."""
 import numpy as np
 import torch
