@@ -1281,8 +1281,9 @@ __device__ __forceinline__ void gather_step(const GatherCtx<KS, MT>& c, int ch, 
 // meet in LDS and partition 0 adds them in a fixed order (deterministic) before the epilogue.  Small
 // grids need this: with one (M-tile, N-group) per wave the 4x50x50 stage has ~1.2 waves of 1728-3456
 // MFMAs per SIMD, i.e. the slowest SIMD does 2 of them; split by 4 it is ~5 waves of 432.
-template <int NT, int KS, int STRIDE, int MT>
-__global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_out_vox, int ksplit) {
+template <int NT, int KS, int STRIDE, int MT, int KSPL>
+__global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_out_vox) {
+  constexpr int ksplit = KSPL;          // compile-time: the unsplit kernel keeps its straight-line code
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, i = lane & 31;
@@ -1664,13 +1665,18 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
       const int f = atoi(e);
       if ((f == 1 || f == 2 || f == 4) && nchunk % f == 0) ksplit = f;
     }
+    if (ksplit > 1 && MT != 1) ksplit = 1;              // the split variants are built for MT = 1
     const int mgroups = 4 / ksplit;                     // M-groups (32*MT voxels each) per block
     dim3 grid((unsigned)pw_cdiv(n_out, 32 * MT * mgroups), (unsigned)ngroups);
     const size_t red_bytes = ksplit > 1 ? (size_t)mgroups * (ksplit - 1) * MT * NT * 4096 : 0;
-#define PW_GATHER(NTv, KSv, STv)                                                                                   \
-  do {                                                                                                             \
-    if (MT == 2) hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 2>), grid, dim3(256), red_bytes, st, a, n_out, ksplit); \
-    else hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1>), grid, dim3(256), red_bytes, st, a, n_out, ksplit);         \
+#define PW_GATHER_L(NTv, KSv, STv, MTv, KSPv) \
+  hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, MTv, KSPv>), grid, dim3(256), red_bytes, st, a, n_out)
+#define PW_GATHER(NTv, KSv, STv)                                        \
+  do {                                                                  \
+    if (ksplit == 4) PW_GATHER_L(NTv, KSv, STv, 1, 4);                  \
+    else if (ksplit == 2) PW_GATHER_L(NTv, KSv, STv, 1, 2);             \
+    else if (MT == 2) PW_GATHER_L(NTv, KSv, STv, 2, 1);                 \
+    else PW_GATHER_L(NTv, KSv, STv, 1, 1);                              \
   } while (0)
     if (ksize == 1) {
       if (NT == 2) PW_GATHER(2, 1, 1); else PW_GATHER(1, 1, 1);
@@ -1682,6 +1688,7 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
       if (NT == 2) PW_GATHER(2, 3, 2); else PW_GATHER(1, 3, 2);
     }
 #undef PW_GATHER
+#undef PW_GATHER_L
   }
   PW_CHECK_LAUNCH();
   return PW_OK;
