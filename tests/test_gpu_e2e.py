@@ -117,6 +117,35 @@ def test_two_samples_in_flight_do_not_interfere():
             assert torch.equal(c.out[k][0], v), k
 
 
+def test_pretrain_attribute_decode_branch_matches_oracle():
+    """if_post_finetune=False (preworld_temporal_traj.py:224-301): density-threshold + semantic-MLP decode of
+    the 7 states, named 0s, 2s..7s like the reference, against the oracle's attribute decode.  The synthetic
+    density MLP is biased so that both sides of the 8.5 threshold occur."""
+    sd = S.synth_state_dict(0)
+    sd['density_mlp.2.bias'] = sd['density_mlp.2.bias'] + np.float32(8.5)
+    net = harness.build_model(harness.model_cfg(GC, if_post_finetune=False), sd, DEV)
+    frames = harness.lifted_frames(4, 1, DEV)
+    with torch.no_grad():
+        res = net.simple_test_from_lift(frames, torch.from_numpy(S.ego_state(4)).to(DEV), n_steps=6)
+    bevs = []
+    for f in range(2):
+        depth, feat = S.lift_inputs(4 * 16 + f, N=1)
+        r = S.synthetic_rig(1, dx=-2.5 * f)
+        bev = O.lss_view_transform(depth, feat, r['sensor2ego'], r['intrin'], r['post_rot'], r['post_tran'],
+                                   r['bda'], GC, S.INPUT_SIZE, S.DOWNSAMPLE)
+        bevs.append(O.pre_process(bev, sd))
+    vf = O.final_conv(O.encoder_forward(bevs[1], bevs[0], sd), sd)
+    states, _ = O.preworld4d_decode(vf, S.ego_state(4), sd, n_steps=6, post_finetune=False)
+    names = [0, 2, 3, 4, 5, 6, 7]
+    assert sorted(k for k in res if k.startswith('semantic_occ')) == sorted('semantic_occ_%ds' % n for n in names)
+    for k, n in enumerate(names):
+        got = res['semantic_occ_%ds' % n][0].cpu().numpy()
+        assert got.shape == states[k].shape
+        assert float((got == states[k]).mean()) >= 0.999, (n, float((got == states[k]).mean()))
+    occ0 = res['semantic_occ_0s'][0]
+    assert 0.02 < float((occ0 != 17).float().mean()) < 0.98       # both branches of the threshold are exercised
+
+
 def test_build_model_rejects_incomplete_state_dict():
     sd = S.synth_state_dict(0)
     sd.pop('final_conv.conv.weight')
