@@ -1,0 +1,116 @@
+// LSSFPN3D fused tail (A8) -- entry point pw_fpn3d_fuse in include/preworld_hip.h.
+#include "pw_conv3d_common.h"
+
+// ------------------------------------------------------------------------------------
+// LSSFPN3D fused (mmdet3d/models/necks/lss_fpn.py:132-148): the reference upsamples the 1/2
+// and 1/4 resolution maps x2/x4 (trilinear, align_corners=True), concatenates 32+64+128
+// channels (a 573 MB tensor) and runs a 1x1x1 conv 224->32 + BN + ReLU.  Trilinear
+// interpolation and a 1x1x1 conv commute (both linear, no bias in between), so the conv is
+// applied at the LOW resolution first (y16 = W[:,32:96] x16, y32 = W[:,96:224] x32 -- plain
+// pw_conv3d_ndhwc 1x1x1 calls) and this kernel computes, at full resolution,
+//   out = ReLU(BN(W[:,0:32] x8 + up2(y16) + up4(y32)))
+// reading x8 once and writing out once: no concat tensor, no upsampled tensors.
+// ------------------------------------------------------------------------------------
+struct FpnArgs {
+  const float* y16;   // (B, D2, H2, W2, 32)
+  const float* y32;   // (B, D4, H4, W4, 32)
+  int D2, H2, W2, D4, H4, W4;
+};
+
+__device__ __forceinline__ float trilerp_ac(const float* __restrict__ y, int b, int Dl, int Hl,
+                                            int Wl, float sd, float sh, float sw, int od, int oh,
+                                            int ow, int ch) {
+  // ATen upsample_trilinear3d, align_corners=True: src = dst*(in-1)/(out-1)
+  const float fd = sd * (float)od, fh = sh * (float)oh, fw = sw * (float)ow;
+  const int d0 = (int)fd, h0 = (int)fh, w0 = (int)fw;
+  const int d1 = d0 + (d0 < Dl - 1), h1 = h0 + (h0 < Hl - 1), w1 = w0 + (w0 < Wl - 1);
+  const float ld1 = fd - (float)d0, ld0 = 1.f - ld1;
+  const float lh1 = fh - (float)h0, lh0 = 1.f - lh1;
+  const float lw1 = fw - (float)w0, lw0 = 1.f - lw1;
+  const float* p = y + (size_t)b * Dl * Hl * Wl * 32 + ch;
+#define YV(d, h, w) p[(unsigned)(((d) * Hl + (h)) * Wl + (w)) * 32u]
+  const float v000 = YV(d0, h0, w0), v001 = YV(d0, h0, w1), v010 = YV(d0, h1, w0), v011 = YV(d0, h1, w1);
+  const float v100 = YV(d1, h0, w0), v101 = YV(d1, h0, w1), v110 = YV(d1, h1, w0), v111 = YV(d1, h1, w1);
+#undef YV
+  return ld0 * (lh0 * (lw0 * v000 + lw1 * v001) + lh1 * (lw0 * v010 + lw1 * v011)) +
+         ld1 * (lh0 * (lw0 * v100 + lw1 * v101) + lh1 * (lw0 * v110 + lw1 * v111));
+}
+
+__global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long long n_vox) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, i = lane & 31;
+  const long long m0 = ((long long)blockIdx.x * 4 + wave) * 32;
+  if (m0 >= n_vox) return;
+  long long m = m0 + i;
+  if (m >= n_vox) m = n_vox - 1;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nchunk = a.Cin / KC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const float* src = a.x + (size_t)m * a.Cin + ch * KC + half * 16;
+    const float* wt = a.wpk + (size_t)ch * 1024 + lane * 16;
+    float4 aq[4], bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      aq[q] = *reinterpret_cast<const float4*>(src + q * 4);
+      bq[q] = *reinterpret_cast<const float4*>(wt + q * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float av[4] = {aq[q].x, aq[q].y, aq[q].z, aq[q].w};
+      const float bv[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+    }
+  }
+  const float sc = a.scale ? a.scale[i] : 1.f;
+  const float bi = a.bias ? a.bias[i] : 0.f;
+  const float sd2 = a.D > 1 ? (float)(f.D2 - 1) / (float)(a.D - 1) : 0.f;
+  const float sh2 = a.H > 1 ? (float)(f.H2 - 1) / (float)(a.H - 1) : 0.f;
+  const float sw2 = a.W > 1 ? (float)(f.W2 - 1) / (float)(a.W - 1) : 0.f;
+  const float sd4 = a.D > 1 ? (float)(f.D4 - 1) / (float)(a.D - 1) : 0.f;
+  const float sh4 = a.H > 1 ? (float)(f.H4 - 1) / (float)(a.H - 1) : 0.f;
+  const float sw4 = a.W > 1 ? (float)(f.W4 - 1) / (float)(a.W - 1) : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const long long vox = m0 + row;
+    if (vox < n_vox) {
+      // 32-bit index math (host guarantees n_vox < 2^31): 64-bit div/mod dominated this kernel
+      const unsigned uv = (unsigned)vox;
+      const unsigned t1 = uv / (unsigned)a.W;
+      const int ow = (int)(uv - t1 * (unsigned)a.W);
+      const unsigned t2 = t1 / (unsigned)a.H;
+      const int oh = (int)(t1 - t2 * (unsigned)a.H);
+      const int b = (int)(t2 / (unsigned)a.D);
+      const int od = (int)(t2 - (unsigned)b * (unsigned)a.D);
+      float v = acc[r];
+      v += trilerp_ac(f.y16, b, f.D2, f.H2, f.W2, sd2, sh2, sw2, od, oh, ow, i);
+      v += trilerp_ac(f.y32, b, f.D4, f.H4, f.W4, sd4, sh4, sw4, od, oh, ow, i);
+      v = v * sc + bi;
+      if (a.relu0) v = fmaxf(v, 0.f);
+      a.y0[(size_t)vox * 32 + i] = v;
+    }
+  }
+}
+
+PW_API int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const float* y32,
+                         const float* scale, const float* bias, float* out, int B, int D, int H,
+                         int W, int Cin8, int D2, int H2, int W2, int D4, int H4, int W4, int relu,
+                         void* stream) {
+  PW_CHECK_ARG(x8 && wpk8 && y16 && y32 && out, "pw_fpn3d_fuse: null pointer");
+  PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin8 > 0 && Cin8 % 32 == 0, "pw_fpn3d_fuse: bad shape");
+  PW_CHECK_ARG(D2 > 0 && H2 > 0 && W2 > 0 && D4 > 0 && H4 > 0 && W4 > 0, "pw_fpn3d_fuse: bad level shape");
+  ConvArgs a = {};
+  a.x = x8; a.wpk = wpk8; a.scale = scale; a.bias = bias; a.y0 = out;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin8; a.relu0 = relu; a.cout_total = 32; a.cout0 = 32; a.ld0 = 32;
+  FpnArgs f = {y16, y32, D2, H2, W2, D4, H4, W4};
+  const long long n = (long long)B * D * H * W;
+  PW_CHECK_ARG(n < (1ll << 31), "pw_fpn3d_fuse: more than 2^31 voxels");
+  hipLaunchKernelGGL(k_fpn3d_fuse, dim3((unsigned)pw_cdiv(n, 128)), dim3(256), 0, pw_stream(stream),
+                     a, f, n);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
