@@ -148,6 +148,17 @@ int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const fl
                   const float* scale, const float* bias, float* out, int B, int D, int H, int W,
                   int Cin8, int D2, int H2, int W2, int D4, int H4, int W4, int relu, void* stream);
 
+/* 3x3x3 stride-1 pad-1 convolution by Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores: same contract
+ * as pw_conv3d_ndhwc (scale/bias, residual, ReLU, two destinations, row strides) with weights in the
+ * transform domain: uwpk = float[Cin/32][64 points][cout_total/16][64 lanes][8],
+ *   uwpk[ch][p][n16][g*16+j][s] = U[n16*16+j][ch*32+g*8+s][p],  U = G w G^T along d, h, w
+ *   (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], p = i_d*16 + i_h*4 + i_w) -- preworld_amd.ops.pack_conv_weight_wino.
+ * 3.375x fewer multiplies than the direct sum; results differ from it by fp32 rounding only. */
+int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale, const float* bias,
+                   const float* residual, float* y0, float* y1, int B, int D, int H, int W, int Cin,
+                   int cout_total, int cout0, int cout1, int ld_y0, int ld_y1, int relu0, int relu1,
+                   void* stream);
+
 /* A11  OccHead fused (mmdet3d/models/heads/occupancy_head.py:124-177, num_level=1,
  * use_deblock=False): conv3x3x3 Cin->16 + BN + ReLU, 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18,
  * argmax -> uint8, in one kernel.  x (B,D,H,W,Cin); scale/bias float[>=16] (folded BN of

@@ -320,6 +320,61 @@ def conv3d_ndhwc(x, wpk, scale=None, bias=None, residual=None, cout0=None, cout1
     return (y0, y1) if cout1 else y0
 
 
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def pack_conv_weight_wino(w, cout_total=None):
+    """torch Conv3d weight (Cout, Cin, 3, 3, 3) -> Winograd F(2,3)^3 transform-domain weights in the
+    operand order of pw_conv3d_wino: float[Cin/32][64][cout_total/16][64][8] (include/preworld_hip.h).
+    The transform U = G w G^T along d, h, w is done in float64 and rounded once."""
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3, 3) or Cin % 32:
+        raise _lib.PreworldHipError('pack_conv_weight_wino expects (Cout, 32k, 3, 3, 3)')
+    if cout_total is None:
+        cout_total = (Cout + 31) // 32 * 32
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    U = torch.einsum('ia,jb,kc,oeabc->oeijk', G, G, G, w.double())           # (Cout, Cin, 4, 4, 4)
+    Up = U.new_zeros(cout_total, Cin, 64)
+    Up[:Cout] = U.reshape(Cout, Cin, 64)
+    n16, nch = cout_total // 16, Cin // 32
+    Up = Up.view(n16, 16, nch, 4, 8, 64)                   # (n16, j, ch, g, s, p)
+    Up = Up.permute(2, 5, 0, 3, 1, 4).contiguous()         # (ch, p, n16, g, j, s)
+    return Up.view(nch, 64, n16, 64, 8).float().contiguous()
+
+
+def pack_conv_weights_wino_concat(ws):
+    """conv1 + downsample of a BasicBlock3D over the same input: each padded to a multiple of 32 columns."""
+    return torch.cat([pack_conv_weight_wino(w) for w in ws], dim=2).contiguous()
+
+
+def conv3d_wino(x, uwpk, scale=None, bias=None, residual=None, cout0=None, cout1=0, relu0=False, relu1=False,
+                out0=None, out1=None):
+    """3x3x3 stride-1 pad-1 conv by Winograd F(2x2x2,3x3x3) (pw_conv3d_wino): same contract as
+    conv3d_ndhwc(ksize=3, stride=1) with weights from pack_conv_weight_wino."""
+    B, D, H, W, Cin = x.shape
+    nch, npts, n16 = uwpk.shape[:3]
+    cout_total = n16 * 16
+    if npts != 64 or nch * 32 != Cin or cout_total % 32:
+        raise _lib.PreworldHipError('packed Winograd weight does not match the input')
+    if cout0 is None:
+        cout0 = cout_total
+    y0 = out0 if out0 is not None else torch.empty(B, D, H, W, cout0, device=x.device, dtype=_f32)
+    ld0 = _row_stride(y0, (B, D, H, W, cout0), 'y0')
+    y1, ld1 = None, 0
+    if cout1:
+        y1 = out1 if out1 is not None else torch.empty(B, D, H, W, cout1, device=x.device, dtype=_f32)
+        ld1 = _row_stride(y1, (B, D, H, W, cout1), 'y1')
+    if residual is not None and _row_stride(residual, (B, D, H, W, cout0), 'residual') != ld0:
+        raise _lib.PreworldHipError('residual must have the same row stride as y0')
+    if scale is not None and scale.numel() != cout_total:
+        raise _lib.PreworldHipError('scale must have cout_total=%d entries' % cout_total)
+    if bias is not None and bias.numel() != cout_total:
+        raise _lib.PreworldHipError('bias must have cout_total=%d entries' % cout_total)
+    _lib.call('pw_conv3d_wino', _chk(x, _f32, 'x'), _chk(uwpk, _f32, 'uwpk'), _p(scale), _p(bias), _p(residual),
+              _p(y0), _p(y1), B, D, H, W, Cin, cout_total, cout0, cout1, ld0, ld1, int(relu0), int(relu1), _stream())
+    return (y0, y1) if cout1 else y0
+
+
 def fpn3d_fuse(x8, wpk8, y16, y32, scale, bias, relu=True, out=None):
     """LSSFPN3D tail: ReLU(BN(W8 x8 + up2(y16) + up4(y32))) -- lss_fpn.py:132-148."""
     B, D, H, W, C8 = x8.shape
