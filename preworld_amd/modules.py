@@ -181,6 +181,17 @@ def from_channels_last_3d(y):
     return y.permute(0, 4, 1, 2, 3)
 
 
+def _use_wino(x_cl, cout_total, ksize, stride):
+    """3x3x3 stride-1 convs with <= 64 packed output columns on grids with >= 128 tiles run on the Winograd
+    F(2x2x2,3x3x3) kernel (pw_conv3d_wino: 3.4x fewer multiplies, 1.3-1.6x faster than the direct MFMA
+    kernels at these shapes); PW_CONV_WINO=0 keeps everything on the direct kernels."""
+    import os
+    if ksize != 3 or stride != 1 or cout_total not in (32, 64) or os.environ.get('PW_CONV_WINO', '1') == '0':
+        return False
+    B, D, H, W, _ = x_cl.shape
+    return B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) >= 128
+
+
 class _PackedCache:
     """Packed/folded weights are derived data: rebuilt lazily when parameters change."""
 
@@ -221,6 +232,7 @@ class ConvModule3d(nn.Module):
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
         assert padding == kernel_size // 2
         self._cache = _PackedCache()
+        self._wcache = _PackedCache()
 
     def folded(self):
         """(packed weight, scale[cout32], bias[cout32]) for the HIP conv."""
@@ -248,6 +260,10 @@ class ConvModule3d(nn.Module):
         """channels-last in -> channels-last out"""
         self._check_eval()
         wpk, sc, bi = self.folded()
+        if algo == 0 and _use_wino(x_cl, sc.numel(), self.kernel_size, self.stride):
+            uw = self._wcache.get([self.conv.weight], lambda: ops.pack_conv_weight_wino(self.conv.weight))
+            return ops.conv3d_wino(x_cl, uw, sc, bi, residual=residual, cout0=self.out_channels,
+                                   relu0=self.with_activation)
         return ops.conv3d_ndhwc(x_cl, wpk, sc, bi, residual=residual, cout0=self.out_channels,
                                 ksize=self.kernel_size, stride=self.stride,
                                 relu0=self.with_activation, algo=algo)
@@ -286,9 +302,17 @@ class BasicBlock3D(nn.Module):
                 return (torch.cat([w1, wd], dim=2).contiguous(), torch.cat([s1, sd]).contiguous(),
                         torch.cat([b1, bd]).contiguous())
             wpk, sc, bi = self._cache.get(params, build)
-            y, identity = ops.conv3d_ndhwc(x, wpk, sc, bi, cout0=c1.out_channels,
-                                           cout1=ds.out_channels, ksize=3, stride=c1.stride,
-                                           relu0=True, relu1=False, out1=out)
+            if _use_wino(x, sc.numel(), 3, c1.stride):
+                if not hasattr(self, '_wcache'):
+                    self._wcache = _PackedCache()
+                uw = self._wcache.get([c1.conv.weight, ds.conv.weight],
+                                      lambda: ops.pack_conv_weights_wino_concat([c1.conv.weight, ds.conv.weight]))
+                y, identity = ops.conv3d_wino(x, uw, sc, bi, cout0=c1.out_channels, cout1=ds.out_channels,
+                                              relu0=True, relu1=False, out1=out)
+            else:
+                y, identity = ops.conv3d_ndhwc(x, wpk, sc, bi, cout0=c1.out_channels,
+                                               cout1=ds.out_channels, ksize=3, stride=c1.stride,
+                                               relu0=True, relu1=False, out1=out)
         else:
             identity = x
             y = c1.forward_cl(x)
@@ -296,6 +320,9 @@ class BasicBlock3D(nn.Module):
         if out is not None and ds is None:
             out.copy_(identity)
             identity = out
+        if _use_wino(y, s2.numel(), 3, 1):
+            uw2 = c2._wcache.get([c2.conv.weight], lambda: ops.pack_conv_weight_wino(c2.conv.weight))
+            return ops.conv3d_wino(y, uw2, s2, b2, residual=identity, cout0=c2.out_channels, relu0=True, out0=out)
         return ops.conv3d_ndhwc(y, w2, s2, b2, residual=identity, cout0=c2.out_channels, ksize=3,
                                 stride=1, relu0=True, out0=out)
 

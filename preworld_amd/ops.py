@@ -277,7 +277,12 @@ def _row_stride(t, shape, name):
     if not t.is_cuda or t.dtype != _f32 or tuple(t.shape) != tuple(shape):
         raise _lib.PreworldHipError('%s must be a float32 device tensor of shape %s' % (name, tuple(shape)))
     B, Do, Ho, Wo, c = shape
-    ld = t.stride(3)
+    ld, below = c, 1                      # the stride of a size-1 axis is arbitrary: take ld from the innermost axis > 1
+    for i in (3, 2, 1, 0):
+        if shape[i] > 1:
+            ld = t.stride(i) // below if t.stride(i) % below == 0 else -1
+            break
+        below *= shape[i]
     want = (Do * Ho * Wo * ld, Ho * Wo * ld, Wo * ld, ld, 1)
     ok = ld >= c and all(t.stride(i) == want[i] or t.shape[i] == 1 for i in range(5))
     if not ok:

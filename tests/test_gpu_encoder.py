@@ -137,6 +137,91 @@ def test_conv3d_channel_split_gather(shape):
     np.testing.assert_array_equal(y1.cpu().numpy(), y2.cpu().numpy())
 
 
+WINO_TOL = dict(rtol=3e-4, atol=3e-4)      # transform-domain products: |err| ~ 2e-5 on O(1) outputs
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 4, 8, 8), (2, 32, 5, 11, 13), (1, 64, 3, 9, 17), (1, 32, 16, 40, 48),
+                                   (1, 64, 1, 1, 1), (1, 32, 2, 7, 3)])
+@pytest.mark.parametrize('cout', [32, 64, 16])
+def test_conv3d_wino_vs_oracle(shape, cout):
+    """pw_conv3d_wino (Winograd F(2x2x2,3x3x3)) against the direct-form oracle conv + folded BN + residual +
+    ReLU, on whole tiles, ragged edges in every axis and grids smaller than one tile."""
+    rs = np.random.RandomState(hash((shape, cout)) % 2 ** 31)
+    x = rs.standard_normal(shape).astype(np.float32)
+    w = _rand_conv(rs, cout, shape[1], 3)
+    scale = (rs.rand(cout) + 0.5).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32)
+    res = rs.standard_normal((shape[0], cout) + shape[2:]).astype(np.float32)
+    want = O.conv3d(x, w, None, 1, 1) * scale[None, :, None, None, None] + bias[None, :, None, None, None]
+    want = np.maximum(want + res, 0)
+    got = ops.conv3d_wino(cl(x), ops.pack_conv_weight_wino(T(w)), ops._pad32(T(scale), 1.0), ops._pad32(T(bias), 0.0),
+                          residual=cl(res), cout0=cout, relu0=True)
+    np.testing.assert_allclose(ncdhw(got), want, **WINO_TOL)
+    again = ops.conv3d_wino(cl(x), ops.pack_conv_weight_wino(T(w)), ops._pad32(T(scale), 1.0), ops._pad32(T(bias), 0.0),
+                            residual=cl(res), cout0=cout, relu0=True)
+    assert torch.equal(got, again)           # no atomics, fixed summation order
+
+
+def test_conv3d_wino_two_outputs_and_channel_slices():
+    """The BasicBlock3D forms: conv1+downsample in one launch (y0 ReLU, y1 not), outputs written into
+    channel slices of wider buffers, residual added in place -- same contract as conv3d_ndhwc."""
+    rs = np.random.RandomState(5)
+    B, D, H, W = 1, 6, 21, 19
+    x = T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32))
+    w = [T(_rand_conv(rs, 32, 32, 3)) for _ in range(2)]
+    sc = T(rs.uniform(0.5, 1.5, 64).astype(np.float32)); bi = T(rs.standard_normal(64).astype(np.float32))
+    res = T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32))
+    d0, d1 = ops.conv3d_ndhwc(x, ops.pack_conv_weights_concat(w), sc, bi, cout0=32, cout1=32, ksize=3, relu0=True, algo=1)
+    uw2 = ops.pack_conv_weights_wino_concat(w)
+    y0, y1 = ops.conv3d_wino(x, uw2, sc, bi, cout0=32, cout1=32, relu0=True, relu1=False)
+    np.testing.assert_allclose(y0.cpu().numpy(), d0.cpu().numpy(), **WINO_TOL)
+    np.testing.assert_allclose(y1.cpu().numpy(), d1.cpu().numpy(), **WINO_TOL)
+    assert float(y1.min()) < 0 <= float(y0.min())
+    buf = torch.full((B, D, H, W, 96), 7.0, device=DEV)
+    s0, s1 = ops.conv3d_wino(x, uw2, sc, bi, cout0=32, cout1=32, relu0=True, out0=buf[..., 0:32], out1=buf[..., 64:96])
+    assert s0.data_ptr() == buf.data_ptr()
+    np.testing.assert_array_equal(buf[..., 0:32].cpu().numpy(), y0.cpu().numpy())
+    np.testing.assert_array_equal(buf[..., 64:96].cpu().numpy(), y1.cpu().numpy())
+    assert bool((buf[..., 32:64] == 7.0).all())
+    uw1 = ops.pack_conv_weight_wino(w[0])
+    dense = ops.conv3d_wino(x, uw1, sc[:32].contiguous(), bi[:32].contiguous(), residual=res, relu0=True)
+    buf2 = torch.full((B, D, H, W, 64), -3.0, device=DEV)
+    buf2[..., 32:64] = res
+    ops.conv3d_wino(x, uw1, sc[:32].contiguous(), bi[:32].contiguous(), residual=buf2[..., 32:64], relu0=True,
+                    out0=buf2[..., 32:64])
+    np.testing.assert_array_equal(buf2[..., 32:64].cpu().numpy(), dense.cpu().numpy())
+    assert bool((buf2[..., 0:32] == -3.0).all())
+    with pytest.raises(Exception):
+        ops.conv3d_wino(x, uw1, residual=res, out0=buf2[..., 32:64])           # residual stride != y0 stride
+    with pytest.raises(Exception):
+        ops.conv3d_wino(x, ops.pack_conv_weight_wino(T(_rand_conv(rs, 128, 32, 3))))   # > 64 columns: direct kernels only
+    with pytest.raises(Exception):
+        ops.conv3d_wino(x[..., :24].contiguous(), uw1)
+
+
+def test_module_dispatch_wino_matches_direct():
+    """modules._use_wino: the module stack on the Winograd kernel (default) and with PW_CONV_WINO=0 agree to
+    the conv tolerance, and the dispatch really changes the kernel (results differ in the last bits)."""
+    import os
+    rs = np.random.RandomState(9)
+    blk = M.BasicBlock3D(32, 32, stride=1, downsample=M.ConvModule3d(32, 32, 3, stride=1, padding=1, bias=False, norm_cfg=dict(type='BN3d'), act_cfg=None)).to(DEV).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.from_numpy(rs.standard_normal(tuple(p_.shape)).astype(np.float32) * 0.05).to(DEV))
+    x = T(rs.standard_normal((1, 16, 48, 56, 32)).astype(np.float32))
+    assert M._use_wino(x, 64, 3, 1) and not M._use_wino(x[:, :2, :8, :8], 64, 3, 1) and not M._use_wino(x, 128, 3, 1)
+    with torch.no_grad():
+        a = blk.forward_cl(x)
+        os.environ['PW_CONV_WINO'] = '0'
+        try:
+            assert not M._use_wino(x, 64, 3, 1)
+            b = blk.forward_cl(x)
+        finally:
+            os.environ.pop('PW_CONV_WINO', None)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), **WINO_TOL)
+    assert not torch.equal(a, b)
+
+
 def test_conv3d_bad_arguments_raise():
     x = torch.zeros(1, 4, 8, 8, 24, device=DEV)
     with pytest.raises(Exception):
