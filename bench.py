@@ -93,7 +93,7 @@ class KernelProbe:
         self._orig = {}
 
     def __enter__(self):
-        for name in ('conv3d_ndhwc', 'occ_head_fused', 'forecast_steps', 'fpn3d_fuse',
+        for name in ('conv3d_ndhwc', 'conv3d_wino', 'occ_head_fused', 'forecast_steps', 'fpn3d_fuse',
                      'bev_pool_dense', 'segment_sort'):
             self._orig[name] = getattr(ops, name)
             setattr(ops, name, self._wrap(name, self._orig[name]))
@@ -131,6 +131,15 @@ class KernelProbe:
                                            D, H, W, Cin, cout)
             byts = 4.0 * (x.numel() + nv * cout + wpk.numel())
             return label, 2.0 * nv * taps * Cin * cout, byts
+        if name == 'conv3d_wino':
+            # algorithmic work = the direct-form conv; the kernel itself executes 64 transform-
+            # domain products per 2x2x2 outputs instead of 8*27: x8/27 of these flops on the matrix pipe
+            x, uw = args[0], args[1]
+            B, D, H, W, Cin = x.shape
+            cout = (kw.get('cout0') or uw.shape[2] * 16) + (kw.get('cout1') or 0)
+            nv = B * D * H * W
+            label = 'conv3d_wino_mfma %dx%dx%d %d->%d' % (D, H, W, Cin, cout)
+            return label, 2.0 * nv * 27 * Cin * cout, 4.0 * (x.numel() + nv * cout + uw.numel())
         if name == 'occ_head_fused':
             x = args[0]
             nv = x.numel() // x.shape[-1]
@@ -271,6 +280,10 @@ def main():
                         algorithmic_bytes=int(a['bytes'] / a['launches']),
                         avg_launch_us=round(a['ms'] * 1e3 / a['launches'], 2),
                         launches_per_step=a['launches'] // 3,
+                        **(dict(executed_tflops=round(tf * 8 / 27, 2), executed_frac=round(tf * 8 / 27 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                note='Winograd F(2x2x2,3x3x3): achieved = direct-form (algorithmic) FLOPs / time, which can '
+                                     'exceed the matrix-pipe peak; executed_* counts the 8/27 of them the MFMAs really do')
+                           if label.startswith('conv3d_wino') else {}),
                         all_kernels={k: dict(us_per_step=round(v['ms'] * 1e3 / 3, 1),
                                              launches=v['launches'] // 3,
                                              tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),

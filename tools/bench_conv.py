@@ -13,6 +13,16 @@ x32 = torch.randn(1, 16, 200, 200, 32, device=dev)
 x64 = torch.randn(1, 16, 200, 200, 64, device=dev)
 w = lambda co, ci: ops.pack_conv_weight(torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05)
 w3232, w3264, w6464 = w(32, 32), w(64, 32), w(64, 64)
+if os.environ.get('WINO'):         # the Winograd kernel on the same three full-resolution shapes
+    uw = lambda co, ci: ops.pack_conv_weight_wino(torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05)
+    u3232, u3264, u6464 = uw(32, 32), uw(64, 32), uw(64, 64)
+    for _ in range(int(os.environ.get('N', 3))):
+        ops.conv3d_wino(x32, u3232)
+        ops.conv3d_wino(x32, u3264)
+        ops.conv3d_wino(x64, u6464)
+    torch.cuda.synchronize()
+    print('done')
+    sys.exit(0)
 for _ in range(int(os.environ.get('N', 3))):
     ops.conv3d_ndhwc(x32, w3232, ksize=3, algo=1)
     ops.conv3d_ndhwc(x32, w3264, ksize=3, algo=1)

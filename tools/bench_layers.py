@@ -1,5 +1,7 @@
 """Sustained timing of every conv layer shape of the C3 encoder (one line per shape).
-Environment knobs of the library (PW_CONV_PIPE, PW_CONV_WD) apply; LOOP_S seconds per shape."""
+Environment knobs of the library (PW_CONV_PIPE, PW_CONV_WD) apply; LOOP_S seconds per shape.
+ALGO=<0..3> picks the direct kernel (pw_conv3d_ndhwc's algo); ALGO=wino runs the Winograd kernel on the
+shapes it supports (k3 s1, <= 64 output columns) and skips the others.  TFLOP/s are direct-form FLOPs / time."""
 import json
 import os
 import sys
@@ -14,7 +16,7 @@ dev = 'cuda:0'
 torch.manual_seed(0)
 SHAPES = [  # (D, H, W, Cin, Cout, ksize, stride)
     (16, 200, 200, 32, 32, 3, 1), (16, 200, 200, 32, 64, 3, 1), (16, 200, 200, 64, 64, 3, 1),
-    (8, 100, 100, 64, 64, 3, 1), (8, 100, 100, 64, 128, 3, 1), (4, 50, 50, 128, 128, 3, 1), (4, 50, 50, 128, 256, 3, 1),
+    (8, 100, 100, 64, 64, 3, 1), (8, 100, 100, 64, 32, 3, 1), (8, 100, 100, 64, 128, 3, 1), (4, 50, 50, 128, 128, 3, 1), (4, 50, 50, 128, 256, 3, 1),
     (16, 200, 200, 32, 128, 3, 2), (8, 100, 100, 64, 256, 3, 2),
 ]
 only = os.environ.get('ONLY')
@@ -26,7 +28,13 @@ for (D, H, W, ci, co, ks, st) in SHAPES:
         continue
     x = torch.randn(1, D, H, W, ci, device=dev)
     w = ops.pack_conv_weight(torch.randn(co, ci, ks, ks, ks, device=dev) * 0.05)
-    fn = lambda: ops.conv3d_ndhwc(x, w, ksize=ks, stride=st, algo=int(os.environ.get('ALGO', 0)))
+    if os.environ.get('ALGO') == 'wino':
+        if ks != 3 or st != 1 or co > 64:
+            continue
+        uw = ops.pack_conv_weight_wino(torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05)
+        fn = lambda: ops.conv3d_wino(x, uw)
+    else:
+        fn = lambda: ops.conv3d_ndhwc(x, w, ksize=ks, stride=st, algo=int(os.environ.get('ALGO', 0)))
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
