@@ -1,5 +1,5 @@
 set -x
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/v6
 python bench.py > gpurun_out/v6/bench.json 2> gpurun_out/v6/bench.err
 python bench.py --in-flight 1 --no-cpu-baseline > gpurun_out/v6/bench_serial.json 2>> gpurun_out/v6/bench.err
