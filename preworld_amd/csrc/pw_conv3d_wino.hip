@@ -35,12 +35,28 @@ __device__ __forceinline__ int wino_row16(int t) {
   return (t & 8) | ((t & 2) << 1) | ((t & 1) << 1) | (((t >> 2) ^ (t >> 3)) & 1);
 }
 
+// Packed fp32 adds: the transforms are pure add/sub streams, v_pk_add_f32 does two per instruction (the
+// compiler packs fadd but not fsub, hence the neg_lo/neg_hi form by hand).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
+  const f32x2 lo = pk_sub(a.xy, b.xy), hi = pk_sub(a.zw, b.zw);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] applied to (x0..x3)
-__device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 f4add(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ void bt4(const float4& x0, const float4& x1, const float4& x2, const float4& x3,
-                                    float4& y0, float4& y1, float4& y2, float4& y3) {
-  y0 = f4sub(x0, x2); y1 = f4add(x1, x2); y2 = f4sub(x2, x1); y3 = f4sub(x1, x3);
+__device__ __forceinline__ void bt4(const f32x4& x0, const f32x4& x1, const f32x4& x2, const f32x4& x3,
+                                    f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) {
+  y0 = sub4(x0, x2); y1 = x1 + x2; y2 = sub4(x2, x1); y3 = sub4(x1, x3);
+}
+__device__ __forceinline__ f32x4 lds_read4(lds3_t base, unsigned off) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(base + off);
+}
+__device__ __forceinline__ void lds_write4(lds3_t base, unsigned off, const f32x4& v) {
+  *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(base + off) = v;
 }
 }  // namespace
 
@@ -49,15 +65,18 @@ __device__ __forceinline__ constexpr int at_sign(int o, int i) {
   return o == 0 ? (i < 3 ? 1 : 0) : (i == 0 ? 0 : (i == 1 ? 1 : -1));
 }
 
-template <int ID, int XI>     // chunk ID = i_d, XI = i_h*4 + i_w: add the fresh product M into the outputs it feeds
-__device__ __forceinline__ void wino_scatter(const f32x4& M, f32x4 (&Y)[8]) {
-  constexpr int ih = XI >> 2, iw = XI & 3;
+// Output transform of one row of points (i_d = ID, i_h = IH, i_w = 0..3): along w first
+// (t0 = M0 + M1 + M2, t1 = M1 - M2 - M3), then each t into the (o_d, o_h) outputs it feeds --
+// 8.5 adds per accumulator register and row instead of 13.5 for point-by-point scattering.
+template <int ID, int IH>
+__device__ __forceinline__ void wino_scatter_row(const f32x4 (&M)[4], f32x4 (&Y)[8]) {
+  const f32x4 s12 = M[1] + M[2], d12 = sub4(M[1], M[2]);
+  const f32x4 t[2] = {M[0] + s12, sub4(d12, M[3])};
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    const int sd = at_sign(o >> 2, ID), sh = at_sign((o >> 1) & 1, ih), sw = at_sign(o & 1, iw);
-    const int sg = sd * sh * sw;
-    if (sg > 0) Y[o] += M;
-    else if (sg < 0) Y[o] -= M;
+    const int sg = at_sign(o >> 2, ID) * at_sign((o >> 1) & 1, IH);
+    if (sg > 0) Y[o] = Y[o] + t[o & 1];
+    else if (sg < 0) Y[o] = sub4(Y[o], t[o & 1]);
   }
 }
 
@@ -69,96 +88,88 @@ struct WinoCtx {
   unsigned ustep;            // bytes between the weights of consecutive points
 };
 
-// Points are processed in PAIRS (two independent MFMA chains interleaved: a single 16x16x4 chain is
-// latency-bound), operands of the next pair are requested before the MFMAs, and the add/sub of a pair's
-// products into the outputs is deferred until the next pair's MFMAs have been issued.
-template <int XI>
-__device__ __forceinline__ void wino_load_pair(const WinoCtx& c, unsigned usoff, float4 (&aq)[2][2], float4 (&bq)[2][2]) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
+// Points are processed a ROW (4 points = 4 independent MFMA chains, interleaved) at a time; the operands
+// of the next row are requested before this row's MFMAs, and the output transform of a row's products is
+// deferred until the next row's MFMAs have been issued (it runs in their shadow).
+template <int IH>
+__device__ __forceinline__ void wino_load_row(const WinoCtx& c, unsigned usoff, f32x4 (&aq)[4][2], f32x4 (&bq)[4][2]) {
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const v4f v = *reinterpret_cast<const __attribute__((address_space(3))) v4f*>(
-          c.lds3 + c.a_addr[q] + (XI + k) * 4096);
-      aq[k][q] = make_float4(v[0], v[1], v[2], v[3]);
-      bq[k][q] = buf_load4(c.wr, c.lane_off + (unsigned)(q * 16), usoff + (unsigned)(XI + k) * c.ustep);
+      aq[k][q] = lds_read4(c.lds3, c.a_addr[q] + (unsigned)(IH * 4 + k) * 4096u);
+      const float4 w = buf_load4(c.wr, c.lane_off + (unsigned)(q * 16), usoff + (unsigned)(IH * 4 + k) * c.ustep);
+      bq[k][q] = f32x4{w.x, w.y, w.z, w.w};
     }
 }
 
-template <int ID, int XI>     // XI even: points XI, XI+1
-__device__ __forceinline__ void wino_pair(const WinoCtx& c, unsigned usoff, float4 (&ac)[2][2], float4 (&bc)[2][2],
-                                          float4 (&an)[2][2], float4 (&bn)[2][2], f32x4 (&Mp)[2], f32x4 (&Y)[8]) {
-  if constexpr (XI + 2 < 16) wino_load_pair<XI + 2>(c, usoff, an, bn);
+template <int ID, int IH>
+__device__ __forceinline__ void wino_row(const WinoCtx& c, unsigned usoff, f32x4 (&ac)[4][2], f32x4 (&bc)[4][2],
+                                         f32x4 (&an)[4][2], f32x4 (&bn)[4][2], f32x4 (&Mp)[4], f32x4 (&Y)[8]) {
+  if constexpr (IH + 1 < 4) wino_load_row<IH + 1>(c, usoff, an, bn);
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 M0 = {0.f, 0.f, 0.f, 0.f}, M1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 M[4];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float a0[4] = {ac[0][q].x, ac[0][q].y, ac[0][q].z, ac[0][q].w};
-    const float b0[4] = {bc[0][q].x, bc[0][q].y, bc[0][q].z, bc[0][q].w};
-    const float a1[4] = {ac[1][q].x, ac[1][q].y, ac[1][q].z, ac[1][q].w};
-    const float b1[4] = {bc[1][q].x, bc[1][q].y, bc[1][q].z, bc[1][q].w};
+  for (int k = 0; k < 4; ++k) M[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      M0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], M0, 0, 0, 0);
-      M1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], M1, 0, 0, 0);
-    }
-  }
-  if constexpr (XI >= 2) {                 // the previous pair's products, under this pair's MFMAs
-    wino_scatter<ID, XI - 2>(Mp[0], Y);
-    wino_scatter<ID, XI - 1>(Mp[1], Y);
-  }
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        M[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k][q][e], bc[k][q][e], M[k], 0, 0, 0);
+  if constexpr (IH >= 1) wino_scatter_row<ID, IH - 1>(Mp, Y);      // the previous row's products, under this row's MFMAs
   __builtin_amdgcn_sched_barrier(0);
-  Mp[0] = M0; Mp[1] = M1;
-  if constexpr (XI + 2 < 16) wino_pair<ID, XI + 2>(c, usoff, an, bn, ac, bc, Mp, Y);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) Mp[k] = M[k];
+  if constexpr (IH + 1 < 4) wino_row<ID, IH + 1>(c, usoff, an, bn, ac, bc, Mp, Y);
 }
 
 // d-transform row ID of this thread's tile: 16 (h, w) positions x one channel quad, then h and w transforms, -> V
 template <int ID>
-__device__ __forceinline__ void wino_transform_chunk(const char* ldsb, char* vb, unsigned r_base, unsigned v_base) {
+__device__ __forceinline__ void wino_transform_chunk(lds3_t lds3, unsigned r_base, unsigned v_base) {
   // B^T row ID: (plane A, plane B, sign of B): 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
   constexpr int pa = ID == 0 ? 0 : (ID == 2 ? 2 : 1);
   constexpr int pb = ID == 0 ? 2 : (ID == 1 ? 2 : (ID == 2 ? 1 : 3));
   constexpr bool plus = ID == 1;
   // one w-column at a time (8 reads -> 4 combined values -> h-transform): keeps the live set at the 16
   // h-transformed values + one column instead of two full 4x4 arrays
-  float4 y[4][4];
+  f32x4 y[4][4];
 #pragma unroll
   for (int ww = 0; ww < 4; ++ww) {
-    float4 x[4];
+    f32x4 x[4];
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh) {
-      const float4 A = *reinterpret_cast<const float4*>(ldsb + r_base + (unsigned)(((pa * TH + hh) * TW + ww) * 128));
-      const float4 B = *reinterpret_cast<const float4*>(ldsb + r_base + (unsigned)(((pb * TH + hh) * TW + ww) * 128));
-      x[hh] = plus ? f4add(A, B) : f4sub(A, B);
+      const f32x4 A = lds_read4(lds3, r_base + (unsigned)(((pa * TH + hh) * TW + ww) * 128));
+      const f32x4 B = lds_read4(lds3, r_base + (unsigned)(((pb * TH + hh) * TW + ww) * 128));
+      x[hh] = plus ? A + B : sub4(A, B);
     }
     bt4(x[0], x[1], x[2], x[3], y[0][ww], y[1][ww], y[2][ww], y[3][ww]);
   }
 #pragma unroll
   for (int ih = 0; ih < 4; ++ih) {
-    float4 z0, z1, z2, z3;
+    f32x4 z0, z1, z2, z3;
     bt4(y[ih][0], y[ih][1], y[ih][2], y[ih][3], z0, z1, z2, z3);
-    *reinterpret_cast<float4*>(vb + v_base + (unsigned)((ih * 4 + 0) * 4096)) = z0;
-    *reinterpret_cast<float4*>(vb + v_base + (unsigned)((ih * 4 + 1) * 4096)) = z1;
-    *reinterpret_cast<float4*>(vb + v_base + (unsigned)((ih * 4 + 2) * 4096)) = z2;
-    *reinterpret_cast<float4*>(vb + v_base + (unsigned)((ih * 4 + 3) * 4096)) = z3;
+    lds_write4(lds3, (unsigned)WINO_R_BYTES + v_base + (unsigned)((ih * 4 + 0) * 4096), z0);
+    lds_write4(lds3, (unsigned)WINO_R_BYTES + v_base + (unsigned)((ih * 4 + 1) * 4096), z1);
+    lds_write4(lds3, (unsigned)WINO_R_BYTES + v_base + (unsigned)((ih * 4 + 2) * 4096), z2);
+    lds_write4(lds3, (unsigned)WINO_R_BYTES + v_base + (unsigned)((ih * 4 + 3) * 4096), z3);
   }
 }
 
 template <int ID, int NG>
-__device__ __forceinline__ void wino_chunk(const WinoCtx& c, const char* ldsb, char* vb, unsigned r_base, unsigned v_base,
-                                           unsigned usoff, f32x4 (&Y)[NG][8]) {
-  wino_transform_chunk<ID>(ldsb, vb, r_base, v_base);
+__device__ __forceinline__ void wino_chunk(const WinoCtx& c, unsigned r_base, unsigned v_base, unsigned usoff,
+                                           f32x4 (&Y)[NG][8]) {
+  wino_transform_chunk<ID>(c.lds3, r_base, v_base);
   __syncthreads();                                   // V of this chunk complete
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {                  // the transformed tile serves every 32-cout group
-    float4 a0[2][2], a1[2][2], b0[2][2], b1[2][2];
-    f32x4 Mp[2];
+    f32x4 a0[4][2], a1[4][2], b0[4][2], b1[4][2];
+    f32x4 Mp[4];
     const unsigned us = usoff + (unsigned)ng * 4096u;            // 2 n16 blocks of 2048 B per 32-cout group
-    wino_load_pair<0>(c, us, a0, b0);
-    wino_pair<ID, 0>(c, us, a0, b0, a1, b1, Mp, Y[ng]);
-    wino_scatter<ID, 14>(Mp[0], Y[ng]);
-    wino_scatter<ID, 15>(Mp[1], Y[ng]);
+    wino_load_row<0>(c, us, a0, b0);
+    wino_row<ID, 0>(c, us, a0, b0, a1, b1, Mp, Y[ng]);
+    wino_scatter_row<ID, 3>(Mp, Y[ng]);
   }
   __syncthreads();                                   // everyone done reading V before the next chunk overwrites it
 }
@@ -176,74 +187,10 @@ __device__ __forceinline__ void wino_lane_offsets(const ConvArgs& a, int w0, int
   }
 }
 
-// One block per output tile, all 32-cout groups of the layer inside the block (the transformed tile is
-// reused by every group).  A persistent variant with the next tile's halo DMA issued early was tried
-// (dedicated DMA wave: starved by the MFMA waves; early issue from the compute waves: needs the chunk's 16
-// weight taps preloaded past the in-order vmcnt, 128 more live registers -> spills): 195 us for 32->32 but
-// far slower for two cout groups, so the halo load stays exposed (~15 % of a tile).
-template <int NG>    // 32-cout groups (cout_total = 32 NG)
-__global__ void __launch_bounds__(256, 1) k_conv3d_wino(ConvArgs a, int n16_total) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  const int mh = wave & 1, nh = wave >> 1;            // tile half (d-pair) and cout half of this wave
-  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-  const int tw_ = bid % a.tiles_w; bid /= a.tiles_w;
-  const int th_ = bid % a.tiles_h; bid /= a.tiles_h;
-  const int td_ = bid % a.tiles_d;
-  const int b = bid / a.tiles_d;
-  const int d0 = td_ * BD, h0 = th_ * BH, w0 = tw_ * BW;
-  const char* ldsb = reinterpret_cast<const char*>(lds);
-  char* vb = reinterpret_cast<char*>(lds) + WINO_R_BYTES;
-
-  // transform role: thread = (tile 0..31, channel quad 0..7)
-  const int tile = tid >> 3, quad = tid & 7;
-  const int ttd = tile >> 4, tth = (tile >> 2) & 3, ttw = tile & 3;
-  const unsigned r_base = (unsigned)((((2 * ttd) * TH + 2 * tth) * TW + 2 * ttw) * 128 + quad * 16);
-  const int t16 = tile & 15;
-  const unsigned v_base = (unsigned)(((ttd * 16 + wino_row16(t16)) * 8 + (quad ^ (t16 & 7))) * 16);
-
-  // GEMM role: lane = (tile l&15 of the wave's half, k-group l>>4)
-  WinoCtx c;
-  c.lds3 = (lds3_t)lds;
-  {
-    const int lt = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      c.a_addr[q] = (unsigned)WINO_R_BYTES + (unsigned)(((mh * 16 + wino_row16(lt)) * 8 + ((g * 2 + q) ^ (lt & 7))) * 16);
-  }
-  const int nchunk = a.Cin / KC;
-  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 64 * n16_total * 2048));
-  c.lane_off = (unsigned)lane * 32u;
-  c.ustep = (unsigned)n16_total * 2048u;               // bytes between the weights of consecutive points
-  const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
-  f32x4 Y[NG][8];
-#pragma unroll
-  for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-    for (int o = 0; o < 8; ++o) Y[ng][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  PipeDma dm;
-  wino_lane_offsets(a, w0, lane, dm);
-  dm.b = b; dm.d0 = d0; dm.h0 = h0; dm.wbase = w0 > 0 ? w0 - 1 : 0; dm.ldsbuf = 0; dm.live = true;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const unsigned ubase = (unsigned)(((ch * 64) * n16_total + nh) * 2048);
-    const unsigned ustep = c.ustep;
-    if (ch > 0) __syncthreads();
-    dm.ch = ch;
-    pipe_dma_row<0>(a, xr, c.lds3, dm, wave); pipe_dma_row<1>(a, xr, c.lds3, dm, wave); pipe_dma_row<2>(a, xr, c.lds3, dm, wave);
-    pipe_dma_row<3>(a, xr, c.lds3, dm, wave); pipe_dma_row<4>(a, xr, c.lds3, dm, wave); pipe_dma_row<5>(a, xr, c.lds3, dm, wave);
-    pipe_dma_row<6>(a, xr, c.lds3, dm, wave); pipe_dma_row<7>(a, xr, c.lds3, dm, wave); pipe_dma_row<8>(a, xr, c.lds3, dm, wave);
-    pipe_dma_row<9>(a, xr, c.lds3, dm, wave); pipe_dma_row<10>(a, xr, c.lds3, dm, wave); pipe_dma_row<11>(a, xr, c.lds3, dm, wave);
-    pipe_dma_row<12>(a, xr, c.lds3, dm, wave); pipe_dma_row<13>(a, xr, c.lds3, dm, wave); pipe_dma_row<14>(a, xr, c.lds3, dm, wave);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    // point index = i_d*16 + i_h*4 + i_w; weights of point p at ubase + p * n16_total * 2048
-    wino_chunk<0, NG>(c, ldsb, vb, r_base, v_base, ubase + 0u * 16u * ustep, Y);
-    wino_chunk<1, NG>(c, ldsb, vb, r_base, v_base, ubase + 16u * ustep, Y);
-    wino_chunk<2, NG>(c, ldsb, vb, r_base, v_base, ubase + 32u * ustep, Y);
-    wino_chunk<3, NG>(c, ldsb, vb, r_base, v_base, ubase + 48u * ustep, Y);
-  }
+// scale/bias, residual, ReLU and the two destinations for the wave's 16 tiles (d-pair mh) x 16 couts (half nh)
+template <int NG>
+__device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y)[NG][8], int b, int d0, int h0, int w0,
+                                              int mh, int nh, int lane) {
   // ---- epilogue: lane holds cout l&15 for tiles (l>>4)*4 + r of its half; output o = (od, oh, ow)
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
@@ -297,6 +244,303 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_wino(ConvArgs a, int n16_tota
   }   // ng
 }
 
+// One block per output tile, all 32-cout groups of the layer inside the block (the transformed tile is
+// reused by every group).  A persistent variant with the next tile's halo DMA issued early was tried
+// (dedicated DMA wave: starved by the MFMA waves; early issue from the compute waves: needs the chunk's 16
+// weight taps preloaded past the in-order vmcnt, 128 more live registers -> spills): 195 us for 32->32 but
+// far slower for two cout groups, so the halo load stays exposed (~15 % of a tile).
+template <int NG>    // 32-cout groups (cout_total = 32 NG)
+__global__ void __launch_bounds__(256, 1) k_conv3d_wino(ConvArgs a, int n16_total) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int mh = wave & 1, nh = wave >> 1;            // tile half (d-pair) and cout half of this wave
+  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int tw_ = bid % a.tiles_w; bid /= a.tiles_w;
+  const int th_ = bid % a.tiles_h; bid /= a.tiles_h;
+  const int td_ = bid % a.tiles_d;
+  const int b = bid / a.tiles_d;
+  const int d0 = td_ * BD, h0 = th_ * BH, w0 = tw_ * BW;
+
+  // transform role: thread = (tile 0..31, channel quad 0..7)
+  const int tile = tid >> 3, quad = tid & 7;
+  const int ttd = tile >> 4, tth = (tile >> 2) & 3, ttw = tile & 3;
+  const unsigned r_base = (unsigned)((((2 * ttd) * TH + 2 * tth) * TW + 2 * ttw) * 128 + quad * 16);
+  const int t16 = tile & 15;
+  const unsigned v_base = (unsigned)(((ttd * 16 + wino_row16(t16)) * 8 + (quad ^ (t16 & 7))) * 16);
+
+  // GEMM role: lane = (tile l&15 of the wave's half, k-group l>>4)
+  WinoCtx c;
+  c.lds3 = (lds3_t)lds;
+  {
+    const int lt = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      c.a_addr[q] = (unsigned)WINO_R_BYTES + (unsigned)(((mh * 16 + wino_row16(lt)) * 8 + ((g * 2 + q) ^ (lt & 7))) * 16);
+  }
+  const int nchunk = a.Cin / KC;
+  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 64 * n16_total * 2048));
+  c.lane_off = (unsigned)lane * 32u;
+  c.ustep = (unsigned)n16_total * 2048u;               // bytes between the weights of consecutive points
+  const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
+  f32x4 Y[NG][8];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) Y[ng][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  PipeDma dm;
+  wino_lane_offsets(a, w0, lane, dm);
+  dm.b = b; dm.d0 = d0; dm.h0 = h0; dm.wbase = w0 > 0 ? w0 - 1 : 0; dm.ldsbuf = 0; dm.live = true;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const unsigned ubase = (unsigned)(((ch * 64) * n16_total + nh) * 2048);
+    const unsigned ustep = c.ustep;
+    if (ch > 0) __syncthreads();
+    dm.ch = ch;
+    pipe_dma_row<0>(a, xr, c.lds3, dm, wave); pipe_dma_row<1>(a, xr, c.lds3, dm, wave); pipe_dma_row<2>(a, xr, c.lds3, dm, wave);
+    pipe_dma_row<3>(a, xr, c.lds3, dm, wave); pipe_dma_row<4>(a, xr, c.lds3, dm, wave); pipe_dma_row<5>(a, xr, c.lds3, dm, wave);
+    pipe_dma_row<6>(a, xr, c.lds3, dm, wave); pipe_dma_row<7>(a, xr, c.lds3, dm, wave); pipe_dma_row<8>(a, xr, c.lds3, dm, wave);
+    pipe_dma_row<9>(a, xr, c.lds3, dm, wave); pipe_dma_row<10>(a, xr, c.lds3, dm, wave); pipe_dma_row<11>(a, xr, c.lds3, dm, wave);
+    pipe_dma_row<12>(a, xr, c.lds3, dm, wave); pipe_dma_row<13>(a, xr, c.lds3, dm, wave); pipe_dma_row<14>(a, xr, c.lds3, dm, wave);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    // point index = i_d*16 + i_h*4 + i_w; weights of point p at ubase + p * n16_total * 2048
+    wino_chunk<0, NG>(c, r_base, v_base, ubase + 0u * 16u * ustep, Y);
+    wino_chunk<1, NG>(c, r_base, v_base, ubase + 16u * ustep, Y);
+    wino_chunk<2, NG>(c, r_base, v_base, ubase + 32u * ustep, Y);
+    wino_chunk<3, NG>(c, r_base, v_base, ubase + 48u * ustep, Y);
+  }
+  wino_epilogue<NG>(a, Y, b, d0, h0, w0, mh, nh, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised persistent variant: 512 threads = 4 GEMM waves + 4 transform waves, one per SIMD each.
+// The kernel above runs its phases back to back in every wave (halo DMA -> transform -> MFMAs -> store)
+// with one wave per SIMD, so every LDS / L2 latency and every barrier skew is exposed: the matrix pipe is
+// busy 31-42 % of the time and 45 % of the wave cycles are s_waitcnt (profiles/r01_pmc_wino.md).  Here
+//   * the transform waves run ONE HALF-STEP AHEAD of the GEMM waves: V is two 32 KB buffers of 8 points
+//     (two i_h rows); while the GEMM waves do the MFMAs of half-step g from V[g & 1], the transform waves
+//     write half-step g + 1 into V[(g + 1) & 1]; one workgroup barrier per half-step;
+//   * the raw halo R is read only by the even half-steps (d-combine + h-transform of all four i_h rows, the
+//     second pair stays in registers), the last time in step 5 of a 32-channel chunk: the DMA of the next
+//     chunk's / next tile's halo is issued by the transform waves in step 6 and has landed by the barrier
+//     that ends it, so the halo load overlaps the MFMAs too, and the kernel is persistent over tiles;
+//   * the GEMM waves stream weight rows one row (4 points) ahead across half-steps, chunks and tiles.
+// Measured (16x200x200, sustained): 32->32 158 us (tile-per-block kernel 201), 32->64 263 (332), 64->64 ~485 (623).
+// With the transform switched off the GEMM waves alone take 129 us for 68 us of MFMA time, with the GEMM off the
+// transform waves take 76 us, neither: 25 us (first DMA, epilogue, barriers): what remains is the cost of the
+// operand loads and output-transform adds issued next to the MFMAs, not exposed latency.
+// s_setprio on either role changes nothing or costs 4 % (raised transform waves), so none is set.
+template <int ID>       // R -> y[i_h][w]: d-combine of the two planes of B^T row ID, then the h transform
+__device__ __forceinline__ void ws_transform_read(lds3_t lds3, unsigned r_base, f32x4 (&y)[4][4]) {
+  constexpr int pa = ID == 0 ? 0 : (ID == 2 ? 2 : 1);
+  constexpr int pb = ID == 0 ? 2 : (ID == 1 ? 2 : (ID == 2 ? 1 : 3));
+  constexpr bool plus = ID == 1;
+#pragma unroll
+  for (int ww = 0; ww < 4; ++ww) {
+    f32x4 A[4], B[4], x[4];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      A[hh] = lds_read4(lds3, r_base + (unsigned)(((pa * TH + hh) * TW + ww) * 128));
+      B[hh] = lds_read4(lds3, r_base + (unsigned)(((pb * TH + hh) * TW + ww) * 128));
+    }
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) x[hh] = plus ? A[hh] + B[hh] : sub4(A[hh], B[hh]);
+    bt4(x[0], x[1], x[2], x[3], y[0][ww], y[1][ww], y[2][ww], y[3][ww]);
+  }
+}
+
+template <int HH>       // w transform of rows i_h = 2 HH, 2 HH + 1 -> V[HH] (8 points)
+__device__ __forceinline__ void ws_transform_write(lds3_t lds3, unsigned v_base, const f32x4 (&y)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    f32x4 z0, z1, z2, z3;
+    bt4(y[2 * HH + r][0], y[2 * HH + r][1], y[2 * HH + r][2], y[2 * HH + r][3], z0, z1, z2, z3);
+    const unsigned o = (unsigned)WINO_R_BYTES + (unsigned)HH * 32768u + v_base + (unsigned)(r * 4) * 4096u;
+    lds_write4(lds3, o, z0);
+    lds_write4(lds3, o + 4096u, z1);
+    lds_write4(lds3, o + 8192u, z2);
+    lds_write4(lds3, o + 12288u, z3);
+  }
+}
+
+// flat row index R of a 32-channel chunk: R = ((ID * 2 + HH) * 2 + r) * NG + ng, i_h = 2 HH + r: the NG
+// cout groups of a row of points follow each other and share the row's A operands
+template <int R, int NG> struct WsRow {
+  static constexpr int H = R / (2 * NG), ID = H >> 1, HH = H & 1, ng = R % NG, r = (R / NG) & 1, IH = 2 * HH + r;
+  static constexpr bool first = R % (2 * NG) == 0, last = R % (2 * NG) == 2 * NG - 1;
+  static constexpr unsigned point = (unsigned)(ID * 16 + IH * 4);     // first point of the row
+  static constexpr unsigned a_off = (unsigned)HH * 32768u + (unsigned)(r * 4) * 4096u;
+};
+
+template <int R, int NG>
+__device__ __forceinline__ void ws_load_a(const WinoCtx& c, f32x4 (&aq)[4][2]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) aq[k][q] = lds_read4(c.lds3, c.a_addr[q] + WsRow<R, NG>::a_off + (unsigned)k * 4096u);
+}
+
+template <int R, int NG>
+__device__ __forceinline__ void ws_load_b(const WinoCtx& c, unsigned ubase, f32x4 (&bq)[4][2]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4 w = buf_load4(c.wr, c.lane_off + (unsigned)(q * 16),
+                                 ubase + (WsRow<R, NG>::point + (unsigned)k) * c.ustep + (unsigned)WsRow<R, NG>::ng * 4096u);
+      bq[k][q] = f32x4{w.x, w.y, w.z, w.w};
+    }
+}
+
+// rows R .. 16 NG - 1 of one chunk; bc holds row R's weights on entry; on exit of the last row bc/ac of the
+// CALLER hold the first row of the next chunk (ubase_next) again -- the row count is even, so the ping-pong
+// ends where it started
+template <int R, int NG>
+__device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsigned ubase_next, f32x4 (&ac)[4][2],
+                                        f32x4 (&bc)[4][2], f32x4 (&an)[4][2], f32x4 (&bn)[4][2], f32x4 (&Mp)[4],
+                                        f32x4 (&Y)[NG][8]) {
+  typedef WsRow<R, NG> W;
+  constexpr int TOTAL = 16 * NG;
+  // A operands: NG == 1: the first row of a half-step loads its own (the V buffer became valid at the barrier),
+  // the second row's are prefetched with its weights; NG == 2: loaded once per row of points (every second R)
+  // into a0 and used by both cout groups -- no prefetch, the registers go to the second accumulator set
+  f32x4 (&acur)[4][2] = NG == 1 ? ac : (W::ng == 0 ? ac : an);
+  if constexpr (NG == 1 ? W::first : W::ng == 0) ws_load_a<R, NG>(c, acur);
+  if constexpr (R + 1 < TOTAL) {
+    ws_load_b<R + 1, NG>(c, ubase, bn);
+    if constexpr (NG == 1 && !W::last) ws_load_a<R + 1, NG>(c, an);
+  } else {
+    ws_load_b<0, NG>(c, ubase_next, bn);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 M[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) M[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        M[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[k][q][e], bc[k][q][e], M[k], 0, 0, 0);
+  if constexpr (R >= 1) {
+    typedef WsRow<R - 1, NG> P;
+    wino_scatter_row<P::ID, P::IH>(Mp, Y[P::ng]);               // the previous row's products, under this row's MFMAs
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) Mp[k] = M[k];
+  if constexpr (W::last) __syncthreads();                       // end of the half-step
+  if constexpr (R + 1 < TOTAL) ws_rows<R + 1, NG>(c, ubase, ubase_next, an, bn, ac, bc, Mp, Y);
+}
+
+template <int NG>
+__global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs p, int n16_total) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int nslots = (int)gridDim.x >> 3;
+  const int per = (p.n_items + 7) >> 3;
+  const int it_end = min(((int)blockIdx.x & 7) * per + per, p.n_items);
+  int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (item >= it_end) return;
+  const int nchunk = a.Cin / KC;
+  const lds3_t lds3 = (lds3_t)lds;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ transform + DMA role
+    const int tw = wave - 4, tt = tid - 256;
+    const int tile = tt >> 3, quad = tt & 7;
+    const int ttd = tile >> 4, tth = (tile >> 2) & 3, ttw = tile & 3;
+    const unsigned r_base = (unsigned)((((2 * ttd) * TH + 2 * tth) * TW + 2 * ttw) * 128 + quad * 16);
+    const int t16 = tile & 15;
+    const unsigned v_base = (unsigned)(((ttd * 16 + wino_row16(t16)) * 8 + (quad ^ (t16 & 7))) * 16);
+    const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
+    PipeDma dm;
+    dm.ldsbuf = 0; dm.live = true;
+    auto aim = [&](int it, int ch) {
+      const PipeTile t = pipe_decode(a, p, it);
+      wino_lane_offsets(a, t.w0, lane, dm);
+      dm.b = t.b; dm.d0 = t.d0; dm.h0 = t.h0; dm.wbase = t.w0 > 0 ? t.w0 - 1 : 0; dm.ch = ch;
+    };
+    auto dma = [&]() {
+      pipe_dma_row<0>(a, xr, lds3, dm, tw); pipe_dma_row<1>(a, xr, lds3, dm, tw); pipe_dma_row<2>(a, xr, lds3, dm, tw);
+      pipe_dma_row<3>(a, xr, lds3, dm, tw); pipe_dma_row<4>(a, xr, lds3, dm, tw); pipe_dma_row<5>(a, xr, lds3, dm, tw);
+      pipe_dma_row<6>(a, xr, lds3, dm, tw); pipe_dma_row<7>(a, xr, lds3, dm, tw); pipe_dma_row<8>(a, xr, lds3, dm, tw);
+      pipe_dma_row<9>(a, xr, lds3, dm, tw); pipe_dma_row<10>(a, xr, lds3, dm, tw); pipe_dma_row<11>(a, xr, lds3, dm, tw);
+      pipe_dma_row<12>(a, xr, lds3, dm, tw); pipe_dma_row<13>(a, xr, lds3, dm, tw); pipe_dma_row<14>(a, xr, lds3, dm, tw);
+    };
+    f32x4 y[4][4];
+    aim(item, 0);
+    dma();
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();                                            // barrier A: R of the first chunk
+    ws_transform_read<0>(lds3, r_base, y);
+    ws_transform_write<0>(lds3, v_base, y);
+    __syncthreads();                                            // barrier B: half-step 0 in V[0]
+    for (; item < it_end; item += nslots) {
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const bool more_ch = ch + 1 < nchunk;
+        const bool has_next = more_ch || item + nslots < it_end;
+        ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 0
+        ws_transform_read<1>(lds3, r_base, y); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 1
+        ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 2
+        ws_transform_read<2>(lds3, r_base, y); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 3
+        ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 4
+        ws_transform_read<3>(lds3, r_base, y); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 5: last read of R
+        if (has_next) {                                                                                // step 6
+          aim(more_ch ? item : item + nslots, more_ch ? ch + 1 : 0);
+          dma();
+        }
+        ws_transform_write<1>(lds3, v_base, y);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (has_next) {                                                                                // step 7
+          ws_transform_read<0>(lds3, r_base, y);
+          ws_transform_write<0>(lds3, v_base, y);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- GEMM + output transform role
+  const int mh = wave & 1, nh = wave >> 1;            // tile half (d-pair) and cout half of this wave
+  WinoCtx c;
+  c.lds3 = lds3;
+  {
+    const int lt = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      c.a_addr[q] = (unsigned)WINO_R_BYTES + (unsigned)(((mh * 16 + wino_row16(lt)) * 8 + ((g * 2 + q) ^ (lt & 7))) * 16);
+  }
+  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 64 * n16_total * 2048));
+  c.lane_off = (unsigned)lane * 32u;
+  c.ustep = (unsigned)n16_total * 2048u;
+  const unsigned chunk_bytes = 64u * c.ustep;
+  f32x4 a0[4][2], a1[4][2], b0[4][2], b1[4][2], Mp[4];
+  ws_load_b<0, NG>(c, (unsigned)(nh * 2048), b0);
+  __syncthreads();                                              // barrier A
+  __syncthreads();                                              // barrier B
+  for (; item < it_end; item += nslots) {
+    f32x4 Y[NG][8];
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+      for (int o = 0; o < 8; ++o) Y[ng][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const unsigned ubase = (unsigned)ch * chunk_bytes + (unsigned)(nh * 2048);
+      const unsigned unext = (ch + 1 < nchunk ? (unsigned)(ch + 1) * chunk_bytes : 0u) + (unsigned)(nh * 2048);
+      ws_rows<0, NG>(c, ubase, unext, a0, b0, a1, b1, Mp, Y);
+      wino_scatter_row<3, 3>(Mp, Y[NG - 1]);
+    }
+    const PipeTile t = pipe_decode(a, p, item);
+    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane);
+  }
+}
+
 PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale, const float* bias,
                           const float* residual, float* y0, float* y1, int B, int D, int H, int W, int Cin,
                           int cout_total, int cout0, int cout1, int ld_y0, int ld_y1, int relu0, int relu1,
@@ -321,6 +565,27 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
   PW_CHECK_ARG(nblk < (1ll << 20), "pw_conv3d_wino: too many tiles");
   const int NG = cout_total / 32;
   PW_CHECK_ARG(NG == 1 || NG == 2, "pw_conv3d_wino: cout_total must be 32 or 64 (got %d)", cout_total);
+  {
+    // wave-specialised persistent kernel (default); PW_WINO_WS=0 keeps the tile-per-block kernel
+    const char* e = getenv("PW_WINO_WS");
+    if (!e || atoi(e)) {
+      PipeArgs p = {};
+      p.ngroups = 1; p.n_items = (int)nblk;
+      p.m_ng = magic_of(1); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
+      const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
+#define PW_WINO_WS(NGv)                                                                                     \
+  do {                                                                                                      \
+    static int once = set_lds_limit(k_conv3d_wino_ws<NGv>, WINO_LDS);                                        \
+    if (once) return once;                                                                                  \
+    hipLaunchKernelGGL(k_conv3d_wino_ws<NGv>, dim3(nb), dim3(512), WINO_LDS, pw_stream(stream), a, p,         \
+                       cout_total / 16);                                                                    \
+  } while (0)
+      if (NG == 1) PW_WINO_WS(1); else PW_WINO_WS(2);
+#undef PW_WINO_WS
+      PW_CHECK_LAUNCH();
+      return PW_OK;
+    }
+  }
 #define PW_WINO(NGv)                                                                                      \
   do {                                                                                                    \
     static int once = set_lds_limit(k_conv3d_wino<NGv>, WINO_LDS);                                         \

@@ -143,9 +143,12 @@ WINO_TOL = dict(rtol=3e-4, atol=3e-4)      # transform-domain products: |err| ~ 
 @pytest.mark.parametrize('shape', [(1, 32, 4, 8, 8), (2, 32, 5, 11, 13), (1, 64, 3, 9, 17), (1, 32, 16, 40, 48),
                                    (1, 64, 1, 1, 1), (1, 32, 2, 7, 3)])
 @pytest.mark.parametrize('cout', [32, 64, 16])
-def test_conv3d_wino_vs_oracle(shape, cout):
+@pytest.mark.parametrize('ws', ['1', '0'])
+def test_conv3d_wino_vs_oracle(shape, cout, ws, monkeypatch):
     """pw_conv3d_wino (Winograd F(2x2x2,3x3x3)) against the direct-form oracle conv + folded BN + residual +
-    ReLU, on whole tiles, ragged edges in every axis and grids smaller than one tile."""
+    ReLU, on whole tiles, ragged edges in every axis and grids smaller than one tile; both kernels: the
+    wave-specialised persistent one (default) and the tile-per-block one (PW_WINO_WS=0)."""
+    monkeypatch.setenv('PW_WINO_WS', ws)
     rs = np.random.RandomState(hash((shape, cout)) % 2 ** 31)
     x = rs.standard_normal(shape).astype(np.float32)
     w = _rand_conv(rs, cout, shape[1], 3)
@@ -160,6 +163,24 @@ def test_conv3d_wino_vs_oracle(shape, cout):
     again = ops.conv3d_wino(cl(x), ops.pack_conv_weight_wino(T(w)), ops._pad32(T(scale), 1.0), ops._pad32(T(bias), 0.0),
                             residual=cl(res), cout0=cout, relu0=True)
     assert torch.equal(got, again)           # no atomics, fixed summation order
+
+
+def test_conv3d_wino_persistent_many_tiles_per_block():
+    """More tiles than CUs x 1: every block of the persistent kernel walks several tiles (halo DMA of the next tile
+    issued under the current tile's MFMAs) and two 32-channel chunks; must equal the tile-per-block kernel bit for bit
+    (same arithmetic, same order)."""
+    import os
+    rs = np.random.RandomState(11)
+    x = T(rs.standard_normal((2, 16, 88, 104, 64)).astype(np.float32))           # 2*4*11*13 = 1144 tiles
+    uw = ops.pack_conv_weight_wino(T(_rand_conv(rs, 64, 64, 3)))
+    sc = T(rs.uniform(0.5, 1.5, 64).astype(np.float32)); bi = T(rs.standard_normal(64).astype(np.float32))
+    a = ops.conv3d_wino(x, uw, sc, bi, relu0=True)
+    os.environ['PW_WINO_WS'] = '0'
+    try:
+        b = ops.conv3d_wino(x, uw, sc, bi, relu0=True)
+    finally:
+        os.environ.pop('PW_WINO_WS', None)
+    assert torch.equal(a, b)
 
 
 def test_conv3d_wino_two_outputs_and_channel_slices():
