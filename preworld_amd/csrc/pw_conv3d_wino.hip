@@ -190,15 +190,15 @@ __device__ __forceinline__ void wino_lane_offsets(const ConvArgs& a, int w0, int
 // scale/bias, residual, ReLU and the two destinations for the wave's 16 tiles (d-pair mh) x 16 couts (half nh)
 template <int NG>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y)[NG][8], int b, int d0, int h0, int w0,
-                                              int mh, int nh, int lane) {
+                                              int mh, int nh, int lane, int ng0 = 0) {
   // ---- epilogue: lane holds cout l&15 for tiles (l>>4)*4 + r of its half; output o = (od, oh, ow)
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int n = ng * 32 + nh * 16 + (lane & 15);
+    const int n = (ng0 + ng) * 32 + nh * 16 + (lane & 15);
     const float sc = a.scale ? a.scale[n] : 1.f;
     const float bi = a.bias ? a.bias[n] : 0.f;
     const int tth_e = lane >> 4;
-    const int n0 = ng * 32 + nh * 16;                   // first packed column of this wave (uniform)
+    const int n0 = (ng0 + ng) * 32 + nh * 16;           // first packed column of this wave (uniform)
     const bool to_y0 = n0 < a.cout0;
     float* dst = to_y0 ? a.y0 : a.y1;
     const int ncols = to_y0 ? a.cout0 : a.cout1, ld = to_y0 ? a.ld0 : a.ld1;
@@ -521,7 +521,10 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
   c.ustep = (unsigned)n16_total * 2048u;
   const unsigned chunk_bytes = 64u * c.ustep;
   f32x4 a0[4][2], a1[4][2], b0[4][2], b1[4][2], Mp[4];
-  ws_load_b<0, NG>(c, (unsigned)(nh * 2048), b0);
+  // work item = (tile, group of NG x 32 couts); the group's weights start (group * 2 NG + nh) n16-blocks in
+  PipeTile t = pipe_decode(a, p, item);
+  unsigned gbase = (unsigned)((t.ng * 2 * NG + nh) * 2048);
+  ws_load_b<0, NG>(c, gbase, b0);
   __syncthreads();                                              // barrier A
   __syncthreads();                                              // barrier B
   for (; item < it_end; item += nslots) {
@@ -530,14 +533,16 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
     for (int ng = 0; ng < NG; ++ng)
 #pragma unroll
       for (int o = 0; o < 8; ++o) Y[ng][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const PipeTile tn = pipe_decode(a, p, item + nslots < it_end ? item + nslots : item);
+    const unsigned gnext = (unsigned)((tn.ng * 2 * NG + nh) * 2048);
     for (int ch = 0; ch < nchunk; ++ch) {
-      const unsigned ubase = (unsigned)ch * chunk_bytes + (unsigned)(nh * 2048);
-      const unsigned unext = (ch + 1 < nchunk ? (unsigned)(ch + 1) * chunk_bytes : 0u) + (unsigned)(nh * 2048);
+      const unsigned ubase = (unsigned)ch * chunk_bytes + gbase;
+      const unsigned unext = ch + 1 < nchunk ? (unsigned)(ch + 1) * chunk_bytes + gbase : gnext;
       ws_rows<0, NG>(c, ubase, unext, a0, b0, a1, b1, Mp, Y);
       wino_scatter_row<3, 3>(Mp, Y[NG - 1]);
     }
-    const PipeTile t = pipe_decode(a, p, item);
-    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane);
+    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane, t.ng * NG);
+    t = tn; gbase = gnext;
   }
 }
 
@@ -563,16 +568,20 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
                "pw_conv3d_wino: tensors must be < 4 GiB (32-bit buffer addressing)");
   const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
   PW_CHECK_ARG(nblk < (1ll << 20), "pw_conv3d_wino: too many tiles");
-  const int NG = cout_total / 32;
-  PW_CHECK_ARG(NG == 1 || NG == 2, "pw_conv3d_wino: cout_total must be 32 or 64 (got %d)", cout_total);
   {
-    // wave-specialised persistent kernel (default); PW_WINO_WS=0 keeps the tile-per-block kernel
+    // wave-specialised persistent kernel (default); PW_WINO_WS=0 keeps the tile-per-block kernel (<= 64 columns).
+    // Work item = (tile, group of NG x 32 output columns).  NG = 2 halves the input-transform work per output but
+    // halves the item count: taken when that still leaves >= 2 items per CU (PW_WINO_NG overrides).
     const char* e = getenv("PW_WINO_WS");
     if (!e || atoi(e)) {
-      PipeArgs p = {};
-      p.ngroups = 1; p.n_items = (int)nblk;
-      p.m_ng = magic_of(1); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
       const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
+      int NG = (cout_total % 64 == 0 && nblk * (cout_total / 64) >= 2ll * nb) ? 2 : 1;
+      if (const char* g = getenv("PW_WINO_NG")) NG = (atoi(g) == 2 && cout_total % 64 == 0) ? 2 : 1;
+      PipeArgs p = {};
+      p.ngroups = cout_total / (32 * NG);
+      PW_CHECK_ARG(nblk * p.ngroups < (1ll << 20), "pw_conv3d_wino: too many work items");
+      p.n_items = (int)nblk * p.ngroups;
+      p.m_ng = magic_of(p.ngroups); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
 #define PW_WINO_WS(NGv)                                                                                     \
   do {                                                                                                      \
     static int once = set_lds_limit(k_conv3d_wino_ws<NGv>, WINO_LDS);                                        \
@@ -586,6 +595,8 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
       return PW_OK;
     }
   }
+  const int NG = cout_total / 32;
+  PW_CHECK_ARG(NG == 1 || NG == 2, "pw_conv3d_wino: the tile-per-block kernel takes cout_total 32 or 64 (got %d)", cout_total);
 #define PW_WINO(NGv)                                                                                      \
   do {                                                                                                    \
     static int once = set_lds_limit(k_conv3d_wino<NGv>, WINO_LDS);                                         \

@@ -182,14 +182,14 @@ def from_channels_last_3d(y):
 
 
 def _use_wino(x_cl, cout_total, ksize, stride):
-    """3x3x3 stride-1 convs with <= 64 packed output columns on grids with >= 128 tiles run on the Winograd
-    F(2x2x2,3x3x3) kernel (pw_conv3d_wino: 3.4x fewer multiplies, 1.3-1.6x faster than the direct MFMA
-    kernels at these shapes); PW_CONV_WINO=0 keeps everything on the direct kernels."""
+    """3x3x3 stride-1 convs whose (4x8x8 tile, 32-column group) work items number >= 128 run on the Winograd
+    F(2x2x2,3x3x3) kernel (pw_conv3d_wino: 3.4x fewer multiplies, 1.7-2.2x faster than the direct MFMA
+    kernels at the C3 shapes); PW_CONV_WINO=0 keeps everything on the direct kernels."""
     import os
-    if ksize != 3 or stride != 1 or cout_total not in (32, 64) or os.environ.get('PW_CONV_WINO', '1') == '0':
+    if ksize != 3 or stride != 1 or cout_total % 32 or os.environ.get('PW_CONV_WINO', '1') == '0':
         return False
     B, D, H, W, _ = x_cl.shape
-    return B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) >= 128
+    return B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) * (cout_total // 32) >= 128
 
 
 class _PackedCache:

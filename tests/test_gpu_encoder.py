@@ -183,7 +183,24 @@ def test_conv3d_wino_persistent_many_tiles_per_block():
     assert torch.equal(a, b)
 
 
-def test_conv3d_wino_two_outputs_and_channel_slices():
+@pytest.mark.parametrize('shape', [(1, 4, 50, 50, 128, 128), (1, 8, 20, 28, 64, 96), (2, 5, 9, 11, 32, 160)])
+@pytest.mark.parametrize('ng', ['1', '2'])
+def test_conv3d_wino_cout_groups(shape, ng, monkeypatch):
+    """More than 64 output columns: work items = (tile, group of 32 or 64 columns) of the persistent kernel, residual
+    and ReLU on every group, against the direct gather kernel."""
+    monkeypatch.setenv('PW_WINO_NG', ng)
+    B, D, H, W, ci, co = shape
+    rs = np.random.RandomState(13)
+    x = T(rs.standard_normal((B, D, H, W, ci)).astype(np.float32))
+    w = T(_rand_conv(rs, co, ci, 3))
+    sc = T(rs.uniform(0.5, 1.5, co).astype(np.float32)); bi = T(rs.standard_normal(co).astype(np.float32))
+    res = T(rs.standard_normal((B, D, H, W, co)).astype(np.float32))
+    ref = ops.conv3d_ndhwc(x, ops.pack_conv_weight(w), sc, bi, residual=res, cout0=co, ksize=3, relu0=True, algo=2)
+    got = ops.conv3d_wino(x, ops.pack_conv_weight_wino(w), sc, bi, residual=res, cout0=co, relu0=True)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), **WINO_TOL)
+
+
+def test_conv3d_wino_two_outputs_and_channel_slices(monkeypatch):
     """The BasicBlock3D forms: conv1+downsample in one launch (y0 ReLU, y1 not), outputs written into
     channel slices of wider buffers, residual added in place -- same contract as conv3d_ndhwc."""
     rs = np.random.RandomState(5)
@@ -214,8 +231,10 @@ def test_conv3d_wino_two_outputs_and_channel_slices():
     assert bool((buf2[..., 0:32] == -3.0).all())
     with pytest.raises(Exception):
         ops.conv3d_wino(x, uw1, residual=res, out0=buf2[..., 32:64])           # residual stride != y0 stride
+    monkeypatch.setenv('PW_WINO_WS', '0')
     with pytest.raises(Exception):
-        ops.conv3d_wino(x, ops.pack_conv_weight_wino(T(_rand_conv(rs, 128, 32, 3))))   # > 64 columns: direct kernels only
+        ops.conv3d_wino(x, ops.pack_conv_weight_wino(T(_rand_conv(rs, 128, 32, 3))))   # > 64 columns: persistent kernel only
+    monkeypatch.delenv('PW_WINO_WS')
     with pytest.raises(Exception):
         ops.conv3d_wino(x[..., :24].contiguous(), uw1)
 
@@ -230,7 +249,7 @@ def test_module_dispatch_wino_matches_direct():
         for p_ in blk.parameters():
             p_.copy_(torch.from_numpy(rs.standard_normal(tuple(p_.shape)).astype(np.float32) * 0.05).to(DEV))
     x = T(rs.standard_normal((1, 16, 48, 56, 32)).astype(np.float32))
-    assert M._use_wino(x, 64, 3, 1) and not M._use_wino(x[:, :2, :8, :8], 64, 3, 1) and not M._use_wino(x, 128, 3, 1)
+    assert M._use_wino(x, 64, 3, 1) and not M._use_wino(x[:, :2, :8, :8], 64, 3, 1) and M._use_wino(x, 128, 3, 1) and not M._use_wino(x, 48, 3, 1)
     with torch.no_grad():
         a = blk.forward_cl(x)
         os.environ['PW_CONV_WINO'] = '0'

@@ -29,7 +29,7 @@ for (D, H, W, ci, co, ks, st) in SHAPES:
     x = torch.randn(1, D, H, W, ci, device=dev)
     w = ops.pack_conv_weight(torch.randn(co, ci, ks, ks, ks, device=dev) * 0.05)
     if os.environ.get('ALGO') == 'wino':
-        if ks != 3 or st != 1 or co > 64:
+        if ks != 3 or st != 1:
             continue
         uw = ops.pack_conv_weight_wino(torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05)
         fn = lambda: ops.conv3d_wino(x, uw)
