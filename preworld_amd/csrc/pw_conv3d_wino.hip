@@ -20,73 +20,7 @@
 //     8 v_mfma_f32_16x16x4_f32 into a fresh accumulator, which is then added/subtracted into the (at most
 //     8) outputs it contributes to -- 8 x 4 accumulator registers per lane hold the whole output tile;
 //   * epilogue = the direct kernels' (scale/bias, residual, ReLU, two destinations, row stride).
-#include "pw_conv3d_common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-namespace {
-constexpr int WINO_R_BYTES = TV * KC * 4;            // 76800: raw halo
-constexpr int WINO_V_BYTES = 16 * 32 * KC * 4;       // 65536: 16 points x 32 tiles x 32 ch
-constexpr int WINO_LDS = WINO_R_BYTES + WINO_V_BYTES;
-
-// LDS row of tile t16 (0..15) inside a 16-tile half: bit0 = t2 ^ t3 so that the two ds_read_b128 lane
-// groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each touch 16 distinct 16-byte slots of a 256-byte bank row
-__device__ __forceinline__ int wino_row16(int t) {
-  return (t & 8) | ((t & 2) << 1) | ((t & 1) << 1) | (((t >> 2) ^ (t >> 3)) & 1);
-}
-
-// Packed fp32 adds: the transforms are pure add/sub streams, v_pk_add_f32 does two per instruction (the
-// compiler packs fadd but not fsub, hence the neg_lo/neg_hi form by hand).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
-  const f32x2 lo = pk_sub(a.xy, b.xy), hi = pk_sub(a.zw, b.zw);
-  return f32x4{lo.x, lo.y, hi.x, hi.y};
-}
-// B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] applied to (x0..x3)
-__device__ __forceinline__ void bt4(const f32x4& x0, const f32x4& x1, const f32x4& x2, const f32x4& x3,
-                                    f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) {
-  y0 = sub4(x0, x2); y1 = x1 + x2; y2 = sub4(x2, x1); y3 = sub4(x1, x3);
-}
-__device__ __forceinline__ f32x4 lds_read4(lds3_t base, unsigned off) {
-  return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(base + off);
-}
-__device__ __forceinline__ void lds_write4(lds3_t base, unsigned off, const f32x4& v) {
-  *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(base + off) = v;
-}
-}  // namespace
-
-// A^T = [[1,1,1,0],[0,1,-1,-1]]: sign of point index i (0..3) in output o (0..1), 0 = no contribution
-__device__ __forceinline__ constexpr int at_sign(int o, int i) {
-  return o == 0 ? (i < 3 ? 1 : 0) : (i == 0 ? 0 : (i == 1 ? 1 : -1));
-}
-
-// Output transform of one row of points (i_d = ID, i_h = IH, i_w = 0..3): along w first
-// (t0 = M0 + M1 + M2, t1 = M1 - M2 - M3), then each t into the (o_d, o_h) outputs it feeds --
-// 8.5 adds per accumulator register and row instead of 13.5 for point-by-point scattering.
-template <int ID, int IH>
-__device__ __forceinline__ void wino_scatter_row(const f32x4 (&M)[4], f32x4 (&Y)[8]) {
-  const f32x4 s12 = M[1] + M[2], d12 = sub4(M[1], M[2]);
-  const f32x4 t[2] = {M[0] + s12, sub4(d12, M[3])};
-#pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    const int sg = at_sign(o >> 2, ID) * at_sign((o >> 1) & 1, IH);
-    if (sg > 0) Y[o] = Y[o] + t[o & 1];
-    else if (sg < 0) Y[o] = sub4(Y[o], t[o & 1]);
-  }
-}
-
-struct WinoCtx {
-  lds3_t lds3;
-  rsrc_t wr;
-  unsigned a_addr[2];        // LDS byte address of this lane's A fragment in point 0 of V, q = 0, 1
-  unsigned lane_off;         // lane * 32
-  unsigned ustep;            // bytes between the weights of consecutive points
-};
+#include "pw_wino_common.h"
 
 // Points are processed a ROW (4 points = 4 independent MFMA chains, interleaved) at a time; the operands
 // of the next row are requested before this row's MFMAs, and the output transform of a row's products is
@@ -172,19 +106,6 @@ __device__ __forceinline__ void wino_chunk(const WinoCtx& c, unsigned r_base, un
     wino_scatter_row<ID, 3>(Mp, Y[ng]);
   }
   __syncthreads();                                   // everyone done reading V before the next chunk overwrites it
-}
-
-// unswizzled halo offsets of a lane for a tile column position (the transform reads whole 128-byte rows)
-__device__ __forceinline__ void wino_lane_offsets(const ConvArgs& a, int w0, int lane, PipeDma& dm) {
-  const int shift = w0 == 0 ? 1 : 0;
-  {
-    const int ww = lane >> 3, slot = lane & 7;
-    dm.voff[0][0] = dm.voff[1][0] = (unsigned)(w0 - 1 + ww) < (unsigned)a.W ? (unsigned)((ww - shift) * a.Cin + slot * 4) * 4u : PIPE_OOB;
-  }
-  {
-    const int ww = 8 + (lane >> 5), dw = lane & 31;
-    dm.voff[0][1] = dm.voff[1][1] = (unsigned)(w0 - 1 + ww) < (unsigned)a.W ? (unsigned)((ww - shift) * a.Cin + dw) * 4u : PIPE_OOB;
-  }
 }
 
 // scale/bias, residual, ReLU and the two destinations for the wave's 16 tiles (d-pair mh) x 16 couts (half nh)
@@ -331,39 +252,6 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_wino(ConvArgs a, int n16_tota
 // transform waves take 76 us, neither: 25 us (first DMA, epilogue, barriers): what remains is the cost of the
 // operand loads and output-transform adds issued next to the MFMAs, not exposed latency.
 // s_setprio on either role changes nothing or costs 4 % (raised transform waves), so none is set.
-template <int ID>       // R -> y[i_h][w]: d-combine of the two planes of B^T row ID, then the h transform
-__device__ __forceinline__ void ws_transform_read(lds3_t lds3, unsigned r_base, f32x4 (&y)[4][4]) {
-  constexpr int pa = ID == 0 ? 0 : (ID == 2 ? 2 : 1);
-  constexpr int pb = ID == 0 ? 2 : (ID == 1 ? 2 : (ID == 2 ? 1 : 3));
-  constexpr bool plus = ID == 1;
-#pragma unroll
-  for (int ww = 0; ww < 4; ++ww) {
-    f32x4 A[4], B[4], x[4];
-#pragma unroll
-    for (int hh = 0; hh < 4; ++hh) {
-      A[hh] = lds_read4(lds3, r_base + (unsigned)(((pa * TH + hh) * TW + ww) * 128));
-      B[hh] = lds_read4(lds3, r_base + (unsigned)(((pb * TH + hh) * TW + ww) * 128));
-    }
-#pragma unroll
-    for (int hh = 0; hh < 4; ++hh) x[hh] = plus ? A[hh] + B[hh] : sub4(A[hh], B[hh]);
-    bt4(x[0], x[1], x[2], x[3], y[0][ww], y[1][ww], y[2][ww], y[3][ww]);
-  }
-}
-
-template <int HH>       // w transform of rows i_h = 2 HH, 2 HH + 1 -> V[HH] (8 points)
-__device__ __forceinline__ void ws_transform_write(lds3_t lds3, unsigned v_base, const f32x4 (&y)[4][4]) {
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    f32x4 z0, z1, z2, z3;
-    bt4(y[2 * HH + r][0], y[2 * HH + r][1], y[2 * HH + r][2], y[2 * HH + r][3], z0, z1, z2, z3);
-    const unsigned o = (unsigned)WINO_R_BYTES + (unsigned)HH * 32768u + v_base + (unsigned)(r * 4) * 4096u;
-    lds_write4(lds3, o, z0);
-    lds_write4(lds3, o + 4096u, z1);
-    lds_write4(lds3, o + 8192u, z2);
-    lds_write4(lds3, o + 12288u, z3);
-  }
-}
-
 // flat row index R of a 32-channel chunk: R = ((ID * 2 + HH) * 2 + r) * NG + ng, i_h = 2 HH + r: the NG
 // cout groups of a row of points follow each other and share the row's A operands
 template <int R, int NG> struct WsRow {
@@ -449,60 +337,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
   const lds3_t lds3 = (lds3_t)lds;
 
   if (wave >= 4) {
-    // ------------------------------------------------------------------ transform + DMA role
-    const int tw = wave - 4, tt = tid - 256;
-    const int tile = tt >> 3, quad = tt & 7;
-    const int ttd = tile >> 4, tth = (tile >> 2) & 3, ttw = tile & 3;
-    const unsigned r_base = (unsigned)((((2 * ttd) * TH + 2 * tth) * TW + 2 * ttw) * 128 + quad * 16);
-    const int t16 = tile & 15;
-    const unsigned v_base = (unsigned)(((ttd * 16 + wino_row16(t16)) * 8 + (quad ^ (t16 & 7))) * 16);
-    const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
-    PipeDma dm;
-    dm.ldsbuf = 0; dm.live = true;
-    auto aim = [&](int it, int ch) {
-      const PipeTile t = pipe_decode(a, p, it);
-      wino_lane_offsets(a, t.w0, lane, dm);
-      dm.b = t.b; dm.d0 = t.d0; dm.h0 = t.h0; dm.wbase = t.w0 > 0 ? t.w0 - 1 : 0; dm.ch = ch;
-    };
-    auto dma = [&]() {
-      pipe_dma_row<0>(a, xr, lds3, dm, tw); pipe_dma_row<1>(a, xr, lds3, dm, tw); pipe_dma_row<2>(a, xr, lds3, dm, tw);
-      pipe_dma_row<3>(a, xr, lds3, dm, tw); pipe_dma_row<4>(a, xr, lds3, dm, tw); pipe_dma_row<5>(a, xr, lds3, dm, tw);
-      pipe_dma_row<6>(a, xr, lds3, dm, tw); pipe_dma_row<7>(a, xr, lds3, dm, tw); pipe_dma_row<8>(a, xr, lds3, dm, tw);
-      pipe_dma_row<9>(a, xr, lds3, dm, tw); pipe_dma_row<10>(a, xr, lds3, dm, tw); pipe_dma_row<11>(a, xr, lds3, dm, tw);
-      pipe_dma_row<12>(a, xr, lds3, dm, tw); pipe_dma_row<13>(a, xr, lds3, dm, tw); pipe_dma_row<14>(a, xr, lds3, dm, tw);
-    };
-    f32x4 y[4][4];
-    aim(item, 0);
-    dma();
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();                                            // barrier A: R of the first chunk
-    ws_transform_read<0>(lds3, r_base, y);
-    ws_transform_write<0>(lds3, v_base, y);
-    __syncthreads();                                            // barrier B: half-step 0 in V[0]
-    for (; item < it_end; item += nslots) {
-      for (int ch = 0; ch < nchunk; ++ch) {
-        const bool more_ch = ch + 1 < nchunk;
-        const bool has_next = more_ch || item + nslots < it_end;
-        ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 0
-        ws_transform_read<1>(lds3, r_base, y); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 1
-        ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 2
-        ws_transform_read<2>(lds3, r_base, y); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 3
-        ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 4
-        ws_transform_read<3>(lds3, r_base, y); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 5: last read of R
-        if (has_next) {                                                                                // step 6
-          aim(more_ch ? item : item + nslots, more_ch ? ch + 1 : 0);
-          dma();
-        }
-        ws_transform_write<1>(lds3, v_base, y);
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (has_next) {                                                                                // step 7
-          ws_transform_read<0>(lds3, r_base, y);
-          ws_transform_write<0>(lds3, v_base, y);
-        }
-        __syncthreads();
-      }
-    }
+    ws_transform_role(a, p, lds3, item, it_end, nslots, nchunk, wave - 4, tid - 256, lane);
     return;
   }
 

@@ -1,5 +1,5 @@
 // Fused OccHead kernels (A11) -- entry point pw_occ_head_fused in include/preworld_hip.h.
-#include "pw_conv3d_common.h"
+#include "pw_wino_common.h"
 
 // ------------------------------------------------------------------------------------
 // OccHead on v_mfma_f32_16x16x4_f32: the head's 3x3x3 conv has only 16 output channels, which
@@ -366,6 +366,168 @@ __global__ void __launch_bounds__(256, 1) k_occ_head16_pipe(ConvArgs a, PipeArgs
 }
 
 // A11  fused OccHead: conv3x3x3 (Cin->16, BN, ReLU) + 1x1x1 16->8 (BN, ReLU) + 1x1x1 8->18 + argmax
+// ------------------------------------------------------------------------------------
+// OccHead on the Winograd machinery (pw_wino_common.h, pw_conv3d_wino.hip): the 3x3x3 32->16 conv as
+// F(2x2x2,3x3x3) in the wave-specialised persistent form -- 4 transform + DMA waves one half-step ahead of
+// 4 GEMM waves -- with the 16->8->18 + argmax tail in the GEMM waves' epilogue.
+// 16 output columns are one MFMA N-tile, so the four GEMM waves split (tile half mh) x (row of points RSEL
+// of each half-step) instead of (tile half) x (column half): every wave accumulates a partial sum over its
+// rows for all 8 outputs of its 16 tiles; at the end of a tile the two row-partners swap halves through LDS
+// (wave RSEL keeps o_d = RSEL) under the half-step's own barrier, and each wave finishes 64 voxels x 16
+// channels -- exactly the shape of k_occ_head16's tail (transpose through LDS, one voxel per lane).
+// LDS: R 76.8 KB + V 2 x 32 KB + 4 x 4352 B exchange / transpose areas = 159 744 B.
+constexpr int OCCW_XCH = 64 * 17 * 4;                            // per GEMM wave
+constexpr int OCCW_LDS = WINO_LDS + 4 * OCCW_XCH;
+
+template <int H, int RSEL> struct OccRow {                       // the wave's row of half-step H
+  static constexpr int ID = H >> 1, HH = H & 1, IH = 2 * HH + RSEL;
+  static constexpr unsigned point = (unsigned)(ID * 16 + IH * 4);
+  static constexpr unsigned a_off = (unsigned)HH * 32768u + (unsigned)(RSEL * 4) * 4096u;
+};
+
+template <int H, int RSEL>
+__device__ __forceinline__ void occw_load_b(const WinoCtx& c, f32x4 (&bq)[4][2]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4 w = buf_load4(c.wr, c.lane_off + (unsigned)(q * 16), (OccRow<H, RSEL>::point + (unsigned)k) * 2048u);
+      bq[k][q] = f32x4{w.x, w.y, w.z, w.w};
+    }
+}
+
+// half-steps H..7 of one tile.  Entry: the barrier that made V[H & 1] valid has been passed, bc = this row's
+// weights.  Order inside a half-step: A loads, next row's weights, the PREVIOUS row's output transform (fills
+// the LDS latency), 32 MFMAs, barrier.
+template <int H, int RSEL>
+__device__ __forceinline__ void occw_rows(const WinoCtx& c, f32x4 (&bc)[4][2], f32x4 (&bn)[4][2], f32x4 (&Mp)[4],
+                                          f32x4 (&Y)[8], unsigned xch_mine) {
+  typedef OccRow<H, RSEL> W;
+  f32x4 aq[4][2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) aq[k][q] = lds_read4(c.lds3, c.a_addr[q] + W::a_off + (unsigned)k * 4096u);
+  occw_load_b<(H + 1) & 7, RSEL>(c, bn);
+  if constexpr (H >= 1) wino_scatter_row<OccRow<H - 1, RSEL>::ID, OccRow<H - 1, RSEL>::IH>(Mp, Y);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 M[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) M[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        M[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k][q][e], bc[k][q][e], M[k], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (H < 7) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Mp[k] = M[k];
+    __syncthreads();
+    occw_rows<H + 1, RSEL>(c, bn, bc, Mp, Y, xch_mine);
+  } else {
+    wino_scatter_row<W::ID, W::IH>(M, Y);
+    // the partner finishes o_d = 1 - RSEL: hand it those four outputs
+    const unsigned lane16 = (unsigned)(threadIdx.x & 63) * 16u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lds_write4(c.lds3, xch_mine + (unsigned)j * 1024u + lane16, Y[(1 - RSEL) * 4 + j]);
+    __syncthreads();
+  }
+}
+
+template <int RSEL>
+__device__ __forceinline__ void occw_gemm_role(const ConvArgs& a, const PipeArgs& p, const OccTail& tail, lds3_t lds3,
+                                               int item, int it_end, int nslots, int mh, int lane) {
+  WinoCtx c;
+  c.lds3 = lds3;
+  {
+    const int lt = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      c.a_addr[q] = (unsigned)WINO_R_BYTES + (unsigned)(((mh * 16 + wino_row16(lt)) * 8 + ((g * 2 + q) ^ (lt & 7))) * 16);
+  }
+  c.wr = make_rsrc(a.wpk, 64u * 2048u);
+  c.lane_off = (unsigned)lane * 32u;
+  c.ustep = 2048u;
+  const unsigned xch_mine = (unsigned)WINO_LDS + (unsigned)((mh * 2 + RSEL) * OCCW_XCH);
+  const unsigned xch_peer = (unsigned)WINO_LDS + (unsigned)((mh * 2 + 1 - RSEL) * OCCW_XCH);
+  const int i = lane & 15, g = lane >> 4;
+  const float sc = a.scale ? a.scale[i] : 1.f;
+  const float bi = a.bias ? a.bias[i] : 0.f;
+  f32x4 b0[4][2], b1[4][2], Mp[4];
+  occw_load_b<0, RSEL>(c, b0);
+  __syncthreads();                                              // barrier A (halo of the first tile)
+  __syncthreads();                                              // barrier B (half-step 0 in V[0])
+  for (; item < it_end; item += nslots) {
+    f32x4 Y[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) Y[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    occw_rows<0, RSEL>(c, b0, b1, Mp, Y, xch_mine);             // 8 rows: b0 holds row 0 of the next tile again
+    // ---- tail: add the partner's half, BN + ReLU, transpose 64 voxels x 16 channels through the partner's area
+    // (it is ours once read), then one voxel per lane: 16->8 (+BN+ReLU), 8->18, argmax
+    constexpr int MS = 17;
+    f32x4 Z[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Z[j] = Y[RSEL * 4 + j] + lds_read4(lds3, xch_peer + (unsigned)j * 1024u + (unsigned)lane * 16u);
+    __attribute__((address_space(3))) float* sm = reinterpret_cast<__attribute__((address_space(3))) float*>(lds3 + xch_peer);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // tile (t_h = g, t_w = r) of the wave's d-pair, output (o_h, o_w) = (j >> 1, j & 1) -> voxel (h, w) of the 8x8 plane
+        const int vh = 2 * g + (j >> 1), vw = 2 * r + (j & 1);
+        sm[(vh * 8 + vw) * MS + i] = fmaxf(Z[j][r] * sc + bi, 0.f);
+      }
+    const PipeTile t = pipe_decode(a, p, item);
+    const int od = t.d0 + 2 * mh + RSEL, oh = t.h0 + (lane >> 3), ow = t.w0 + (lane & 7);
+    if (od < a.Do && oh < a.Ho && ow < a.Wo) {
+      const size_t vox = (((size_t)t.b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+      float mid[16], hid[8];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) mid[k] = sm[lane * MS + k];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_ += mid[k] * tail.w1[o * 16 + k];
+        hid[o] = fmaxf(s_ * tail.s1[o] + tail.b1[o], 0.f);
+      }
+      float best = 0.f;
+      int arg = 0;
+#pragma unroll
+      for (int cc = 0; cc < 18; ++cc) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) s_ += hid[o] * tail.w2[cc * 8 + o];
+        if (tail.logits) tail.logits[vox * 18 + cc] = s_;
+        if (cc == 0 || s_ > best) { best = s_; arg = cc; }
+      }
+      tail.occ[vox] = (uint8_t)arg;
+      if (tail.geo) tail.geo[vox] = arg != tail.empty_idx ? (uint8_t)0 : (uint8_t)(tail.n_cls - 1);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512, 1) k_occ_head_wino(ConvArgs a, PipeArgs p, OccTail tail) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int nslots = (int)gridDim.x >> 3;
+  const int per = (p.n_items + 7) >> 3;
+  const int it_end = min(((int)blockIdx.x & 7) * per + per, p.n_items);
+  const int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (item >= it_end) return;
+  const lds3_t lds3 = (lds3_t)lds;
+  if (wave >= 4) {
+    ws_transform_role(a, p, lds3, item, it_end, nslots, 1, wave - 4, tid - 256, lane);
+    return;
+  }
+  if (wave >> 1) occw_gemm_role<1>(a, p, tail, lds3, item, it_end, nslots, wave & 1, lane);
+  else occw_gemm_role<0>(a, p, tail, lds3, item, it_end, nslots, wave & 1, lane);
+}
+
 PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, const float* bias,
                              const float* w1, const float* s1, const float* b1, const float* w2,
                              uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D,
@@ -386,7 +548,21 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
   OccTail t = {w1, s1, b1, w2, occ, logits, geo, empty_idx, n_mid, n_hid, n_cls};
   a.dma_stage = dma_stage_default();
   long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
-  PW_CHECK_ARG(wpk_layout == 16, "pw_occ_head_fused: wpk_layout must be 16 (the 16x16x4 MFMA packing)");
+  if (wpk_layout == 64) {
+    // Winograd-domain weights (pack_conv_weight_wino with 16 columns): the wave-specialised persistent kernel
+    PW_CHECK_ARG(Cin == KC, "pw_occ_head_fused: the Winograd kernel takes 32 input channels");
+    PW_CHECK_ARG(nblk < (1ll << 20), "pw_occ_head_fused: too many tiles");
+    PipeArgs p = {};
+    p.ngroups = 1; p.n_items = (int)nblk;
+    p.m_ng = magic_of(1); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
+    const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
+    static int once = set_lds_limit(k_occ_head_wino, OCCW_LDS);
+    if (once) return once;
+    hipLaunchKernelGGL(k_occ_head_wino, dim3(nb), dim3(512), OCCW_LDS, pw_stream(stream), a, p, t);
+    PW_CHECK_LAUNCH();
+    return PW_OK;
+  }
+  PW_CHECK_ARG(wpk_layout == 16, "pw_occ_head_fused: wpk_layout must be 16 (direct 16x16x4 MFMA packing) or 64 (Winograd)");
   // persistent DMA-pipelined variant: opt-in with PW_OCC_PIPE=1.  Measured at 16x200x200: 176 us vs
   // 160 us for the tile-per-block kernel -- with one block per CU nothing overlaps the fused tail
   // (two LDS transposes, ~330 VALU, the 16->8->18 weights) that the second resident block hides there.

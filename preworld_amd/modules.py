@@ -451,7 +451,7 @@ class OccHead(nn.Module):
                 nn.ReLU(inplace=True), nn.Conv3d(mid // 2, self.num_point_sampling_feat, 1, bias=False))
         self._cache = _PackedCache()
 
-    def _folded(self, transposed=False):
+    def _folded(self, transposed=False, wino=False):
         c0, bn0 = self.occ_convs[0][0], self.occ_convs[0][1]
         c1, bn1, c2 = self.occ_pred_conv[0], self.occ_pred_conv[1], self.occ_pred_conv[3]
         params = [c0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, c1.weight,
@@ -461,12 +461,14 @@ class OccHead(nn.Module):
             s0, b0 = ops.fold_bn(bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, bn0.eps)
             s1, b1 = ops.fold_bn(bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps)
             w0 = c0.weight
-            return (ops.pack_conv_weight16(w0), ops.pack_conv_weight16(w0.permute(0, 1, 4, 3, 2).contiguous()),
+            w0t = w0.permute(0, 1, 4, 3, 2).contiguous()
+            return ((ops.pack_conv_weight16(w0), ops.pack_conv_weight16(w0t)),
+                    (ops.pack_conv_weight_wino(w0, cout_total=16), ops.pack_conv_weight_wino(w0t, cout_total=16)),
                     ops._pad32(s0, 1.0), ops._pad32(b0, 0.0),
                     c1.weight.reshape(c1.weight.shape[0], -1).float().contiguous(), s1, b1,
                     c2.weight.reshape(c2.weight.shape[0], -1).float().contiguous())
-        wpk, wpk_t, s0, b0, w1, s1, b1, w2 = self._cache.get(params, build)
-        return (wpk_t if transposed else wpk), s0, b0, w1, s1, b1, w2
+        wpk, uwpk, s0, b0, w1, s1, b1, w2 = self._cache.get(params, build)
+        return (uwpk if wino else wpk)[1 if transposed else 0], s0, b0, w1, s1, b1, w2
 
     def decode_cl(self, x_cl, want_logits=False, transposed=False, want_geo=False):
         """x_cl (B,D,H,W,C) channels-last -> uint8 argmax (B,D,H,W) [, logits (B,D,H,W,18)].
@@ -476,7 +478,13 @@ class OccHead(nn.Module):
         (Z,Y,X) array whose .permute(0,3,2,1) view is the reference's (X,Y,Z) output."""
         if self.training:
             raise NotImplementedError('OccHead HIP path is eval-only')
-        wpk, s0, b0, w1, s1, b1, w2 = self._folded(transposed)
+        # the 32->16 conv runs as Winograd F(2x2x2,3x3x3) (k_occ_head_wino) on grids with enough 4x8x8 tiles to
+        # keep the persistent blocks busy; PW_OCC_WINO=0 keeps the direct 16x16x4 MFMA kernel
+        import os
+        B, D, H, W, C = x_cl.shape
+        wino = (C == 32 and B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) >= 256
+                and os.environ.get('PW_OCC_WINO', '1') != '0')
+        wpk, s0, b0, w1, s1, b1, w2 = self._folded(transposed, wino)
         return ops.occ_head_fused(x_cl, wpk, s0, b0, w1, s1, b1, w2, want_logits=want_logits,
                                   want_geo=want_geo, empty_idx=self.empty_idx)
 

@@ -405,7 +405,8 @@ def pack_conv_weight16(w):
 
 def occ_head_fused(x, wpk, scale, bias, w1, s1, b1, w2, want_logits=False, occ=None, want_geo=False,
                    empty_idx=17):
-    """OccHead (occupancy_head.py:124-177) on channels-last x (B,D,H,W,32):
+    """OccHead (occupancy_head.py:124-177) on channels-last x (B,D,H,W,32); wpk from pack_conv_weight16 (direct
+    MFMA kernel) or pack_conv_weight_wino(w, cout_total=16) (Winograd kernel, 32 input channels):
     returns uint8 argmax (B,D,H,W) [, logits (B,D,H,W,18)] [, geo_occ uint8 (B,D,H,W) =
     0 where occupied / 17 where empty, preworld_temporal_traj.py:313-319]."""
     B, D, H, W, Cin = x.shape
@@ -416,7 +417,7 @@ def occ_head_fused(x, wpk, scale, bias, w1, s1, b1, w2, want_logits=False, occ=N
     _lib.call('pw_occ_head_fused', _chk(x, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
               _chk(bias, _f32, 'bias'), _chk(w1, _f32, 'w1'), _chk(s1, _f32, 's1'), _chk(b1, _f32, 'b1'),
               _chk(w2, _f32, 'w2'), _p(occ), _p(logits), _p(geo), int(empty_idx), B, D, H, W, Cin, 16, 8, 18,
-              16 if wpk.shape[-1] == 8 else 32, _stream())
+              64 if wpk.dim() == 5 else (16 if wpk.shape[-1] == 8 else 32), _stream())
     out = (occ,) + ((logits,) if want_logits else ()) + ((geo,) if want_geo else ())
     return out if len(out) > 1 else occ
 

@@ -346,6 +346,43 @@ def test_conv_stack_golden(golden):
     np.testing.assert_allclose(out.cpu().numpy(), g['pre_key'], **TOL)
 
 
+@pytest.mark.parametrize('shape', [(1, 16, 200, 200), (2, 5, 19, 27), (1, 4, 8, 8), (1, 16, 96, 104)])
+def test_occ_head_wino_matches_direct_and_oracle(shape):
+    """k_occ_head_wino (Winograd conv + fused 16->8->18 + argmax, wave-specialised persistent) against the direct
+    16x16x4 MFMA kernel: logits to the conv tolerance, occupancy = argmax of its own logits, geo_occ consistent;
+    on a crop the logits are checked against the oracle's OccHead restatement."""
+    B, D, H, W = shape
+    rs = np.random.RandomState(17)
+    x = T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32))
+    w0 = T(_rand_conv(rs, 16, 32, 3))
+    s0 = T(rs.uniform(0.5, 1.5, 16).astype(np.float32)); b0 = T((rs.standard_normal(16) * 0.3).astype(np.float32))
+    w1 = T((rs.standard_normal((8, 16)) * 0.4).astype(np.float32))
+    s1 = T(rs.uniform(0.5, 1.5, 8).astype(np.float32)); b1 = T((rs.standard_normal(8) * 0.3).astype(np.float32))
+    w2 = T((rs.standard_normal((18, 8)) * 0.5).astype(np.float32))
+    args = (ops._pad32(s0, 1.0), ops._pad32(b0, 0.0), w1, s1, b1, w2)
+    occ_d, lg_d, geo_d = ops.occ_head_fused(x, ops.pack_conv_weight16(w0), *args, want_logits=True, want_geo=True)
+    occ_w, lg_w, geo_w = ops.occ_head_fused(x, ops.pack_conv_weight_wino(w0, cout_total=16), *args, want_logits=True,
+                                            want_geo=True)
+    np.testing.assert_allclose(lg_w.cpu().numpy(), lg_d.cpu().numpy(), rtol=5e-4, atol=5e-4)
+    assert torch.equal(occ_w.long(), lg_w.argmax(-1))
+    assert float((occ_w == occ_d).float().mean()) > 0.999
+    np.testing.assert_array_equal(geo_w.cpu().numpy(), np.where(occ_w.cpu().numpy() != 17, 0, 17).astype(np.uint8))
+    occ_only = ops.occ_head_fused(x, ops.pack_conv_weight_wino(w0, cout_total=16), *args)
+    assert torch.equal(occ_only, occ_w)                      # deterministic, logits optional
+    # oracle on a corner crop (true zero padding on the low sides)
+    d1, h1, w1_ = min(D, 6), min(H, 12), min(W, 12)
+    xc = x[:1, :d1, :h1, :w1_].permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
+    mid = np.maximum(O.conv3d(xc, w0.cpu().numpy()) * s0.cpu().numpy()[None, :, None, None, None]
+                     + b0.cpu().numpy()[None, :, None, None, None], 0)
+    hid = np.maximum(np.einsum('oc,bcdhw->bodhw', w1.cpu().numpy(), mid) * s1.cpu().numpy()[None, :, None, None, None]
+                     + b1.cpu().numpy()[None, :, None, None, None], 0)
+    want = np.einsum('oc,bcdhw->bdhwo', w2.cpu().numpy(), hid)
+    got = lg_w[:1, :d1, :h1, :w1_].cpu().numpy()
+    sl = (slice(None), slice(0, d1 if d1 == D else d1 - 1), slice(0, h1 if h1 == H else h1 - 1),
+          slice(0, w1_ if w1_ == W else w1_ - 1))
+    np.testing.assert_allclose(got[sl], want[sl], rtol=5e-4, atol=5e-4)
+
+
 def test_forecast_golden(golden):
     g = golden('forecast_small.npz')
     net, sd = _load_net(int(g['seed_sd']))
