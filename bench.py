@@ -143,8 +143,10 @@ class KernelProbe:
         if name == 'occ_head_fused':
             x = args[0]
             nv = x.numel() // x.shape[-1]
-            return 'conv3d_k3s1_mfma<occ_head>', 2.0 * nv * (27 * 32 * 16 + 16 * 8 + 8 * 18), \
-                4.0 * x.numel() + nv
+            # Winograd-domain weights are 5-d (pack_conv_weight_wino): same algorithmic work, 8/27 of the conv's
+            # multiplies executed
+            label = 'conv3d_wino_mfma<occ_head>' if args[1].dim() == 5 else 'conv3d_k3s1_mfma<occ_head>'
+            return label, 2.0 * nv * (27 * 32 * 16 + 16 * 8 + 8 * 18), 4.0 * x.numel() + nv
         if name == 'forecast_steps':
             v0, n_steps = args[0], args[6]
             nv = v0.numel() // 32

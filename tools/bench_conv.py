@@ -16,10 +16,15 @@ w3232, w3264, w6464 = w(32, 32), w(64, 32), w(64, 64)
 if os.environ.get('WINO'):         # the Winograd kernel on the same three full-resolution shapes
     uw = lambda co, ci: ops.pack_conv_weight_wino(torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05)
     u3232, u3264, u6464 = uw(32, 32), uw(64, 32), uw(64, 64)
+    uocc = ops.pack_conv_weight_wino(torch.randn(16, 32, 3, 3, 3, device=dev) * 0.05, cout_total=16)
+    sc, bi = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+    w1 = torch.randn(8, 16, device=dev); s1 = torch.ones(8, device=dev); b1 = torch.zeros(8, device=dev)
+    w2 = torch.randn(18, 8, device=dev)
     for _ in range(int(os.environ.get('N', 3))):
         ops.conv3d_wino(x32, u3232)
         ops.conv3d_wino(x32, u3264)
         ops.conv3d_wino(x64, u6464)
+        ops.occ_head_fused(x32, uocc, sc, bi, w1, s1, b1, w2, want_geo=True)
     torch.cuda.synchronize()
     print('done')
     sys.exit(0)
