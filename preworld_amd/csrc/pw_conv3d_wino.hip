@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_wino(ConvArgs a, int n16_tota
 // Wave-specialised persistent variant: 512 threads = 4 GEMM waves + 4 transform waves, one per SIMD each.
 // The kernel above runs its phases back to back in every wave (halo DMA -> transform -> MFMAs -> store)
 // with one wave per SIMD, so every LDS / L2 latency and every barrier skew is exposed: the matrix pipe is
-// busy 31-42 % of the time and 45 % of the wave cycles are s_waitcnt (profiles/r01_pmc_wino.md).  Here
+// busy 31-42 % of the time and 45 % of the wave cycles are s_waitcnt (profiles/r01_pmc_wino_v6.md).  Here
 //   * the transform waves run ONE HALF-STEP AHEAD of the GEMM waves: V is two 32 KB buffers of 8 points
 //     (two i_h rows); while the GEMM waves do the MFMAs of half-step g from V[g & 1], the transform waves
 //     write half-step g + 1 into V[(g + 1) & 1]; one workgroup barrier per half-step;
