@@ -153,7 +153,9 @@ int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const fl
  * transform domain: uwpk = float[Cin/32][64 points][cout_total/16][64 lanes][8],
  *   uwpk[ch][p][n16][g*16+j][s] = U[n16*16+j][ch*32+g*8+s][p],  U = G w G^T along d, h, w
  *   (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], p = i_d*16 + i_h*4 + i_w) -- preworld_amd.ops.pack_conv_weight_wino.
- * 3.375x fewer multiplies than the direct sum; results differ from it by fp32 rounding only. */
+ * 3.375x fewer multiplies than the direct sum; results differ from it by fp32 rounding only.
+ * cout_total: any multiple of 32 (work items = 4x8x8 tile x group of 32 or 64 columns of the wave-specialised
+ * persistent kernel; PW_WINO_WS=0 selects the tile-per-block kernel, which takes 32 or 64). */
 int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale, const float* bias,
                    const float* residual, float* y0, float* y1, int B, int D, int H, int W, int Cin,
                    int cout_total, int cout0, int cout1, int ld_y0, int ld_y1, int relu0, int relu1,
@@ -166,8 +168,9 @@ int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale, const 
  * uint8[B*D*H*W]; logits float[B*D*H*W][18] or NULL; geo uint8[B*D*H*W] or NULL receives the
  * reference's geo_occ (preworld_temporal_traj.py:313-319): 0 where occ != empty_idx, n_cls-1 elsewhere.
  * wpk_layout 16: wpk = float[Cin/32][27][64][8], wpk[ch][tap][g*16+j][s] = w[j][ch*32+g*8+s][tap]
- *   (v_mfma_f32_16x16x4_f32 kernel, no padded output columns -- the fast path);
- * (only layout 16 is built). */
+ *   (direct-form v_mfma_f32_16x16x4_f32 kernel, no padded output columns);
+ * wpk_layout 64: Cin == 32, wpk = pw_conv3d_wino's transform-domain layout with cout_total = 16
+ *   (float[1][64 points][1][64 lanes][8]): the Winograd kernel k_occ_head_wino, 1.4x faster at 16x200x200. */
 int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, const float* bias,
                       const float* w1, const float* s1, const float* b1, const float* w2,
                       uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H,
