@@ -383,6 +383,26 @@ def test_occ_head_wino_matches_direct_and_oracle(shape):
     np.testing.assert_allclose(got[sl], want[sl], rtol=5e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize('shape', [(1, 8, 40, 72), (2, 4, 12, 200), (1, 16, 200, 200), (1, 4, 8, 24)])
+def test_fpn3d_fuse_vs_torch_interpolate(shape):
+    """k_fpn3d_fuse against ReLU(BN(conv1x1(x8) + up2(y16) + up4(y32))) built from torch's own trilinear
+    align_corners=True upsampling (lss_fpn.py:132-148 after commuting the 1x1x1 conv below the upsample): W >= 32
+    takes the per-tile path (decode and d/h terms hoisted), the last shape the per-row path."""
+    import torch.nn.functional as F
+    B, D, H, W = shape
+    rs = np.random.RandomState(23)
+    x8 = T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32))
+    y16 = T(rs.standard_normal((B, D // 2, H // 2, W // 2, 32)).astype(np.float32))
+    y32 = T(rs.standard_normal((B, max(D // 4, 1), H // 4, W // 4, 32)).astype(np.float32))
+    w8 = T(_rand_conv(rs, 32, 32, 1))
+    sc = T(rs.uniform(0.5, 1.5, 32).astype(np.float32)); bi = T(rs.standard_normal(32).astype(np.float32))
+    got = ops.fpn3d_fuse(x8, ops.pack_conv_weight(w8), y16, y32, sc, bi, relu=True)
+    up = lambda y: F.interpolate(y.permute(0, 4, 1, 2, 3), size=(D, H, W), mode='trilinear', align_corners=True)
+    lin = torch.einsum('bdhwc,oc->bodhw', x8.double(), w8.view(32, 32).double()).float()
+    want = torch.relu((lin + up(y16) + up(y32)) * sc.view(1, 32, 1, 1, 1) + bi.view(1, 32, 1, 1, 1)).permute(0, 2, 3, 4, 1)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
 def test_forecast_golden(golden):
     g = golden('forecast_small.npz')
     net, sd = _load_net(int(g['seed_sd']))
