@@ -345,6 +345,40 @@ int pw_voxel_loss_grad(const float* logits, const uint8_t* target, const uint8_t
 int pw_voxel_loss_finish(const double* stats, int n_cls, float* losses, void* stream);
 int pw_voxel_loss_coef(const double* stats, int n_cls, const float* grad_losses, float* coef, void* stream);
 
+/* SURVEY 8f row 2, the finetune configs' other two voxel losses (preworld.py:146-155).
+ * Same logits / target / cam_mask / stride conventions as pw_voxel_loss_*.
+ *
+ * CustomFocalLoss.forward (mmdet3d/models/loss_utils/focal_loss.py:206-262): over the valid voxels (target !=
+ *   ignore_index, cam_mask) mean of sum_c class_weights[c] * r(x, y) * FL(logit_c, [target == c]) times loss_weight,
+ *   FL = mmcv-full's sigmoid_focal_loss element (gamma, alpha), r = |(x - X/2, y - Y/2)| / max + 1 (:196-203; the
+ *   reference hard-codes X = Y = 200).
+ *   pw_focal_loss_stats ACCUMULATES into stats double[2] = {weighted sum, valid count} (zero it first);
+ *   pw_focal_loss_finish: loss float[1] = loss_weight * stats[0] / stats[1];
+ *   pw_focal_loss_grad: grad_logits (logits' strides) = grad_loss[0] (device float) * d(loss)/d(logits).
+ *
+ * lovasz_softmax (mmdet3d/models/detectors/lovasz_softmax.py:157-232; classes='present', per_image=False):
+ *   probas = softmax probabilities (B,C,X,Y,Z) by strides; valid voxels = target != ignore_index (and cam_mask);
+ *   loss float[1] = mean over the classes present among them of  sort_desc(|[t==c] - p_c|) . lovasz_grad(sorted fg);
+ *   inv_present float[1] = 1 / number of present classes; dprob (probas' strides, ZERO-FILLED by the caller, or NULL)
+ *   receives d(sum_c loss_c)/d(probas) with lovasz_grad held constant like the reference, i.e. the gradient of the loss
+ *   is dprob * inv_present.  workspace: pw_lovasz_workspace_bytes(n_vox = B*X*Y*Z, n_cls, ignore_index) bytes of
+ *   device memory (sort keys/values double-buffered + rocPRIM temporary); n_cls <= 32, n_vox < 2^31. */
+int pw_focal_loss_stats(const float* logits, const uint8_t* target, const uint8_t* cam_mask,
+                        const float* class_weights, int B, int n_cls, int X, int Y, int Z, int64_t sb,
+                        int64_t sc, int64_t sx, int64_t sy, int64_t sz, int ignore_index, float gamma,
+                        float alpha, double* stats, void* stream);
+int pw_focal_loss_finish(const double* stats, float loss_weight, float* loss, void* stream);
+int pw_focal_loss_grad(const float* logits, const uint8_t* target, const uint8_t* cam_mask,
+                       const float* class_weights, int B, int n_cls, int X, int Y, int Z, int64_t sb,
+                       int64_t sc, int64_t sx, int64_t sy, int64_t sz, int ignore_index, float gamma,
+                       float alpha, const double* stats, float loss_weight, const float* grad_loss,
+                       float* grad_logits, void* stream);
+size_t pw_lovasz_workspace_bytes(int64_t n_vox, int n_cls, int ignore_index);
+int pw_lovasz_softmax(const float* probas, const uint8_t* target, const uint8_t* cam_mask, int B, int n_cls,
+                      int X, int Y, int Z, int64_t sb, int64_t sc, int64_t sx, int64_t sy, int64_t sz,
+                      int ignore_index, void* workspace, size_t workspace_bytes, float* loss,
+                      float* inv_present, float* dprob, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

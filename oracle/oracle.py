@@ -776,6 +776,86 @@ def voxel_losses(pred, target, class_weights=None, ignore_index=255, empty_idx=1
     return float(ce), float(sem), float(geo)
 
 
+def focal_radial_map(H, W):
+    """CustomFocalLoss.__init__ (mmdet3d/models/loss_utils/focal_loss.py:196-203): c = |(h - H/2, w - W/2)| / max + 1
+    on the (H, W) = first two grid axes (the reference hard-codes 200 x 200)."""
+    xy, yx = np.meshgrid(np.arange(H, dtype=np.float32) - np.float32(H / 2), np.arange(W, dtype=np.float32) - np.float32(W / 2),
+                         indexing='ij')
+    c = np.sqrt(xy * xy + yx * yx).astype(np.float32)
+    return (c / c.max() + np.float32(1)).astype(np.float32)
+
+
+def focal_loss_voxel(pred, target, class_weights, ignore_index=255, camera_mask=None, gamma=2.0, alpha=0.25,
+                     loss_weight=100.0, want_grad=False):
+    """CustomFocalLoss.forward (focal_loss.py:206-262) as loss_voxel calls it (preworld.py:146-148): per valid voxel
+    (target != ignore, camera mask) the sigmoid focal loss of its C logits, weighted by class_weights[c] * radial_map[h, w],
+    summed over classes, averaged over the valid voxels, times loss_weight.
+    The per-element term is mmcv-full 1.6.0's sigmoid_focal_loss CUDA op (third-party dependency, not vendored in the
+    reference tree; its published kernel: -[t==c] a (1-p)^g log(max(p, FLT_MIN)) - [t!=c] (1-a) p^g log(max(1-p, FLT_MIN)),
+    p = sigmoid(x)); the reference's own CPU branch (py_sigmoid_focal_loss, focal_loss.py:12-57) is the same function
+    and is what the golden fixture was generated with.  pred (B,C,X,Y,Z), target (B,X,Y,Z).  float64 sums."""
+    z = np.asarray(pred, np.float64)
+    B, C, X, Y, Z = z.shape
+    t = np.asarray(target).astype(np.int64)
+    valid = t != ignore_index
+    if camera_mask is not None:
+        valid &= np.asarray(camera_mask).astype(bool)
+    cmap = focal_radial_map(X, Y).astype(np.float64)[None, :, :, None]
+    w = np.asarray(class_weights, np.float64)
+    p = 1.0 / (1.0 + np.exp(-z))
+    tiny = np.finfo(np.float32).tiny
+    onehot = (t[:, None] == np.arange(C)[None, :, None, None, None])
+    term_p = (1 - p) ** gamma * np.log(np.maximum(p, tiny))
+    term_n = p ** gamma * np.log(np.maximum(1 - p, tiny))
+    el = np.where(onehot, -alpha * term_p, -(1 - alpha) * term_n)
+    wm = w[None, :, None, None, None] * cmap[:, None]
+    n = valid.sum()
+    loss = loss_weight * (el * wm * valid[:, None]).sum() / n
+    if not want_grad:
+        return float(loss)
+    gp = (1 - p) ** gamma * (1 - p - gamma * p * np.log(np.maximum(p, tiny)))
+    gn = p ** gamma * (gamma * (1 - p) * np.log(np.maximum(1 - p, tiny)) - p)
+    g = np.where(onehot, -alpha * gp, -(1 - alpha) * gn) * wm * valid[:, None] * (loss_weight / n)
+    return float(loss), g.astype(np.float32)
+
+
+def lovasz_softmax(probas, labels, ignore=None, camera_mask=None, want_grad=False):
+    """mmdet3d/models/detectors/lovasz_softmax.py:157-232 (classes='present', per_image=False): flatten_probas keeps
+    the voxels with label != ignore (and camera mask); for every class present among them the errors |fg - p_c| are
+    sorted descending and dotted with lovasz_grad (:20-33) of the sorted foreground indicator; mean over those classes.
+    probas (B,C,X,Y,Z), labels (B,X,Y,Z).  The gradient treats lovasz_grad as a constant, like the reference
+    (Variable(lovasz_grad(fg_sorted)))."""
+    P = np.asarray(probas, np.float32)
+    B, C = P.shape[:2]
+    lab = np.asarray(labels).astype(np.int64).reshape(-1)
+    pr = np.moveaxis(P.reshape(B, C, -1), 1, 2).reshape(-1, C)
+    valid = np.ones_like(lab, bool) if ignore is None else lab != ignore
+    if camera_mask is not None:
+        valid &= np.asarray(camera_mask).astype(bool).reshape(-1)
+    vp, vl = pr[valid], lab[valid]
+    losses, grads = [], np.zeros_like(vp)
+    for c in range(C):
+        fg = (vl == c).astype(np.float32)
+        if fg.sum() == 0:
+            continue
+        err = np.abs(fg - vp[:, c])
+        perm = np.argsort(-err, kind='stable')
+        es, fs = err[perm], fg[perm]
+        gts = fs.sum()
+        inter = gts - np.cumsum(fs, dtype=np.float32)
+        union = gts + np.cumsum(1 - fs, dtype=np.float32)
+        jac = (np.float32(1) - inter / union).astype(np.float32)
+        jac[1:] = jac[1:] - jac[:-1]
+        losses.append(np.dot(es.astype(np.float64), jac.astype(np.float64)))
+        grads[perm, c] = jac * np.where(fg[perm] > 0, -1.0, 1.0) * (es != 0)
+    loss = float(np.mean(losses)) if losses else 0.0
+    if not want_grad:
+        return loss
+    g = np.zeros_like(pr)
+    g[valid] = grads / max(len(losses), 1)
+    return loss, np.moveaxis(g.reshape(B, -1, C), 2, 1).reshape(P.shape)
+
+
 # --------------------------------------------------------------------------- ray table + WRS weights
 def pts2ray(coor, label_depth, label_seg, label_img, c2w, K):
     """mmdet3d/datasets/ray.py:34-55: get_rays(x+0.5, y+0.5, K, c2w, inverse_y=True) + the (n,16) row."""

@@ -1,7 +1,9 @@
-"""GPU drop-ins for mmdet3d/models/detectors/loss.py:20-113: CE_ssc_loss,
-sem_scal_loss, geo_scal_loss -- same names, same arguments -- and `voxel_losses`, the three of them
-from ONE pass over the logits (what loss_voxel, preworld_temporal_traj.py:176-199, needs), with an
-autograd backward that is one more pass (pw_voxel_loss_stats / pw_voxel_loss_grad).
+"""GPU drop-ins for the voxel-grid training losses with the reference's names and arguments:
+CE_ssc_loss, sem_scal_loss, geo_scal_loss (mmdet3d/models/detectors/loss.py:20-113) -- and `voxel_losses`, the three
+of them from ONE pass over the logits (what loss_voxel, preworld_temporal_traj.py:176-199, needs), with an autograd
+backward that is one more pass (pw_voxel_loss_stats / pw_voxel_loss_grad) -- plus the two the finetune configs add
+(preworld.py:146-155): CustomFocalLoss (loss_utils/focal_loss.py:163-262) and lovasz_softmax
+(detectors/lovasz_softmax.py:157-232), see the end of this file and csrc/pw_loss2.hip.
 
 The scalar algebra on the 104 accumulated sums runs in two one-block kernels (pw_voxel_loss_finish,
 pw_voxel_loss_coef): no host sync, 2 launches forward and 2 backward."""
@@ -77,3 +79,91 @@ def sem_scal_loss(pred, ssc_target, ignore_index, camera_mask=None):
 def geo_scal_loss(pred, ssc_target, ignore_index, non_empty_idx=0, camera_mask=None):
     """loss.py:83-113 (ignore_index is unused by the reference's geo term as well)."""
     return voxel_losses(pred, ssc_target, None, ignore_index, non_empty_idx, camera_mask)[2]
+
+
+# ------------------------------------------------------------------------------- focal + Lovasz
+class _FocalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, camera_mask, class_weights, ignore_index, gamma, alpha, loss_weight):
+        dims, t, cm, cw = _args(pred, target, camera_mask, class_weights)
+        B, C, X, Y, Z = dims
+        stats = torch.zeros(2, device=pred.device, dtype=torch.float64)
+        sb, sc, sx, sy, sz = pred.stride()
+        _lib.call('pw_focal_loss_stats', ops._p(pred), ops._p(t), ops._p(cm), ops._p(cw), B, C, X, Y, Z, sb, sc, sx, sy,
+                  sz, int(ignore_index), float(gamma), float(alpha), ops._p(stats), ops._stream())
+        out = torch.empty(1, device=pred.device, dtype=torch.float32)
+        _lib.call('pw_focal_loss_finish', ops._p(stats), float(loss_weight), ops._p(out), ops._stream())
+        ctx.save_for_backward(pred, t, cm if cm is not None else torch.empty(0), cw if cw is not None else torch.empty(0), stats)
+        ctx.meta = (dims, ignore_index, gamma, alpha, loss_weight, cm is not None, cw is not None)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, t, cm, cw, stats = ctx.saved_tensors
+        dims, ignore_index, gamma, alpha, loss_weight, has_cm, has_cw = ctx.meta
+        B, C, X, Y, Z = dims
+        gout = g.reshape(1).to(torch.float32).contiguous()
+        grad = torch.empty_strided(pred.shape, pred.stride(), device=pred.device, dtype=pred.dtype)
+        sb, sc, sx, sy, sz = pred.stride()
+        _lib.call('pw_focal_loss_grad', ops._p(pred), ops._p(t), ops._p(cm) if has_cm else None,
+                  ops._p(cw) if has_cw else None, B, C, X, Y, Z, sb, sc, sx, sy, sz, int(ignore_index), float(gamma),
+                  float(alpha), ops._p(stats), float(loss_weight), ops._p(gout), ops._p(grad), ops._stream())
+        return grad, None, None, None, None, None, None, None
+
+
+class CustomFocalLoss(torch.nn.Module):
+    """Drop-in for mmdet3d/models/loss_utils/focal_loss.py:163-262 (same constructor arguments, same forward
+    signature) on the fused kernels: forward(pred (B,C,X,Y,Z) logits, target (B,X,Y,Z), weight (C,), ...,
+    ignore_index=255, camera_mask=None) -> scalar.  The radial map follows the grid's first two axes (the reference
+    hard-codes 200 x 200, which is what the configs use)."""
+
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=100.0, activated=False):
+        super().__init__()
+        assert use_sigmoid is True, 'Only sigmoid focal loss supported now.'
+        if activated:
+            raise NotImplementedError('activated=True (probabilities as input) is not built')
+        self.gamma, self.alpha, self.reduction, self.loss_weight = gamma, alpha, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, ignore_index=255, reduction_override=None,
+                camera_mask=None):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        # the reference's weighted branch ends in loss.sum(-1).mean() whatever `reduction` says (focal_loss.py:156-158)
+        return _FocalLoss.apply(pred, target, camera_mask, weight, ignore_index, self.gamma, self.alpha, self.loss_weight)
+
+
+class _Lovasz(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probas, labels, camera_mask, ignore):
+        dims, t, cm, _ = _args(probas, labels, camera_mask, None)
+        B, C, X, Y, Z = dims
+        ign = -1 if ignore is None else int(ignore)
+        nbytes = _lib.call_size('pw_lovasz_workspace_bytes', B * X * Y * Z, C, ign)
+        if nbytes == 0:
+            raise _lib.PreworldHipError('pw_lovasz_workspace_bytes failed (n_cls > 32?)')
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=probas.device)
+        out = torch.empty(2, device=probas.device, dtype=torch.float32)
+        need_grad = probas.requires_grad
+        dprob = torch.zeros_like(probas, memory_format=torch.preserve_format) if need_grad else None
+        sb, sc, sx, sy, sz = probas.stride()
+        if need_grad and dprob.stride() != probas.stride():
+            dprob = torch.empty_strided(probas.shape, probas.stride(), device=probas.device, dtype=probas.dtype).zero_()
+        _lib.call('pw_lovasz_softmax', ops._p(probas), ops._p(t), ops._p(cm), B, C, X, Y, Z, sb, sc, sx, sy, sz, ign,
+                  ops._p(ws), nbytes, ops._p(out[0:1]), ops._p(out[1:2]), ops._p(dprob), ops._stream())
+        if need_grad:
+            ctx.save_for_backward(dprob, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dprob, out = ctx.saved_tensors
+        return dprob * (g * out[1]), None, None, None
+
+
+def lovasz_softmax(probas, labels, classes='present', per_image=False, ignore=None, camera_mask=None):
+    """Drop-in for mmdet3d/models/detectors/lovasz_softmax.py:157-174 as loss_voxel calls it (preworld.py:155):
+    probas (B,C,X,Y,Z) softmax probabilities, labels (B,X,Y,Z); classes='present', per_image=False only."""
+    if classes != 'present' or per_image:
+        raise NotImplementedError("only classes='present', per_image=False (the reference's call) is built")
+    if probas.dim() != 5:
+        raise _lib.PreworldHipError('probas must be (B, C, X, Y, Z)')
+    return _Lovasz.apply(probas, labels, camera_mask, ignore)

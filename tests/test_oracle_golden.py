@@ -228,6 +228,32 @@ def test_voxel_losses(golden):
         np.testing.assert_allclose(geo, float(g['geo_' + tag]), rtol=2e-5)
 
 
+def _softmax1(z):
+    e = np.exp(z - z.max(1, keepdims=True))
+    return (e / e.sum(1, keepdims=True)).astype(np.float32)
+
+
+def test_focal_and_lovasz_losses(golden):
+    """SURVEY 8f row 2, finetune losses: oracle restatements of CustomFocalLoss (focal_loss.py:163-262) and
+    lovasz_softmax (lovasz_softmax.py:157-232) vs values and autograd gradients of the reference modules."""
+    g = golden('voxel_losses2.npz')
+    cw = golden('voxel_losses.npz')['class_weights']
+    pred, target, cam = S.voxel_loss_inputs(int(g['seed_focal']), shape=(1, 18, 200, 200, 2))
+    for tag, cm in (('cam', cam), ('nocam', None)):
+        loss, grad = O.focal_loss_voxel(pred, target, cw, 255, cm, want_grad=True)
+        np.testing.assert_allclose(loss, float(g['focal_' + tag]), rtol=2e-6)
+        np.testing.assert_allclose(grad.reshape(-1)[::97], g['focal_grad_' + tag], rtol=1e-4, atol=1e-9)
+    pred, target, cam = S.voxel_loss_inputs(int(g['seed_lovasz']))
+    pr = _softmax1(pred)
+    for tag, cm in (('cam', cam), ('nocam', None)):
+        loss, gp = O.lovasz_softmax(pr, target, 17, cm, want_grad=True)
+        np.testing.assert_allclose(loss, float(g['lovasz_' + tag]), rtol=2e-6)
+        gz = pr * (gp - (gp * pr).sum(1, keepdims=True))                 # through the softmax, as the reference's autograd
+        np.testing.assert_allclose(gz, g['lovasz_grad_' + tag], rtol=1e-4, atol=1e-9)
+    # every class absent / everything ignored
+    assert O.lovasz_softmax(pr, np.full_like(target, 17), 17, None) == 0.0
+
+
 # ----------------------------------------------------------------------------- render
 def test_render_small(golden):
     g = golden('render_small.npz')

@@ -212,6 +212,42 @@ def bench_loss():
     t2 = timeit(fwd_bwd, iters=10)
     res['loss_fwd_bwd_us'] = t2
     res['loss_bwd_GBps'] = (2 * pred.numel() * 4 + 2 * 640000) / max(t2 - t, 1e-3) / 1e3
+    # the finetune configs' other two: CustomFocalLoss and lovasz_softmax (+ the same ops in plain torch as the
+    # reference composes them, for scale: C sequential sorts)
+    focal = L.CustomFocalLoss()
+
+    def focal_fb():
+        pred.grad = None
+        focal(pred, target, cw, None, 255, camera_mask=cam).backward()
+    with torch.no_grad():
+        res['focal_fwd_us'] = timeit(lambda: focal(pred, target, cw, None, 255, camera_mask=cam), iters=10)
+    res['focal_fwd_bwd_us'] = timeit(focal_fb, iters=10)
+
+    def lovasz_fb():
+        pred.grad = None
+        L.lovasz_softmax(torch.softmax(pred, 1), target, ignore=17, camera_mask=cam).backward()
+    with torch.no_grad():
+        pr = torch.softmax(pred, 1)
+        res['lovasz_fwd_us'] = timeit(lambda: L.lovasz_softmax(pr, target, ignore=17, camera_mask=cam), iters=5)
+
+        def torch_lovasz():          # lovasz_softmax_flat's loop in torch ops (no autograd), valid rows gathered first
+            valid = (target != 17) & cam
+            vp = pr.permute(0, 2, 3, 4, 1)[valid]
+            vl = target[valid]
+            tot = 0.0
+            for c in range(18):
+                fg = (vl == c).float()
+                if fg.sum() == 0:
+                    continue
+                es, perm = torch.sort((fg - vp[:, c]).abs(), 0, descending=True)
+                fs = fg[perm]
+                g = fs.sum()
+                jac = 1. - (g - fs.cumsum(0)) / (g + (1 - fs).cumsum(0))
+                jac[1:] = jac[1:] - jac[:-1]
+                tot = tot + torch.dot(es, jac)
+            return tot
+        res['lovasz_fwd_torch_ops_us'] = timeit(torch_lovasz, iters=3)
+    res['lovasz_fwd_bwd_incl_softmax_us'] = timeit(lovasz_fb, iters=5)
     return res
 
 

@@ -499,6 +499,42 @@ def gen_losses():
     save('voxel_losses.npz', seed=np.int64(41), class_weights=cw.numpy(), **{k: np.asarray(v) for k, v in out.items()})
 
 
+def gen_losses2():
+    """G11b (the finetune configs' other two voxel losses): CustomFocalLoss
+    (mmdet3d/models/loss_utils/focal_loss.py:163-262, CPU branch = py_sigmoid_focal_loss) on a (1,18,200,200,2) grid
+    (the class hard-codes the 200x200 radial map) -- loss value + every 97th gradient element -- and lovasz_softmax
+    (mmdet3d/models/detectors/lovasz_softmax.py:157-232) on the small voxel-loss inputs with full gradients."""
+    _mod('mmcv.ops', sigmoid_focal_loss=None)
+    _mod('mmdet.models.losses')
+    _mod('mmdet.models.losses.utils', weight_reduce_loss=None)
+    sys.modules['mmdet.models.builder'].LOSSES = _Registry()
+    fl = load_ref('ref_focal', 'mmdet3d/models/loss_utils/focal_loss.py')
+    lv = load_ref('ref_lovasz', 'mmdet3d/models/detectors/lovasz_softmax.py')
+    cw = torch.from_numpy(np.load(os.path.join(OUT, 'voxel_losses.npz'))['class_weights'])
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # CustomFocalLoss.__init__ moves its map to the GPU
+    try:
+        focal = fl.CustomFocalLoss()
+    finally:
+        torch.Tensor.cuda = real_cuda
+    out = {}
+    pred_np, target_np, cam_np = S.voxel_loss_inputs(43, shape=(1, 18, 200, 200, 2))
+    for tag, cam in (('cam', torch.from_numpy(cam_np)), ('nocam', None)):
+        pred = torch.from_numpy(pred_np).clone().requires_grad_()
+        loss = focal(pred, torch.from_numpy(target_np), cw, 255, camera_mask=cam)
+        loss.backward()
+        out['focal_' + tag] = loss.item()
+        out['focal_grad_' + tag] = pred.grad.numpy().reshape(-1)[::97].copy()
+    pred_np, target_np, cam_np = S.voxel_loss_inputs(41)
+    for tag, cam in (('cam', torch.from_numpy(cam_np)), ('nocam', None)):
+        pred = torch.from_numpy(pred_np).clone().requires_grad_()
+        loss = lv.lovasz_softmax(torch.softmax(pred, dim=1), torch.from_numpy(target_np), ignore=17, camera_mask=cam)
+        loss.backward()
+        out['lovasz_' + tag] = loss.item()
+        out['lovasz_grad_' + tag] = pred.grad.numpy().copy()
+    save('voxel_losses2.npz', seed_focal=np.int64(43), seed_lovasz=np.int64(41), **{k: np.asarray(v) for k, v in out.items()})
+
+
 def gen_render(nh):
     """G7: NerfHead.sample_ray / render_one_scene / render_* through the reference Python."""
     head = nh.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4,
@@ -581,6 +617,7 @@ def main():
     gen_traj(occ)
     gen_rays()
     gen_losses()
+    gen_losses2()
     gen_stereo(vtm)
     gen_render(nh)
     gen_metric(om)
