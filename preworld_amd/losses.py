@@ -167,3 +167,23 @@ def lovasz_softmax(probas, labels, classes='present', per_image=False, ignore=No
     if probas.dim() != 5:
         raise _lib.PreworldHipError('probas must be (B, C, X, Y, Z)')
     return _Lovasz.apply(probas, labels, camera_mask, ignore)
+
+
+def loss_voxel(output_voxels, target_voxels, class_weights, camera_mask=None, empty_idx=17, use_focal_loss=True,
+               weight_voxel_ce=1.0, weight_voxel_sem_scal=1.0, weight_voxel_geo_scal=1.0, weight_voxel_lovasz=1.0,
+               focal_loss=None):
+    """PreWorld.loss_voxel (mmdet3d/models/detectors/preworld.py:136-157) with the same dictionary keys:
+    class_weights = the detector's 17 `1/log(freq)` weights (a 0 for the free class is appended here as there, :147);
+    NaN / Inf logits are zeroed in place first (:137-138).  Four passes over the logits forward (focal or CE+sem+geo
+    share one when use_focal_loss is False) instead of the reference's several hundred masked reductions."""
+    output_voxels[torch.isnan(output_voxels)] = 0
+    output_voxels[torch.isinf(output_voxels)] = 0
+    cw = torch.cat([class_weights.to(output_voxels.device), torch.zeros(1, device=output_voxels.device)]).type_as(output_voxels)
+    ce, sem, geo = voxel_losses(output_voxels, target_voxels, cw, 255, empty_idx, camera_mask)
+    if use_focal_loss:
+        ce = (focal_loss or CustomFocalLoss())(output_voxels, target_voxels, cw, 255, camera_mask=camera_mask)
+    return {'loss_voxel_ce': weight_voxel_ce * ce,
+            'loss_voxel_sem': weight_voxel_sem_scal * sem,
+            'loss_voxel_geo': weight_voxel_geo_scal * geo,
+            'loss_voxel_lovasz': weight_voxel_lovasz * lovasz_softmax(torch.softmax(output_voxels, dim=1), target_voxels,
+                                                                      ignore=empty_idx, camera_mask=camera_mask)}
