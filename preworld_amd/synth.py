@@ -212,3 +212,34 @@ def stereo_inputs(seed, C=8, H=6, W=11, D=12, n_cams=2):
     y = np.linspace(0, hi - 1, H, dtype=np.float32)
     frustum = np.stack(np.broadcast_arrays(x[None, None, :], y[None, :, None], d[:, None, None]), -1).astype(np.float32)
     return prev, curr, k2s, K, post_rot, post_tran, np.ascontiguousarray(frustum)
+
+
+def seeded_module_state(module, seed):
+    """Deterministic state dict for any torch module, identified by its (sorted) keys and shapes only, so that the
+    reference module (tools/gen_golden.py) and the restated one (tests) get identical numbers without shipping weights:
+    BN running_var / LayerNorm & BN weights positive, everything else ~N(0, 0.08^2)."""
+    import torch
+    rs = np.random.RandomState(seed)
+    out = {}
+    for k in sorted(module.state_dict().keys()):
+        v = module.state_dict()[k]
+        if 'num_batches_tracked' in k or 'relative_position_index' in k:
+            continue
+        shape = tuple(v.shape)
+        if k.endswith('running_var'):
+            a = rs.uniform(0.5, 1.5, shape)
+        elif k.endswith('.weight') and v.dim() == 1:
+            a = rs.uniform(0.5, 1.5, shape)
+        else:
+            a = rs.standard_normal(shape) * 0.08
+        out[k] = torch.from_numpy(a.astype(np.float32))
+    return out
+
+
+def small_swin_cfg():
+    """A 4-stage Swin at toy width with the PreWorld settings that change the data flow (out_indices (2,3),
+    return_stereo_feat, shifted windows that need padding at 64x96 input)."""
+    return dict(pretrain_img_size=224, patch_size=4, window_size=4, mlp_ratio=4, embed_dims=16, depths=[2, 2, 2, 2],
+                num_heads=[2, 2, 4, 4], strides=(4, 2, 2, 2), out_indices=(2, 3), qkv_bias=True, qk_scale=None,
+                patch_norm=True, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, use_abs_pos_embed=False,
+                return_stereo_feat=True, pretrain_style='official', output_missing_index_as_none=False)

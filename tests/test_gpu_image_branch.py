@@ -1,0 +1,66 @@
+"""SURVEY 8f row 4 on the GPU: the DepthNet's stereo branch (HIP cost volume inside the PyTorch module) against the
+reference DepthNet's output, and images -> (depth, context) -> occupancy wiring of the whole detector."""
+import numpy as np
+import pytest
+import torch
+
+from preworld_amd import harness, image_encoder as IE, synth as S
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_depthnet_stereo_branch_matches_reference(golden):
+    """DepthNet.forward with a previous stereo feature: cost volume from pw_stereo_cost_volume, then cost_volumn_net,
+    depth_conv (BasicBlocks + ASPP) -- against the reference module's output (grid_sample cost volume on the CPU)."""
+    g = golden('image_branch_small.npz')
+    dn = IE.DepthNet(16, 16, 4, 12, use_dcn=False, aspp_mid_channels=8, stereo=True, bias=5.0).eval()
+    dn.load_state_dict(S.seeded_module_state(dn, 54))
+    dn = dn.to(DEV)
+    prev, curr, k2s, K, post_rot, post_tran, frustum = S.stereo_inputs(55, C=8, H=8, W=12, D=12, n_cams=2)
+    rs = np.random.RandomState(56)
+    xin = T(rs.standard_normal((2, 16, 2, 3)).astype(np.float32))
+    mlp = T(rs.standard_normal((1, 2, 27)).astype(np.float32))
+    metas = dict(k2s_sensor=T(k2s), intrins=T(K), post_rots=T(post_rot), post_trans=T(post_tran), frustum=T(frustum),
+                 cv_downsample=4, downsample=16, cv_feat_list=[T(prev), T(curr)])
+    with torch.no_grad():
+        out = dn(xin, mlp, metas)
+        metas['cv_feat_list'] = [None, T(curr)]
+        out0 = dn(xin, mlp, metas)
+    np.testing.assert_allclose(out.cpu().numpy(), g['depthnet_stereo'], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(out0.cpu().numpy(), g['depthnet_nostereo'], rtol=3e-4, atol=3e-5)
+    assert float((out - out0).abs().max()) > 1e-4          # the stereo branch is live
+
+
+def test_images_to_occupancy_wiring():
+    """ImageBranch.frames_from_images (extract_img_feat's frame loop: extra reference frame -> adjacent -> key, each
+    cost volume against the older frame) feeding PreWorld4DTraj.simple_test_from_lift: a toy-width Swin at the real
+    512x1408 input so that the DepthNet output has the (88+32, 32, 88) shape the C1 voxel path expects."""
+    cfg = IE.preworld_image_cfg()
+    cfg['backbone_cfg'] = dict(S.small_swin_cfg(), window_size=4)
+    cfg['neck_cfg'] = dict(in_channels=64 + 128, out_channels=48, extra_upsample=None, input_feature_index=(0, 1), scale_factor=2)
+    cfg['in_channels'] = 48
+    torch.manual_seed(0)
+    branch = IE.ImageBranch(**cfg).to(DEV).eval()
+    n_cams = 1
+    rigs = [S.synthetic_rig(n_cams, dx=-2.5 * f) for f in range(3)]
+    imgs = [torch.randn(1, n_cams, 3, 512, 1408, device=DEV) for _ in range(3)]
+    s2k = [T(r['sensor2ego']) for r in rigs]
+    e2g = [torch.eye(4, device=DEV).view(1, 1, 4, 4).repeat(1, n_cams, 1, 1) for _ in range(3)]
+    intr, prot, ptran = [T(r['intrin']) for r in rigs], [T(r['post_rot']) for r in rigs], [T(r['post_tran']) for r in rigs]
+    k2s = torch.eye(4, device=DEV).view(1, 1, 4, 4).repeat(1, n_cams, 1, 1)
+    k2s[..., 0, 3] = 0.3
+    frames = branch.frames_from_images(imgs, s2k, e2g, intr, prot, ptran, T(rigs[0]['bda']), [k2s, k2s, None])
+    assert len(frames) == 2                                # key + one adjacent; the extra frame only lends its stereo feature
+    for f in frames:
+        assert tuple(f['depth'].shape) == (n_cams, 88, 32, 88) and tuple(f['tran_feat'].shape) == (n_cams, 32, 88, 32)
+        np.testing.assert_allclose(f['depth'].sum(1).cpu().numpy(), 1.0, rtol=1e-4)
+    net = harness.build_model(harness.model_cfg(S.GRID_CONFIG_C1), S.synth_state_dict(0), DEV)
+    with torch.no_grad():
+        res = net.simple_test_from_lift(frames, T(S.ego_state(1)), n_steps=2)
+    occ = res['semantic_occ_0s'][0]
+    assert tuple(occ.shape) == (100, 100, 8) and occ.dtype == torch.uint8 and int(occ.max()) <= 17

@@ -52,7 +52,9 @@ class _Registry:
 
 def _build_norm_layer(cfg, num_features, postfix=''):
     t = cfg['type']
-    assert t in ('BN3d', 'BN', 'SyncBN', 'BN2d', 'BN1d')
+    assert t in ('BN3d', 'BN', 'SyncBN', 'BN2d', 'BN1d', 'LN')
+    if t == 'LN':
+        return 'ln' + str(postfix), nn.LayerNorm(num_features)
     layer = {'BN3d': nn.BatchNorm3d, 'SyncBN': nn.BatchNorm3d, 'BN': nn.BatchNorm2d,
              'BN2d': nn.BatchNorm2d, 'BN1d': nn.BatchNorm1d}[t](num_features)
     return 'bn' + str(postfix), layer
@@ -535,6 +537,95 @@ def gen_losses2():
     save('voxel_losses2.npz', seed_focal=np.int64(43), seed_lovasz=np.int64(41), **{k: np.asarray(v) for k, v in out.items()})
 
 
+class _RefBasicBlock(nn.Module):
+    """mmdet 2.24 ResNet BasicBlock (third-party, absent here) for the reference DepthNet: conv1/bn1/conv2/bn2/downsample."""
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, **kw):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        return self.relu(out + (x if self.downsample is None else self.downsample(x)))
+
+
+class _RefBaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+
+
+class _RefFFN(nn.Module):
+    """mmcv-full 1.6.0 FFN (third-party, absent here), num_fcs=2, add_identity=True."""
+
+    def __init__(self, embed_dims, feedforward_channels, num_fcs=2, ffn_drop=0., dropout_layer=None, act_cfg=None,
+                 add_identity=True, init_cfg=None):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.GELU(), nn.Dropout(ffn_drop)),
+                                    nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop))
+
+    def forward(self, x, identity=None):
+        return (x if identity is None else identity) + self.layers(x)
+
+
+def gen_image_branch(vtm, fpn):
+    """G12: the reference SwinTransformer (backbones/swin.py), FPN_LSS (necks/lss_fpn.py) and DepthNet
+    (necks/view_transformer.py) at reduced sizes with seeded weights (synth.seeded_module_state) -> outputs only."""
+    _mod('mmcv.cnn.bricks.transformer', FFN=_RefFFN, build_dropout=lambda cfg: nn.Identity())
+    _mod('mmcv.cnn.utils')
+    _mod('mmcv.cnn.utils.weight_init', constant_init=None)
+    _mod('mmcv.cnn.bricks.registry', ATTENTION=_Registry())
+    _mod('mmcv.runner.base_module', BaseModule=_RefBaseModule, ModuleList=nn.ModuleList)
+    sys.modules['mmcv.runner']._load_checkpoint = None
+    sys.modules['mmcv.cnn'].trunc_normal_init = None
+    _mod('mmseg'); _mod('mmseg.ops', resize=None)
+    _mod('mmdet3d.utils', get_root_logger=None)
+    sys.modules['mmdet3d.models.builder'].BACKBONES = sys.modules['mmdet3d.models.builder'].NECKS
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        sw = load_ref('mmdet3d.models.backbones.swin', 'mmdet3d/models/backbones/swin.py')
+        cfg = S.small_swin_cfg()
+        net = sw.SwinTransformer(**cfg, with_cp=False)
+        net.eval()                      # the reference's train() override returns None
+    net.load_state_dict(S.seeded_module_state(net, 51), strict=False)
+    x = torch.from_numpy(np.random.RandomState(52).standard_normal((2, 3, 64, 96)).astype(np.float32))
+    with torch.no_grad():
+        outs = net(x)
+        # extract_stereo_ref_feat's Swin branch (bevdet.py:589-603)
+        t = net.drop_after_pos(net.patch_embed(x))
+        _, _, o0, hw0 = net.stages[0](t, (net.patch_embed.DH, net.patch_embed.DW))
+        ref0 = o0.view(-1, *hw0, net.num_features[0]).permute(0, 3, 1, 2).contiguous()
+    neck = fpn.FPN_LSS(in_channels=64 + 128, out_channels=24, extra_upsample=None, input_feature_index=(0, 1), scale_factor=2).eval()
+    neck.load_state_dict(S.seeded_module_state(neck, 53))
+    with torch.no_grad():
+        nout = neck(outs[1:])
+    vtm.BasicBlock = _RefBasicBlock
+    dn = vtm.DepthNet(16, 16, 4, 12, use_dcn=False, aspp_mid_channels=8, stereo=True, bias=5.0).eval()
+    dn.load_state_dict(S.seeded_module_state(dn, 54))
+    st = dict(zip(('prev', 'curr', 'k2s_sensor', 'intrins', 'post_rots', 'post_trans', 'frustum'),
+                  S.stereo_inputs(55, C=8, H=8, W=12, D=12, n_cams=2)))
+    rs = np.random.RandomState(56)
+    xin = torch.from_numpy(rs.standard_normal((2, 16, 2, 3)).astype(np.float32))
+    mlp = torch.from_numpy(rs.standard_normal((1, 2, 27)).astype(np.float32))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    metas = dict(k2s_sensor=T(st['k2s_sensor']), intrins=T(st['intrins']), post_rots=T(st['post_rots']),
+                 post_trans=T(st['post_trans']), frustum=T(st['frustum']), cv_downsample=4, downsample=16,
+                 cv_feat_list=[T(st['prev']), T(st['curr'])])
+    with torch.no_grad():
+        d_st = dn(xin, mlp, metas)
+        metas['cv_feat_list'] = [None, T(st['curr'])]
+        d_no = dn(xin, mlp, metas)
+    save('image_branch_small.npz', swin_stereo=outs[0].numpy(), swin_s2=outs[1].numpy(), swin_s3=outs[2].numpy(),
+         swin_ref0=ref0.numpy(), neck=nout.numpy(), depthnet_stereo=d_st.numpy(), depthnet_nostereo=d_no.numpy(),
+         swin_keys=np.array(sorted(net.state_dict().keys())), neck_keys=np.array(sorted(neck.state_dict().keys())),
+         depthnet_keys=np.array(sorted(dn.state_dict().keys())))
+
+
 def gen_render(nh):
     """G7: NerfHead.sample_ray / render_one_scene / render_* through the reference Python."""
     head = nh.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4,
@@ -618,6 +709,7 @@ def main():
     gen_rays()
     gen_losses()
     gen_losses2()
+    gen_image_branch(vtm, fpn)
     gen_stereo(vtm)
     gen_render(nh)
     gen_metric(om)
