@@ -78,44 +78,51 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
   const unsigned um0 = (unsigned)m0;
   const unsigned q1 = um0 / (unsigned)a.W;
   const int ow0 = (int)(um0 - q1 * (unsigned)a.W);
-  if (ow0 + 32 <= a.W && m0 + 32 <= n_vox) {
+  // source-column windows of the tile at both levels (<= 20 columns each for the 1/2 and 1/4 maps)
+  const int wb2 = (int)(sw2 * (float)ow0), wl2 = min((int)(sw2 * (float)(ow0 + 31)) + 1, f.W2 - 1);
+  const int wb4 = (int)(sw4 * (float)ow0), wl4 = min((int)(sw4 * (float)(ow0 + 31)) + 1, f.W4 - 1);
+  if (ow0 + 32 <= a.W && m0 + 32 <= n_vox && wl2 - wb2 < 20 && wl4 - wb4 < 20) {
     const unsigned q2 = q1 / (unsigned)a.H;
     const int oh = (int)(q1 - q2 * (unsigned)a.H);
     const int b = (int)(q2 / (unsigned)a.D);
     const int od = (int)(q2 - (unsigned)b * (unsigned)a.D);
-    struct Lvl { const float* p00; const float* p01; const float* p10; const float* p11; float ld1, lh1; };
-    auto level = [&](const float* y, int Dl, int Hl, int Wl, float sd, float sh) {
+    // Two-stage trilinear: (1) the low-resolution source columns this tile touches (<= 18 at 1/2, <= 10 at 1/4
+    // resolution) are interpolated along d and h ONCE per wave and parked in LDS -- 4 loads per column instead of 8
+    // corner loads per output voxel and level; (2) every output voxel finishes with one lerp along w between two LDS
+    // values per level.  (Interpolating d/h before w reassociates the reference's w-h-d order: ~1e-7 relative.)
+    __shared__ float cols[4][2][20][32];
+    float (&c2)[20][32] = cols[wave][0];
+    float (&c4)[20][32] = cols[wave][1];
+    auto stage = [&](const float* y, int Dl, int Hl, int Wl, float sd, float sh, float (&dst)[20][32], int wbase, int wlast) {
       const float fd = sd * (float)od, fh = sh * (float)oh;
       const int d0 = (int)fd, h0 = (int)fh;
       const int d1 = d0 + (d0 < Dl - 1), h1 = h0 + (h0 < Hl - 1);
+      const float ld1 = fd - (float)d0, ld0 = 1.f - ld1, lh1 = fh - (float)h0, lh0 = 1.f - lh1;
       const float* base = y + (size_t)b * Dl * Hl * Wl * 32 + i;
-      Lvl l;
-      l.p00 = base + (size_t)((d0 * Hl + h0) * Wl) * 32; l.p01 = base + (size_t)((d0 * Hl + h1) * Wl) * 32;
-      l.p10 = base + (size_t)((d1 * Hl + h0) * Wl) * 32; l.p11 = base + (size_t)((d1 * Hl + h1) * Wl) * 32;
-      l.ld1 = fd - (float)d0; l.lh1 = fh - (float)h0;
-      return l;
+      const float* p00 = base + (size_t)((d0 * Hl + h0) * Wl) * 32; const float* p01 = base + (size_t)((d0 * Hl + h1) * Wl) * 32;
+      const float* p10 = base + (size_t)((d1 * Hl + h0) * Wl) * 32; const float* p11 = base + (size_t)((d1 * Hl + h1) * Wl) * 32;
+      for (int j = wbase + half; j <= wlast; j += 2) {
+        const unsigned o = (unsigned)j * 32u;
+        dst[j - wbase][i] = ld0 * (lh0 * p00[o] + lh1 * p01[o]) + ld1 * (lh0 * p10[o] + lh1 * p11[o]);
+      }
     };
-    const Lvl l2 = level(f.y16, f.D2, f.H2, f.W2, sd2, sh2), l4 = level(f.y32, f.D4, f.H4, f.W4, sd4, sh4);
-    auto lerp_w = [](const Lvl& l, int Wl, float sw, int ow) {
-      // same operation order as trilerp_ac: ld0*(lh0*(lw0 v000 + lw1 v001) + lh1*(...)) + ld1*(...)
+    stage(f.y16, f.D2, f.H2, f.W2, sd2, sh2, c2, wb2, wl2);
+    stage(f.y32, f.D4, f.H4, f.W4, sd4, sh4, c4, wb4, wl4);
+    __builtin_amdgcn_wave_barrier();                    // a wave's LDS accesses execute in program order: no s_barrier
+    auto lerp_w = [&](const float (&src)[20][32], int Wl, float sw, int wbase, int ow) {
       const float fw = sw * (float)ow;
       const int w0 = (int)fw;
       const int w1 = w0 + (w0 < Wl - 1);
-      const float lw1 = fw - (float)w0, lw0 = 1.f - lw1;
-      const float lh0 = 1.f - l.lh1, ld0 = 1.f - l.ld1;
-      const unsigned o0 = (unsigned)w0 * 32u, o1 = (unsigned)w1 * 32u;
-      const float v000 = l.p00[o0], v001 = l.p00[o1], v010 = l.p01[o0], v011 = l.p01[o1];
-      const float v100 = l.p10[o0], v101 = l.p10[o1], v110 = l.p11[o0], v111 = l.p11[o1];
-      return ld0 * (lh0 * (lw0 * v000 + lw1 * v001) + l.lh1 * (lw0 * v010 + lw1 * v011)) +
-             l.ld1 * (lh0 * (lw0 * v100 + lw1 * v101) + l.lh1 * (lw0 * v110 + lw1 * v111));
+      const float lw1 = fw - (float)w0;
+      return (1.f - lw1) * src[w0 - wbase][i] + lw1 * src[w1 - wbase][i];
     };
     float* out = a.y0 + (size_t)m0 * 32 + i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
       float v = acc[r];
-      v += lerp_w(l2, f.W2, sw2, ow0 + row);
-      v += lerp_w(l4, f.W4, sw4, ow0 + row);
+      v += lerp_w(c2, f.W2, sw2, wb2, ow0 + row);
+      v += lerp_w(c4, f.W4, sw4, wb4, ow0 + row);
       v = v * sc + bi;
       if (a.relu0) v = fmaxf(v, 0.f);
       out[(unsigned)row * 32u] = v;
