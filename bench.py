@@ -182,25 +182,31 @@ def cpu_baseline(sd, budget_s=25.0):
     from oracle import oracle as O
     threads = O.num_threads()
     gc = S.GRID_CONFIG_C1
-    rig = S.synthetic_rig(1)
-    t0 = time.time()
-    bevs = []
-    for f in range(2):
-        depth, feat = S.lift_inputs(100 + f, N=1)
-        r = S.synthetic_rig(1, dx=-2.5 * f)
-        bev = O.lss_view_transform(depth, feat, r['sensor2ego'], r['intrin'], r['post_rot'],
-                                   r['post_tran'], r['bda'], gc, S.INPUT_SIZE, S.DOWNSAMPLE)
-        bevs.append(O.pre_process(bev, sd))
-    x = O.encoder_forward(bevs[1], bevs[0], sd)
-    vf = O.final_conv(x, sd)
-    states, _ = O.preworld4d_decode(vf, S.ego_state(0), sd, n_steps=6, post_finetune=True)
-    dt = time.time() - t0
-    assert len(states) == 7 and states[0].shape == (100, 100, 8)
     scale = (200 * 200 * 16) / (100 * 100 * 8)
+    times = []
+    t_all = time.time()
+    # repeat with fresh seeds until ~10 s of CPU work are in the sample (at most 6 runs, at least 2)
+    while len(times) < 2 or (time.time() - t_all < 10.0 and len(times) < 6):
+        seed = 100 + 16 * len(times)
+        t0 = time.time()
+        bevs = []
+        for f in range(2):
+            depth, feat = S.lift_inputs(seed + f, N=1)
+            r = S.synthetic_rig(1, dx=-2.5 * f)
+            bev = O.lss_view_transform(depth, feat, r['sensor2ego'], r['intrin'], r['post_rot'],
+                                       r['post_tran'], r['bda'], gc, S.INPUT_SIZE, S.DOWNSAMPLE)
+            bevs.append(O.pre_process(bev, sd))
+        x = O.encoder_forward(bevs[1], bevs[0], sd)
+        vf = O.final_conv(x, sd)
+        states, _ = O.preworld4d_decode(vf, S.ego_state(len(times)), sd, n_steps=6, post_finetune=True)
+        times.append(time.time() - t0)
+        assert len(states) == 7 and states[0].shape == (100, 100, 8)
+    dt = float(np.mean(times))
     return dict(value=1.0 / (dt * scale), unit='samples/s', cores=threads, kind='port',
-                sample='C3 pipeline on the C1-sized grid (1 cam, 100x100x8 = 1/8 of the voxels): '
-                       '%.2f s on %d OpenMP threads, scaled x%d by voxel count; the reference has '
-                       'no CPU path for these ops' % (dt, threads, int(scale)))
+                sample='%d runs of the C3 pipeline on the C1-sized grid (1 cam, 100x100x8 = 1/8 of the voxels): '
+                       'mean %.2f s (min %.2f, max %.2f; %.1f s of CPU work) on %d OpenMP threads, scaled x%d by voxel '
+                       'count; the reference has no CPU path for these ops'
+                       % (len(times), dt, min(times), max(times), sum(times), threads, int(scale)))
 
 
 # ------------------------------------------------------------------------------ main
