@@ -31,7 +31,9 @@ class CapturedSample:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread_local: a HIP call from another thread of the process (the RCCL watchdog of a multi-GPU run polls
+        # events) must not invalidate this thread's capture
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'), torch.no_grad():
             self.out = self._step()
 
     def _step(self):
