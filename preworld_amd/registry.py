@@ -12,7 +12,7 @@ mmdet.models.HEADS, occupancy_head.py:13,45, nerf_head.py:103-104).  Re-registra
 this image, so the adapter takes the registry objects as arguments and is unit-tested against a
 minimal stand-in with the same `register_module(name=None, force=False, module=None)` signature.
 """
-from . import modules
+from . import losses, modules
 
 # reference type name -> (which registry, replacement class)
 REPLACEMENTS = {
@@ -21,14 +21,18 @@ REPLACEMENTS = {
     'LSSFPN3D': ('mmdet.NECKS', modules.LSSFPN3D),
     'OccHead': ('mmdet.HEADS', modules.OccHead),
     'NerfHead': ('mmdet.HEADS', modules.NerfHead),
+    # mmdet3d/models/loss_utils/focal_loss.py:7,162 registers it in mmdet's LOSSES; preworld.py:117 builds it by name
+    'CustomFocalLoss': ('mmdet.LOSSES', losses.CustomFocalLoss),
 }
 
 
 def register(registries):
-    """registries: dict with keys 'mmdet3d.NECKS', 'mmdet.BACKBONES', 'mmdet.NECKS', 'mmdet.HEADS'
+    """registries: dict with keys 'mmdet3d.NECKS', 'mmdet.BACKBONES', 'mmdet.NECKS', 'mmdet.HEADS' [, 'mmdet.LOSSES']
     mapping to mmcv-style Registry objects.  Returns the list of (registry key, type name)."""
     done = []
     for name, (key, cls) in REPLACEMENTS.items():
+        if key not in registries:            # callers that only replace modules may leave LOSSES out
+            continue
         registries[key].register_module(name=name, force=True, module=cls)
         done.append((key, name))
     return done
@@ -37,6 +41,7 @@ def register(registries):
 def register_into_mmdet3d():
     """Resolve the real registries (needs mmdet3d's dependencies importable) and register."""
     from mmdet.models import BACKBONES, HEADS, NECKS as MMDET_NECKS   # noqa: F401
+    from mmdet.models.builder import LOSSES
     from mmdet3d.models.builder import NECKS as MMDET3D_NECKS
     return register({'mmdet3d.NECKS': MMDET3D_NECKS, 'mmdet.BACKBONES': BACKBONES,
-                     'mmdet.NECKS': MMDET_NECKS, 'mmdet.HEADS': HEADS})
+                     'mmdet.NECKS': MMDET_NECKS, 'mmdet.HEADS': HEADS, 'mmdet.LOSSES': LOSSES})

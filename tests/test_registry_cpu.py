@@ -52,6 +52,11 @@ def test_force_reregistration_and_build_from_reference_cfg():
     assert sum(p.numel() for p in nk.parameters()) == 7232
     assert sum(p.numel() for p in hd.parameters()) == 14296
     assert set(nh.state_dict()) == {'scene_center', 'scene_radius', 'xyz_min', 'xyz_max', 'act_shift'}
+    assert ('mmdet.LOSSES', 'CustomFocalLoss') not in done           # no LOSSES registry was passed: skipped, not an error
+    regs['mmdet.LOSSES'] = FakeRegistry()
+    assert ('mmdet.LOSSES', 'CustomFocalLoss') in R.register(regs)
+    fl = regs['mmdet.LOSSES'].build(dict(type='CustomFocalLoss'))      # preworld.py:117
+    assert (fl.gamma, fl.alpha, fl.loss_weight) == (2.0, 0.25, 100.0)
 
 
 def test_state_dict_keys_match_reference_names():
