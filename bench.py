@@ -146,7 +146,9 @@ class KernelProbe:
             # Winograd-domain weights are 5-d (pack_conv_weight_wino): same algorithmic work, 8/27 of the conv's
             # multiplies executed
             label = 'conv3d_wino_mfma<occ_head>' if args[1].dim() == 5 else 'conv3d_k3s1_mfma<occ_head>'
-            return label, 2.0 * nv * (27 * 32 * 16 + 16 * 8 + 8 * 18), 4.0 * x.numel() + nv
+            # the six forecast states are decoded by ONE launch over a batch of 6: counted as 6 units of one state
+            # each, so that per-launch figures (duration, algorithmic bytes, PMC traffic) stay per 200x200x16 state
+            return label, 2.0 * nv * (27 * 32 * 16 + 16 * 8 + 8 * 18), 4.0 * x.numel() + nv, int(x.shape[0])
         if name == 'forecast_steps':
             v0, n_steps = args[0], args[6]
             nv = v0.numel() // 32
@@ -164,9 +166,10 @@ class KernelProbe:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, (label, fl, by), s, e in self.records:
+        for name, work, s, e in self.records:
+            label, fl, by = work[:3]
             a = agg.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-            a['launches'] += 1
+            a['launches'] += work[3] if len(work) > 3 else 1
             a['ms'] += s.elapsed_time(e)
             a['flops'] += fl
             a['bytes'] += by
@@ -290,7 +293,9 @@ def main():
                         launches_per_step=a['launches'] // 3,
                         **(dict(executed_tflops=round(tf * 8 / 27, 2), executed_frac=round(tf * 8 / 27 / PEAK_FP32_MFMA_TFLOPS, 4),
                                 note='Winograd F(2x2x2,3x3x3): achieved = direct-form (algorithmic) FLOPs / time, which can '
-                                     'exceed the matrix-pipe peak; executed_* counts the 8/27 of them the MFMAs really do')
+                                     'exceed the matrix-pipe peak; executed_* counts the 8/27 of them the MFMAs really do'
+                                     + ('; a launch here = one 200x200x16 state (states 1-6 share one kernel launch over a '
+                                        'batch of 6)' if 'occ_head' in label else ''))
                            if label.startswith('conv3d_wino') else {}),
                         all_kernels={k: dict(us_per_step=round(v['ms'] * 1e3 / 3, 1),
                                              launches=v['launches'] // 3,

@@ -743,12 +743,18 @@ class PreWorld4DTraj(nn.Module):
             return self._simple_test_attributes(v0, temporal_ego_states, n_steps)
         res = {}
         feats = [v0]
+        B = v0.shape[0]
+        # OccHead on state 0, then on ALL forecast states in one launch (they are one contiguous (n_steps*B, Z, Y, X, C)
+        # buffer): one persistent-kernel prologue and one partial last round of tiles instead of n_steps of each
+        outs = [self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True)]
         if n_steps > 0:
             states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps)
             feats += [states[k] for k in range(n_steps)]
+            o = self.occupancy_head.decode_cl(states.view((n_steps * B,) + tuple(v0.shape[1:])), want_logits=want_logits,
+                                              transposed=True, want_geo=True)
+            outs += [tuple(t[k * B:(k + 1) * B] for t in o) for k in range(n_steps)]
         logits_all = []
-        for k, f in enumerate(feats):
-            out = self.occupancy_head.decode_cl(f, want_logits=want_logits, transposed=True, want_geo=True)
+        for k, out in enumerate(outs):
             occ, geo = out[0], out[-1]                                 # geo_occ from the same kernel (:313-319)
             if want_logits:
                 logits_all.append(out[1])
