@@ -82,3 +82,33 @@ def evaluate(net, samples, device='cuda:0', use_image_mask=True):
         for h, gt in s['gt'].items():
             metric.add_batch(st, gt, None, s.get('mask_camera'), h)
     return metric.count_miou(), stacks
+
+
+@torch.no_grad()
+def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=False):
+    """The latency mode of DESIGN.md section 7 wired to the real modules (one process per GPU, torch.distributed
+    initialised): frame f is lifted + pre-processed on rank f % W and broadcast (parallel.lift_frames_sharded), every rank
+    runs the encoder, state k is forecast + decoded on rank k % W, one all_gather of the uint8 grids assembles all states
+    on every rank.  Returns {'semantic_occ_%ds': [(X,Y,Z) uint8]} like simple_test_from_lift.
+    gather_on_host=True moves the 0.64 MB grids through host memory (for process groups that cannot all_gather device
+    tensors: gloo in the tests; RCCL takes device tensors)."""
+    from . import parallel
+    vt = net.img_view_transformer
+    _, _, size = vt._grid()
+    f0 = frames[0]
+    B, C = f0['sensor2keyego'].shape[0], vt.out_channels
+    n = net.num_adj + 1
+    lifted = parallel.lift_frames_sharded(frames[:n], lambda fr: net.lift_frame_cl(**fr),
+                                          (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device, group)
+    x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                       # [adjacent ..., key] (bevdet_occ.py:266)
+    if len(lifted) < n:
+        x = torch.cat([x.new_zeros(x.shape[:-1] + ((n - len(lifted)) * C,)), x], dim=-1)
+    v0 = net.final_conv.forward_cl(net.bev_encoder_cl(x))
+
+    def decode(f):
+        occ = net.occupancy_head.decode_cl(f, transposed=True)
+        occ = occ.permute(0, 3, 2, 1)[0].contiguous()                          # batch element 0, (X,Y,Z) (:306)
+        return occ.cpu() if gather_on_host else occ
+
+    grids = parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k)[0][k - 1], decode, n_steps + 1, group)
+    return {'semantic_occ_%ds' % k: [g] for k, g in enumerate(grids)}
