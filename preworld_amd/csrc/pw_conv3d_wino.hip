@@ -319,6 +319,7 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 4; ++k) Mp[k] = M[k];
+  if constexpr (W::H == 7 && R % (2 * NG) == NG - 1) __syncthreads();   // barrier X: the next halo has landed (pw_wino_common.h)
   if constexpr (W::last) __syncthreads();                       // end of the half-step
   if constexpr (R + 1 < TOTAL) ws_rows<R + 1, NG>(c, ubase, ubase_next, an, bn, ac, bc, Mp, Y);
 }

@@ -128,8 +128,8 @@ __device__ __forceinline__ void ws_transform_write(lds3_t lds3, unsigned v_base,
 }
 
 // The transform + DMA role of the wave-specialised kernels (4 waves, tw = 0..3, tt = thread 0..255 = (tile, channel
-// quad)): runs one half-step ahead of the GEMM waves, see pw_conv3d_wino.hip.  Two barriers of prologue, then 8 per
-// (work item, 32-channel chunk); consecutive items of a block are item, item + nslots, ... < it_end.
+// quad)): runs one half-step ahead of the GEMM waves, see pw_conv3d_wino.hip.  Two barriers of prologue, then 9 per
+// (work item, 32-channel chunk) -- one per half-step plus barrier X inside the last one; consecutive items of a block are item, item + nslots, ... < it_end.
 __device__ __forceinline__ void ws_transform_role(const ConvArgs& a, const PipeArgs& p, lds3_t lds3, int item, int it_end,
                                                   int nslots, int nchunk, int tw, int tt, int lane) {
   const int tile = tt >> 3, quad = tt & 7;
@@ -138,19 +138,38 @@ __device__ __forceinline__ void ws_transform_role(const ConvArgs& a, const PipeA
   const int t16 = tile & 15;
   const unsigned v_base = (unsigned)(((ttd * 16 + wino_row16(t16)) * 8 + (quad ^ (t16 & 7))) * 16);
   const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
-  PipeDma dm;
-  dm.ldsbuf = 0; dm.live = true;
+  // Halo DMA of a tile and chunk: this wave moves halo rows tw + 4 K, K = 0..14 (row = d * 10 + h of the 6 x 10 x 10
+  // halo), two buffer_load ... lds each (8 + 2 voxels).  What depends only on the row -- its byte offset inside the volume
+  // and its (d, h) -- is computed ONCE, vectorially, lane K holding row K's values; per tile a row then costs a readlane, an
+  // add and two selects next to its two DMA instructions.  (The generic pipe_dma_row recomputes ~30 scalar instructions
+  // per row; in this role they sit between two barriers of a wave that shares its SIMD with an MFMA stream, and the
+  // tile decode + 15 rows were the longest barrier wait of the GEMM waves: 4.7 k cycles per tile.)
+  const int krow = tw + 4 * (lane & 15);
+  const int kdd = krow / TH, khh = krow - kdd * TH;
+  const unsigned v_rowoff = (unsigned)((kdd * a.H + khh) * a.W) * (unsigned)a.Cin * 4u;
+  unsigned dma_base = 0, voff0 = 0, voff1 = 0;
+  unsigned long long dma_ok = 0;
   auto aim = [&](int it, int ch) {
     const PipeTile t = pipe_decode(a, p, it);
+    PipeDma dm;
     wino_lane_offsets(a, t.w0, lane, dm);
-    dm.b = t.b; dm.d0 = t.d0; dm.h0 = t.h0; dm.wbase = t.w0 > 0 ? t.w0 - 1 : 0; dm.ch = ch;
+    voff0 = dm.voff[0][0]; voff1 = dm.voff[0][1];
+    const int wbase = t.w0 > 0 ? t.w0 - 1 : 0;
+    dma_base = (unsigned)(((((t.b * a.D + t.d0 - 1) * a.H + t.h0 - 1) * a.W + wbase) * a.Cin + ch * KC) * 4);
+    const int gd = t.d0 + kdd - 1, gh = t.h0 + khh - 1;
+    dma_ok = __ballot((unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H);
+  };
+  auto dma_row = [&](int K) {                            // K is a compile-time constant at every call site
+    const unsigned soff = dma_base + (unsigned)__builtin_amdgcn_readlane((int)v_rowoff, K);
+    const bool ok = (dma_ok >> K) & 1ull;
+    const unsigned v0 = ok ? voff0 : PIPE_OOB, v1 = ok ? voff1 : PIPE_OOB;
+    lds3_t dst = lds3 + (unsigned)(tw + 4 * K) * (TW * 128);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, v0, ok ? soff : 0u, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst + 1024, 4, v1, ok ? soff : 0u, 0, 0);
   };
   auto dma = [&]() {
-    pipe_dma_row<0>(a, xr, lds3, dm, tw); pipe_dma_row<1>(a, xr, lds3, dm, tw); pipe_dma_row<2>(a, xr, lds3, dm, tw);
-    pipe_dma_row<3>(a, xr, lds3, dm, tw); pipe_dma_row<4>(a, xr, lds3, dm, tw); pipe_dma_row<5>(a, xr, lds3, dm, tw);
-    pipe_dma_row<6>(a, xr, lds3, dm, tw); pipe_dma_row<7>(a, xr, lds3, dm, tw); pipe_dma_row<8>(a, xr, lds3, dm, tw);
-    pipe_dma_row<9>(a, xr, lds3, dm, tw); pipe_dma_row<10>(a, xr, lds3, dm, tw); pipe_dma_row<11>(a, xr, lds3, dm, tw);
-    pipe_dma_row<12>(a, xr, lds3, dm, tw); pipe_dma_row<13>(a, xr, lds3, dm, tw); pipe_dma_row<14>(a, xr, lds3, dm, tw);
+    dma_row(0); dma_row(1); dma_row(2); dma_row(3); dma_row(4); dma_row(5); dma_row(6); dma_row(7);
+    dma_row(8); dma_row(9); dma_row(10); dma_row(11); dma_row(12); dma_row(13); dma_row(14);
   };
   f32x4 y[4][4], P1[4][4], P2[4][4];
   aim(item, 0);
@@ -168,16 +187,24 @@ __device__ __forceinline__ void ws_transform_role(const ConvArgs& a, const PipeA
       ws_transform_read<1>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 1
       ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 2
       ws_transform_read<2>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 3
-      ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 4
-      ws_transform_read<3>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 5: last read of R
-      if (has_next) {                                                                                // step 6
-        aim(more_ch ? item : item + nslots, more_ch ? ch + 1 : 0);
-        dma();
-      }
+      // step 4 (light): the next tile's decode is done here, off the DMA step's critical path -- a wave that shares its SIMD
+      // with an MFMA stream issues roughly one instruction per 14 cycles, so WHERE its instructions sit decides who waits
       ws_transform_write<1>(lds3, v_base, y);
-      __builtin_amdgcn_s_waitcnt(0);
+      if (has_next) aim(more_ch ? item : item + nslots, more_ch ? ch + 1 : 0);
       __syncthreads();
-      if (has_next) {                                                                                // step 7
+      ws_transform_read<3>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 5: last read of R
+      if (has_next) dma();                                                                           // step 6
+      ws_transform_write<1>(lds3, v_base, y);
+      // end of step 6 WITHOUT waiting for the DMA: __syncthreads() would (correctly, for a release fence) drain vmcnt
+      // because the in-flight buffer_load ... lds are LDS writes; here only this wave's ds_writes must have landed
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // step 7.  The halo DMA issued in step 6 takes ~3.5 k cycles to land (measured: it was the longest barrier wait of
+      // the GEMM waves when awaited inside step 6): it is awaited here instead, and an extra mid-step barrier X -- the
+      // GEMM waves take it between their two rows of this half-step -- publishes "every wave's DMA has landed" before
+      // anyone reads R.  The DMA then flies under step 6 and the first row of step 7, the heavy transform under the second.
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();                                                                               // barrier X
+      if (has_next) {
         ws_transform_read<0>(lds3, r_base, y, P1, P2);
         ws_transform_write<0>(lds3, v_base, y);
       }
