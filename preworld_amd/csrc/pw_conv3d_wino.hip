@@ -243,9 +243,9 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_wino(ConvArgs a, int n16_tota
 //     (two i_h rows); while the GEMM waves do the MFMAs of half-step g from V[g & 1], the transform waves
 //     write half-step g + 1 into V[(g + 1) & 1]; one workgroup barrier per half-step;
 //   * the raw halo R is read only by the even half-steps (d-combine + h-transform of all four i_h rows, the
-//     second pair stays in registers), the last time in step 5 of a 32-channel chunk: the DMA of the next
-//     chunk's / next tile's halo is issued by the transform waves in step 6 and has landed by the barrier
-//     that ends it, so the halo load overlaps the MFMAs too, and the kernel is persistent over tiles;
+//     second pair stays in registers), the last time in step 3 of a 32-channel chunk (plane d3 is prefetched
+//     there): the DMA of the next chunk's / next tile's halo is issued by the transform waves in step 5 and
+//     awaited at the end of step 6, so the halo load overlaps the MFMAs too, and the kernel is persistent;
 //   * the GEMM waves stream weight rows one row (4 points) ahead across half-steps, chunks and tiles.
 // Measured (16x200x200, sustained): 32->32 158 us (tile-per-block kernel 201), 32->64 263 (332), 64->64 ~485 (623).
 // With the transform switched off the GEMM waves alone take 129 us for 68 us of MFMA time, with the GEMM off the
@@ -319,7 +319,6 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 4; ++k) Mp[k] = M[k];
-  if constexpr (W::H == 7 && R % (2 * NG) == NG - 1) __syncthreads();   // barrier X: the next halo has landed (pw_wino_common.h)
   if constexpr (W::last) __syncthreads();                       // end of the half-step
   if constexpr (R + 1 < TOTAL) ws_rows<R + 1, NG>(c, ubase, ubase_next, an, bn, ac, bc, Mp, Y);
 }

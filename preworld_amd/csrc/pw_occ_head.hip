@@ -428,7 +428,6 @@ __device__ __forceinline__ void occw_rows(const WinoCtx& c, f32x4 (&bc)[4][2], f
     __syncthreads();
     occw_rows<H + 1, RSEL>(c, bn, bc, Mp, Y, xch_mine);
   } else {
-    __syncthreads();                                            // barrier X of the last half-step (pw_wino_common.h)
     wino_scatter_row<W::ID, W::IH>(M, Y);
     // the partner finishes o_d = 1 - RSEL: hand it those four outputs
     const unsigned lane16 = (unsigned)(threadIdx.x & 63) * 16u;

@@ -104,9 +104,11 @@ __device__ __forceinline__ void ws_transform_read(lds3_t lds3, unsigned r_base, 
         x[hh] = P1[hh][ww] + P2[hh][ww];
       } else if constexpr (ID == 2) {
         x[hh] = sub4(P2[hh][ww], P1[hh][ww]);
+        // d2 is dead from here on: its registers take plane d3 now, in a step where this role has slack, so that the
+        // last read of R happens two half-steps before the halo DMA of the next tile needs the buffer
+        P2[hh][ww] = lds_read4(lds3, r_base + (unsigned)(((3 * TH + hh) * TW + ww) * 128));
       } else {
-        const f32x4 p3 = lds_read4(lds3, r_base + (unsigned)(((3 * TH + hh) * TW + ww) * 128));
-        x[hh] = sub4(P1[hh][ww], p3);
+        x[hh] = sub4(P1[hh][ww], P2[hh][ww]);                 // P2 holds plane d3 (loaded by the ID 2 call)
       }
     }
     bt4(x[0], x[1], x[2], x[3], y[0][ww], y[1][ww], y[2][ww], y[3][ww]);
@@ -128,8 +130,8 @@ __device__ __forceinline__ void ws_transform_write(lds3_t lds3, unsigned v_base,
 }
 
 // The transform + DMA role of the wave-specialised kernels (4 waves, tw = 0..3, tt = thread 0..255 = (tile, channel
-// quad)): runs one half-step ahead of the GEMM waves, see pw_conv3d_wino.hip.  Two barriers of prologue, then 9 per
-// (work item, 32-channel chunk) -- one per half-step plus barrier X inside the last one; consecutive items of a block are item, item + nslots, ... < it_end.
+// quad)): runs one half-step ahead of the GEMM waves, see pw_conv3d_wino.hip.  Two barriers of prologue, then 8 per
+// (work item, 32-channel chunk), one per half-step; consecutive items of a block are item, item + nslots, ... < it_end.
 __device__ __forceinline__ void ws_transform_role(const ConvArgs& a, const PipeArgs& p, lds3_t lds3, int item, int it_end,
                                                   int nslots, int nchunk, int tw, int tt, int lane) {
   const int tile = tt >> 3, quad = tt & 7;
@@ -192,19 +194,17 @@ __device__ __forceinline__ void ws_transform_role(const ConvArgs& a, const PipeA
       ws_transform_write<1>(lds3, v_base, y);
       if (has_next) aim(more_ch ? item : item + nslots, more_ch ? ch + 1 : 0);
       __syncthreads();
-      ws_transform_read<3>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 5: last read of R
-      if (has_next) dma();                                                                           // step 6
-      ws_transform_write<1>(lds3, v_base, y);
-      // end of step 6 WITHOUT waiting for the DMA: __syncthreads() would (correctly, for a release fence) drain vmcnt
-      // because the in-flight buffer_load ... lds are LDS writes; here only this wave's ds_writes must have landed
+      // step 5: R was last read in step 3 (plane d3 is prefetched there), so the next chunk's / tile's halo DMA goes out
+      // now and has steps 5 and 6 (~6 k cycles; it needs ~3.5 k) to land before the step-6 barrier publishes it
+      if (has_next) dma();
+      ws_transform_read<3>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y);
+      // end of step 5 WITHOUT draining the DMA: __syncthreads() would (correctly, for a release fence) wait for vmcnt
+      // because the in-flight buffer_load ... lds are LDS writes; only this wave's ds_writes must have landed here
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // step 7.  The halo DMA issued in step 6 takes ~3.5 k cycles to land (measured: it was the longest barrier wait of
-      // the GEMM waves when awaited inside step 6): it is awaited here instead, and an extra mid-step barrier X -- the
-      // GEMM waves take it between their two rows of this half-step -- publishes "every wave's DMA has landed" before
-      // anyone reads R.  The DMA then flies under step 6 and the first row of step 7, the heavy transform under the second.
+      ws_transform_write<1>(lds3, v_base, y);                                                        // step 6
       __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();                                                                               // barrier X
-      if (has_next) {
+      __syncthreads();
+      if (has_next) {                                                                                // step 7
         ws_transform_read<0>(lds3, r_base, y, P1, P2);
         ws_transform_write<0>(lds3, v_base, y);
       }
