@@ -24,6 +24,17 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (the compiler packs only part of the plain vector adds -- 248 of the GEMM role's 384 output-transform adds per chunk
+// stayed scalar v_add_f32 -- so additions are spelled out as well)
+__device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
+  const f32x2 lo = pk_add(a.xy, b.xy), hi = pk_add(a.zw, b.zw);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
   const f32x2 lo = pk_sub(a.xy, b.xy), hi = pk_sub(a.zw, b.zw);
   return f32x4{lo.x, lo.y, hi.x, hi.y};
@@ -31,7 +42,7 @@ __device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
 // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] applied to (x0..x3)
 __device__ __forceinline__ void bt4(const f32x4& x0, const f32x4& x1, const f32x4& x2, const f32x4& x3,
                                     f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) {
-  y0 = sub4(x0, x2); y1 = x1 + x2; y2 = sub4(x2, x1); y3 = sub4(x1, x3);
+  y0 = sub4(x0, x2); y1 = add4(x1, x2); y2 = sub4(x2, x1); y3 = sub4(x1, x3);
 }
 __device__ __forceinline__ f32x4 lds_read4(lds3_t base, unsigned off) {
   return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(base + off);
@@ -51,12 +62,12 @@ __device__ __forceinline__ constexpr int at_sign(int o, int i) {
 // 8.5 adds per accumulator register and row instead of 13.5 for point-by-point scattering.
 template <int ID, int IH>
 __device__ __forceinline__ void wino_scatter_row(const f32x4 (&M)[4], f32x4 (&Y)[8]) {
-  const f32x4 s12 = M[1] + M[2], d12 = sub4(M[1], M[2]);
-  const f32x4 t[2] = {M[0] + s12, sub4(d12, M[3])};
+  const f32x4 s12 = add4(M[1], M[2]), d12 = sub4(M[1], M[2]);
+  const f32x4 t[2] = {add4(M[0], s12), sub4(d12, M[3])};
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     const int sg = at_sign(o >> 2, ID) * at_sign((o >> 1) & 1, IH);
-    if (sg > 0) Y[o] = Y[o] + t[o & 1];
+    if (sg > 0) Y[o] = add4(Y[o], t[o & 1]);
     else if (sg < 0) Y[o] = sub4(Y[o], t[o & 1]);
   }
 }
@@ -101,7 +112,7 @@ __device__ __forceinline__ void ws_transform_read(lds3_t lds3, unsigned r_base, 
         x[hh] = sub4(p0, P2[hh][ww]);
       } else if constexpr (ID == 1) {
         P1[hh][ww] = lds_read4(lds3, r_base + (unsigned)(((1 * TH + hh) * TW + ww) * 128));
-        x[hh] = P1[hh][ww] + P2[hh][ww];
+        x[hh] = add4(P1[hh][ww], P2[hh][ww]);
       } else if constexpr (ID == 2) {
         x[hh] = sub4(P2[hh][ww], P1[hh][ww]);
         // d2 is dead from here on: its registers take plane d3 now, in a step where this role has slack, so that the
