@@ -247,11 +247,13 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_wino(ConvArgs a, int n16_tota
 //     there): the DMA of the next chunk's / next tile's halo is issued by the transform waves in step 5 and
 //     awaited at the end of step 6, so the halo load overlaps the MFMAs too, and the kernel is persistent;
 //   * the GEMM waves stream weight rows one row (4 points) ahead across half-steps, chunks and tiles.
-// Measured (16x200x200, sustained): 32->32 158 us (tile-per-block kernel 201), 32->64 263 (332), 64->64 ~485 (623).
-// With the transform switched off the GEMM waves alone take 129 us for 68 us of MFMA time, with the GEMM off the
-// transform waves take 76 us, neither: 25 us (first DMA, epilogue, barriers): what remains is the cost of the
-// operand loads and output-transform adds issued next to the MFMAs, not exposed latency.
+// Measured (16x200x200, sustained): 32->32 141 us (tile-per-block kernel 201), 32->64 232 (332), 64->64 431 (623).
+// In the first version of this kernel (158 us) the GEMM waves alone took 129 us for 68 us of MFMA time, the transform
+// waves alone 76 us, neither 25 us (first DMA, epilogue, barriers): the two instruction streams of a SIMD add up
+// (DESIGN.md section 4), so WHERE the transform role's instructions sit between the barriers decides who waits --
+// see the schedule in ws_transform_role (pw_wino_common.h), tuned from per-barrier arrival times of all eight waves.
 // s_setprio on either role changes nothing or costs 4 % (raised transform waves), so none is set.
+
 // flat row index R of a 32-channel chunk: R = ((ID * 2 + HH) * 2 + r) * NG + ng, i_h = 2 HH + r: the NG
 // cout groups of a row of points follow each other and share the row's A operands
 template <int R, int NG> struct WsRow {
