@@ -111,13 +111,15 @@ __device__ __forceinline__ void wino_chunk(const WinoCtx& c, unsigned r_base, un
 // scale/bias, residual, ReLU and the two destinations for the wave's 16 tiles (d-pair mh) x 16 couts (half nh)
 template <int NG>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y)[NG][8], int b, int d0, int h0, int w0,
-                                              int mh, int nh, int lane, int ng0 = 0) {
+                                              int mh, int nh, int lane, int ng0 = 0, const float* scb = nullptr) {
   // ---- epilogue: lane holds cout l&15 for tiles (l>>4)*4 + r of its half; output o = (od, oh, ow)
+  // scb: {scale, bias} per column group already in registers (the persistent kernel requests them at the start of the
+  // tile, a global-load latency before they are needed)
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     const int n = (ng0 + ng) * 32 + nh * 16 + (lane & 15);
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float bi = a.bias ? a.bias[n] : 0.f;
+    const float sc = scb ? scb[2 * ng] : (a.scale ? a.scale[n] : 1.f);
+    const float bi = scb ? scb[2 * ng + 1] : (a.bias ? a.bias[n] : 0.f);
     const int tth_e = lane >> 4;
     const int n0 = (ng0 + ng) * 32 + nh * 16;           // first packed column of this wave (uniform)
     const bool to_y0 = n0 < a.cout0;
@@ -134,20 +136,29 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y
       const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)ld * 4u);
       // lane offset: its h-pair row and column; (od, oh, ow, r) steps are scalar
       const unsigned lane_o = (unsigned)((2 * tth_e * a.Wo) * ld + col0 + (lane & 15)) * 4u;
+      // all 32 residual values of the column group are requested BEFORE the first store: with an in-place residual
+      // (y0 == residual, the BasicBlock3D case) the compiler must keep every later load behind the earlier stores, which
+      // made this loop eight dependent global round trips (+9-15 % kernel time, tools/bench_layers.py EPI=1)
+      unsigned so[8];
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
         const int od = d0 + 2 * mh + (o >> 2), oh = (o >> 1) & 1, ow = o & 1;
-        const unsigned so = (unsigned)((((b * a.Do + od) * a.Ho + h0 + oh) * a.Wo + w0 + ow) * ld) * 4u;
-        float rv[4];
-        if (has_res) {
+        so[o] = (unsigned)((((b * a.Do + od) * a.Ho + h0 + oh) * a.Wo + w0 + ow) * ld) * 4u;
+      }
+      float rv[8][4];
+      if (has_res) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rv[r] = buf_load1(rr, lane_o, so + (unsigned)(2 * r * ld) * 4u);
-        }
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rv[o][r] = buf_load1(rr, lane_o, so[o] + (unsigned)(2 * r * ld) * 4u);
+      }
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = Y[ng][o][r] * sc + bi;
-          if (has_res) v += rv[r];
-          buf_store1(yr, lane_o, so + (unsigned)(2 * r * ld) * 4u, fmaxf(v, lo));
+          if (has_res) v += rv[o][r];
+          buf_store1(yr, lane_o, so[o] + (unsigned)(2 * r * ld) * 4u, fmaxf(v, lo));
         }
       }
     } else {
@@ -370,6 +381,13 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
     for (int ng = 0; ng < NG; ++ng)
 #pragma unroll
       for (int o = 0; o < 8; ++o) Y[ng][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float scb[2 * NG];
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) {
+      const int n = (t.ng * NG + ng) * 32 + nh * 16 + (lane & 15);
+      scb[2 * ng] = a.scale ? a.scale[n] : 1.f;
+      scb[2 * ng + 1] = a.bias ? a.bias[n] : 0.f;
+    }
     const PipeTile tn = pipe_decode(a, p, item + nslots < it_end ? item + nslots : item);
     const unsigned gnext = (unsigned)((tn.ng * 2 * NG + nh) * 2048);
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -378,7 +396,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
       ws_rows<0, NG>(c, ubase, unext, a0, b0, a1, b1, Mp, Y);
       wino_scatter_row<3, 3>(Mp, Y[NG - 1]);
     }
-    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane, t.ng * NG);
+    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane, t.ng * NG, scb);
     t = tn; gbase = gnext;
   }
 }

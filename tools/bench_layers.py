@@ -1,6 +1,6 @@
 """Sustained timing of every conv layer shape of the C3 encoder (one line per shape).
 Environment knobs of the library (PW_CONV_PIPE, PW_CONV_WD) apply; LOOP_S seconds per shape.
-ALGO=<0..3> picks the direct kernel (pw_conv3d_ndhwc's algo); ALGO=wino runs the Winograd kernel on the
+ALGO=<0..3> picks the direct kernel (pw_conv3d_ndhwc's algo); EPI=1 adds scale/bias + in-place residual + ReLU to the Winograd runs.  ALGO=wino runs the Winograd kernel on the
 shapes it supports (k3 s1, <= 64 output columns) and skips the others.  TFLOP/s are direct-form FLOPs / time."""
 import json
 import os
@@ -32,7 +32,12 @@ for (D, H, W, ci, co, ks, st) in SHAPES:
         if ks != 3 or st != 1:
             continue
         uw = ops.pack_conv_weight_wino(torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05)
-        fn = lambda: ops.conv3d_wino(x, uw)
+        if os.environ.get('EPI'):        # the module stack's epilogue: folded BN, in-place residual, ReLU
+            sc, bi = torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev)
+            rbuf = torch.randn(1, D, H, W, co, device=dev)
+            fn = lambda: ops.conv3d_wino(x, uw, sc, bi, residual=rbuf, relu0=True, out0=rbuf)
+        else:
+            fn = lambda: ops.conv3d_wino(x, uw)
     else:
         fn = lambda: ops.conv3d_ndhwc(x, w, ksize=ks, stride=st, algo=int(os.environ.get('ALGO', 0)))
     for _ in range(5):
