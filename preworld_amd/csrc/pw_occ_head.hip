@@ -375,9 +375,12 @@ __global__ void __launch_bounds__(256, 1) k_occ_head16_pipe(ConvArgs a, PipeArgs
 // rows for all 8 outputs of its 16 tiles; at the end of a tile the two row-partners swap halves through LDS
 // (wave RSEL keeps o_d = RSEL) under the half-step's own barrier, and each wave finishes 64 voxels x 16
 // channels -- exactly the shape of k_occ_head16's tail (transpose through LDS, one voxel per lane).
-// LDS: R 76.8 KB + V 2 x 32 KB + 4 x 4352 B exchange / transpose areas = 159 744 B.
+// LDS: R 76.8 KB + V 2 x 32 KB + 4 x 4352 B exchange / transpose areas + 1 152 B of tail weights = 160 896 B.
+// The 16->8->18 weights sit in LDS for the life of the (persistent) block and are read as broadcasts: fetching them per
+// tile with 72 wave-wide global loads made the tail as long as all of the tile's MFMAs (7.9 k of 25 k cycles, probe).
 constexpr int OCCW_XCH = 64 * 17 * 4;                            // per GEMM wave
-constexpr int OCCW_LDS = WINO_LDS + 4 * OCCW_XCH;
+constexpr int OCCW_TAILW = WINO_LDS + 4 * OCCW_XCH;              // 288 floats: w1 [8][16], s1 [8], b1 [8], w2 [18][8]
+constexpr int OCCW_LDS = OCCW_TAILW + 288 * 4;
 
 template <int H, int RSEL> struct OccRow {                       // the wave's row of half-step H
   static constexpr int ID = H >> 1, HH = H & 1, IH = 2 * HH + RSEL;
@@ -458,7 +461,15 @@ __device__ __forceinline__ void occw_gemm_role(const ConvArgs& a, const PipeArgs
   const float bi = a.bias ? a.bias[i] : 0.f;
   f32x4 b0[4][2], b1[4][2], Mp[4];
   occw_load_b<0, RSEL>(c, b0);
-  __syncthreads();                                              // barrier A (halo of the first tile)
+  {
+    __attribute__((address_space(3))) float* wl = reinterpret_cast<__attribute__((address_space(3))) float*>(lds3 + OCCW_TAILW);
+    const int tid = threadIdx.x;                                // 0..255: the four GEMM waves
+    if (tid < 128) wl[tid] = tail.w1[tid];
+    else if (tid < 136) wl[tid] = tail.s1[tid - 128];
+    else if (tid < 144) wl[tid] = tail.b1[tid - 136];
+    if (tid < 144) wl[144 + tid] = tail.w2[tid];
+  }
+  __syncthreads();                                              // barrier A (halo of the first tile; tail weights in LDS)
   __syncthreads();                                              // barrier B (half-step 0 in V[0])
   for (; item < it_end; item += nslots) {
     f32x4 Y[8];
@@ -487,20 +498,31 @@ __device__ __forceinline__ void occw_gemm_role(const ConvArgs& a, const PipeArgs
       float mid[16], hid[8];
 #pragma unroll
       for (int k = 0; k < 16; ++k) mid[k] = sm[lane * MS + k];
+      const unsigned wq = (unsigned)OCCW_TAILW;                   // uniform addresses: LDS broadcasts
+      // every layer's weights are requested in one go and consumed afterwards: read one by one next to their FMAs the 72
+      // LDS round trips were the tail (6.5 k cycles of a 25 k-cycle tile)
+      f32x4 W1[36];
+#pragma unroll
+      for (int q = 0; q < 36; ++q) W1[q] = lds_read4(lds3, wq + (unsigned)q * 16u);            // w1 (32), s1 (2), b1 (2)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
         float s_ = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s_ += mid[k] * tail.w1[o * 16 + k];
-        hid[o] = fmaxf(s_ * tail.s1[o] + tail.b1[o], 0.f);
+        for (int k = 0; k < 16; ++k) s_ += mid[k] * W1[o * 4 + (k >> 2)][k & 3];
+        hid[o] = fmaxf(s_ * W1[32 + (o >> 2)][o & 3] + W1[34 + (o >> 2)][o & 3], 0.f);
       }
+      f32x4 W2[36];
+#pragma unroll
+      for (int q = 0; q < 36; ++q) W2[q] = lds_read4(lds3, wq + 576u + (unsigned)q * 16u);     // w2 [18][8]
+      __builtin_amdgcn_sched_barrier(0);
       float best = 0.f;
       int arg = 0;
 #pragma unroll
       for (int cc = 0; cc < 18; ++cc) {
         float s_ = 0.f;
 #pragma unroll
-        for (int o = 0; o < 8; ++o) s_ += hid[o] * tail.w2[cc * 8 + o];
+        for (int o = 0; o < 8; ++o) s_ += hid[o] * W2[cc * 2 + (o >> 2)][o & 3];
         if (tail.logits) tail.logits[vox * 18 + cc] = s_;
         if (cc == 0 || s_ > best) { best = s_; arg = cc; }
       }
