@@ -1,0 +1,450 @@
+"""Detector-level drop-ins: `BEVStereo4DOCC` (composition base), `PreWorld` (single time step) and
+`PreWorld4DTraj` (state-conditioned 4-D forecasting) -- the classes `configs/preworld/**.py` instantiate through
+`model = dict(type=...)` (mmdet3d/models/detectors/bevdet_occ.py:45-327, preworld.py:23-226,
+preworld_temporal_traj.py:26-370).  Same constructor kwargs, attribute names (= state-dict keys), `simple_test`
+signature and result dicts as the reference.
+
+Everything downstream of the image-view features runs on libpreworld_hip.so (channels-last, no permute copies); the
+image backbone / neck / DepthNet are plain PyTorch-ROCm modules (image_encoder.py), as north_star prescribes.
+`img_backbone` / `img_neck` are optional: the benchmarks and most parity tests start from the lifted inputs
+(`simple_test_from_lift`) and need no 88 M-parameter Swin-B.  Inference only: `forward_train` is not built
+(SURVEY 8a scopes the path to the forward pass)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import builder, ops
+from .modules import (ConvModule3d, DownScaleModule3DCustom, _PackedCache, to_channels_last_3d)
+
+
+class BEVStereo4DOCC(nn.Module):
+    """bevdet.py:20-58 (BEVDet), :273-288 (BEVDet4D), :565-571 (BEVStereo4D) and bevdet_occ.py:45-269 (BEVStereo4DOCC)
+    restricted to what the camera -> occupancy forward pass uses."""
+
+    def __init__(self, img_view_transformer, img_bev_encoder_backbone, img_bev_encoder_neck, img_backbone=None,
+                 img_neck=None, pre_process=None, align_after_view_transfromation=False, num_adj=1, with_prev=True,
+                 loss_occ=None, out_dim=32, num_classes=18, use_predicter=True, class_wise=False,
+                 balance_cls_weight=False, use_depth_gt=False, use_mask=False, **kwargs):
+        super().__init__()
+        if align_after_view_transfromation:
+            raise NotImplementedError('align_after_view_transfromation=True: BEVStereo4DOCC.__init__ forces it to False '
+                                      '(bevdet_occ.py:80)')
+        self.img_backbone = builder.build(img_backbone)
+        self.img_neck = builder.build(img_neck)
+        self.with_img_neck = self.img_neck is not None
+        self.img_view_transformer = builder.build(img_view_transformer, 'LSSViewTransformer')
+        self.img_bev_encoder_backbone = builder.build(img_bev_encoder_backbone, 'CustomResNet3D')
+        self.img_bev_encoder_neck = builder.build(img_bev_encoder_neck, 'LSSFPN3D')
+        self.pre_process = pre_process is not None
+        if self.pre_process:
+            self.pre_process_net = builder.build(pre_process, 'CustomResNet3D')
+        self.align_after_view_transfromation = False
+        self.num_adj, self.with_prev = num_adj, with_prev
+        self.extra_ref_frames = 1                                   # bevdet.py:567-571
+        self.temporal_frame = num_adj + 1
+        self.num_frame = self.temporal_frame + self.extra_ref_frames
+        self.out_dim, self.num_classes = out_dim, num_classes
+        self.use_predicter, self.class_wise, self.use_depth_gt = use_predicter, class_wise, use_depth_gt
+        C = self.img_view_transformer.out_channels
+        self.final_conv = ConvModule3d(C, out_dim if use_predicter else num_classes, 3, stride=1, padding=1, bias=True,
+                                       conv_cfg=dict(type='Conv3d'))
+        if use_predicter:
+            self.predicter = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                           nn.Linear(out_dim * 2, num_classes))
+        self.loss_occ_cfg = loss_occ
+        self._pred_cache = _PackedCache()
+
+    # ---- bevdet_occ.py:88-139 (BEVStereo4DOCC.prepare_inputs): split the stacked inputs into
+    # frames and express every sweep's sensor pose in the KEY frame's ego system (fp64 algebra)
+    def prepare_inputs(self, inputs, stereo=False, num_frame=None, temporal_frame=None,
+                       extra_ref_frames=None):
+        """inputs = (imgs (B, N*T, C, H, W) camera-major/frame-minor, sensor2egos (B, T*N, 4, 4)
+        frame-major, ego2globals, intrins (B,T*N,3,3), post_rots, post_trans (B,T*N,3), bda).
+        Returns (imgs[T], sensor2keyegos[T], ego2globals[T], intrins[T], post_rots[T],
+        post_trans[T], bda, curr2adjsensor) exactly like the reference."""
+        extra_ref_frames = self.extra_ref_frames if extra_ref_frames is None else extra_ref_frames
+        num_frame = num_frame or self.num_frame
+        temporal_frame = temporal_frame or self.temporal_frame
+        B, N, C, H, W = inputs[0].shape
+        N = N // num_frame
+        imgs = inputs[0].view(B, N, num_frame, C, H, W)
+        imgs = [t.squeeze(2) for t in torch.split(imgs, 1, 2)]
+        sensor2egos, ego2globals, intrins, post_rots, post_trans, bda = inputs[1:7]
+        sensor2egos = sensor2egos.view(B, num_frame, N, 4, 4)
+        ego2globals = ego2globals.view(B, num_frame, N, 4, 4)
+        keyego2global = ego2globals[:, 0, 0, ...].unsqueeze(1).unsqueeze(1)
+        global2keyego = torch.inverse(keyego2global.double())
+        sensor2keyegos = (global2keyego @ ego2globals.double() @ sensor2egos.double()).float()
+        curr2adjsensor = None
+        if stereo:
+            s_curr = sensor2egos[:, :temporal_frame, ...].double()
+            e_curr = ego2globals[:, :temporal_frame, ...].double()
+            s_adj = sensor2egos[:, 1:temporal_frame + 1, ...].double()
+            e_adj = ego2globals[:, 1:temporal_frame + 1, ...].double()
+            c2a = (torch.inverse(e_adj @ s_adj) @ e_curr @ s_curr).float()
+            curr2adjsensor = [p.squeeze(1) for p in torch.split(c2a, 1, 1)]
+            curr2adjsensor.extend([None for _ in range(extra_ref_frames)])
+            assert len(curr2adjsensor) == num_frame
+        extra = [sensor2keyegos, ego2globals, intrins.view(B, num_frame, N, 3, 3),
+                 post_rots.view(B, num_frame, N, 3, 3), post_trans.view(B, num_frame, N, 3)]
+        extra = [[p.squeeze(1) for p in torch.split(t, 1, 1)] for t in extra]
+        sensor2keyegos, ego2globals, intrins, post_rots, post_trans = extra
+        return imgs, sensor2keyegos, ego2globals, intrins, post_rots, post_trans, bda, curr2adjsensor
+
+    # ---- bevdet.py:34-50 (PyTorch-ROCm image side)
+    def image_encoder(self, img, stereo=False):
+        if self.img_backbone is None:
+            raise RuntimeError('this detector was built without img_backbone / img_neck: feed lifted inputs to '
+                               'simple_test_from_lift() or pass the image-side configs')
+        B, N, C, imH, imW = img.shape
+        x = self.img_backbone(img.view(B * N, C, imH, imW))
+        stereo_feat = None
+        if stereo:
+            stereo_feat, x = x[0], x[1:]
+        if self.with_img_neck:
+            x = self.img_neck(x)
+            if type(x) in (list, tuple):
+                x = x[0]
+        return x.view(B, N, *x.shape[1:]), stereo_feat
+
+    # ---- bevdet.py:573-603 (Swin branch)
+    def extract_stereo_ref_feat(self, x):
+        B, N, C, imH, imW = x.shape
+        return self.img_backbone.stereo_ref_feat(x.view(B * N, C, imH, imW))
+
+    # ---- bevdet_occ.py:141-165 + the frame loop of :167-241, up to the lifted inputs of every BEV frame
+    @torch.no_grad()
+    def lift_inputs_from_images(self, img_inputs):
+        """img_inputs: prepare_inputs(...) output.  Runs backbone + neck + DepthNet per frame in the reference's order
+        (extra stereo reference -> adjacent -> key, each cost volume against the previously processed frame's stereo
+        feature, `mlp_input` always from the KEY frame's poses, bevdet_occ.py:197-199) and returns the list of per-frame
+        dicts `simple_test_from_lift` consumes, key frame first."""
+        imgs, sensor2keyegos, ego2globals, intrins, post_rots, post_trans, bda, curr2adjsensor = img_inputs
+        vt = self.img_view_transformer
+        frames, feat_prev_iv = [], None
+        for fid in range(self.num_frame - 1, -1, -1):
+            key_frame = fid == 0
+            extra_ref_frame = fid == self.num_frame - self.extra_ref_frames
+            if not (key_frame or self.with_prev):
+                continue
+            if extra_ref_frame:
+                feat_prev_iv = self.extract_stereo_ref_feat(imgs[fid])
+                continue
+            mlp_input = vt.get_mlp_input(sensor2keyegos[0], ego2globals[0], intrins[fid], post_rots[fid], post_trans[fid], bda)
+            x, stereo_feat = self.image_encoder(imgs[fid], stereo=True)
+            B, N, C, H, W = x.shape
+            metas = dict(k2s_sensor=curr2adjsensor[fid], intrins=intrins[fid], post_rots=post_rots[fid],
+                         post_trans=post_trans[fid], frustum=vt.cv_frustum.to(x), cv_downsample=4,
+                         downsample=vt.downsample, grid_config=vt.grid_config, cv_feat_list=[feat_prev_iv, stereo_feat])
+            out = vt.depth_net(x.view(B * N, C, H, W), mlp_input, metas)
+            depth, tran_feat = vt.depthnet_tail(out)                   # view_transformer.py:797-801 (HIP)
+            frames.append(dict(depth=depth, tran_feat=tran_feat, sensor2keyego=sensor2keyegos[fid], intrin=intrins[fid],
+                               post_rot=post_rots[fid], post_tran=post_trans[fid], bda=bda))
+            feat_prev_iv = stereo_feat
+        return frames[::-1]
+
+    # ---- bevdet_occ.py:167-269: images -> encoder output.  Returns ([x (B,C,Z,Y,X) view], depth of the key frame).
+    @torch.no_grad()
+    def extract_img_feat(self, img_inputs, img_metas=None, **kwargs):
+        frames = self.lift_inputs_from_images(img_inputs)
+        x_cl = self.extract_bev_feat_cl(frames)
+        return [x_cl.permute(0, 4, 1, 2, 3)], frames[0]['depth']
+
+    # ---- bevdet.py:139-175: the test-time entry the runner calls (`model(return_loss=False, **data)`)
+    def forward_test(self, points=None, img_metas=None, img_inputs=None, **kwargs):
+        for var, name in [(img_inputs, 'img_inputs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError('{} must be a list, but got {}'.format(name, type(var)))
+        if len(img_inputs) != len(img_metas):
+            raise ValueError('num of augmentations ({}) != num of image meta ({})'.format(len(img_inputs), len(img_metas)))
+        if not isinstance(img_inputs[0][0], list):
+            points = [points] if points is None else points
+            return self.simple_test(points[0], img_metas[0], img_inputs[0], **kwargs)
+        raise NotImplementedError('aug_test is not implemented by the reference either (bevdet.py:177-179)')
+
+    def forward(self, return_loss=True, **kwargs):
+        """base.py:47-62"""
+        if return_loss:
+            return self.forward_train(**kwargs)
+        return self.forward_test(**kwargs)
+
+    def forward_train(self, **kwargs):
+        raise NotImplementedError('preworld_amd detectors are inference drop-ins (forward pass only, SURVEY 8a); '
+                                  'register with inference_only=False to keep the reference class for training')
+
+    # ---- bevdet.py:52-58
+    def bev_encoder_cl(self, x_cl):
+        return self.img_bev_encoder_neck.forward_cl(self.img_bev_encoder_backbone.forward_cl(x_cl))
+
+    # ---- bevdet_occ.py:141-165 minus the image encoder / DepthNet
+    def lift_frame_cl(self, depth, tran_feat, sensor2keyego, intrin, post_rot, post_tran, bda, out=None):
+        vt = self.img_view_transformer
+        B, N = sensor2keyego.shape[:2]
+        H, W = depth.shape[-2:]
+        inp = [depth.new_empty(B, N, 1, H, W), sensor2keyego, None, intrin, post_rot, post_tran, bda]
+        keep = vt.collapse_z
+        vt.collapse_z = False
+        try:
+            bev, _ = vt.view_transform(inp, depth, tran_feat)
+        finally:
+            vt.collapse_z = keep
+        x = to_channels_last_3d(bev)
+        if self.pre_process:
+            x = self.pre_process_net.forward_cl(x, out_last=out)[0]
+        elif out is not None:
+            out.copy_(x)
+            x = out
+        return x
+
+    # ---- bevdet_occ.py:167-269 (frame loop, [adj, key] concat, with_prev=False -> zeros)
+    def extract_bev_feat_cl(self, frames):
+        """frames: list ordered [key, adj, ...] of dicts(depth, tran_feat, sensor2keyego, intrin,
+        post_rot, post_tran, bda).  Returns the bev_encoder output, channels-last (B,Z,Y,X,C)."""
+        # channel order [adjacent ..., key] (bevdet_occ.py:266): every frame's pre_process output is
+        # written straight into its channel slice of ONE buffer (row stride n*C), no torch.cat copy
+        f0 = frames[0]
+        B = f0['sensor2keyego'].shape[0]
+        _, _, size = self.img_view_transformer._grid()
+        C = self.img_view_transformer.out_channels
+        n = self.num_adj + 1
+        x = torch.empty(B, size[2], size[1], size[0], n * C, device=f0['depth'].device, dtype=torch.float32)
+        self.lift_frame_cl(out=x[..., (n - 1) * C:], **f0)
+        for j in range(self.num_adj):                      # adjacent frame j+1 sits left of frame j
+            sl = x[..., (n - 2 - j) * C:(n - 1 - j) * C]
+            if self.with_prev and len(frames) > 1 + j:
+                self.lift_frame_cl(out=sl, **frames[1 + j])
+            else:
+                sl.zero_()
+        return self.bev_encoder_cl(x)
+
+    def extract_voxel_feat_cl(self, frames):
+        """... followed by final_conv: conv + bias + ReLU (preworld.py:72-79), channels-last (B,Z,Y,X,out_dim)."""
+        return self.final_conv.forward_cl(self.extract_bev_feat_cl(frames))
+
+    # ---- bevdet_occ.py:281-301: final_conv -> predicter MLP -> argmax(softmax) (softmax is monotone: argmax of logits)
+    @torch.no_grad()
+    def simple_test_from_lift(self, frames, **kwargs):
+        v = self.extract_voxel_feat_cl(frames)
+        if self.use_predicter:
+            p = self.predicter
+            packed = self._pred_cache.get([p[0].weight, p[0].bias, p[2].weight, p[2].bias],
+                                          lambda: ops.pack_mlp_blocks([p]))
+            v = ops.attr_mlp(v, packed, final_softplus=False)[..., :self.num_classes]
+        occ = v.argmax(-1).to(torch.uint8).permute(0, 3, 2, 1)         # (B,X,Y,Z)
+        return [occ.squeeze(0)]
+
+    def simple_test(self, points, img_metas, img=None, rescale=False, **kwargs):
+        res = self.simple_test_from_lift(self.lift_inputs_from_images(self.prepare_inputs(img, stereo=True)))
+        return [r.cpu().numpy().astype(np.uint8) for r in res]
+
+
+class _PreWorldCommon(BEVStereo4DOCC):
+    """What preworld.py:24-120 and preworld_temporal_traj.py:27-118 share: final_conv (out_dim), the three attribute
+    MLPs, nerf_head, occupancy_head and the flags."""
+
+    def __init__(self, out_dim=32, dataset_type='Nuscenes', num_classes=18, dense_nerf_head=None, nerf_head=None,
+                 occupancy_head=None, test_threshold=8.5, use_lss_depth_loss=True, use_3d_loss=True, if_pretrain=False,
+                 if_render=True, if_post_finetune=False, weight_voxel_ce=0.0, weight_voxel_sem_scal=0.0,
+                 weight_voxel_geo_scal=0.0, weight_voxel_lovasz=0.0, empty_idx=17, use_focal_loss=True,
+                 balance_cls_weight=True, final_softplus=True, **kwargs):
+        kwargs.pop('use_predicter', None)
+        super().__init__(use_predicter=False, out_dim=out_dim, num_classes=num_classes, **kwargs)
+        if dataset_type != 'Nuscenes':
+            raise NotImplementedError('dataset_type=%r: the released PreWorld configs are nuScenes only' % dataset_type)
+        self.dataset_type, self.test_threshold = dataset_type, test_threshold
+        self.use_lss_depth_loss, self.use_3d_loss = use_lss_depth_loss, use_3d_loss
+        self.balance_cls_weight, self.final_softplus = balance_cls_weight, final_softplus
+        self.if_pretrain, self.if_render, self.if_post_finetune = if_pretrain, if_render, if_post_finetune
+        self.empty_idx = empty_idx
+        C = self.img_view_transformer.out_channels
+        self.final_conv = ConvModule3d(C, out_dim, 3, stride=1, padding=1, bias=True, conv_cfg=dict(type='Conv3d'))
+        self.density_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(), nn.Linear(out_dim * 2, 2),
+                                         *([nn.Softplus()] if final_softplus else []))
+        self.semantic_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                          nn.Linear(out_dim * 2, num_classes - 1))
+        self.color_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(), nn.Linear(out_dim * 2, 3))
+        self.nerf_head = builder.build(nerf_head, 'NerfHead')
+        # the hot-path benches build the detector without a head config: the OccHead of the released configs
+        oh = occupancy_head or dict(in_channels=[out_dim], out_channel=num_classes, norm_cfg=dict(type='SyncBN'),
+                                    soft_weights=True)
+        self.occupancy_head = builder.build(oh, 'OccHead')
+        self.weight_voxel_ce, self.weight_voxel_sem_scal = weight_voxel_ce, weight_voxel_sem_scal
+        self.weight_voxel_geo_scal, self.weight_voxel_lovasz = weight_voxel_geo_scal, weight_voxel_lovasz
+        self.use_focal_loss = use_focal_loss
+        if use_focal_loss:
+            self.focal_loss = builder.build(dict(type='CustomFocalLoss'))
+
+    # ---- preworld_temporal_traj.py:231-236: density / semantic / color MLPs, fused
+    def attributes_cl(self, v_cl):
+        """v_cl (B,Z,Y,X,C) -> packed grid (B,Z,Y,X,24): [0:2] density_prob, [2:19] semantic,
+        [19:22] color.  `grid[..., 0]` is the reference's `density`."""
+        mods = (self.density_mlp, self.semantic_mlp, self.color_mlp)
+        params = [m[i].weight for m in mods for i in (0, 2)] + [m[i].bias for m in mods for i in (0, 2)]
+        if not hasattr(self, '_attr_cache'):
+            self._attr_cache = _PackedCache()
+        packed = self._attr_cache.get(params, lambda: ops.pack_attr_mlp(*mods))
+        return ops.attr_mlp(v_cl, packed, final_softplus=len(self.density_mlp) == 4)
+
+    # ---- preworld_temporal_traj.py:237-250: occupancy from density threshold + semantic argmax
+    def attribute_decode(self, grid):
+        dens = grid[..., 0]
+        sem = grid[..., 2:19].argmax(-1)
+        occ = torch.where(dens > self.test_threshold, sem, torch.full_like(sem, self.num_classes - 1))
+        return occ.to(torch.uint8)
+
+    @staticmethod
+    def _to_numpy(res):
+        """the reference's payload: every grid a numpy uint8 (X,Y,Z) array (one D2H copy for all of them)"""
+        keys = [k for k in res if k.startswith(('semantic_occ', 'geo_occ'))]
+        stack = torch.stack([res[k][0] for k in keys]).cpu().numpy().astype(np.uint8)
+        return {k: [stack[i]] for i, k in enumerate(keys)}
+
+
+class PreWorld(_PreWorldCommon):
+    """Drop-in for mmdet3d/models/detectors/preworld.py:23-226 (inference): `simple_test` returns
+    {'semantic_occ': [uint8 (X,Y,Z)], 'geo_occ': [uint8 (X,Y,Z)]} for batch element 0, through either the density-threshold +
+    semantic-MLP decode (:173-194) or the OccHead decode (:196-221, `if_post_finetune=True`)."""
+
+    @torch.no_grad()
+    def simple_test_from_lift(self, frames, want_logits=False, **kwargs):
+        v0 = self.extract_voxel_feat_cl(frames)                       # (B,Z,Y,X,C)
+        res = {'voxel_feats': [v0]}
+        if not self.if_post_finetune:
+            occ = self.attribute_decode(self.attributes_cl(v0)).permute(0, 3, 2, 1)
+            geo = torch.where(occ != self.num_classes - 1, torch.zeros_like(occ), torch.full_like(occ, self.num_classes - 1))
+        else:
+            out = self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True)
+            occ, geo = out[0].permute(0, 3, 2, 1), out[-1].permute(0, 3, 2, 1)
+            if want_logits:
+                res['logits'] = [out[1]]
+        res['semantic_occ'] = [occ[0]]
+        res['geo_occ'] = [geo[0]]
+        return res
+
+    def simple_test(self, points, img_metas, img=None, rescale=False, **kwargs):
+        frames = self.lift_inputs_from_images(self.prepare_inputs(img, stereo=True))
+        return self._to_numpy(self.simple_test_from_lift(frames))
+
+
+class PreWorld4DTraj(_PreWorldCommon):
+    """Drop-in for mmdet3d/models/detectors/preworld_temporal_traj.py:26-370 (inference): 0 s state + 6 recursive
+    state-conditioned forecasting steps -> `semantic_occ_{k}s` / `geo_occ_{k}s`, k = 0..6 (post-finetune branch) or
+    0, 2..7 (density / semantic MLP branch, :294).
+
+    simple_test_from_lift() consumes, per frame, the softmaxed depth (B*N,D,H,W) and context features that
+    LSSViewTransformerBEVDepth.forward produces at view_transformer.py:798-801 plus the camera tensors, and returns the
+    result dict with uint8 (X,Y,Z) torch tensors on the GPU; simple_test() (images in) returns exactly the
+    reference's numpy payload with ONE D2H copy instead of the reference's 14 syncs per sample."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        out_dim = self.out_dim
+        self.velocity_dim, self.past_frame = 3, 5
+        self.plan_head = nn.Sequential(nn.Linear(self.velocity_dim * (self.past_frame + 2), 256),
+                                       nn.ReLU(inplace=True), nn.Linear(256, 256),
+                                       nn.ReLU(inplace=True), nn.Linear(256, out_dim))
+        self.fusion_head = nn.Sequential(nn.Linear(out_dim * 2, out_dim * 4), nn.Softplus(),
+                                         nn.Linear(out_dim * 4, out_dim))
+        # A20 trajectory branch (train-time only, preworld_temporal_traj.py:134-150)
+        self.downscale = DownScaleModule3DCustom(in_dim=out_dim)
+        self.ego_fusion_head = nn.Sequential(nn.Linear(out_dim * 5, out_dim * 8), nn.Softplus(),
+                                             nn.Linear(out_dim * 8, out_dim * 4), nn.Softplus(),
+                                             nn.Linear(out_dim * 4, out_dim * 2), nn.Softplus(),
+                                             nn.Linear(out_dim * 2, out_dim))
+        self.traj_head = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                       nn.Linear(out_dim * 2, 2))
+        self._fc_cache = _PackedCache()
+
+    def set_epoch(self, epoch):
+        self.curr_epoch = epoch
+
+    # ---- preworld_temporal_traj.py:457-470: ego-feature update + 2-D waypoint from one fused state
+    def traj_branch_cl(self, fused_cl, ego_feat):
+        """fused_cl (B,Z,Y,X,C) = v + fusion_head([v, e]); ego_feat (B,C) = plan_head(ego) ("identity").
+        Returns (pred_traj (B,2), fused_ego_feats (B,C))."""
+        down = self.downscale.forward_cl(fused_cl)                          # (B, 4C)
+        h = torch.cat([ego_feat, down], dim=-1).contiguous()                # (B, 5C)
+        efh, th = self.ego_fusion_head, self.traj_head
+        for i in (0, 2, 4):
+            h = ops.linear_act(h, efh[i].weight.contiguous(), efh[i].bias, 'softplus')
+        res = ops.linear_act(h, efh[6].weight.contiguous(), efh[6].bias)
+        fused_ego = ego_feat + res
+        t = ops.linear_act(fused_ego.contiguous(), th[0].weight.contiguous(), th[0].bias, 'softplus')
+        return ops.linear_act(t, th[2].weight.contiguous(), th[2].bias), fused_ego
+
+    def _forecast_weights(self):
+        fh = self.fusion_head
+        return self._fc_cache.get([fh[0].weight, fh[2].weight],
+                                  lambda: ops.forecast_pack(fh[0].weight.float().contiguous(),
+                                                            fh[2].weight.float().contiguous()))
+
+    # ---- preworld_temporal_traj.py:329-368: all recursion steps in one kernel
+    def forecast_cl(self, v_cl, ego_states, n_steps=6):
+        """v_cl (B,Z,Y,X,C); ego_states (B,1,21) (always temporal_ego_states[0], :331).
+        Returns states (n_steps,B,Z,Y,X,C) and the ego feature (B,32)."""
+        ph, fh = self.plan_head, self.fusion_head
+        B = v_cl.shape[0]
+        ego = ego_states.reshape(B, -1).float().contiguous()
+        plan = [(ph[0].weight.contiguous(), ph[0].bias), (ph[2].weight.contiguous(), ph[2].bias),
+                (ph[4].weight.contiguous(), ph[4].bias)]
+        ef, _, c1p = ops.forecast_prologue(ego, plan, fh[0].weight.contiguous(), fh[0].bias)
+        w1p, w2p = self._forecast_weights()
+        states = ops.forecast_steps(v_cl, B, w1p, w2p, c1p, fh[2].bias, n_steps)
+        return states, ef
+
+    # ---- preworld_temporal_traj.py:212-370 (post-finetune branch) from lifted inputs
+    @torch.no_grad()
+    def simple_test_from_lift(self, frames, temporal_ego_states, n_steps=6, want_logits=False):
+        v0 = self.extract_voxel_feat_cl(frames)                       # (B,Z,Y,X,C)
+        if not self.if_post_finetune:
+            return self._simple_test_attributes(v0, temporal_ego_states, n_steps)
+        res = {}
+        feats = [v0]
+        B = v0.shape[0]
+        # OccHead on state 0, then on ALL forecast states in one launch (they are one contiguous (n_steps*B, Z, Y, X, C)
+        # buffer): one persistent-kernel prologue and one partial last round of tiles instead of n_steps of each
+        outs = [self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True)]
+        if n_steps > 0:
+            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps)
+            feats += [states[k] for k in range(n_steps)]
+            o = self.occupancy_head.decode_cl(states.view((n_steps * B,) + tuple(v0.shape[1:])), want_logits=want_logits,
+                                              transposed=True, want_geo=True)
+            outs += [tuple(t[k * B:(k + 1) * B] for t in o) for k in range(n_steps)]
+        logits_all = []
+        for k, out in enumerate(outs):
+            occ, geo = out[0], out[-1]                                 # geo_occ from the same kernel (:313-319)
+            if want_logits:
+                logits_all.append(out[1])
+            occ_xyz = occ.permute(0, 3, 2, 1)                          # (B,X,Y,Z) view
+            geo = geo.permute(0, 3, 2, 1)
+            # the reference indexes batch element 0 (:306) and names states 0s..6s (:361)
+            res['semantic_occ_%ds' % k] = [occ_xyz[0]]
+            res['geo_occ_%ds' % k] = [geo[0]]
+        if want_logits:
+            res['logits'] = logits_all
+        res['voxel_feats'] = feats
+        return res
+
+    # ---- preworld_temporal_traj.py:224-301: density/semantic-MLP decode (if_post_finetune=False).
+    # The reference names the future states 2s..7s in this branch (:294) and never emits 1s.
+    def _simple_test_attributes(self, v0, temporal_ego_states, n_steps):
+        feats = [v0]
+        if n_steps > 0:
+            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps)
+            feats += [states[k] for k in range(n_steps)]
+        res = {}
+        for k, f in enumerate(feats):
+            occ = self.attribute_decode(self.attributes_cl(f)).permute(0, 3, 2, 1)     # (B,X,Y,Z)
+            geo = torch.where(occ != self.num_classes - 1, torch.zeros_like(occ),
+                              torch.full_like(occ, self.num_classes - 1))
+            name = 0 if k == 0 else k + 1
+            res['semantic_occ_%ds' % name] = [occ[0]]
+            res['geo_occ_%ds' % name] = [geo[0]]
+        res['voxel_feats'] = feats
+        return res
+
+    # ---- preworld_temporal_traj.py:212-370 with the reference's signature: images + kwargs['temporal_ego_states']
+    def simple_test(self, points, img_metas, img=None, rescale=False, **kwargs):
+        temporal_ego_states = kwargs['temporal_ego_states'][0]          # (:228,:304)
+        frames = self.lift_inputs_from_images(self.prepare_inputs(img, stereo=True))
+        return self._to_numpy(self.simple_test_from_lift(frames, temporal_ego_states[0]))

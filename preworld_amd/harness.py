@@ -6,18 +6,19 @@ names, feed lifted inputs, collect `semantic_occ_{k}s`, stack states 0/2/4/6
 import numpy as np
 import torch
 
-from . import metrics, modules, synth
+from . import builder, metrics, synth
 
 
-def model_cfg(grid_config=None, with_prev=True, if_post_finetune=True):
-    """The `model = dict(...)` section of configs/preworld/*.py restricted to the hot path
-    (bevstereo-occ.py:62-131), as a plain dict."""
+def model_cfg(grid_config=None, with_prev=True, if_post_finetune=True, detector='PreWorld4DTraj'):
+    """The `model = dict(...)` section of configs/preworld/**.py restricted to the hot path
+    (bevstereo-occ.py:62-131 + preworld-7frame-finetune[-traj].py), as a plain dict; the image side
+    (img_backbone / img_neck) is left out: benches and parity tests start from the lifted inputs."""
     gc = grid_config or synth.GRID_CONFIG_FULL
     sx = int(round((gc['x'][1] - gc['x'][0]) / gc['x'][2]))
     sy = int(round((gc['y'][1] - gc['y'][0]) / gc['y'][2]))
     sz = int(round((gc['z'][1] - gc['z'][0]) / gc['z'][2]))
     return dict(
-        type='PreWorld4DTraj',
+        type=detector,
         img_view_transformer=dict(type='LSSViewTransformerBEVStereo', grid_config=gc,
                                   input_size=synth.INPUT_SIZE, in_channels=512, out_channels=32, sid=False,
                                   collapse_z=False, loss_depth_weight=0.05,
@@ -37,14 +38,14 @@ def model_cfg(grid_config=None, with_prev=True, if_post_finetune=True):
 
 
 def build_model(cfg, state_dict, device='cuda:0'):
-    """cfg: model_cfg(...) (or the reference's own model dict); state_dict: numpy or torch tensors under
-    the reference's key names.  Hot-path keys must all be present; DepthNet/backbone keys are ignored."""
-    cfg = dict(cfg)
-    cfg.pop('type', None)
-    net = modules.PreWorld4DTraj(**cfg)
+    """cfg: model_cfg(...) or the reference's own `model` dict (type PreWorld / PreWorld4DTraj / BEVStereo4DOCC);
+    state_dict: numpy or torch tensors under the reference's key names.  Hot-path keys must all be present; image-side
+    keys (img_backbone / img_neck / depth_net) may be absent when only lifted inputs are fed."""
+    net = builder.build(cfg, 'PreWorld4DTraj')
     sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in state_dict.items()}
     missing, _ = net.load_state_dict(sd, strict=False)
-    bad = [k for k in missing if 'depth_net' not in k and 'num_batches_tracked' not in k]
+    image_side = ('depth_net', 'img_backbone', 'img_neck', 'num_batches_tracked')
+    bad = [k for k in missing if not any(t in k for t in image_side)]
     if bad:
         raise KeyError('state dict lacks hot-path keys: %s' % bad[:8])
     return net.to(device).eval()
@@ -71,25 +72,30 @@ def stack_states(result, horizons=(0, 2, 4, 6)):
 
 @torch.no_grad()
 def evaluate(net, samples, device='cuda:0', use_image_mask=True):
-    """samples: iterable of dict(frames, ego, gt {horizon: (X,Y,Z) uint8}, mask_camera (X,Y,Z) bool).
-    Returns (Metric_mIoU_Temporal.count_miou() dict, list of stacked predictions)."""
+    """samples: iterable of dict(frames, ego, gt {idx: (X,Y,Z) uint8}, mask_camera (X,Y,Z) bool).
+    Scores the stacked states {0,2,4,6} like tools/test_temporal.py -> dataset.evaluate
+    (nuscenes_dataset_occ_trajectory.py:478-526).  Returns (Metric_mIoU_Temporal.report() dict incl. the 0 s horizon and
+    'avg_future', list of stacked predictions); the reference's own return values are metric.count_miou() /
+    count_iou() of the same object (third return value)."""
     metric = metrics.Metric_mIoU_Temporal(num_classes=18, use_image_mask=use_image_mask, device=device)
     stacks = []
     for s in samples:
         res = net.simple_test_from_lift(s['frames'], s['ego'], n_steps=6)
         st = stack_states(res)
         stacks.append(st)
-        for h, gt in s['gt'].items():
-            metric.add_batch(st, gt, None, s.get('mask_camera'), h)
-    return metric.count_miou(), stacks
+        mc = s.get('mask_camera')
+        metric.add_batch(st, s['gt'], None, {h: mc for h in s['gt']} if mc is not None else None)
+    return metric.report(), stacks, metric
 
 
 @torch.no_grad()
 def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=False):
     """The latency mode of DESIGN.md section 7 wired to the real modules (one process per GPU, torch.distributed
-    initialised): frame f is lifted + pre-processed on rank f % W and broadcast (parallel.lift_frames_sharded), every rank
-    runs the encoder, state k is forecast + decoded on rank k % W, one all_gather of the uint8 grids assembles all states
-    on every rank.  Returns {'semantic_occ_%ds': [(X,Y,Z) uint8]} like simple_test_from_lift.
+    initialised): frame f is lifted + pre-processed on rank f % W and all ranks receive every frame's (B,Z,Y,X,32)
+    feature through ONE all_gather (parallel.lift_frames_sharded), every rank runs the encoder, state k is forecast +
+    decoded on rank k % W, one all_gather of the uint8 grids assembles all states on every rank.
+    Returns {'semantic_occ_%ds': [(X,Y,Z) uint8]} like simple_test_from_lift.  `with_prev=False` drops the adjacent
+    frames: their channel slice is zeros (bevdet_occ.py:243-258), exactly as in extract_bev_feat_cl.
     gather_on_host=True moves the 0.64 MB grids through host memory (for process groups that cannot all_gather device
     tensors: gloo in the tests; RCCL takes device tensors)."""
     from . import parallel
@@ -98,7 +104,8 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
     f0 = frames[0]
     B, C = f0['sensor2keyego'].shape[0], vt.out_channels
     n = net.num_adj + 1
-    lifted = parallel.lift_frames_sharded(frames[:n], lambda fr: net.lift_frame_cl(**fr),
+    use = frames[:n] if net.with_prev else frames[:1]
+    lifted = parallel.lift_frames_sharded(use, lambda fr: net.lift_frame_cl(**fr),
                                           (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device, group)
     x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                       # [adjacent ..., key] (bevdet_occ.py:266)
     if len(lifted) < n:

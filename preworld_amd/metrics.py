@@ -69,23 +69,68 @@ class Metric_mIoU:
 
 
 class Metric_mIoU_Temporal:
-    """occ_metrics.py:413-594: one confusion matrix per evaluated horizon; ground truth index
-    idx in {0,2,4,6} (keyframes at 2 Hz = 0/1/2/3 s) is scored against pred[idx // 2] of the
-    stacked states {0,2,4,6} (apis/test.py:218-223, occ_metrics.py:505-510)."""
+    """Drop-in for occ_metrics.py:413-594, same call signatures and return values:
 
-    def __init__(self, num_classes=18, use_lidar_mask=False, use_image_mask=False, horizons=(0, 2, 4, 6),
-                 device='cuda:0'):
-        self.horizons = tuple(horizons)
+    * add_batch(semantics_pred, semantics_gt_temp, mask_lidar_temp, mask_camera_temp): `semantics_pred` is the stack of
+      states {0,2,4,6} (apis/test.py:218-223); the three dicts are keyed by the ground-truth index idx in {0,2,4,6}
+      (keyframes at 2 Hz = 0/1/2/3 s) and idx is scored against semantics_pred[idx // 2] (:505-510);
+    * count_miou() -> (per-class IoU at 1 s, [mIoU 1 s, 2 s, 3 s]) (:548-575); count_iou() -> [IoU 1 s, 2 s, 3 s] (:577-594);
+    * attributes cnt, hist_{0..3}s, occ_hist_{0..3}s.
+    add_idx(...) scores one horizon (what the harness's per-horizon report uses); report() returns every horizon
+    incl. 0 s, which the reference accumulates (:533-535) but never prints."""
+
+    def __init__(self, save_dir='.', num_classes=18, use_lidar_mask=False, use_image_mask=False, device='cuda:0'):
+        self.class_names = CLASS_NAMES
+        self.save_dir, self.num_classes = save_dir, num_classes
+        self.use_lidar_mask, self.use_image_mask = use_lidar_mask, use_image_mask
+        self.occ_names = ['free', 'occupied']
+        self.horizons = (0, 2, 4, 6)
         self.metrics = {h: Metric_mIoU(num_classes=num_classes, use_lidar_mask=use_lidar_mask,
                                        use_image_mask=use_image_mask, device=device)
                         for h in self.horizons}
+        self.cnt = 0
 
-    def add_batch(self, semantics_pred_stack, semantics_gt, mask_lidar, mask_camera, idx):
+    def __getattr__(self, name):
+        # hist_0s .. hist_3s / occ_hist_0s .. occ_hist_3s as float arrays, like the reference's numpy accumulators
+        for prefix, attr in (('occ_hist_', 'occ_hist'), ('hist_', 'hist')):
+            if name.startswith(prefix) and name.endswith('s') and name[len(prefix):-1].isdigit():
+                sec = int(name[len(prefix):-1])
+                if 2 * sec in self.__dict__.get('metrics', {}):
+                    return getattr(self.metrics[2 * sec], attr)
+        raise AttributeError(name)
+
+    def add_idx(self, semantics_pred_stack, semantics_gt, mask_lidar, mask_camera, idx):
         assert idx in self.metrics
         self.metrics[idx].add_batch(semantics_pred_stack[idx // 2], semantics_gt, mask_lidar, mask_camera)
 
-    def count_miou(self):
-        out = {h: m.count_miou()[3] for h, m in self.metrics.items()}
-        fut = [out[h] for h in self.horizons if h != 0]
-        out['avg_future'] = round(float(np.mean(fut)), 2) if fut else float('nan')
+    def add_batch(self, semantics_pred, semantics_gt_temp, mask_lidar_temp, mask_camera_temp):
+        self.cnt += 1
+        for idx in semantics_gt_temp.keys():
+            self.add_idx(semantics_pred, semantics_gt_temp[idx],
+                         mask_lidar_temp[idx] if mask_lidar_temp is not None else None,
+                         mask_camera_temp[idx] if mask_camera_temp is not None else None, idx)
+
+    def _miou(self, h):
+        iu = Metric_mIoU.per_class_iu(self.metrics[h].hist)
+        return iu, round(np.nanmean(iu[:self.num_classes - 1]) * 100, 2)
+
+    def count_miou(self, verbose=False):
+        res = []
+        for sec in (1, 2, 3):
+            iu, m = self._miou(2 * sec)
+            if verbose:
+                print('===> mIoU of %d samples at %ds: %s' % (self.cnt, sec, m))
+            res.append(m)
+        return self._miou(2)[0], res
+
+    def count_iou(self):
+        res = []
+        for sec in (1, 2, 3):
+            iu = Metric_mIoU.per_class_iu(self.metrics[2 * sec].occ_hist)
+            res.append(round(iu[-1] * 100, 2))
+        return res
+
+    def report(self):
+        out = {h: self._miou(h)[1] for h in self.horizons}
+        out['avg_future'] = round(float(np.mean([out[h] for h in self.horizons if h != 0])), 2)
         return out

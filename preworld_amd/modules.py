@@ -86,6 +86,20 @@ class LSSViewTransformer(nn.Module):
         return coor
 
     def _sort(self, sensor2ego, cam2imgs, post_rots, post_trans, bda):
+        """geometry -> voxel ids -> device counting sort.  With accelerate=True the result is kept and reused for as
+        long as the camera tensors are the SAME tensors with unchanged contents (identity + torch version counters;
+        the reference's accelerate flag, view_transformer.py:155-174,263-267, assumes a fixed rig and never checks)."""
+        key = None
+        if self.accelerate:
+            key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (sensor2ego, cam2imgs, post_rots, post_trans, bda))
+            if self._cache is not None and self._cache[0] == key:
+                return self._cache[1]
+        vs = self._sort_now(sensor2ego, cam2imgs, post_rots, post_trans, bda)
+        if key is not None:
+            self._cache = (key, vs)
+        return vs
+
+    def _sort_now(self, sensor2ego, cam2imgs, post_rots, post_trans, bda):
         B, N = sensor2ego.shape[:2]
         lower, interval, size = self._grid()
         ipr, comb, tr = ops.lss_camera_matrices(sensor2ego, cam2imgs, post_rots)
@@ -105,7 +119,7 @@ class LSSViewTransformer(nn.Module):
 
     # ---- view_transformer.py:155-174,263-267
     def init_acceleration_v2(self, input):
-        self._cache = self._sort(input[1], input[3], input[4], input[5], input[6])
+        self._sort(input[1], input[3], input[4], input[5], input[6])
 
     def pre_compute(self, input):
         if self.initial_flag:
@@ -116,10 +130,7 @@ class LSSViewTransformer(nn.Module):
     def view_transform_core(self, input, depth, tran_feat):
         B, N, C, H, W = input[0].shape
         _, _, size = self._grid()
-        if self.accelerate and self._cache is not None:
-            vs = self._cache
-        else:
-            vs = self._sort(input[1], input[3], input[4], input[5], input[6])
+        vs = self._sort(input[1], input[3], input[4], input[5], input[6])
         seg_start, order, n_vox = vs.seg_start, vs.order, vs.n_keys
         if getattr(tran_feat, '_pw_channels_last', False):        # already (B*N,H,W,C) from ops.depthnet_tail
             feat = tran_feat.view(B, N, H, W, self.out_channels)
@@ -162,8 +173,66 @@ class LSSViewTransformer(nn.Module):
         feat._pw_channels_last = True
         return depth, feat
 
-    def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda):
-        return None
+
+
+class LSSViewTransformerBEVDepth(LSSViewTransformer):
+    """Drop-in for view_transformer.py:702-804: the view transformer the PreWorld configs reach through
+    `type='LSSViewTransformerBEVStereo'`.  `depth_net` is the DepthNet of image_encoder.py (plain PyTorch-ROCm, as
+    north_star prescribes for the image side; its stereo cost volume and its softmax/split tail are HIP kernels), the
+    lifting + pooling is the HIP path of the base class.  State-dict keys `depth_net.*` equal the reference's."""
+
+    def __init__(self, loss_depth_weight=3.0, depthnet_cfg=dict(), **kwargs):
+        super().__init__(**kwargs)
+        from .image_encoder import DepthNet
+        self.loss_depth_weight = loss_depth_weight
+        self.depth_net = DepthNet(self.in_channels, self.in_channels, self.out_channels, self.D, **depthnet_cfg)
+
+    # ---- view_transformer.py:713-734
+    def get_mlp_input(self, sensor2ego, ego2global, intrin, post_rot, post_tran, bda):
+        from .image_encoder import get_mlp_input
+        return get_mlp_input(sensor2ego, ego2global, intrin, post_rot, post_tran, bda)
+
+    # ---- view_transformer.py:736-773
+    def get_downsampled_gt_depth(self, gt_depths):
+        """gt_depths (B,N,H,W) -> one-hot (B*N*h*w, D): minimum non-zero depth of every downsample x downsample patch,
+        binned with the depth grid (sid=False)."""
+        B, N, H, W = gt_depths.shape
+        ds = self.downsample
+        g = gt_depths.view(B * N, H // ds, ds, W // ds, ds, 1).permute(0, 1, 3, 5, 2, 4).contiguous().view(-1, ds * ds)
+        g = torch.where(g == 0.0, 1e5 * torch.ones_like(g), g).min(dim=-1).values.view(B * N, H // ds, W // ds)
+        d0, _, dstep = self.grid_config['depth']
+        g = (g - (d0 - dstep)) / dstep
+        g = torch.where((g < self.D + 1) & (g >= 0.0), g, torch.zeros_like(g))
+        return torch.nn.functional.one_hot(g.long(), num_classes=self.D + 1).view(-1, self.D + 1)[:, 1:].float()
+
+    # ---- view_transformer.py:775-789
+    def get_depth_loss(self, depth_labels, depth_preds):
+        depth_labels = self.get_downsampled_gt_depth(depth_labels)
+        depth_preds = depth_preds.permute(0, 2, 3, 1).contiguous().view(-1, self.D)
+        fg_mask = torch.max(depth_labels, dim=1).values > 0.0
+        loss = torch.nn.functional.binary_cross_entropy(depth_preds[fg_mask], depth_labels[fg_mask], reduction='none')
+        return self.loss_depth_weight * (loss.sum() / max(1.0, fg_mask.sum()))
+
+    # ---- view_transformer.py:791-804
+    def forward(self, input, stereo_metas=None, depth_gt=None):
+        x, mlp_input = input[0], input[7]
+        B, N, C, H, W = x.shape
+        x = self.depth_net(x.view(B * N, C, H, W), mlp_input, stereo_metas)
+        if torch.is_grad_enabled() and x.requires_grad:
+            # training: keep the softmax/split in autograd; pooling goes through ops.bev_pool_v2 (QuickCumsumCuda)
+            depth = x[:, :self.D].softmax(dim=1)
+            tran_feat = x[:, self.D:self.D + self.out_channels]
+        else:
+            depth, tran_feat = self.depthnet_tail(x)
+        return self.view_transform(input, depth, tran_feat)
+
+
+class LSSViewTransformerBEVStereo(LSSViewTransformerBEVDepth):
+    """view_transformer.py:807-813: adds the 1/4-resolution frustum of the stereo cost volume."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.cv_frustum = create_frustum(kwargs['grid_config']['depth'], kwargs['input_size'], 4)
 
 
 # =====================================================================================
@@ -533,258 +602,12 @@ class DownScaleModule3DCustom(nn.Module):
         return self.forward_cl(v_cl).view(feats.shape[0], 1, 1, 1, -1)
 
 
-class PreWorld4DTraj(nn.Module):
-    """Hot-path half of mmdet3d/models/detectors/preworld_temporal_traj.py:26-370 (and of its
-    base classes bevdet_occ.py:167-269, bevdet.py:52-58): everything downstream of the
-    image-view features.  Attribute names match the reference detector, so a reference
-    checkpoint's `pre_process_net.*`, `img_bev_encoder_backbone.*`, `img_bev_encoder_neck.*`,
-    `final_conv.*`, `occupancy_head.*`, `plan_head.*`, `fusion_head.*`, `density_mlp.*`,
-    `semantic_mlp.*`, `color_mlp.*` keys load with strict=False (the image backbone / neck /
-    DepthNet stay on PyTorch-ROCm and are outside this class).
-
-    simple_test_from_lift() consumes, per frame, the softmaxed depth (B*N,D,H,W) and context
-    features (B*N,C,H,W) that LSSViewTransformerBEVDepth.forward produces at
-    view_transformer.py:798-801 plus the camera tensors, and returns the reference's result
-    dict {semantic_occ_{k}s, geo_occ_{k}s} with uint8 (X,Y,Z) arrays as torch tensors on the GPU
-    (call .cpu().numpy() to get exactly the reference's payload; keeping them on the device
-    avoids the reference's 14 D2H syncs per sample).
-    """
-
-    def __init__(self, img_view_transformer, img_bev_encoder_backbone, img_bev_encoder_neck,
-                 pre_process=None, occupancy_head=None, out_dim=32, num_classes=18,
-                 test_threshold=8.5, if_post_finetune=True, final_softplus=True, with_prev=True,
-                 num_adj=1, empty_idx=17, **kwargs):
-        super().__init__()
-        vt = dict(img_view_transformer)
-        vt.pop('type', None)
-        for k in ('loss_depth_weight', 'depthnet_cfg'):
-            vt.pop(k, None)
-        self.img_view_transformer = LSSViewTransformer(**vt)
-        bb = dict(img_bev_encoder_backbone); bb.pop('type', None)
-        self.img_bev_encoder_backbone = CustomResNet3D(**bb)
-        nk = dict(img_bev_encoder_neck); nk.pop('type', None)
-        self.img_bev_encoder_neck = LSSFPN3D(**nk)
-        self.pre_process = pre_process is not None
-        if self.pre_process:
-            pp = dict(pre_process); pp.pop('type', None)
-            self.pre_process_net = CustomResNet3D(**pp)
-        C = self.img_view_transformer.out_channels
-        self.out_dim, self.num_classes = out_dim, num_classes
-        self.test_threshold, self.if_post_finetune = test_threshold, if_post_finetune
-        self.with_prev, self.num_adj, self.empty_idx = with_prev, num_adj, empty_idx
-        self.final_conv = ConvModule3d(C, out_dim, 3, stride=1, padding=1, bias=True,
-                                       conv_cfg=dict(type='Conv3d'))
-        self.density_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
-                                         nn.Linear(out_dim * 2, 2),
-                                         *([nn.Softplus()] if final_softplus else []))
-        self.semantic_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
-                                          nn.Linear(out_dim * 2, num_classes - 1))
-        self.color_mlp = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
-                                       nn.Linear(out_dim * 2, 3))
-        oh = dict(occupancy_head or dict(in_channels=[out_dim], out_channel=num_classes,
-                                         norm_cfg=dict(type='SyncBN'), soft_weights=True))
-        oh.pop('type', None)
-        self.occupancy_head = OccHead(**oh)
-        self.velocity_dim, self.past_frame = 3, 5
-        self.plan_head = nn.Sequential(nn.Linear(self.velocity_dim * (self.past_frame + 2), 256),
-                                       nn.ReLU(inplace=True), nn.Linear(256, 256),
-                                       nn.ReLU(inplace=True), nn.Linear(256, out_dim))
-        self.fusion_head = nn.Sequential(nn.Linear(out_dim * 2, out_dim * 4), nn.Softplus(),
-                                         nn.Linear(out_dim * 4, out_dim))
-        # A20 trajectory branch (train-time only, preworld_temporal_traj.py:134-150)
-        self.downscale = DownScaleModule3DCustom(in_dim=out_dim)
-        self.ego_fusion_head = nn.Sequential(nn.Linear(out_dim * 5, out_dim * 8), nn.Softplus(),
-                                             nn.Linear(out_dim * 8, out_dim * 4), nn.Softplus(),
-                                             nn.Linear(out_dim * 4, out_dim * 2), nn.Softplus(),
-                                             nn.Linear(out_dim * 2, out_dim))
-        self.traj_head = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
-                                       nn.Linear(out_dim * 2, 2))
-        self._fc_cache = _PackedCache()
-
-    # ---- preworld_temporal_traj.py:457-470: ego-feature update + 2-D waypoint from one fused state
-    def traj_branch_cl(self, fused_cl, ego_feat):
-        """fused_cl (B,Z,Y,X,C) = v + fusion_head([v, e]); ego_feat (B,C) = plan_head(ego) ("identity").
-        Returns (pred_traj (B,2), fused_ego_feats (B,C))."""
-        down = self.downscale.forward_cl(fused_cl)                          # (B, 4C)
-        h = torch.cat([ego_feat, down], dim=-1).contiguous()                # (B, 5C)
-        efh, th = self.ego_fusion_head, self.traj_head
-        for i in (0, 2, 4):
-            h = ops.linear_act(h, efh[i].weight.contiguous(), efh[i].bias, 'softplus')
-        res = ops.linear_act(h, efh[6].weight.contiguous(), efh[6].bias)
-        fused_ego = ego_feat + res
-        t = ops.linear_act(fused_ego.contiguous(), th[0].weight.contiguous(), th[0].bias, 'softplus')
-        return ops.linear_act(t, th[2].weight.contiguous(), th[2].bias), fused_ego
-
-    # ---- bevdet_occ.py:88-139 (BEVStereo4DOCC.prepare_inputs): split the stacked inputs into
-    # frames and express every sweep's sensor pose in the KEY frame's ego system (fp64 algebra)
-    def prepare_inputs(self, inputs, stereo=False, num_frame=None, temporal_frame=None,
-                       extra_ref_frames=1):
-        """inputs = (imgs (B, N*T, C, H, W) camera-major/frame-minor, sensor2egos (B, T*N, 4, 4)
-        frame-major, ego2globals, intrins (B,T*N,3,3), post_rots, post_trans (B,T*N,3), bda).
-        Returns (imgs[T], sensor2keyegos[T], ego2globals[T], intrins[T], post_rots[T],
-        post_trans[T], bda, curr2adjsensor) exactly like the reference."""
-        num_frame = num_frame or (self.num_adj + 1 + (extra_ref_frames if stereo else 0))
-        temporal_frame = temporal_frame or (num_frame - extra_ref_frames if stereo else num_frame)
-        B, N, C, H, W = inputs[0].shape
-        N = N // num_frame
-        imgs = inputs[0].view(B, N, num_frame, C, H, W)
-        imgs = [t.squeeze(2) for t in torch.split(imgs, 1, 2)]
-        sensor2egos, ego2globals, intrins, post_rots, post_trans, bda = inputs[1:7]
-        sensor2egos = sensor2egos.view(B, num_frame, N, 4, 4)
-        ego2globals = ego2globals.view(B, num_frame, N, 4, 4)
-        keyego2global = ego2globals[:, 0, 0, ...].unsqueeze(1).unsqueeze(1)
-        global2keyego = torch.inverse(keyego2global.double())
-        sensor2keyegos = (global2keyego @ ego2globals.double() @ sensor2egos.double()).float()
-        curr2adjsensor = None
-        if stereo:
-            s_curr = sensor2egos[:, :temporal_frame, ...].double()
-            e_curr = ego2globals[:, :temporal_frame, ...].double()
-            s_adj = sensor2egos[:, 1:temporal_frame + 1, ...].double()
-            e_adj = ego2globals[:, 1:temporal_frame + 1, ...].double()
-            c2a = (torch.inverse(e_adj @ s_adj) @ e_curr @ s_curr).float()
-            curr2adjsensor = [p.squeeze(1) for p in torch.split(c2a, 1, 1)]
-            curr2adjsensor.extend([None for _ in range(extra_ref_frames)])
-            assert len(curr2adjsensor) == num_frame
-        extra = [sensor2keyegos, ego2globals, intrins.view(B, num_frame, N, 3, 3),
-                 post_rots.view(B, num_frame, N, 3, 3), post_trans.view(B, num_frame, N, 3)]
-        extra = [[p.squeeze(1) for p in torch.split(t, 1, 1)] for t in extra]
-        sensor2keyegos, ego2globals, intrins, post_rots, post_trans = extra
-        return imgs, sensor2keyegos, ego2globals, intrins, post_rots, post_trans, bda, curr2adjsensor
-
-    # ---- bevdet.py:52-58
-    def bev_encoder_cl(self, x_cl):
-        return self.img_bev_encoder_neck.forward_cl(self.img_bev_encoder_backbone.forward_cl(x_cl))
-
-    # ---- bevdet_occ.py:141-165 minus the image encoder / DepthNet
-    def lift_frame_cl(self, depth, tran_feat, sensor2keyego, intrin, post_rot, post_tran, bda, out=None):
-        vt = self.img_view_transformer
-        B, N = sensor2keyego.shape[:2]
-        H, W = depth.shape[-2:]
-        inp = [depth.new_empty(B, N, 1, H, W), sensor2keyego, None, intrin, post_rot, post_tran, bda]
-        keep = vt.collapse_z
-        vt.collapse_z = False
-        try:
-            bev, _ = vt.view_transform(inp, depth, tran_feat)
-        finally:
-            vt.collapse_z = keep
-        x = to_channels_last_3d(bev)
-        if self.pre_process:
-            x = self.pre_process_net.forward_cl(x, out_last=out)[0]
-        elif out is not None:
-            out.copy_(x)
-            x = out
-        return x
-
-    # ---- bevdet_occ.py:167-269 (frame loop, [adj, key] concat, with_prev=False -> zeros)
-    def extract_voxel_feat_cl(self, frames):
-        """frames: list ordered [key, adj, ...] of dicts(depth, tran_feat, sensor2keyego, intrin,
-        post_rot, post_tran, bda).  Returns final_conv output, channels-last (B,Z,Y,X,out_dim)."""
-        # channel order [adjacent ..., key] (bevdet_occ.py:266): every frame's pre_process output is
-        # written straight into its channel slice of ONE buffer (row stride n*C), no torch.cat copy
-        f0 = frames[0]
-        B = f0['sensor2keyego'].shape[0]
-        _, _, size = self.img_view_transformer._grid()
-        C = self.img_view_transformer.out_channels
-        n = self.num_adj + 1
-        x = torch.empty(B, size[2], size[1], size[0], n * C, device=f0['depth'].device, dtype=torch.float32)
-        self.lift_frame_cl(out=x[..., (n - 1) * C:], **f0)
-        for j in range(self.num_adj):                      # adjacent frame j+1 sits left of frame j
-            sl = x[..., (n - 2 - j) * C:(n - 1 - j) * C]
-            if self.with_prev and len(frames) > 1 + j:
-                self.lift_frame_cl(out=sl, **frames[1 + j])
-            else:
-                sl.zero_()
-        x = self.bev_encoder_cl(x)
-        return self.final_conv.forward_cl(x)              # conv + bias + ReLU (preworld.py:72-79)
-
-    def _forecast_weights(self):
-        fh = self.fusion_head
-        return self._fc_cache.get([fh[0].weight, fh[2].weight],
-                                  lambda: ops.forecast_pack(fh[0].weight.float().contiguous(),
-                                                            fh[2].weight.float().contiguous()))
-
-    # ---- preworld_temporal_traj.py:329-368: all recursion steps in one kernel
-    def forecast_cl(self, v_cl, ego_states, n_steps=6):
-        """v_cl (B,Z,Y,X,C); ego_states (B,1,21) (always temporal_ego_states[0], :331).
-        Returns states (n_steps,B,Z,Y,X,C) and the ego feature (B,32)."""
-        ph, fh = self.plan_head, self.fusion_head
-        B = v_cl.shape[0]
-        ego = ego_states.reshape(B, -1).float().contiguous()
-        plan = [(ph[0].weight.contiguous(), ph[0].bias), (ph[2].weight.contiguous(), ph[2].bias),
-                (ph[4].weight.contiguous(), ph[4].bias)]
-        ef, _, c1p = ops.forecast_prologue(ego, plan, fh[0].weight.contiguous(), fh[0].bias)
-        w1p, w2p = self._forecast_weights()
-        states = ops.forecast_steps(v_cl, B, w1p, w2p, c1p, fh[2].bias, n_steps)
-        return states, ef
-
-    # ---- preworld_temporal_traj.py:231-236: density / semantic / color MLPs, fused
-    def attributes_cl(self, v_cl):
-        """v_cl (B,Z,Y,X,C) -> packed grid (B,Z,Y,X,24): [0:2] density_prob, [2:19] semantic,
-        [19:22] color.  `grid[..., 0]` is the reference's `density`."""
-        mods = (self.density_mlp, self.semantic_mlp, self.color_mlp)
-        params = [m[i].weight for m in mods for i in (0, 2)] + [m[i].bias for m in mods for i in (0, 2)]
-        if not hasattr(self, '_attr_cache'):
-            self._attr_cache = _PackedCache()
-        packed = self._attr_cache.get(params, lambda: ops.pack_attr_mlp(*mods))
-        return ops.attr_mlp(v_cl, packed, final_softplus=len(self.density_mlp) == 4)
-
-    # ---- preworld_temporal_traj.py:237-250: occupancy from density threshold + semantic argmax
-    def attribute_decode(self, grid):
-        dens = grid[..., 0]
-        sem = grid[..., 2:19].argmax(-1)
-        occ = torch.where(dens > self.test_threshold, sem, torch.full_like(sem, self.num_classes - 1))
-        return occ.to(torch.uint8)
-
-    # ---- preworld_temporal_traj.py:212-370 (post-finetune branch) from lifted inputs
-    @torch.no_grad()
-    def simple_test_from_lift(self, frames, temporal_ego_states, n_steps=6, want_logits=False):
-        v0 = self.extract_voxel_feat_cl(frames)                       # (B,Z,Y,X,C)
-        if not self.if_post_finetune:
-            return self._simple_test_attributes(v0, temporal_ego_states, n_steps)
-        res = {}
-        feats = [v0]
-        B = v0.shape[0]
-        # OccHead on state 0, then on ALL forecast states in one launch (they are one contiguous (n_steps*B, Z, Y, X, C)
-        # buffer): one persistent-kernel prologue and one partial last round of tiles instead of n_steps of each
-        outs = [self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True)]
-        if n_steps > 0:
-            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps)
-            feats += [states[k] for k in range(n_steps)]
-            o = self.occupancy_head.decode_cl(states.view((n_steps * B,) + tuple(v0.shape[1:])), want_logits=want_logits,
-                                              transposed=True, want_geo=True)
-            outs += [tuple(t[k * B:(k + 1) * B] for t in o) for k in range(n_steps)]
-        logits_all = []
-        for k, out in enumerate(outs):
-            occ, geo = out[0], out[-1]                                 # geo_occ from the same kernel (:313-319)
-            if want_logits:
-                logits_all.append(out[1])
-            occ_xyz = occ.permute(0, 3, 2, 1)                          # (B,X,Y,Z) view
-            geo = geo.permute(0, 3, 2, 1)
-            # the reference indexes batch element 0 (:306) and names states 0s..6s (:361)
-            res['semantic_occ_%ds' % k] = [occ_xyz[0]]
-            res['geo_occ_%ds' % k] = [geo[0]]
-        if want_logits:
-            res['logits'] = logits_all
-        res['voxel_feats'] = feats
-        return res
-
-    # ---- preworld_temporal_traj.py:224-301: density/semantic-MLP decode (if_post_finetune=False).
-    # The reference names the future states 2s..7s in this branch (:294) and never emits 1s.
-    def _simple_test_attributes(self, v0, temporal_ego_states, n_steps):
-        feats = [v0]
-        if n_steps > 0:
-            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps)
-            feats += [states[k] for k in range(n_steps)]
-        res = {}
-        for k, f in enumerate(feats):
-            occ = self.attribute_decode(self.attributes_cl(f)).permute(0, 3, 2, 1)     # (B,X,Y,Z)
-            geo = torch.where(occ != self.num_classes - 1, torch.zeros_like(occ),
-                              torch.full_like(occ, self.num_classes - 1))
-            name = 0 if k == 0 else k + 1
-            res['semantic_occ_%ds' % name] = [occ[0]]
-            res['geo_occ_%ds' % name] = [geo[0]]
-        res['voxel_feats'] = feats
-        return res
+# PreWorld / PreWorld4DTraj / BEVStereo4DOCC live in detectors.py; `modules.PreWorld4DTraj` keeps working (PEP 562)
+def __getattr__(name):
+    if name in ('PreWorld', 'PreWorld4DTraj', 'BEVStereo4DOCC'):
+        from . import detectors
+        return getattr(detectors, name)
+    raise AttributeError('module %r has no attribute %r' % (__name__, name))
 
 
 # =====================================================================================

@@ -571,22 +571,28 @@ def _mfma_pack_indices(n_tiles):
     return t, i, k
 
 
-def pack_attr_mlp(density_mlp, semantic_mlp, color_mlp):
-    """nn.Sequential(Linear(32,64), Softplus, Linear(64,n)[, Softplus]) x3 -> (w1p, w2p, b1p, b2)
-    in the operand order pw_attr_mlp consumes."""
+def pack_mlp_blocks(mlps):
+    """Up to three nn.Sequential(Linear(32,64), Softplus, Linear(64,n_i)[, ...]) over the same 32-channel input ->
+    (w1p, w2p, b1p, b2) in the operand order pw_attr_mlp consumes: hidden block i occupies units [64i, 64i+64), its n_i
+    outputs follow block i-1's in the packed output row (sum n_i <= 24); absent blocks are zero."""
     import numpy as np
-    dev = density_mlp[0].weight.device
-    W1 = torch.cat([m[0].weight for m in (density_mlp, semantic_mlp, color_mlp)], 0).float()   # (192,32)
-    b1 = torch.cat([m[0].bias for m in (density_mlp, semantic_mlp, color_mlp)], 0).float()     # (192)
+    dev = mlps[0][0].weight.device
+    W1 = torch.zeros(192, 32, device=dev)
+    b1 = torch.zeros(192, device=dev)
     W2 = torch.zeros(32, 192, device=dev)
     b2 = torch.zeros(32, device=dev)
     row = 0
-    for blk, m in enumerate((density_mlp, semantic_mlp, color_mlp)):
+    for blk, m in enumerate(mlps):
+        if tuple(m[0].weight.shape) != (64, 32) or m[2].weight.shape[1] != 64:
+            raise _lib.PreworldHipError('pw_attr_mlp is built for Linear(32,64) -> Softplus -> Linear(64,n) blocks')
         n = m[2].weight.shape[0]
+        W1[blk * 64:(blk + 1) * 64] = m[0].weight.float()
+        b1[blk * 64:(blk + 1) * 64] = m[0].bias.float()
         W2[row:row + n, blk * 64:(blk + 1) * 64] = m[2].weight.float()
         b2[row:row + n] = m[2].bias.float()
         row += n
-    assert row == 22
+    if row > 24 or len(mlps) > 3:
+        raise _lib.PreworldHipError('pw_attr_mlp writes 24 packed output channels from at most 3 blocks')
     t, i, k = _mfma_pack_indices(6)
     ti, ii, ki = [torch.from_numpy(a.reshape(-1)).to(dev) for a in (t, i, k)]
     w1p = W1[ti * 32 + ii, ki].contiguous()                       # W1[t*32+i][k]
@@ -595,6 +601,11 @@ def pack_attr_mlp(density_mlp, semantic_mlp, color_mlp):
     idx = tt * 32 + ((rr & 3) + 8 * (rr >> 2) + 4 * hh)
     b1p = b1[torch.from_numpy(idx.reshape(-1)).to(dev)].contiguous()
     return w1p, w2p, b1p, b2.contiguous()
+
+
+def pack_attr_mlp(density_mlp, semantic_mlp, color_mlp):
+    """density (2) / semantic (17) / color (3) MLPs of preworld.py:81-104 -> packed channels [0:2], [2:19], [19:22]."""
+    return pack_mlp_blocks([density_mlp, semantic_mlp, color_mlp])
 
 
 def attr_mlp(v_cl, packed, final_softplus=True, out=None):

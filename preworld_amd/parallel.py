@@ -10,9 +10,9 @@ RCCL over xGMI on ROCm, 'gloo' in the CPU tests).
   rank recomputes the cheap recursion locally up to its largest owned state and decodes only its
   own states; ONE all_gather of uint8 grids (0.64 MB each) assembles the 7 states everywhere.
 * frame-sharded lift (the literal north_star wording): input frame f (key / adjacent) is lifted,
-  pooled and pre-processed on rank f % W and its (B,Z,Y,X,32) fp32 feature (81.92 MB) is
-  broadcast before cat + bev_encoder (bevdet_occ.py:266-267).  xGMI is point-to-point
-  (7 links x ~153 GB/s per GPU): a broadcast/all-gather of one 81.92 MB shard costs ~0.5 ms
+  pooled and pre-processed on rank f % W and the (B,Z,Y,X,32) fp32 features (81.92 MB each) are
+  exchanged with ONE all_gather before cat + bev_encoder (bevdet_occ.py:266-267).  xGMI is point-to-point
+  (7 links x ~153 GB/s per GPU): an all-gather of one 81.92 MB shard costs ~0.5 ms
   direct vs ~3.7 ms around a ring, i.e. comparable to the ~1 ms of lift+pre_process it saves --
   which is why replicas, not this mode, is the throughput mode.
 """
@@ -54,19 +54,23 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None):
 
 
 def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None):
-    """frames: list of per-frame inputs (present on every rank); frame f is lifted by rank f % W
-    and broadcast.  Returns the list of lifted features on every rank."""
+    """frames: list of per-frame inputs (present on every rank); frame f is lifted by rank f % W.  The features reach
+    every rank through ONE all_gather of a (slots, *out_shape) buffer per rank (slots = ceil(F / W); 81.92 MB per frame at
+    C3) -- on xGMI's point-to-point links every rank's shard travels its own link.  Returns the list of lifted features
+    on every rank, in frame order."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    outs = []
-    for f, fr in enumerate(frames):
-        owner = f % world
-        if owner == rank:
-            buf = lift_fn(fr).contiguous()
-            assert tuple(buf.shape) == tuple(out_shape)
-        else:
-            buf = torch.empty(out_shape, dtype=dtype, device=device)
-        if world > 1:
-            dist.broadcast(buf, src=owner, group=group)
-        outs.append(buf)
-    return outs
+    F = len(frames)
+    if world == 1:
+        outs = [lift_fn(fr).contiguous() for fr in frames]
+        assert all(tuple(o.shape) == tuple(out_shape) for o in outs)
+        return outs
+    slots = (F + world - 1) // world
+    send = torch.zeros((slots,) + tuple(out_shape), dtype=dtype, device=device)
+    for i, f in enumerate(range(rank, F, world)):
+        buf = lift_fn(frames[f])
+        assert tuple(buf.shape) == tuple(out_shape)
+        send[i].copy_(buf)
+    recv = torch.empty((world, slots) + tuple(out_shape), dtype=dtype, device=device)
+    dist.all_gather_into_tensor(recv.view(world * slots, *out_shape), send, group=group)
+    return [recv[f % world, f // world] for f in range(F)]

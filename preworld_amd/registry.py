@@ -1,47 +1,75 @@
-"""Optional adapter that plugs the drop-in modules into the reference's mmdet3d registries so
-that `configs/preworld/*.py` build them unmodified ("B-module").
+"""Optional adapter that plugs the drop-in classes into the reference's mmdet / mmdet3d registries so that
+`configs/preworld/**.py` build them unmodified ("B-module").
 
     import preworld_amd.registry as R
     R.register_into_mmdet3d()        # after `import mmdet3d.models`
 
-The reference registers its classes in DIFFERENT registries (view transformers in
-mmdet3d.models.builder.NECKS, view_transformer.py:12-15; CustomResNet3D in mmdet.models.BACKBONES,
-resnet.py:7,126; LSSFPN3D in mmdet.models.NECKS, lss_fpn.py:9,103; OccHead / NerfHead in
-mmdet.models.HEADS, occupancy_head.py:13,45, nerf_head.py:103-104).  Re-registration needs
-`force=True` (mmcv 1.6.0 Registry raises KeyError on duplicates).  mmcv/mmdet are not installed in
-this image, so the adapter takes the registry objects as arguments and is unit-tested against a
-minimal stand-in with the same `register_module(name=None, force=False, module=None)` signature.
-"""
-from . import losses, modules
+Every `type` the six PreWorld configs put on the camera -> occupancy path is covered (tests/test_registry_cpu.py builds
+all six resolved `model` dicts, tests/golden/preworld_configs.json): the view transformer the configs really name
+(`LSSViewTransformerBEVStereo`, and its bases), `CustomResNet3D`, `LSSFPN3D`, `OccHead`, `NerfHead`,
+`CustomFocalLoss`, and the detectors `BEVStereo4DOCC` / `PreWorld` / `PreWorld4DTraj` -- the forecasting recursion,
+`final_conv` and the attribute MLPs are attributes of the detector, so they can only be swapped by re-registering the
+detector.
 
-# reference type name -> (which registry, replacement class)
-REPLACEMENTS = {
-    'LSSViewTransformer': ('mmdet3d.NECKS', modules.LSSViewTransformer),
-    'CustomResNet3D': ('mmdet.BACKBONES', modules.CustomResNet3D),
-    'LSSFPN3D': ('mmdet.NECKS', modules.LSSFPN3D),
-    'OccHead': ('mmdet.HEADS', modules.OccHead),
-    'NerfHead': ('mmdet.HEADS', modules.NerfHead),
-    # mmdet3d/models/loss_utils/focal_loss.py:7,162 registers it in mmdet's LOSSES; preworld.py:117 builds it by name
-    'CustomFocalLoss': ('mmdet.LOSSES', losses.CustomFocalLoss),
+The reference registers its classes in DIFFERENT registries (view transformers in mmdet3d.models.builder.NECKS,
+view_transformer.py:12-15,807; CustomResNet3D in mmdet.models.BACKBONES, resnet.py:7,126; LSSFPN3D / FPN_LSS in
+mmdet.models.NECKS, lss_fpn.py:9,12,103; OccHead / NerfHead in mmdet.models.HEADS, occupancy_head.py:13,45,
+nerf_head.py:103-104; detectors in mmdet.models.DETECTORS, preworld.py:6,23).  Re-registration needs `force=True`
+(mmcv 1.6.0 Registry raises KeyError on duplicates).  mmcv / mmdet are not installed in this image, so the adapter takes
+the registry objects as arguments and is unit-tested against a minimal stand-in with the same
+`register_module(name=None, force=False, module=None)` signature.
+
+The drop-ins are INFERENCE classes (eval-mode BatchNorm folded into the convs, no conv backward): `register()` therefore
+defaults to `inference_only=True` semantics -- it replaces the classes for `tools/test*.py` runs; for a training run call
+`register(..., training=True)`, which leaves every class that cannot train (conv stack, OccHead, NerfHead, detectors)
+on the reference implementation and swaps only the pieces that have a backward (`CustomFocalLoss`)."""
+from . import builder
+
+# reference type name -> (registry, can it train?)
+REGISTRY_OF = {
+    'LSSViewTransformer': ('mmdet3d.NECKS', False),
+    'LSSViewTransformerBEVDepth': ('mmdet3d.NECKS', False),
+    'LSSViewTransformerBEVStereo': ('mmdet3d.NECKS', False),
+    'CustomResNet3D': ('mmdet.BACKBONES', False),
+    'LSSFPN3D': ('mmdet.NECKS', False),
+    'OccHead': ('mmdet.HEADS', False),
+    'NerfHead': ('mmdet.HEADS', False),
+    'CustomFocalLoss': ('mmdet.LOSSES', True),
+    'BEVStereo4DOCC': ('mmdet.DETECTORS', False),
+    'PreWorld': ('mmdet.DETECTORS', False),
+    'PreWorld4DTraj': ('mmdet.DETECTORS', False),
 }
 
 
-def register(registries):
-    """registries: dict with keys 'mmdet3d.NECKS', 'mmdet.BACKBONES', 'mmdet.NECKS', 'mmdet.HEADS' [, 'mmdet.LOSSES']
-    mapping to mmcv-style Registry objects.  Returns the list of (registry key, type name)."""
+def replacements():
+    """{type name: (registry key, class)} -- the image-side stand-ins (SwinTransformer, FPN_LSS) are NOT registered: with
+    mmcv present the reference's own classes serve the image side."""
+    tab = builder.table()
+    return {name: (key, tab[name]) for name, (key, _) in REGISTRY_OF.items()}
+
+
+REPLACEMENTS = None     # filled lazily (builder.table() imports every module of the package)
+
+
+def register(registries, training=False):
+    """registries: dict with keys 'mmdet3d.NECKS', 'mmdet.BACKBONES', 'mmdet.NECKS', 'mmdet.HEADS', 'mmdet.DETECTORS'
+    [, 'mmdet.LOSSES'] mapping to mmcv-style Registry objects (missing keys are skipped).  Returns the list of
+    (registry key, type name) that were replaced."""
     done = []
-    for name, (key, cls) in REPLACEMENTS.items():
-        if key not in registries:            # callers that only replace modules may leave LOSSES out
+    for name, (key, cls) in replacements().items():
+        if key not in registries:
+            continue
+        if training and not REGISTRY_OF[name][1]:
             continue
         registries[key].register_module(name=name, force=True, module=cls)
         done.append((key, name))
     return done
 
 
-def register_into_mmdet3d():
+def register_into_mmdet3d(training=False):
     """Resolve the real registries (needs mmdet3d's dependencies importable) and register."""
-    from mmdet.models import BACKBONES, HEADS, NECKS as MMDET_NECKS   # noqa: F401
+    from mmdet.models import BACKBONES, DETECTORS, HEADS, NECKS as MMDET_NECKS
     from mmdet.models.builder import LOSSES
     from mmdet3d.models.builder import NECKS as MMDET3D_NECKS
-    return register({'mmdet3d.NECKS': MMDET3D_NECKS, 'mmdet.BACKBONES': BACKBONES,
-                     'mmdet.NECKS': MMDET_NECKS, 'mmdet.HEADS': HEADS, 'mmdet.LOSSES': LOSSES})
+    return register({'mmdet3d.NECKS': MMDET3D_NECKS, 'mmdet.BACKBONES': BACKBONES, 'mmdet.NECKS': MMDET_NECKS,
+                     'mmdet.HEADS': HEADS, 'mmdet.DETECTORS': DETECTORS, 'mmdet.LOSSES': LOSSES}, training=training)

@@ -281,7 +281,8 @@ def _net(grid=None):
         img_view_transformer=dict(type='LSSViewTransformerBEVStereo',
                                   grid_config=grid or S.GRID_CONFIG_FULL, input_size=S.INPUT_SIZE,
                                   in_channels=512, out_channels=32, sid=False, collapse_z=False,
-                                  loss_depth_weight=0.05, depthnet_cfg=dict(), downsample=16),
+                                  loss_depth_weight=0.05,
+                                  depthnet_cfg=dict(use_dcn=False, aspp_mid_channels=96, stereo=True, bias=5.0), downsample=16),
         img_bev_encoder_backbone=dict(type='CustomResNet3D', numC_input=64, num_layer=[1, 2, 4],
                                       with_cp=False, num_channels=[32, 64, 128], stride=[1, 2, 2],
                                       backbone_output_ids=[0, 1, 2]),

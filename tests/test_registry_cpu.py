@@ -24,6 +24,9 @@ class FakeRegistry:
         return self.module_dict[cfg.pop('type')](**cfg)
 
 
+ALL_REGS = ('mmdet3d.NECKS', 'mmdet.BACKBONES', 'mmdet.NECKS', 'mmdet.HEADS', 'mmdet.DETECTORS', 'mmdet.LOSSES')
+
+
 def test_force_reregistration_and_build_from_reference_cfg():
     regs = {k: FakeRegistry() for k in ('mmdet3d.NECKS', 'mmdet.BACKBONES', 'mmdet.NECKS', 'mmdet.HEADS')}
     regs['mmdet.BACKBONES'].register_module(name='CustomResNet3D', module=object)    # the reference's
@@ -57,6 +60,91 @@ def test_force_reregistration_and_build_from_reference_cfg():
     assert ('mmdet.LOSSES', 'CustomFocalLoss') in R.register(regs)
     fl = regs['mmdet.LOSSES'].build(dict(type='CustomFocalLoss'))      # preworld.py:117
     assert (fl.gamma, fl.alpha, fl.loss_weight) == (2.0, 0.25, 100.0)
+
+
+def test_training_registration_keeps_inference_only_classes_on_the_reference():
+    """the conv stack / heads / detectors have no backward, so a training run must not get them."""
+    regs = {k: FakeRegistry() for k in ALL_REGS}
+    done = R.register(regs, training=True)
+    assert done == [('mmdet.LOSSES', 'CustomFocalLoss')]
+    done = R.register(regs)
+    assert {n for _, n in done} == set(R.REGISTRY_OF)
+
+
+def _hot_types(cfg, found):
+    if isinstance(cfg, dict):
+        if 'type' in cfg:
+            found.append(cfg['type'])
+        for v in cfg.values():
+            _hot_types(v, found)
+    return found
+
+
+def test_every_preworld_config_builds_through_the_registry():
+    """The resolved `model` dict of each of the six configs/preworld/**.py files (tests/golden/preworld_configs.json,
+    produced by tools/gen_golden.py executing the reference configs) builds through the stand-in registry after
+    R.register(), and every component on the camera -> occupancy path is a preworld_amd class -- in particular the
+    view transformer the configs name (LSSViewTransformerBEVStereo) and the detectors PreWorld / PreWorld4DTraj."""
+    import json
+    import os
+    from preworld_amd import detectors as D, image_encoder as IE, losses as L
+    cfgs = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'preworld_configs.json')))
+    assert len(cfgs) == 6
+    regs = {k: FakeRegistry() for k in ALL_REGS}
+    R.register(regs)
+    want_cls = {'BEVStereo4DOCC': D.BEVStereo4DOCC, 'PreWorld': D.PreWorld, 'PreWorld4DTraj': D.PreWorld4DTraj}
+    for name, model in cfgs.items():
+        types_used = set(_hot_types(model, []))
+        # every type on the path resolves to a class of this package (GELU / LN / SyncBN / CrossEntropyLoss are layer
+        # or loss names inside act_cfg / norm_cfg / loss_occ, not registry builds on this path)
+        from preworld_amd import builder
+        path_types = types_used - {'GELU', 'LN', 'SyncBN', 'CrossEntropyLoss'}
+        assert path_types <= set(builder.table()), (name, path_types - set(builder.table()))
+        model = dict(model)
+        model['img_backbone'] = dict(model['img_backbone'], depths=[1, 1, 1, 1])     # shallow Swin: the test builds, it does not run
+        det = regs['mmdet.DETECTORS'].build(model)
+        assert type(det) is want_cls[model['type']], name
+        assert type(det.img_view_transformer) is M.LSSViewTransformerBEVStereo
+        assert type(det.img_view_transformer.depth_net) is IE.DepthNet
+        assert type(det.img_bev_encoder_backbone) is M.CustomResNet3D and type(det.pre_process_net) is M.CustomResNet3D
+        assert type(det.img_bev_encoder_neck) is M.LSSFPN3D
+        assert type(det.img_backbone) is IE.SwinTransformer and type(det.img_neck) is IE.FPN_LSS
+        assert det.num_frame == 3 and det.temporal_frame == 2 and det.num_adj == 1
+        if model['type'] != 'BEVStereo4DOCC':
+            assert type(det.occupancy_head) is M.OccHead and type(det.nerf_head) is M.NerfHead
+            assert type(det.focal_loss) is L.CustomFocalLoss
+            assert det.if_post_finetune == model.get('if_post_finetune', False)
+            keys = set(det.state_dict())
+            for k in ('final_conv.conv.bias', 'density_mlp.2.weight', 'semantic_mlp.0.bias', 'color_mlp.2.bias',
+                      'occupancy_head.occ_pred_conv.3.weight', 'nerf_head.act_shift',
+                      'img_view_transformer.depth_net.reduce_conv.0.weight',
+                      'img_view_transformer.depth_net.depth_conv.4.weight', 'img_neck.conv.0.weight',
+                      'img_backbone.patch_embed.projection.weight'):
+                assert k in keys, (name, k)
+            has_traj = model['type'] == 'PreWorld4DTraj'
+            assert ('fusion_head.0.weight' in keys) == has_traj and ('plan_head.4.bias' in keys) == has_traj
+            assert ('downscale.downscale3.weight' in keys) == has_traj
+        else:
+            assert 'predicter.2.weight' in det.state_dict()
+        with pytest.raises(NotImplementedError):
+            det.forward_train()
+
+
+def test_bevdepth_host_methods_match_reference(golden):
+    """LSSViewTransformerBEVStereo.get_mlp_input / get_downsampled_gt_depth / get_depth_loss / cv_frustum
+    (view_transformer.py:713-789, 807-813) against outputs of the imported reference class."""
+    g = golden('bevdepth_small.npz')
+    vt = M.LSSViewTransformerBEVStereo(grid_config=S.GRID_CONFIG_FULL, input_size=(64, 96), in_channels=16, out_channels=8,
+                                       sid=False, collapse_z=False, loss_depth_weight=0.05, downsample=16,
+                                       depthnet_cfg=dict(use_dcn=False, aspp_mid_channels=8, stereo=True, bias=5.0))
+    T = torch.from_numpy
+    mlp = vt.get_mlp_input(T(g['sensor2ego']), T(g['ego2global']), T(g['intrin']), T(g['post_rot']), T(g['post_tran']), T(g['bda']))
+    assert torch.equal(mlp, T(g['mlp_input']))
+    assert torch.equal(vt.get_downsampled_gt_depth(T(g['depth_gt'])), T(g['onehot']))
+    loss = vt.get_depth_loss(T(g['depth_gt']), T(g['depth_pred']))
+    assert abs(float(loss) - float(g['depth_loss'])) <= 1e-6 * abs(float(g['depth_loss']))
+    assert torch.equal(vt.cv_frustum, T(g['cv_frustum'])) and torch.equal(vt.frustum, T(g['frustum']))
+    assert vt.D == 88 and vt.loss_depth_weight == 0.05
 
 
 def test_state_dict_keys_match_reference_names():
@@ -100,7 +188,7 @@ def test_prepare_inputs_pose_algebra():
         img_view_transformer=dict(grid_config=S.GRID_CONFIG_FULL, input_size=S.INPUT_SIZE,
                                   in_channels=512, out_channels=32, collapse_z=False, downsample=16),
         img_bev_encoder_backbone=dict(numC_input=64, num_layer=[1], num_channels=[32], stride=[1]),
-        img_bev_encoder_neck=dict(in_channels=224, out_channels=32))
+        img_bev_encoder_neck=dict(in_channels=224, out_channels=32), num_adj=1)
     B, N, T = 1, 6, 3
     rs = np.random.RandomState(0)
 

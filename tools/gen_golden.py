@@ -678,6 +678,111 @@ def gen_metric(om):
          hist=m2.hist, iou=iu2, miou=np.float64(miou2))
 
 
+# ----------------------------------------------------------------------------- configs -> resolved model dicts
+def _merge_cfg(a, b):
+    """mmcv Config._merge_a_into_b: child `a` over base `b`, dicts merged recursively unless a['_delete_']."""
+    b = dict(b)
+    for k, v in a.items():
+        if isinstance(v, dict) and isinstance(b.get(k), dict) and not v.get('_delete_', False):
+            b[k] = _merge_cfg(v, b[k])
+        elif isinstance(v, dict):
+            b[k] = {kk: vv for kk, vv in v.items() if kk != '_delete_'}
+        else:
+            b[k] = v
+    return b
+
+
+def _load_cfg(path):
+    """mmcv Config.fromfile restricted to what the PreWorld configs use: python files, `_base_` inheritance."""
+    ns = {}
+    exec(compile(open(path).read(), path, 'exec'), ns)
+    cfg = {k: v for k, v in ns.items() if not k.startswith('__') and not isinstance(v, types.ModuleType)
+           and not callable(v)}
+    bases = cfg.pop('_base_', [])
+    bases = [bases] if isinstance(bases, str) else bases
+    base_cfg = {}
+    for b in bases:
+        base_cfg = _merge_cfg(_load_cfg(os.path.normpath(os.path.join(os.path.dirname(path), b))), base_cfg)
+    return _merge_cfg(cfg, base_cfg)
+
+
+def _jsonable(v):
+    if isinstance(v, dict):
+        return {k: _jsonable(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_jsonable(x) for x in v]
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.floating,)):
+        return float(v)
+    return v
+
+
+def gen_configs():
+    """The `model` dict of each of the six configs/preworld/**.py files with `_base_` inheritance resolved (data: the
+    values the reference's registry would be asked to build) -> tests/golden/preworld_configs.json."""
+    import glob
+    import json
+    out = {}
+    for path in sorted(glob.glob(os.path.join(REF, 'configs', 'preworld', '*', '*.py'))):
+        cfg = _load_cfg(path)
+        out[os.path.relpath(path, os.path.join(REF, 'configs'))] = _jsonable(cfg['model'])
+    assert len(out) == 6, sorted(out)
+    with open(os.path.join(OUT, 'preworld_configs.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('preworld_configs.json', {k: v['type'] for k, v in out.items()})
+
+
+def gen_bevdepth(vtm):
+    """LSSViewTransformerBEVStereo host-side methods (view_transformer.py:713-789, :807-813): get_mlp_input,
+    get_downsampled_gt_depth, get_depth_loss, cv_frustum on seeded inputs."""
+    gc = dict(S.GRID_CONFIG_FULL)
+    vtm.BasicBlock = _RefBasicBlock
+    vt = vtm.LSSViewTransformerBEVStereo(grid_config=gc, input_size=(64, 96), in_channels=16, out_channels=8, sid=False,
+                                         collapse_z=False, loss_depth_weight=0.05, downsample=16,
+                                         depthnet_cfg=dict(use_dcn=False, aspp_mid_channels=8, stereo=True, bias=5.0))
+    g = torch.Generator().manual_seed(11)
+    B, N = 2, 3
+    s2e = torch.randn(B, N, 4, 4, generator=g)
+    e2g = torch.randn(B, N, 4, 4, generator=g)
+    K = torch.randn(B, N, 3, 3, generator=g)
+    pr = torch.randn(B, N, 3, 3, generator=g)
+    pt = torch.randn(B, N, 3, generator=g)
+    bda = torch.randn(B, 3, 3, generator=g)
+    mlp = vt.get_mlp_input(s2e, e2g, K, pr, pt, bda)
+    gt = torch.rand(B, N, 64, 96, generator=g) * 60.0
+    gt[torch.rand(B, N, 64, 96, generator=g) < 0.7] = 0.0
+    onehot = vt.get_downsampled_gt_depth(gt)
+    pred = torch.rand(B * N, vt.D, 4, 6, generator=g).softmax(1)
+    loss = vt.get_depth_loss(gt, pred)
+    save('bevdepth_small.npz', sensor2ego=s2e.numpy(), ego2global=e2g.numpy(), intrin=K.numpy(), post_rot=pr.numpy(),
+         post_tran=pt.numpy(), bda=bda.numpy(), mlp_input=mlp.numpy(), depth_gt=gt.numpy(), onehot=onehot.numpy(),
+         depth_pred=pred.numpy(), depth_loss=np.float32(loss.item()), cv_frustum=vt.cv_frustum.numpy(),
+         frustum=vt.frustum.numpy())
+
+
+def gen_metric_temporal(om):
+    """Metric_mIoU_Temporal (occ_metrics.py:413-594) on seeded labels: dict-keyed add_batch, count_miou, count_iou."""
+    import contextlib
+    import io
+    rng = np.random.RandomState(5)
+    m = om.Metric_mIoU_Temporal(num_classes=18, use_image_mask=True)
+    preds, gts, masks = [], [], []
+    for _ in range(2):
+        gt = {i: rng.randint(0, 18, (25, 25, 4)).astype(np.uint8) for i in (0, 2, 4, 6)}
+        mk = {i: rng.rand(25, 25, 4) < 0.7 for i in (0, 2, 4, 6)}
+        pred = np.stack([np.where(rng.rand(25, 25, 4) < 0.5, gt[i], rng.randint(0, 18, (25, 25, 4))).astype(np.uint8)
+                         for i in (0, 2, 4, 6)])
+        m.add_batch(pred, gt, mk, mk)
+        preds.append(pred); gts.append(np.stack([gt[i] for i in (0, 2, 4, 6)])); masks.append(np.stack([mk[i] for i in (0, 2, 4, 6)]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        iu1, mious = m.count_miou()
+        ious = m.count_iou()
+    save('metric_miou_temporal.npz', pred=np.stack(preds), gt=np.stack(gts), mask=np.stack(masks),
+         hist_0s=m.hist_0s, hist_1s=m.hist_1s, hist_2s=m.hist_2s, hist_3s=m.hist_3s, occ_hist_1s=m.occ_hist_1s,
+         iou_1s=iu1, mious=np.array(mious), ious=np.array(ious), cnt=np.int64(m.cnt))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shim()
@@ -701,6 +806,18 @@ def main():
     finally:
         cpp_ext.load = real_load
     nh = load_ref('mmdet3d.models.nerf.nerf_head', 'mmdet3d/models/nerf/nerf_head.py')
+    only = set(sys.argv[1:])          # e.g. `python tools/gen_golden.py configs metric_temporal` regenerates just those
+
+    def want(name):
+        return not only or name in only
+    if want('configs'):
+        gen_configs()
+    if want('bevdepth'):
+        gen_bevdepth(vtm)
+    if want('metric_temporal'):
+        gen_metric_temporal(om)
+    if only:
+        return
     gen_kat(bp)
     gen_geometry(vtm)
     gen_conv_stack(res, fpn, occ)
