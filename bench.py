@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: samples/s of PreWorld's camera->voxel occupancy hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2] [--mode replicas|sharded] [--no-graph]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,20 +9,26 @@ One "step" = one sample through the whole hot path with every input already resi
   C3 (default, BASELINE.json configs[2], the config north_star's target is quoted on):
      2 frames (key + adjacent) x [LSS geometry -> voxel sort -> voxel pooling -> pre_process],
      concat -> CustomResNet3D [1,2,4] -> LSSFPN3D -> final_conv -> 6-step state-conditioned
-     forecast -> OccHead x 7 states -> 7 uint8 200x200x16 occupancy grids.
-  C2 (configs[1]): key frame only (with_prev=False), 1 state.
+     forecast -> OccHead x 7 states -> 7 semantic + 7 geometric uint8 200x200x16 grids, delivered as the reference
+     delivers them: contiguous (X,Y,Z) uint8 arrays in HOST memory (one async D2H copy per sample, inside the step).
+  C2 (configs[1]): key frame only (with_prev=False), the PreWorld detector, 1 state.
 Inputs are what LSSViewTransformerBEVDepth.forward hands to view_transform
 (mmdet3d/models/necks/view_transformer.py:798-803): softmaxed depth (6,88,32,88) and context
 features (6,32,32,88) per frame plus the camera tensors; the image backbone / DepthNet stay on
 PyTorch and are outside the measured path.  Weights are random (seeded), data
 synthetic -- there is no dataset or checkpoint in this environment.
 
-N > 1: one process per GPU, each rank runs its own sample stream (samples are independent:
-no data-path collective), barrier + synchronize on both sides, max over ranks -> weak scaling.
+--mode replicas (default; what the driver runs): N > 1 = one process per GPU, each rank runs its own sample stream
+  (samples are independent: no data-path collective), barrier + synchronize on both sides, max over ranks -> weak scaling.
+--mode sharded (BASELINE.json configs[3], the latency mode of DESIGN.md section 7): ONE sample per step for the whole
+  job -- frames lifted on different ranks + RCCL all_gather of the voxel features, encoder on every rank, the 7 states
+  forecast + decoded round-robin + RCCL all_gather of the uint8 grids (harness.simple_test_sharded) -> strong scaling.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (MFMA fp32 conv3d), FLOP/launch / HIP-event duration
-  cpu_baseline -- the CPU oracle (a port: the reference has no CPU path) on a bounded sample.
+  roofline     -- the kernel with the largest share of the step BY ROCPROF KERNEL NAME (plus the HBM-bound voxel-pooling
+                  kernel under `also`): algorithmic work / HIP-event duration measured live on the launch stream
+  cpu_baseline -- the same C3 sample at FULL size on the host cores (no extrapolation): the PyTorch-CPU composition
+                  (median of 5 after a warm-up) and the OpenMP port (the reference has no CPU path for its native ops).
 """
 import argparse
 import json
@@ -36,65 +42,43 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from preworld_amd import modules as M  # noqa: E402
+from preworld_amd import _lib  # noqa: E402
+from preworld_amd import harness  # noqa: E402
 from preworld_amd import ops  # noqa: E402
 from preworld_amd import synth as S  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks and HBM3E
+PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0}
 PEAK_HBM_GBPS = 8000.0
 
 
-def build_net(dev, with_prev=True):
-    net = M.PreWorld4DTraj(
-        img_view_transformer=dict(type='LSSViewTransformerBEVStereo', grid_config=S.GRID_CONFIG_FULL,
-                                  input_size=S.INPUT_SIZE, in_channels=512, out_channels=32,
-                                  sid=False, collapse_z=False, loss_depth_weight=0.05,
-                                  depthnet_cfg=dict(use_dcn=False, aspp_mid_channels=96, stereo=True,
-                                                    bias=5.0), downsample=16),
-        img_bev_encoder_backbone=dict(type='CustomResNet3D', numC_input=64, num_layer=[1, 2, 4],
-                                      with_cp=False, num_channels=[32, 64, 128], stride=[1, 2, 2],
-                                      backbone_output_ids=[0, 1, 2]),
-        img_bev_encoder_neck=dict(type='LSSFPN3D', in_channels=224, out_channels=32),
-        pre_process=dict(type='CustomResNet3D', numC_input=32, with_cp=False, num_layer=[1],
-                         num_channels=[32], stride=[1], backbone_output_ids=[0]),
-        occupancy_head=dict(type='OccHead', with_cp=False, use_deblock=False,
-                            norm_cfg=dict(type='SyncBN', requires_grad=True), soft_weights=True,
-                            final_occ_size=[200, 200, 16], empty_idx=17, num_level=1,
-                            in_channels=[32], out_channel=18,
-                            point_cloud_range=[-40, -40, -1, 40, 40, 5.4]),
-        if_post_finetune=True, with_prev=with_prev)
+def build_net(dev, config):
+    cfg = harness.model_cfg(S.GRID_CONFIG_FULL, with_prev=config == 'C3',
+                            detector='PreWorld4DTraj' if config == 'C3' else 'PreWorld')
     sd = S.synth_state_dict(0)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    return net.to(dev).eval(), sd
+    return harness.build_model(cfg, sd, dev), sd
 
 
 def make_inputs(dev, seed, n_frames):
-    def T(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    frames = []
-    for f in range(n_frames):
-        rig = S.synthetic_rig(6, dx=-2.5 * f)              # adjacent frame: ego moved 2.5 m
-        depth, feat = S.lift_inputs(seed * 16 + f)
-        frames.append(dict(depth=T(depth).view(6, 88, 32, 88), tran_feat=T(feat).view(6, 32, 32, 88),
-                           sensor2keyego=T(rig['sensor2ego']), intrin=T(rig['intrin']),
-                           post_rot=T(rig['post_rot']), post_tran=T(rig['post_tran']),
-                           bda=T(rig['bda'])))
-    ego = T(S.ego_state(seed))
+    frames = harness.lifted_frames(seed, 6, dev, n_frames=n_frames)
+    ego = torch.from_numpy(S.ego_state(seed)).to(dev)
     return frames, ego
 
 
 # ------------------------------------------------------------------------------ roofline probe
 class KernelProbe:
-    """Times every conv-family launch of one eager step with HIP events recorded on the launch
-    stream (torch's current stream == the stream passed through the C ABI)."""
+    """Times every hot launch of one eager step with HIP events recorded on the launch stream (torch's current stream ==
+    the stream passed through the C ABI) and asks the library which kernel it picked (pw_last_kernel)."""
+
+    OPS = ('conv3d_ndhwc', 'conv3d_wino', 'occ_head_fused', 'forecast_steps', 'fpn3d_fuse', 'bev_pool_dense',
+           'segment_sort', 'lss_voxel_index')
 
     def __init__(self):
         self.records = []
         self._orig = {}
 
     def __enter__(self):
-        for name in ('conv3d_ndhwc', 'conv3d_wino', 'occ_head_fused', 'forecast_steps', 'fpn3d_fuse',
-                     'bev_pool_dense', 'segment_sort'):
+        for name in self.OPS:
             self._orig[name] = getattr(ops, name)
             setattr(ops, name, self._wrap(name, self._orig[name]))
         return self
@@ -109,107 +93,174 @@ class KernelProbe:
             s.record()
             out = fn(*args, **kw)
             e.record()
-            self.records.append((name, self._work(name, args, kw), s, e))
+            kernel = _lib.lib().pw_last_kernel().decode() or name
+            self.records.append((self._work(name, args, kw, out), kernel, s, e))
             return out
         return inner
 
     @staticmethod
-    def _work(name, args, kw):
-        """(kernel variant label, algorithmic flops, algorithmic HBM bytes) of one launch."""
+    def _work(name, args, kw, out):
+        """label + algorithmic (direct-form) flops, flops the matrix pipe really executes, algorithmic HBM bytes, dtype of the
+        MFMA operands, and how many 'units' (the reference's own launch granularity) the launch covers."""
+        w = dict(label=name, flops=0.0, exec_flops=0.0, bytes=0.0, mfma='f32', units=1)
         if name == 'conv3d_ndhwc':
             x, wpk = args[0], args[1]
             B, D, H, W, Cin = x.shape
             taps, nt = wpk.shape[1], wpk.shape[2]
-            ks = kw.get('ksize', 3)
-            st = kw.get('stride', 1)
+            ks, st = kw.get('ksize', 3), kw.get('stride', 1)
             nv = B * (D // st) * (H // st) * (W // st)
             cout = (kw.get('cout0') or nt * 32) + (kw.get('cout1') or 0)
-            tiled = ks == 3 and st == 1 and kw.get('algo', 0) != 2
-            # one label per (kernel family, grid, channels): the library picks the tile/N-group variant
-            # per grid size, and small grids fill the 256 CUs less well than the full-resolution ones
-            label = '%s %dx%dx%d %d->%d' % ('conv3d_k3s1_mfma' if tiled else 'conv3d_gather_mfma<k%d,s%d>' % (ks, st),
-                                           D, H, W, Cin, cout)
-            byts = 4.0 * (x.numel() + nv * cout + wpk.numel())
-            return label, 2.0 * nv * taps * Cin * cout, byts
-        if name == 'conv3d_wino':
-            # algorithmic work = the direct-form conv (SURVEY.md 8d); the kernel itself executes 64 transform-
-            # domain products per 2x2x2 outputs instead of 8*27: x8/27 of these flops on the matrix pipe
+            fl = 2.0 * nv * taps * Cin * cout
+            w.update(label='conv3d k%d s%d %dx%dx%d %d->%d' % (ks, st, D, H, W, Cin, cout), flops=fl, exec_flops=fl,
+                     bytes=4.0 * (x.numel() + nv * cout + wpk.numel()))
+        elif name == 'conv3d_wino':
+            # algorithmic work = the direct-form conv (SURVEY.md 8d); Winograd F(2,3)^3 executes 64 transform-domain
+            # products per 2x2x2 outputs instead of 8*27: x8/27 of these flops on the matrix pipe
             x, uw = args[0], args[1]
             B, D, H, W, Cin = x.shape
             cout = (kw.get('cout0') or uw.shape[2] * 16) + (kw.get('cout1') or 0)
             nv = B * D * H * W
-            label = 'conv3d_wino_mfma %dx%dx%d %d->%d' % (D, H, W, Cin, cout)
-            return label, 2.0 * nv * 27 * Cin * cout, 4.0 * (x.numel() + nv * cout + uw.numel())
-        if name == 'occ_head_fused':
+            fl = 2.0 * nv * 27 * Cin * cout
+            w.update(label='conv3d k3 s1 %dx%dx%d %d->%d' % (D, H, W, Cin, cout), flops=fl, exec_flops=fl * 8 / 27,
+                     bytes=4.0 * (x.numel() + nv * cout + uw.numel()))
+        elif name == 'occ_head_fused':
             x = args[0]
             nv = x.numel() // x.shape[-1]
-            # Winograd-domain weights are 5-d (pack_conv_weight_wino): same algorithmic work, 8/27 of the conv's
-            # multiplies executed
-            label = 'conv3d_wino_mfma<occ_head>' if args[1].dim() == 5 else 'conv3d_k3s1_mfma<occ_head>'
-            # the six forecast states are decoded by ONE launch over a batch of 6: counted as 6 units of one state
-            # each, so that per-launch figures (duration, algorithmic bytes, PMC traffic) stay per 200x200x16 state
-            return label, 2.0 * nv * (27 * 32 * 16 + 16 * 8 + 8 * 18), 4.0 * x.numel() + nv, int(x.shape[0])
-        if name == 'forecast_steps':
+            wino = args[1].dim() == 5
+            conv, tail = 2.0 * nv * 27 * 32 * 16, 2.0 * nv * (16 * 8 + 8 * 18)
+            # the six forecast states are decoded by ONE launch over a batch of 6: counted as 6 units of one state each
+            w.update(label='occ_head 32->16->8->18 + argmax', flops=conv + tail,
+                     exec_flops=(conv * 8 / 27 if wino else conv) + tail, bytes=4.0 * x.numel() + 2.0 * nv,
+                     units=int(x.shape[0]))
+        elif name == 'forecast_steps':
             v0, n_steps = args[0], args[6]
             nv = v0.numel() // 32
-            return 'forecast_mfma', 2.0 * nv * n_steps * (32 * 128 + 128 * 32), \
-                4.0 * v0.numel() * (1 + n_steps)
-        if name == 'fpn3d_fuse':
+            fl = 2.0 * nv * n_steps * (32 * 128 + 128 * 32)
+            w.update(label='forecast %d steps' % n_steps, flops=fl, exec_flops=fl, bytes=4.0 * v0.numel() * (1 + n_steps))
+        elif name == 'fpn3d_fuse':
             x = args[0]
-            return 'fpn3d_fuse', 2.0 * (x.numel() // 32) * 32 * 32, 8.0 * x.numel()
-        if name == 'bev_pool_dense':
+            fl = 2.0 * (x.numel() // 32) * 32 * 32
+            w.update(label='fpn3d_fuse', flops=fl, exec_flops=fl, bytes=8.0 * x.numel())
+        elif name == 'bev_pool_dense':
             depth, feat, vs = args[0], args[1], args[2]
-            return 'bev_pool_dense', 2.0 * 32 * vs.order.numel() * 0.6, \
-                4.0 * (vs.n_keys * 32 + depth.numel() + feat.numel() + vs.n_keys + 2 * 879748)
-        return name, 0.0, 0.0
+            kept = int(vs.seg_start[-1].item())                # points inside the grid (device value; eager probe only)
+            C = feat.shape[-1]
+            w.update(label='bev_pool_dense', flops=2.0 * C * kept, exec_flops=0.0, mfma=None,
+                     bytes=4.0 * (vs.n_keys * C + depth.numel() + feat.numel() + (vs.n_keys + 1) + 2 * kept))
+        elif name == 'segment_sort':
+            keys, n_keys = args[0], args[1]
+            w.update(label='segment_sort', mfma=None, bytes=4.0 * (3 * keys.numel() + 2 * n_keys))
+        elif name == 'lss_voxel_index':
+            fr = args[0]
+            n = args[9] * args[10] * fr.shape[0] * fr.shape[1] * fr.shape[2]
+            w.update(label='lss_voxel_index', mfma=None, bytes=16.0 * n)
+        return w
 
     def summary(self):
         torch.cuda.synchronize()
-        agg = {}
-        for name, work, s, e in self.records:
-            label, fl, by = work[:3]
-            a = agg.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-            a['launches'] += work[3] if len(work) > 3 else 1
-            a['ms'] += s.elapsed_time(e)
-            a['flops'] += fl
-            a['bytes'] += by
-        return agg
+        by_kernel = {}
+        for w, kernel, s, e in self.records:
+            a = by_kernel.setdefault(kernel, dict(launches=0, units=0, ms=0.0, flops=0.0, exec_flops=0.0, bytes=0.0,
+                                                  mfma=w['mfma'], labels={}))
+            dt = s.elapsed_time(e)
+            a['launches'] += 1
+            a['units'] += w['units']
+            a['ms'] += dt
+            for k in ('flops', 'exec_flops', 'bytes'):
+                a[k] += w[k]
+            lab = a['labels'].setdefault(w['label'], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            lab['launches'] += 1
+            lab['ms'] += dt
+            lab['flops'] += w['flops']
+            lab['bytes'] += w['bytes']
+        return by_kernel
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (PMC counters cannot be read from inside this
+    process; profiles/*_pmc_traffic.json says how they were collected and corrected), newest round first."""
+    prof = os.path.join(ROOT, 'profiles')
+    for name in sorted((f for f in os.listdir(prof) if f.endswith('_pmc_traffic.json')), reverse=True):
+        ent = json.load(open(os.path.join(prof, name))).get('by_kernel', {}).get(kernel)
+        if ent:
+            return int(ent['fetch_bytes'] + ent['write_bytes']), name
+    return None, None
+
+
+def roofline_object(agg, n_probe_steps):
+    def entry(kernel, a):
+        sec = a['ms'] * 1e-3
+        traffic, src = _pmc_traffic(kernel)
+        ent = dict(kernel=kernel, launches_per_step=a['launches'] // n_probe_steps,
+                   avg_launch_us=round(a['ms'] * 1e3 / a['launches'], 2), us_per_step=round(a['ms'] * 1e3 / n_probe_steps, 1),
+                   algorithmic_bytes=int(a['bytes'] / a['launches']), traffic=traffic,
+                   traffic_unit='HBM bytes per launch (PMC, %s)' % src if src else None)
+        if a['mfma']:
+            peak = PEAK_TFLOPS[a['mfma']]
+            direct, execd = a['flops'] / sec / 1e12, a['exec_flops'] / sec / 1e12
+            ent.update(bound='mfma', achieved=round(direct, 2), peak=peak, unit='TFLOP/s', frac=round(execd / peak, 4),
+                       executed_tflops=round(execd, 2), mfma_operands=a['mfma'],
+                       note='achieved = direct-form (algorithmic) FLOPs / time; frac = FLOPs the matrix pipe executes / time '
+                            '/ dense peak of the MFMA operand type (Winograd F(2,3)^3 executes 8/27 of a 3x3x3 conv\'s '
+                            'direct-form multiplies, so achieved can exceed the peak while frac cannot)')
+        else:
+            gbps = a['bytes'] / sec / 1e9
+            ent.update(bound='hbm', achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit='GB/s', frac=round(gbps / PEAK_HBM_GBPS, 4))
+        ent['shapes'] = {k: dict(launches=v['launches'] // n_probe_steps, avg_us=round(v['ms'] * 1e3 / v['launches'], 1),
+                                 tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
+                                 alg_GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1))
+                         for k, v in sorted(a['labels'].items(), key=lambda kv: -kv[1]['ms'])}
+        return ent
+    order = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])
+    dom = entry(*order[0])
+    dom['also'] = [entry(k, a) for k, a in order[1:] if k.startswith('k_pool_dense')]
+    dom['all_kernels'] = {k: dict(us_per_step=round(a['ms'] * 1e3 / n_probe_steps, 1), launches=a['launches'] // n_probe_steps,
+                                  tflops=round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2),
+                                  alg_GBps=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1)) for k, a in order}
+    return dom
 
 
 # ------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(sd, budget_s=25.0):
-    """The CPU oracle (oracle/ -- a port: the reference ships no CPU implementation of these ops,
-    SURVEY.md 0) timed on the host cores for the C3 pipeline on a BOUNDED sample: the C1-sized
-    grid (100x100x8 = 1/8 of the voxels, 1 camera), scaled to full-size samples/s by the voxel
-    ratio (the conv/MLP stack, >99% of the CPU time, is linear in the voxel count)."""
+def cpu_baseline(sd, seed=100):
+    """The C3 sample at FULL size (6 cameras, 200x200x16, key + adjacent frame, 7 states) on the host cores, no
+    extrapolation.  Two stand-ins, because the reference has NO CPU path for its native ops:
+      * torch-cpu: the reference's nn.Modules are plain torch layers, so oracle/torch_ref.py runs the same composition on
+        PyTorch-CPU (oneDNN convolutions, torch.set_num_threads(all cores)); median of 5 runs after 1 warm-up;
+      * openmp-port: oracle/pw_oracle.c (the parity checker), one run.
+    `value` is the faster of the two.  The voxel pooling of both comes from the C oracle and is inside the timed region."""
     from oracle import oracle as O
+    from oracle import torch_ref as TR
     threads = O.num_threads()
-    gc = S.GRID_CONFIG_C1
-    scale = (200 * 200 * 16) / (100 * 100 * 8)
-    times = []
-    t_all = time.time()
-    # repeat with fresh seeds until ~10 s of CPU work are in the sample (at most 6 runs, at least 2)
-    while len(times) < 2 or (time.time() - t_all < 10.0 and len(times) < 6):
-        seed = 100 + 16 * len(times)
-        t0 = time.time()
-        bevs = []
-        for f in range(2):
-            depth, feat = S.lift_inputs(seed + f, N=1)
-            r = S.synthetic_rig(1, dx=-2.5 * f)
-            bev = O.lss_view_transform(depth, feat, r['sensor2ego'], r['intrin'], r['post_rot'],
-                                       r['post_tran'], r['bda'], gc, S.INPUT_SIZE, S.DOWNSAMPLE)
-            bevs.append(O.pre_process(bev, sd))
-        x = O.encoder_forward(bevs[1], bevs[0], sd)
-        vf = O.final_conv(x, sd)
-        states, _ = O.preworld4d_decode(vf, S.ego_state(len(times)), sd, n_steps=6, post_finetune=True)
-        times.append(time.time() - t0)
-        assert len(states) == 7 and states[0].shape == (100, 100, 8)
-    dt = float(np.mean(times))
-    return dict(value=1.0 / (dt * scale), unit='samples/s', cores=threads, kind='port',
-                sample='%d runs of the C3 pipeline on the C1-sized grid (1 cam, 100x100x8 = 1/8 of the voxels): '
-                       'mean %.2f s (min %.2f, max %.2f; %.1f s of CPU work) on %d OpenMP threads, scaled x%d by voxel '
-                       'count; the reference has no CPU path for these ops'
-                       % (len(times), dt, min(times), max(times), sum(times), threads, int(scale)))
+    torch.set_num_threads(threads)
+    gc = S.GRID_CONFIG_FULL
+    ego = S.ego_state(seed)
+
+    def torch_run():
+        t0 = time.perf_counter()
+        bevs = TR.lifted_bevs(seed, 6, gc)
+        st = TR.c3_sample(bevs, ego, sd, n_steps=6)
+        assert len(st) == 7 and st[0].shape == (200, 200, 16)
+        return time.perf_counter() - t0
+
+    torch_run()
+    tt = sorted(torch_run() for _ in range(5))
+    t0 = time.perf_counter()
+    bevs = TR.lifted_bevs(seed, 6, gc)
+    pre = [O.pre_process(b, sd) for b in bevs]
+    vf = O.final_conv(O.encoder_forward(pre[1], pre[0], sd), sd)
+    states, _ = O.preworld4d_decode(vf, ego, sd, n_steps=6, post_finetune=True)
+    t_port = time.perf_counter() - t0
+    assert len(states) == 7 and states[0].shape == (200, 200, 16)
+    t_torch = tt[2]
+    best = min(t_torch, t_port)
+    return dict(value=1.0 / best, unit='samples/s', cores=threads, kind='port',
+                torch_cpu=dict(samples_per_s=round(1.0 / t_torch, 4), median_s=round(t_torch, 3), min_s=round(tt[0], 3),
+                               max_s=round(tt[-1], 3), runs=5, warmup=1, threads=threads),
+                openmp_port=dict(samples_per_s=round(1.0 / t_port, 4), seconds=round(t_port, 3), runs=1, threads=threads),
+                sample='full-size C3 sample (6 cams, 200x200x16, key+adjacent, 7 states), unscaled: PyTorch-CPU composition '
+                       'of the reference modules, median of 5 runs after 1 warm-up = %.2f s; OpenMP port (oracle/pw_oracle.c) '
+                       '1 run = %.2f s; %d host threads; value = the faster one; the reference itself has no CPU path for '
+                       'bev_pool_v2 / render ops (CUDA only)' % (t_torch, t_port, threads))
 
 
 # ------------------------------------------------------------------------------ main
@@ -224,7 +275,9 @@ def main():
     ap.add_argument('--in-flight', type=int, default=2,
                     help='independent samples in flight per GPU (one hipGraph + HIP stream each); 1 = strictly serial')
     ap.add_argument('--config', default='C3', choices=['C3', 'C2'])
+    ap.add_argument('--mode', default='replicas', choices=['replicas', 'sharded'])
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-d2h', action='store_true', help='leave the occupancy grids on the device (no host payload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -242,21 +295,28 @@ def main():
     dev_index = local_rank % max(n_dev, 1)
     torch.cuda.set_device(dev_index)
     dev = 'cuda:%d' % dev_index
-    if world > 1:
+    if world > 1 or args.mode == 'sharded':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('gloo' if oversubscribed else 'nccl',       # 'nccl' == RCCL on ROCm
                                 rank=rank, world_size=world)
 
+    sharded = args.mode == 'sharded'
     n_frames, n_steps_fc = (2, 6) if args.config == 'C3' else (1, 0)
-    net, sd = build_net(dev, with_prev=args.config == 'C3')
-    frames, ego = make_inputs(dev, seed=rank, n_frames=n_frames)
+    net, sd = build_net(dev, args.config)
+    # sharded mode: every rank works on the SAME sample; replicas: each rank has its own
+    frames, ego = make_inputs(dev, seed=0 if sharded else rank, n_frames=n_frames)
 
     def step():
-        return net.simple_test_from_lift(frames, ego, n_steps=n_steps_fc)
+        if sharded:
+            return harness.simple_test_sharded(net, frames, ego, n_steps=n_steps_fc, gather_on_host=oversubscribed)
+        if args.config == 'C3':
+            return net.simple_test_from_lift(frames, ego, n_steps=n_steps_fc)
+        return net.simple_test_from_lift(frames)
 
     # eager warmup (also fills the packed-weight caches and sets kernel attributes)
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, min(args.warmup, 3))):
         out = step()
     torch.cuda.synchronize()
 
@@ -269,50 +329,23 @@ def main():
     # live per-kernel timing for the roofline object (eager, HIP events on the launch stream)
     roofline = None
     if rank == 0:
+        n_probe = 3
         with KernelProbe() as probe:
-            for _ in range(3):
+            for _ in range(n_probe):
                 step()
-        agg = probe.summary()
-        dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
-        label, a = dom
-        tf = a['flops'] / (a['ms'] * 1e-3) / 1e12
-        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this
-        # process, so the figure comes from the committed rocprofv3 --pmc passes (same kernel, same
-        # shape; profiles/r01_pmc_hbm_traffic.md says how it was collected and corrected)
-        traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(pmc):
-            ent = json.load(open(pmc)).get(label)
-            if ent:
-                traffic = int(ent['fetch_bytes'] + ent['write_bytes'])
-        roofline = dict(bound='mfma', kernel=label, achieved=round(tf, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit='TFLOP/s', frac=round(tf / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                        traffic_unit='bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
-                        algorithmic_bytes=int(a['bytes'] / a['launches']),
-                        avg_launch_us=round(a['ms'] * 1e3 / a['launches'], 2),
-                        launches_per_step=a['launches'] // 3,
-                        **(dict(executed_tflops=round(tf * 8 / 27, 2), executed_frac=round(tf * 8 / 27 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                note='Winograd F(2x2x2,3x3x3): achieved = direct-form (algorithmic) FLOPs / time, which can '
-                                     'exceed the matrix-pipe peak; executed_* counts the 8/27 of them the MFMAs really do'
-                                     + ('; a launch here = one 200x200x16 state (states 1-6 share one kernel launch over a '
-                                        'batch of 6)' if 'occ_head' in label else ''))
-                           if label.startswith('conv3d_wino') else {}),
-                        all_kernels={k: dict(us_per_step=round(v['ms'] * 1e3 / 3, 1),
-                                             launches=v['launches'] // 3,
-                                             tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
-                                             alg_GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1))
-                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])})
+        roofline = roofline_object(probe.summary(), n_probe)
 
     graph = None
     latency_ms = None
-    if not args.no_graph:
+    d2h = not args.no_d2h
+    if not args.no_graph and not sharded:
         from preworld_amd.pipeline import CapturedSample
         # M independent samples in flight, each a hipGraph over its own static buffers on its own HIP
         # stream: while one sample sits in a stage that cannot fill 256 CUs (the 8x100x100 / 4x50x50
         # encoder levels, the last partial wave of tiles of every launch, the latency-bound sort), the other
         # one's kernels take the idle CUs.  A step is still one sample; steps alternate between the streams.
         M = max(1, args.in_flight)
-        caps = [CapturedSample(net, *make_inputs(dev, seed=rank * 8 + k, n_frames=n_frames), n_steps=n_steps_fc)
+        caps = [CapturedSample(net, *make_inputs(dev, seed=rank * 8 + k, n_frames=n_frames), n_steps=n_steps_fc, d2h=d2h)
                 for k in range(M)]
         streams = [torch.cuda.Stream() for _ in range(M)]
         graph = caps[0]
@@ -357,12 +390,21 @@ def main():
         elapsed = float(t.item())
 
     # sanity on the produced states (cheap, outside the timed region)
-    occ0 = out['semantic_occ_0s'][0]
-    assert occ0.shape == (200, 200, 16) and occ0.dtype == torch.uint8
-    n_states = sum(1 for k in out if k.startswith('semantic_occ_'))
+    key0 = 'semantic_occ_0s' if args.config == 'C3' else 'semantic_occ'
+    occ0 = out[key0][0]
+    assert tuple(occ0.shape) == (200, 200, 16) and occ0.dtype == torch.uint8
+    n_states = sum(1 for k in out if k.startswith('semantic_occ'))
+    if graph is not None and d2h:
+        host = graph.host.numpy()
+        assert host.shape == (2 * n_states, 200, 200, 16) and np.array_equal(host[graph.host_keys.index(key0)], occ0.cpu().numpy())
 
     if rank == 0:
-        samples = args.steps * world                 # one sample per step per rank
+        samples = args.steps * (1 if sharded else world)       # replicas: one sample per step per rank
+        workload = ('C3: 7-state temporal, 6 cams, key+adjacent frame, 200x200x16, '
+                    'LSS pooling x2 + pre_process x2 + CustomResNet3D + LSSFPN3D + final_conv '
+                    '+ 6-step forecast + OccHead x7 -> 7 semantic + 7 geometric uint8 occupancy grids'
+                    if args.config == 'C3' else
+                    'C2: single frame (with_prev=False), 6 cams, 200x200x16, PreWorld detector, OccHead decode, 1 state')
         res = {
             'metric': 'samples/sec (6-cam frame -> 200x200x16 occ)',
             'value': round(samples / elapsed, 3),
@@ -372,27 +414,28 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if sharded else 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': ('C3: 7-state temporal, 6 cams, key+adjacent frame, 200x200x16, '
-                             'LSS pooling x2 + pre_process x2 + CustomResNet3D + LSSFPN3D + final_conv '
-                             '+ 6-step forecast + OccHead x7 -> 7 uint8 occupancy grids')
-                if args.config == 'C3' else
-                'C2: single frame (with_prev=False), 6 cams, 200x200x16, 1 state',
+                'workload': workload,
                 'states_per_sample': n_states,
                 'launch': ('hipGraph replay, %d independent sample(s) in flight on %d HIP stream(s)' % (M, M))
                 if graph is not None else 'eager',
+                'outputs': ('host: %d contiguous (X,Y,Z) uint8 grids per sample in pinned memory, one async D2H copy inside '
+                            'the step (the reference payload, preworld_temporal_traj.py:311-366)' % (2 * n_states))
+                if graph is not None and d2h else 'device (uint8 grids stay in HBM)',
                 'single_sample_latency_ms': round(latency_ms, 4) if latency_ms else None,
-                'parallelism': 'replicas x%d (independent samples, no data-path collective)%s' % (
-                    world, ' -- OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else ''),
+                'parallelism': ('frames + states sharded over %d rank(s), 2 RCCL all_gathers per sample '
+                                '(harness.simple_test_sharded)' % world) if sharded else
+                'replicas x%d (independent samples, no data-path collective)' % world,
+                'note': ' OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else None,
                 'excluded': 'image backbone + DepthNet (stay on PyTorch, SURVEY 8a)',
             },
             'roofline': roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not sharded:
             res['cpu_baseline'] = cpu_baseline(sd)
         print(json.dumps(res))
     if dist is not None:

@@ -45,6 +45,9 @@ extern "C" {
 
 int pw_version(void);
 const char* pw_last_error(void);
+/* name, as rocprofv3 --kernel-trace prints it, of the dominant kernel the calling thread's last pw_* compute call
+ * launched (which variant the library picked); measurement aid for bench.py's roofline object */
+const char* pw_last_kernel(void);
 /* device the library was built for / runs on: fills CU count, returns 0 */
 int pw_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
 

@@ -11,6 +11,8 @@
 #define PW_WAVE 64
 
 void pw_set_error(const char* fmt, ...);
+// records the name (as rocprofv3 prints it) of the dominant kernel an entry point launched; read by pw_last_kernel()
+void pw_note_kernel(const char* fmt, ...);
 
 #define PW_CHECK_ARG(cond, ...)                \
   do {                                         \

@@ -541,10 +541,12 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
       static int once = set_lds_limit(k_conv3d_k3s1_pipe<2>, PLDS);
       if (once) return once;
       hipLaunchKernelGGL((k_conv3d_k3s1_pipe<2>), dim3(nb), dim3(256), PLDS, st, a, p);
+      pw_note_kernel("k_conv3d_k3s1_pipe<2>");
     } else {
       static int once = set_lds_limit(k_conv3d_k3s1_pipe<1>, PLDS);
       if (once) return once;
       hipLaunchKernelGGL((k_conv3d_k3s1_pipe<1>), dim3(nb), dim3(256), PLDS, st, a, p);
+      pw_note_kernel("k_conv3d_k3s1_pipe<1>");
     }
   } else if (tiled) {
     const int WD = choose_wd(B, a.Do, a.Ho, a.Wo, ngroups);
@@ -557,6 +559,7 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
     static int once = set_lds_limit(k_conv3d_k3s1<NTv, WDv>, TileGeom<WDv>::LDS);               \
     if (once) return once;                                                                     \
     hipLaunchKernelGGL((k_conv3d_k3s1<NTv, WDv>), grid, dim3(256 * WDv), TileGeom<WDv>::LDS, st, a); \
+    pw_note_kernel("k_conv3d_k3s1<%d, %d>", NTv, WDv);                                          \
   } while (0)
     if (NT == 2 && WD == 2) PW_LAUNCH_TILED(2, 2);
     else if (NT == 2) PW_LAUNCH_TILED(2, 1);

@@ -210,8 +210,11 @@ int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, i
     const int mgroups = 4 / ksplit;                     // M-groups (32*MT voxels each) per block
     dim3 grid((unsigned)pw_cdiv(n_out, 32 * MT * mgroups), (unsigned)ngroups);
     const size_t red_bytes = ksplit > 1 ? (size_t)mgroups * (ksplit - 1) * MT * NT * 4096 : 0;
-#define PW_GATHER_L(NTv, KSv, STv, MTv, KSPv) \
-  hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, MTv, KSPv>), grid, dim3(256), red_bytes, st, a, n_out)
+#define PW_GATHER_L(NTv, KSv, STv, MTv, KSPv)                                                                    \
+  do {                                                                                                           \
+    hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, MTv, KSPv>), grid, dim3(256), red_bytes, st, a, n_out);   \
+    pw_note_kernel("k_conv3d_gather<%d, %d, %d, %d, %d>", NTv, KSv, STv, MTv, KSPv);                             \
+  } while (0)
 #define PW_GATHER(NTv, KSv, STv)                                        \
   do {                                                                  \
     if (ksplit == 4) PW_GATHER_L(NTv, KSv, STv, 1, 4);                  \

@@ -443,6 +443,7 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
     if (once) return once;                                                                                  \
     hipLaunchKernelGGL(k_conv3d_wino_ws<NGv>, dim3(nb), dim3(512), WINO_LDS, pw_stream(stream), a, p,         \
                        cout_total / 16);                                                                    \
+    pw_note_kernel("k_conv3d_wino_ws<%d>", NGv);                                                            \
   } while (0)
       if (NG == 1) PW_WINO_WS(1); else PW_WINO_WS(2);
 #undef PW_WINO_WS
@@ -458,6 +459,7 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
     if (once) return once;                                                                                \
     hipLaunchKernelGGL(k_conv3d_wino<NGv>, dim3((unsigned)nblk), dim3(256), WINO_LDS, pw_stream(stream), a, \
                        cout_total / 16);                                                                  \
+    pw_note_kernel("k_conv3d_wino<%d>", NGv);                                                             \
   } while (0)
   if (NG == 1) PW_WINO(1); else PW_WINO(2);
 #undef PW_WINO

@@ -12,7 +12,18 @@ void pw_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-PW_API int pw_version(void) { return 100; }
+static thread_local char g_kernel[128] = "";
+
+void pw_note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
+PW_API const char* pw_last_kernel(void) { return g_kernel; }
+
+PW_API int pw_version(void) { return 200; }
 
 PW_API const char* pw_last_error(void) { return g_err; }
 

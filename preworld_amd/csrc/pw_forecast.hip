@@ -231,6 +231,7 @@ PW_API int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_sa
   hipLaunchKernelGGL(k_forecast, dim3(nb), dim3(256), lds_bytes, pw_stream(stream), v0,
                      (long long)n_vox_per_sample, n_samples, w1p, w2p, c1p, fusion_b2, n_steps,
                      states);
+  pw_note_kernel("k_forecast");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

@@ -167,6 +167,7 @@ PW_API int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, c
   PW_CHECK_ARG(n < (1ll << 31), "pw_fpn3d_fuse: more than 2^31 voxels");
   hipLaunchKernelGGL(k_fpn3d_fuse, dim3((unsigned)pw_cdiv(n, 128)), dim3(256), 0, pw_stream(stream),
                      a, f, n);
+  pw_note_kernel("k_fpn3d_fuse");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

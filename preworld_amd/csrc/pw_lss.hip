@@ -158,6 +158,7 @@ PW_API int pw_lss_voxel_index(int B, int N, int D, int H, int W, const float* fr
   hipLaunchKernelGGL(k_voxel_index, dim3((unsigned)pw_cdiv(total, 256)), dim3(256), 0,
                      pw_stream(stream), N, DHW, total, frustum, inv_post_rot, post_trans, combine,
                      trans, bda, gp, vox, coor_out);
+  pw_note_kernel("k_voxel_index");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
@@ -441,6 +442,7 @@ PW_API int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void*
   if (split)
     hipLaunchKernelGGL(k_sort_long, dim3(1024), dim3(256), SORT_LDS_MAX * 4, st, seg_start, tmp,
                        long_list, n_long, order, aux_div, aux_mod, order_aux);
+  pw_note_kernel("k_hist + 3 scan + k_scatter + k_ranksort + k_sort_long");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
@@ -758,9 +760,11 @@ PW_API int pw_bev_pool_dense(const float* depth, const float* feat, const int32_
                                             (const float4*)feat, seg_start, order, order_feat,
                                             n_voxels, long_threshold, long_list, n_long,
                                             (float4*)out));
+    pw_note_kernel("k_pool_dense<%d>", lpv);
   } else {
     hipLaunchKernelGGL(k_pool_dense_generic, dim3((unsigned)pw_cdiv(n_voxels * c, 256)), dim3(256),
                        0, st, c, depth, feat, seg_start, order, order_feat, n_voxels, out);
+    pw_note_kernel("k_pool_dense_generic");
   }
   PW_CHECK_LAUNCH();
   return PW_OK;

@@ -581,6 +581,7 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
     static int once = set_lds_limit(k_occ_head_wino, OCCW_LDS);
     if (once) return once;
     hipLaunchKernelGGL(k_occ_head_wino, dim3(nb), dim3(512), OCCW_LDS, pw_stream(stream), a, p, t);
+    pw_note_kernel("k_occ_head_wino");
     PW_CHECK_LAUNCH();
     return PW_OK;
   }
@@ -601,6 +602,7 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
       static int once = set_lds_limit(k_occ_head16_pipe, PLDS);
       if (once) return once;
       hipLaunchKernelGGL(k_occ_head16_pipe, dim3(nb), dim3(256), PLDS, pw_stream(stream), a, p, t);
+      pw_note_kernel("k_occ_head16_pipe");
       PW_CHECK_LAUNCH();
       return PW_OK;
     }
@@ -613,11 +615,13 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
     if (once) return once;
     hipLaunchKernelGGL(k_occ_head16<2>, dim3((unsigned)nblk, 1), dim3(512), TileGeom<2>::LDS,
                        pw_stream(stream), a, t);
+    pw_note_kernel("k_occ_head16<2>");
   } else {
     static int once = set_lds_limit(k_occ_head16<1>, TileGeom<1>::LDS);
     if (once) return once;
     hipLaunchKernelGGL(k_occ_head16<1>, dim3((unsigned)nblk, 1), dim3(256), TileGeom<1>::LDS,
                        pw_stream(stream), a, t);
+    pw_note_kernel("k_occ_head16<1>");
   }
   PW_CHECK_LAUNCH();
   return PW_OK;

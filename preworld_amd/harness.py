@@ -106,7 +106,8 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
     n = net.num_adj + 1
     use = frames[:n] if net.with_prev else frames[:1]
     lifted = parallel.lift_frames_sharded(use, lambda fr: net.lift_frame_cl(**fr),
-                                          (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device, group)
+                                          (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device, group,
+                                          via_host=gather_on_host)
     x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                       # [adjacent ..., key] (bevdet_occ.py:266)
     if len(lifted) < n:
         x = torch.cat([x.new_zeros(x.shape[:-1] + ((n - len(lifted)) * C,)), x], dim=-1)

@@ -19,6 +19,9 @@ RCCL over xGMI on ROCm, 'gloo' in the CPU tests).
 import torch
 import torch.distributed as dist
 
+# tests set this to run the collectives even in a 1-rank group (RCCL init + device-tensor all_gather on one GPU)
+ALWAYS_COLLECTIVE = False
+
 
 def owned_states(n_states, rank, world):
     """round-robin ownership: cheap states (few recursion steps) and expensive ones interleave"""
@@ -36,7 +39,7 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None):
     for k in mine:
         feats = v0 if k == 0 else forecast_fn(v0, k)
         local[k] = decode_fn(feats)
-    if world == 1:
+    if world == 1 and not ALWAYS_COLLECTIVE:
         return [local[k] for k in range(n_states)]
     # pad every rank to the same number of slots so one all_gather moves everything
     slots = (n_states + world - 1) // world
@@ -53,15 +56,16 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None):
     return out
 
 
-def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None):
+def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, via_host=False):
     """frames: list of per-frame inputs (present on every rank); frame f is lifted by rank f % W.  The features reach
     every rank through ONE all_gather of a (slots, *out_shape) buffer per rank (slots = ceil(F / W); 81.92 MB per frame at
     C3) -- on xGMI's point-to-point links every rank's shard travels its own link.  Returns the list of lifted features
-    on every rank, in frame order."""
+    on every rank, in frame order.  via_host=True stages the buffers through host memory (gloo cannot all_gather device
+    tensors; RCCL takes them as they are)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     F = len(frames)
-    if world == 1:
+    if world == 1 and not ALWAYS_COLLECTIVE:
         outs = [lift_fn(fr).contiguous() for fr in frames]
         assert all(tuple(o.shape) == tuple(out_shape) for o in outs)
         return outs
@@ -71,6 +75,9 @@ def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None):
         buf = lift_fn(frames[f])
         assert tuple(buf.shape) == tuple(out_shape)
         send[i].copy_(buf)
-    recv = torch.empty((world, slots) + tuple(out_shape), dtype=dtype, device=device)
-    dist.all_gather_into_tensor(recv.view(world * slots, *out_shape), send, group=group)
+    if via_host:
+        send = send.cpu()
+    recv = torch.empty((world * slots,) + tuple(out_shape), dtype=dtype, device=send.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.to(device).view((world, slots) + tuple(out_shape))
     return [recv[f % world, f // world] for f in range(F)]

@@ -20,8 +20,13 @@ class CapturedSample:
     the static buffers, replays the graph and returns the (static) result dict: consume or clone the
     outputs before the next run()."""
 
-    def __init__(self, net, frames, ego, n_steps=6):
-        self.net, self.n_steps = net, n_steps
+    def __init__(self, net, frames, ego, n_steps=6, d2h=False):
+        """d2h=True: the replay also delivers the reference's host payload (preworld_temporal_traj.py:311-366: every
+        semantic_occ / geo_occ grid as a contiguous uint8 (X,Y,Z) host array) -- one device-side gather of the (X,Y,Z)
+        views into a (n_grids, X, Y, Z) buffer and ONE async copy into pinned host memory (`self.host`, rows in the
+        order of `self.host_keys`) instead of the reference's 14 synchronous .cpu() calls per sample."""
+        self.net, self.n_steps, self.d2h = net, n_steps, d2h
+        self.host = self.host_keys = None
         self.frames = [{k: v.clone() for k, v in f.items()} for f in frames]
         self.ego = ego.clone()
         side = torch.cuda.Stream()
@@ -37,7 +42,17 @@ class CapturedSample:
             self.out = self._step()
 
     def _step(self):
-        return self.net.simple_test_from_lift(self.frames, self.ego, n_steps=self.n_steps)
+        kw = dict(n_steps=self.n_steps) if hasattr(self.net, 'forecast_cl') else {}
+        args = (self.frames, self.ego) if hasattr(self.net, 'forecast_cl') else (self.frames,)
+        out = self.net.simple_test_from_lift(*args, **kw)
+        if self.d2h:
+            keys = [k for k in out if k.startswith(('semantic_occ', 'geo_occ'))]
+            dev = torch.stack([out[k][0] for k in keys])                  # (n_grids, X, Y, Z) contiguous uint8
+            if self.host is None:
+                self.host = torch.empty(dev.shape, dtype=torch.uint8, pin_memory=True)
+                self.host_keys = keys
+            self.host.copy_(dev, non_blocking=True)
+        return out
 
     def replay(self):
         self.graph.replay()

@@ -7,6 +7,7 @@ import torch
 
 from oracle import oracle as O
 from preworld_amd import harness, synth as S
+from _parity import check_argmax
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -23,29 +24,33 @@ def _oracle_sample(seed, sd):
         bevs.append(O.pre_process(bev, sd))
     x = O.encoder_forward(bevs[1], bevs[0], sd)            # cat([adjacent, key])
     vf = O.final_conv(x, sd)
-    states, _ = O.preworld4d_decode(vf, S.ego_state(seed), sd, n_steps=6, post_finetune=True)
-    return states
+    states, feats = O.preworld4d_decode(vf, S.ego_state(seed), sd, n_steps=6, post_finetune=True)
+    return states, [O.occ_decode(f, sd)[1] for f in feats]
+
+
+LOGIT_TIE = 2e-4          # a flipped voxel must have an oracle top-2 margin below this (measured: <= 8e-6 on <= 1 flip per state)
 
 
 def test_mini_split_states_and_miou_match_oracle():
     sd = S.synth_state_dict(0)
     net = harness.build_model(harness.model_cfg(GC), sd, DEV)
     rs = np.random.RandomState(77)
-    samples, oracle_states = [], []
+    samples, oracle_states, oracle_logits = [], [], []
     for seed in (1, 2):
         gt = {h: rs.randint(0, 18, size=(100, 100, 8)).astype(np.uint8) for h in (0, 2, 4, 6)}
         mask = rs.rand(100, 100, 8) < 0.7
         samples.append(dict(frames=harness.lifted_frames(seed, 1, DEV), ego=torch.from_numpy(S.ego_state(seed)).to(DEV),
                             gt=gt, mask_camera=mask))
-        oracle_states.append(_oracle_sample(seed, sd))
-    miou, stacks = harness.evaluate(net, samples, DEV)
+        st_, lg_ = _oracle_sample(seed, sd)
+        oracle_states.append(st_)
+        oracle_logits.append(lg_)
+    miou, stacks, metric = harness.evaluate(net, samples, DEV)
 
     # states: argmax agreement per stacked horizon
-    for st, ost in zip(stacks, oracle_states):
+    for i, (st, ost) in enumerate(zip(stacks, oracle_states)):
         assert st.shape == (4, 100, 100, 8) and st.dtype == np.uint8
         for j, h in enumerate((0, 2, 4, 6)):
-            agree = float((st[j] == ost[h]).mean())
-            assert agree >= 0.999, (h, agree)
+            check_argmax('e2e C1 sample %d state %ds' % (i, h), st[j], ost[h], oracle_logits[i][h], LOGIT_TIE)
 
     # temporal mIoU restated with the oracle's metric on the oracle's states
     want = {}
@@ -58,6 +63,10 @@ def test_mini_split_states_and_miou_match_oracle():
     for h in (0, 2, 4, 6):
         assert abs(miou[h] - want[h]) <= 0.05, (h, miou[h], want[h])
     assert abs(miou['avg_future'] - round(float(np.mean([want[2], want[4], want[6]])), 2)) <= 0.05
+    # the reference's own return values (occ_metrics.py:548-575): (per-class IoU at 1 s, [mIoU 1 s, 2 s, 3 s])
+    iu1, lst = metric.count_miou()
+    assert lst == [miou[2], miou[4], miou[6]] and iu1.shape == (18,) and metric.cnt == 2
+    assert len(metric.count_iou()) == 3
 
 
 def test_geo_occ_comes_from_the_same_kernel():
@@ -135,13 +144,20 @@ def test_pretrain_attribute_decode_branch_matches_oracle():
                                    r['bda'], GC, S.INPUT_SIZE, S.DOWNSAMPLE)
         bevs.append(O.pre_process(bev, sd))
     vf = O.final_conv(O.encoder_forward(bevs[1], bevs[0], sd), sd)
-    states, _ = O.preworld4d_decode(vf, S.ego_state(4), sd, n_steps=6, post_finetune=False)
+    states, feats = O.preworld4d_decode(vf, S.ego_state(4), sd, n_steps=6, post_finetune=False)
     names = [0, 2, 3, 4, 5, 6, 7]
     assert sorted(k for k in res if k.startswith('semantic_occ')) == sorted('semantic_occ_%ds' % n for n in names)
     for k, n in enumerate(names):
         got = res['semantic_occ_%ds' % n][0].cpu().numpy()
         assert got.shape == states[k].shape
-        assert float((got == states[k]).mean()) >= 0.999, (n, float((got == states[k]).mean()))
+        # a flip needs the density to sit at the 8.5 threshold or the semantic argmax to be a near-tie
+        od, osem = O.attribute_decode(feats[k], sd)[1:]
+        osem_s = np.sort(osem, -1)
+        tie = np.minimum(np.abs(od - 8.5)[0], (osem_s[..., -1] - osem_s[..., -2])[0])
+        flips = got != states[k]
+        print('[parity] attribute decode state %ds: agreement %.6f, largest tie distance among %d flips %.3e'
+              % (n, 1 - flips.mean(), int(flips.sum()), float(tie[flips].max()) if flips.any() else 0.0))
+        assert 1 - flips.mean() >= 0.9999 and (not flips.any() or float(tie[flips].max()) <= 2e-3)
     occ0 = res['semantic_occ_0s'][0]
     assert 0.02 < float((occ0 != 17).float().mean()) < 0.98       # both branches of the threshold are exercised
 

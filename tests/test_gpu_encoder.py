@@ -339,7 +339,8 @@ def test_conv_stack_golden(golden):
         np.testing.assert_allclose(lg.permute(0, 4, 3, 2, 1).cpu().numpy(), g['logits'],
                                    rtol=5e-4, atol=5e-4)
         occ_xyz = occ.permute(0, 3, 2, 1)[0].cpu().numpy()
-        assert (occ_xyz == g['occ']).mean() > 0.999
+        from _parity import check_argmax
+        check_argmax('conv_stack_small occ vs reference', occ_xyz, g['occ'], np.moveaxis(g['logits'][0], 0, -1), 2e-3)
         assert np.array_equal(occ_xyz, lg.permute(0, 3, 2, 1, 4)[0].argmax(-1).cpu().numpy())
     # module-level (B,C,D,H,W) API == reference call convention
     with torch.no_grad():
@@ -366,7 +367,8 @@ def test_occ_head_wino_matches_direct_and_oracle(shape):
                                             want_geo=True)
     np.testing.assert_allclose(lg_w.cpu().numpy(), lg_d.cpu().numpy(), rtol=5e-4, atol=5e-4)
     assert torch.equal(occ_w.long(), lg_w.argmax(-1))
-    assert float((occ_w == occ_d).float().mean()) > 0.999
+    from _parity import check_argmax
+    check_argmax('occ_head wino vs direct %s' % (shape,), occ_w, occ_d, lg_d, 2e-3)
     np.testing.assert_array_equal(geo_w.cpu().numpy(), np.where(occ_w.cpu().numpy() != 17, 0, 17).astype(np.uint8))
     occ_only = ops.occ_head_fused(x, ops.pack_conv_weight_wino(w0, cout_total=16), *args)
     assert torch.equal(occ_only, occ_w)                      # deterministic, logits optional

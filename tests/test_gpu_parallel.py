@@ -38,6 +38,12 @@ def _worker(rank, world, port, q):
             want = net.simple_test_from_lift(frames, ego, n_steps=6)
         got = harness.simple_test_sharded(net, frames, ego, n_steps=6, gather_on_host=True)
         same = [bool(torch.equal(got['semantic_occ_%ds' % k][0].cpu(), want['semantic_occ_%ds' % k][0].cpu())) for k in range(7)]
+        # with_prev=False (C2's frame handling): the adjacent frame is dropped, its channel slice is zeros
+        net.with_prev = False
+        with torch.no_grad():
+            want = net.simple_test_from_lift(frames, ego, n_steps=2)
+        got = harness.simple_test_sharded(net, frames, ego, n_steps=2, gather_on_host=True)
+        same += [bool(torch.equal(got['semantic_occ_%ds' % k][0].cpu(), want['semantic_occ_%ds' % k][0].cpu())) for k in range(3)]
         q.put((rank, same))
     finally:
         dist.destroy_process_group()
@@ -57,3 +63,39 @@ def test_sharded_lift_and_decode_two_ranks_equal_single_process():
     assert sorted(r for r, _ in res) == [0, 1]
     for _, same in res:
         assert all(same), same
+
+
+def _rccl_worker(port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    from preworld_amd import harness, parallel, synth as S
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)            # 'nccl' == RCCL on ROCm
+    try:
+        dev = 'cuda:0'
+        net = harness.build_model(harness.model_cfg(S.GRID_CONFIG_C1), S.synth_state_dict(0), dev)
+        frames = harness.lifted_frames(5, 1, dev)
+        ego = torch.from_numpy(S.ego_state(5)).to(dev)
+        with torch.no_grad():
+            want = net.simple_test_from_lift(frames, ego, n_steps=6)
+        parallel.ALWAYS_COLLECTIVE = True                            # run both all_gathers even with one rank
+        got = harness.simple_test_sharded(net, frames, ego, n_steps=6)
+        torch.cuda.synchronize()
+        same = [bool(torch.equal(got['semantic_occ_%ds' % k][0], want['semantic_occ_%ds' % k][0])) for k in range(7)]
+        q.put((dist.get_backend(), same, bool(got['semantic_occ_0s'][0].is_cuda)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_device_tensor_all_gathers_world_size_1():
+    """RCCL really initialised (backend 'nccl') and both data-path collectives of the sharded mode -- the 10.24 MB frame
+    all_gather (C1 grid) and the uint8 state all_gather -- executed on DEVICE tensors; one rank is all a 1-GPU box allows."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    backend, same, on_dev = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert backend == 'nccl' and on_dev and all(same), (backend, same)

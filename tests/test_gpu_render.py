@@ -161,7 +161,12 @@ def test_attr_mlp_vs_oracle_and_golden(golden):
         occ = net.attribute_decode(grid2)
     o_occ, o_dens, o_sem = O.attribute_decode(v2, sd)
     np.testing.assert_allclose(grid2[..., 0].cpu().numpy(), o_dens, rtol=2e-4, atol=2e-5)
-    assert (occ.cpu().numpy() == o_occ).mean() > 0.995
+    flips = occ.cpu().numpy() != o_occ
+    osem_s = np.sort(o_sem, -1)
+    tie = np.minimum(np.abs(o_dens - 8.5), osem_s[..., -1] - osem_s[..., -2])
+    print('[parity] attribute decode (3x5x7): %d of %d differ; largest tie distance among them %.3e'
+          % (int(flips.sum()), flips.size, float(tie[flips].max()) if flips.any() else 0.0))
+    assert not flips.any() or float(tie[flips].max()) <= 2e-3       # a flip must sit on the threshold / be a semantic near-tie
 
 
 def test_nerf_head_losses_vs_oracle():
@@ -213,8 +218,18 @@ def test_metric_miou_golden_and_oracle(golden):
     # temporal indexing: gt idx 4 is scored against stacked state 2
     mt = Metric_mIoU_Temporal(device=DEV)
     stack = np.stack([pred, gt, gt, pred])
-    mt.add_batch(stack, gt, None, None, 4)
+    mt.add_idx(stack, gt, None, None, 4)
     assert mt.metrics[4].count_miou()[3] == 100.0
+    # the reference's Metric_mIoU_Temporal on seeded labels: dict-keyed add_batch, count_miou / count_iou return values
+    gt_ = golden('metric_miou_temporal.npz')
+    mt = Metric_mIoU_Temporal(num_classes=18, use_image_mask=True, device=DEV)
+    for p_, g_, k_ in zip(gt_['pred'], gt_['gt'], gt_['mask']):
+        mt.add_batch(p_, {i: g_[j] for j, i in enumerate((0, 2, 4, 6))}, None, {i: k_[j] for j, i in enumerate((0, 2, 4, 6))})
+    for name in ('hist_0s', 'hist_1s', 'hist_2s', 'hist_3s', 'occ_hist_1s'):
+        np.testing.assert_array_equal(getattr(mt, name), gt_[name])
+    iu1, mious = mt.count_miou()
+    np.testing.assert_allclose(iu1, gt_['iou_1s'], rtol=1e-12)
+    assert mious == list(gt_['mious']) and mt.count_iou() == list(gt_['ious']) and mt.cnt == int(gt_['cnt'])
 
 
 def test_ray_table_and_wrs_weights_gpu(golden):

@@ -145,7 +145,8 @@ def test_conv_stack_small(golden):
     np.testing.assert_allclose(vf.transpose(0, 4, 3, 2, 1), g['final_conv'], **tol)
     occ, logits = O.occ_decode(vf, sd)
     np.testing.assert_allclose(logits.transpose(3, 0, 1, 2)[None], g['logits'], rtol=5e-4, atol=5e-4)
-    assert (occ == g['occ']).mean() > 0.999
+    from _parity import check_argmax
+    check_argmax('oracle occ vs reference (conv_stack_small)', occ, g['occ'], np.moveaxis(g['logits'][0], 0, -1), 2e-3)
 
 
 def test_forecast_small(golden):
