@@ -164,6 +164,29 @@ int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale, const 
                    int cout_total, int cout0, int cout1, int ld_y0, int ld_y1, int relu0, int relu1,
                    void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Split-fp16 ("h2") path of the voxel encoder: fp32-level accuracy on the fp16 matrix cores.
+ * x = hi + lo with hi = fp16(x), lo = fp16(x - hi); a product block is three v_mfma_f32_32x32x16_f16
+ * (hi.hi + lo.hi + hi.lo) with fp32 accumulation (preworld_amd/csrc/pw_h2.h; measured error = that of an fp32 FMA chain).
+ * An h2 tensor has the shape and byte size of its fp32 counterpart ((.., C) channels-last, C % 32 == 0); each 32-channel
+ * chunk of a voxel is 8 slots of 16 bytes, slot 4*half + 2*ks + p = plane p (0 hi, 1 lo) of channels 16*ks + 8*half + 0..7.
+ * pw_f32_to_h2 / pw_h2_to_f32 convert (n_vox, C) rows with row strides ld_x / ld_y floats (0 = dense). */
+int pw_f32_to_h2(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, void* stream);
+int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, void* stream);
+
+/* 3x3x3 stride-1 pad-1 convolution, same contract as pw_conv3d_ndhwc(ksize 3, stride 1) -- scale/bias, residual, ReLU,
+ * two destinations, row strides -- with
+ *   x        (B, D, H, W, Cin) in h2 storage;
+ *   wpk      split-fp16 packed weights float[Cin/32][27][cout_total/32][64 lanes][16]: lane (j = l & 31, h = l >> 5) holds,
+ *            for q = 2*ks + p, the 8 halves plane p of S[n] * w[n = nt*32 + j][c = ch*32 + 16*ks + 8*h + 0..7][tap], S[n] a
+ *            power of two that the caller folds back into scale[n] (preworld_amd.ops.pack_conv_weight_h2);
+ *   cout0 / cout1 / ld_y0 / ld_y1 multiples of 32;
+ *   fmt_y0 / fmt_y1 / fmt_res: 0 = fp32, 1 = h2 storage of y0 / y1 / residual (the residual shares y0's row stride and
+ *   may be y0 itself).  Results saturate at +-65504 when written as h2. */
+int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* residual,
+                 float* y0, float* y1, int B, int D, int H, int W, int Cin, int cout_total, int cout0, int cout1,
+                 int ld_y0, int ld_y1, int relu0, int relu1, int fmt_y0, int fmt_y1, int fmt_res, void* stream);
+
 /* A11  OccHead fused (mmdet3d/models/heads/occupancy_head.py:124-177, num_level=1,
  * use_deblock=False): conv3x3x3 Cin->16 + BN + ReLU, 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18,
  * argmax -> uint8, in one kernel.  x (B,D,H,W,Cin); scale/bias float[>=16] (folded BN of

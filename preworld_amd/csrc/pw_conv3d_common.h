@@ -35,6 +35,7 @@ struct ConvArgs {
   int tiles_d, tiles_h, tiles_w;
   long long* probe;       // development aid: per-wave phase timestamps (PW_CONV_PROBE) or null
   int dma_stage;          // tile-per-block kernels: stage the halo with buffer_load ... lds
+  int fmt_y0, fmt_y1, fmt_res;  // split-fp16 kernels (pw_h2.h): 0 = fp32, 1 = h2 storage of y0 / y1 / residual
 };
 
 // MFMA row (0..31) -> voxel of the 4x8 patch, chosen for conflict-free ds_read_b128 groups

@@ -380,6 +380,150 @@ def conv3d_wino(x, uwpk, scale=None, bias=None, residual=None, cout0=None, cout1
     return (y0, y1) if cout1 else y0
 
 
+# ------------------------------------------------------------------------------ split-fp16 ("h2") path
+class H2:
+    """A channels-last activation tensor in h2 storage (include/preworld_hip.h): `.buf` is a float32-typed torch
+    tensor of the logical shape (.., C), C % 32 == 0, whose bytes are the split-fp16 encoding.  Channel slices at
+    multiples of 32 and leading-axis slices of `.buf` are again valid h2 tensors."""
+    __slots__ = ('buf',)
+
+    def __init__(self, buf):
+        if buf.dtype != _f32 or buf.shape[-1] % 32:
+            raise _lib.PreworldHipError('h2 tensors are float32-typed with a multiple of 32 channels')
+        self.buf = buf
+
+    @property
+    def shape(self):
+        return self.buf.shape
+
+    def __getitem__(self, idx):
+        return H2(self.buf[idx])
+
+
+def _rows(t, name):
+    """(n_vox, C, ld) of a channels-last tensor that is dense or a channel slice of a dense buffer."""
+    C = t.shape[-1]
+    n = t.numel() // C
+    if t.is_contiguous():
+        return n, C, C
+    ld, expect = None, None
+    for i in range(t.dim() - 2, -1, -1):                 # innermost voxel axis of extent > 1 defines the row stride
+        if t.shape[i] == 1:
+            continue
+        if ld is None:
+            ld, expect = t.stride(i), t.stride(i) * t.shape[i]
+        elif t.stride(i) != expect:
+            ld = -1
+            break
+        else:
+            expect *= t.shape[i]
+    if ld is None:
+        ld = C
+    if t.stride(-1) != 1 or ld < C:
+        raise _lib.PreworldHipError('%s must be dense or a channel slice of a dense channels-last buffer' % name)
+    return n, C, ld
+
+
+def f32_to_h2(x, out=None):
+    """fp32 channels-last (.., C) -> H2 of the same shape (pw_f32_to_h2)."""
+    n, C, ldx = _rows(x, 'x')
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=_f32)
+    _, _, ldy = _rows(out, 'out')
+    _lib.call('pw_f32_to_h2', _p(x), _p(out), n, C, ldx, ldy, _stream())
+    return H2(out)
+
+
+def h2_to_f32(x, out=None):
+    """H2 -> fp32 channels-last tensor of the same shape (pw_h2_to_f32): hi + lo, exact."""
+    n, C, ldx = _rows(x.buf, 'x')
+    if out is None:
+        out = torch.empty(x.shape, device=x.buf.device, dtype=_f32)
+    _, _, ldy = _rows(out, 'out')
+    _lib.call('pw_h2_to_f32', _p(x.buf), _p(out), n, C, ldx, ldy, _stream())
+    return out
+
+
+def pack_conv_weight_h2(w, cout_total=None):
+    """torch Conv3d weight (Cout, Cin, 3,3,3) -> (wpk, inv_scale): split-fp16 weights in the operand order of
+    pw_conv3d_h2 (include/preworld_hip.h) as a float32-typed tensor [Cin/32][27][cout_total/32][64][16], and the
+    per-column factor (cout_total,) = 1 / S[n] to multiply into the epilogue scale.  S[n] = 2^k puts the largest
+    |w[n]| in [512, 1024): both halves of the split are then normal fp16 numbers for every weight above 2^-13 of it."""
+    Cout, Cin = w.shape[:2]
+    taps = w.shape[2] * w.shape[3] * w.shape[4]
+    if Cin % 32:
+        raise _lib.PreworldHipError('pack_conv_weight_h2 expects Cin % 32 == 0')
+    if cout_total is None:
+        cout_total = (Cout + 31) // 32 * 32
+    wf = w.reshape(Cout, -1).double()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-30)
+    S = torch.exp2(torch.floor(torch.log2(1023.0 / amax)))                       # power of two per output channel
+    ws = torch.zeros(cout_total, Cin, taps, dtype=torch.float64, device=w.device)
+    ws[:Cout] = (wf * S[:, None]).view(Cout, Cin, taps)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.double()).to(torch.float16)
+    planes = torch.stack([hi, lo], 0)                                            # (p, n, c, tap)
+    nt, nch = cout_total // 32, Cin // 32
+    t = planes.view(2, nt, 32, nch, 2, 2, 8, taps)                               # (p, nt, j, ch, ks, h, e, tap)
+    t = t.permute(3, 7, 1, 5, 2, 4, 0, 6).contiguous()                           # (ch, tap, nt, h, j, ks, p, e)
+    wpk = t.view(nch, taps, nt, 64, 32).view(torch.float32).view(nch, taps, nt, 64, 16).contiguous()
+    inv = torch.ones(cout_total, dtype=torch.float64, device=w.device)
+    inv[:Cout] = 1.0 / S
+    return wpk, inv.float()
+
+
+def pack_conv_weights_h2_concat(ws):
+    """conv1 + downsample of a BasicBlock3D over the same input: packed columns side by side."""
+    parts = [pack_conv_weight_h2(w) for w in ws]
+    return torch.cat([p[0] for p in parts], dim=2).contiguous(), torch.cat([p[1] for p in parts]).contiguous()
+
+
+def conv3d_h2(x, wpk, scale, bias=None, residual=None, cout0=None, cout1=0, relu0=False, relu1=False, out0=None,
+              out1=None, out_h2=(True, True)):
+    """3x3x3 stride-1 pad-1 conv on the fp16 matrix cores with split-fp16 operands (pw_conv3d_h2).
+    x: H2 (B,D,H,W,Cin); wpk from pack_conv_weight_h2; scale (cout_total,) MUST already contain the packer's
+    inv_scale (scale = bn_scale * inv_scale).  residual: H2 or fp32 tensor with y0's layout (may be out0 itself).
+    out_h2: storage of (y0, y1): True -> H2, False -> fp32 tensor.  Returns y0 [, y1]."""
+    if not isinstance(x, H2):
+        raise _lib.PreworldHipError('conv3d_h2 takes an ops.H2 input (ops.f32_to_h2)')
+    B, D, H, W, Cin = x.shape
+    nch, taps, nt = wpk.shape[:3]
+    cout_total = nt * 32
+    if nch * 32 != Cin or taps != 27:
+        raise _lib.PreworldHipError('packed h2 weight does not match Cin / 3x3x3')
+    if cout0 is None:
+        cout0 = cout_total
+    fm0, fm1 = int(bool(out_h2[0])), int(bool(out_h2[1]))
+
+    def _dst(o, c):
+        if o is None:
+            return torch.empty(B, D, H, W, c, device=x.buf.device, dtype=_f32)
+        return o.buf if isinstance(o, H2) else o
+    y0 = _dst(out0, cout0)
+    ld0 = _row_stride(y0, (B, D, H, W, cout0), 'y0')
+    y1, ld1 = None, 0
+    if cout1:
+        y1 = _dst(out1, cout1)
+        ld1 = _row_stride(y1, (B, D, H, W, cout1), 'y1')
+    res, fmr = None, 0
+    if residual is not None:
+        fmr = int(isinstance(residual, H2))
+        res = residual.buf if fmr else residual
+        if _row_stride(res, (B, D, H, W, cout0), 'residual') != ld0:
+            raise _lib.PreworldHipError('residual must have the same row stride as y0')
+    if scale is None or scale.numel() != cout_total or (bias is not None and bias.numel() != cout_total):
+        raise _lib.PreworldHipError('scale (with the weight pre-scale folded in) / bias must have cout_total=%d entries' % cout_total)
+    xb = x.buf
+    if not xb.is_contiguous():
+        raise _lib.PreworldHipError('x must be dense')
+    _lib.call('pw_conv3d_h2', _p(xb), _chk(wpk, _f32, 'wpk'), _p(scale), _p(bias), _p(res), _p(y0), _p(y1), B, D, H, W,
+              Cin, cout_total, cout0, cout1, ld0, ld1, int(relu0), int(relu1), fm0, fm1, fmr, _stream())
+    r0 = H2(y0) if fm0 else y0
+    if cout1:
+        return r0, (H2(y1) if fm1 else y1)
+    return r0
+
+
 def fpn3d_fuse(x8, wpk8, y16, y32, scale, bias, relu=True, out=None):
     """LSSFPN3D tail: ReLU(BN(W8 x8 + up2(y16) + up4(y32))) -- lss_fpn.py:132-148."""
     B, D, H, W, C8 = x8.shape

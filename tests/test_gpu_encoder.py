@@ -502,3 +502,72 @@ def test_softplus_accuracy():
     err = (y.double().cpu() - ref).abs()
     rel = err / ref.clamp_min(1e-30)
     assert float(torch.minimum(err / 3e-7, rel / 1e-6).max()) <= 1.0   # abs 3e-7 or rel 1e-6
+
+
+# ----------------------------------------------------------------------------- split-fp16 ("h2") path
+def test_h2_round_trip_and_slices():
+    """fp32 -> h2 -> fp32 is hi + lo: exact to 2^-22 relative (2^-25 absolute below 0.125), saturating at 65504; works on
+    channel slices of wider buffers."""
+    rs = np.random.RandomState(5)
+    x = (rs.standard_normal((2, 3, 5, 7, 64)) * np.exp(rs.uniform(-12, 6, (2, 3, 5, 7, 64)))).astype(np.float32)
+    x[0, 0, 0, 0, :4] = [70000.0, -1e9, 0.0, 65504.0]
+    xt = T(x)
+    back = ops.h2_to_f32(ops.f32_to_h2(xt)).cpu().numpy()
+    want = np.clip(x, -65504, 65504)
+    err = np.abs(back - want)
+    assert (err <= np.maximum(np.abs(want) * 2.0 ** -21, 2.0 ** -24)).all(), float((err / np.maximum(np.abs(want), 1e-30)).max())
+    buf = torch.zeros(2, 3, 5, 7, 96, device=DEV)
+    h = ops.f32_to_h2(xt[..., 32:64], out=buf[..., 64:96])
+    np.testing.assert_array_equal(ops.h2_to_f32(h).cpu().numpy(), back[..., 32:64])
+    assert float(buf[..., :64].abs().max()) == 0.0
+    np.testing.assert_array_equal(ops.h2_to_f32(ops.f32_to_h2(xt)[..., 0:32]).cpu().numpy(), back[..., 0:32])
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 4, 8, 8), (2, 32, 5, 11, 13), (1, 64, 3, 9, 17), (1, 128, 4, 6, 10),
+                                   (1, 32, 8, 40, 48)])
+@pytest.mark.parametrize('cout', [32, 64, 128])
+@pytest.mark.parametrize('fmt', ['f32', 'h2'])
+def test_conv3d_h2_vs_oracle(shape, cout, fmt):
+    """pw_conv3d_h2 (split-fp16 operands on the fp16 matrix cores) against the fp32 oracle: same tolerance class as the
+    exact-fp32 MFMA kernels (measured ~1e-6 relative, printed), fp32 and h2 outputs / residuals, NT = 1 and 2."""
+    from _parity import check_close
+    rs = np.random.RandomState(hash((shape, cout)) % 2 ** 31)
+    x = rs.standard_normal(shape).astype(np.float32)
+    x[rs.rand(*shape) < 0.3] = 0
+    w = _rand_conv(rs, cout, shape[1], 3)
+    scale = (rs.rand(cout) + 0.5).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32)
+    res = rs.standard_normal((shape[0], cout) + shape[2:]).astype(np.float32)
+    want = O.conv3d(x, w, None, 1, 1) * scale[None, :, None, None, None] + bias[None, :, None, None, None]
+    want = np.maximum(want + res, 0)
+    wpk, inv = ops.pack_conv_weight_h2(T(w))
+    xh = ops.f32_to_h2(cl(x))
+    h2 = fmt == 'h2'
+    r = ops.f32_to_h2(cl(res)) if h2 else cl(res)
+    got = ops.conv3d_h2(xh, wpk, T(scale) * inv, T(bias), residual=r, cout0=cout, relu0=True, out_h2=(h2, h2))
+    if h2:
+        got = ops.h2_to_f32(got)
+    check_close('conv3d_h2 %s %d->%d %s' % (shape[2:], shape[1], cout, fmt), ncdhw(got), want, 3e-6, atol=1e-6)
+
+
+def test_conv3d_h2_two_outputs_strided_inplace_residual():
+    """conv1 (+ReLU) and downsample in one pass into channel slices of a wider h2 buffer; conv2 adds onto its residual in
+    place (BasicBlock3D's data flow) -- equal to the separate dense calls bit for bit."""
+    rs = np.random.RandomState(3)
+    B, D, H, W = 1, 6, 20, 26
+    x = ops.f32_to_h2(T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32)))
+    wa, wb = T(_rand_conv(rs, 32, 32, 3)), T(_rand_conv(rs, 32, 32, 3))
+    wpk, inv = ops.pack_conv_weights_h2_concat([wa, wb])
+    sc = T(rs.uniform(0.5, 1.5, 64).astype(np.float32)) * inv
+    bi = T(rs.standard_normal(64).astype(np.float32))
+    y0, y1 = ops.conv3d_h2(x, wpk, sc, bi, cout0=32, cout1=32, relu0=True)
+    buf = torch.full((B, D, H, W, 96), 7.0, device=DEV)
+    s0, s1 = ops.conv3d_h2(x, wpk, sc, bi, cout0=32, cout1=32, relu0=True, out0=buf[..., 0:32], out1=buf[..., 64:96])
+    assert torch.equal(s0.buf, y0.buf) and torch.equal(s1.buf, y1.buf) and bool((buf[..., 32:64] == 7.0).all())
+    wp1, inv1 = ops.pack_conv_weight_h2(wa)
+    dense = ops.conv3d_h2(y0, wp1, sc[:32].contiguous() / inv[:32] * inv1, bi[:32].contiguous(), residual=y1, relu0=True)
+    ops.conv3d_h2(y0, wp1, sc[:32].contiguous() / inv[:32] * inv1, bi[:32].contiguous(), residual=s1, relu0=True, out0=s1)
+    assert torch.equal(buf[..., 64:96], dense.buf)
+    # separate fp32-output run of the same conv agrees with the decoded h2 result to the format's resolution
+    f = ops.conv3d_h2(y0, wp1, sc[:32].contiguous() / inv[:32] * inv1, bi[:32].contiguous(), residual=y1, relu0=True, out_h2=(False, False))
+    np.testing.assert_allclose(ops.h2_to_f32(dense).cpu().numpy(), f.cpu().numpy(), rtol=5e-7, atol=1e-7)
