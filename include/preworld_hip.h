@@ -113,11 +113,12 @@ int pw_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* fea
 /* A4 (fused fast path)  dense voxel-driven pooling: every voxel of out (n_voxels, C),
  * channels-last = (B,Z,Y,X,C), is written exactly once (sum or zero) -- no memset, no permute.
  * seg_start/order/order_feat(=order_aux)/long_list/n_long come from pw_segment_sort over the
- * voxel ids (long_list/n_long may be NULL).  Sums run in ascending point order per voxel. */
+ * voxel ids (long_list/n_long may be NULL).  Sums run in ascending point order per voxel.
+ * out_h2 != 0 (C % 32 == 0): the same fp32 sums are written in split-fp16 "h2" storage (see pw_conv3d_h2). */
 int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_start,
                       const int32_t* order, const int32_t* order_feat, int64_t n_voxels, int c,
                       int long_threshold, const int32_t* long_list, const int32_t* n_long,
-                      float* out, void* stream);
+                      float* out, int out_h2, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A6-A9, A11  3-D convolution on channels-last activations, exact-fp32 MFMA implicit GEMM.
@@ -146,10 +147,13 @@ int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const 
 /* A8  LSSFPN3D fused (mmdet3d/models/necks/lss_fpn.py:132-148): out = ReLU(BN(W8 x8 +
  * up2(y16) + up4(y32))) where y16/y32 are the 1x1x1 conv already applied at 1/2 and 1/4
  * resolution (32 channels each; interpolation and 1x1x1 conv commute).  trilinear,
- * align_corners=True.  x8 (B,D,H,W,Cin8), wpk8 packed [Cin8/32][1][1][64][16], out (B,D,H,W,32). */
+ * align_corners=True.  x8 (B,D,H,W,Cin8), wpk8 packed [Cin8/32][1][1][64][16], out (B,D,H,W,32).
+ * x_h2 != 0: x8 is in split-fp16 "h2" storage and wpk8 comes from pack_conv_weight_h2 (its inv_scale folded into `scale`);
+ * out_h2 != 0: out is written in h2 storage (see pw_conv3d_h2).  y16 / y32 are always fp32. */
 int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const float* y32,
                   const float* scale, const float* bias, float* out, int B, int D, int H, int W,
-                  int Cin8, int D2, int H2, int W2, int D4, int H4, int W4, int relu, void* stream);
+                  int Cin8, int D2, int H2, int W2, int D4, int H4, int W4, int relu, int x_h2, int out_h2,
+                  void* stream);
 
 /* 3x3x3 stride-1 pad-1 convolution by Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores: same contract
  * as pw_conv3d_ndhwc (scale/bias, residual, ReLU, two destinations, row strides) with weights in the
@@ -174,10 +178,11 @@ int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale, const 
 int pw_f32_to_h2(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, void* stream);
 int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, void* stream);
 
-/* 3x3x3 stride-1 pad-1 convolution, same contract as pw_conv3d_ndhwc(ksize 3, stride 1) -- scale/bias, residual, ReLU,
- * two destinations, row strides -- with
+/* Convolution with split-fp16 operands, same contract as pw_conv3d_ndhwc -- scale/bias, residual, ReLU, two destinations,
+ * row strides -- for ksize 3 (stride 1: persistent LDS-tiled kernel; stride 2: gather kernel) and ksize 1 (stride 1); algo 2 / 3
+ * force the gather kernel (3 = input-channel chunks split over the 4 waves, tiny grids), with
  *   x        (B, D, H, W, Cin) in h2 storage;
- *   wpk      split-fp16 packed weights float[Cin/32][27][cout_total/32][64 lanes][16]: lane (j = l & 31, h = l >> 5) holds,
+ *   wpk      split-fp16 packed weights float[Cin/32][ksize^3][cout_total/32][64 lanes][16]: lane (j = l & 31, h = l >> 5) holds,
  *            for q = 2*ks + p, the 8 halves plane p of S[n] * w[n = nt*32 + j][c = ch*32 + 16*ks + 8*h + 0..7][tap], S[n] a
  *            power of two that the caller folds back into scale[n] (preworld_amd.ops.pack_conv_weight_h2);
  *   cout0 / cout1 / ld_y0 / ld_y1 multiples of 32;
@@ -185,7 +190,8 @@ int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int l
  *   may be y0 itself).  Results saturate at +-65504 when written as h2. */
 int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* residual,
                  float* y0, float* y1, int B, int D, int H, int W, int Cin, int cout_total, int cout0, int cout1,
-                 int ld_y0, int ld_y1, int relu0, int relu1, int fmt_y0, int fmt_y1, int fmt_res, void* stream);
+                 int ld_y0, int ld_y1, int ksize, int stride, int relu0, int relu1, int algo, int fmt_y0, int fmt_y1,
+                 int fmt_res, void* stream);
 
 /* A11  OccHead fused (mmdet3d/models/heads/occupancy_head.py:124-177, num_level=1,
  * use_deblock=False): conv3x3x3 Cin->16 + BN + ReLU, 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18,

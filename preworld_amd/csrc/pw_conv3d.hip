@@ -485,7 +485,7 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
   PW_CHECK_ARG(!(ksize == 1 && stride != 1), "pw_conv3d_ndhwc: 1x1x1 stride 2 unsupported");
   PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)wpk) & 15) == 0, "pw_conv3d_ndhwc: x/wpk must be 16-B aligned");
   const int pad = (ksize - 1) / 2;
-  ConvArgs a;
+  ConvArgs a = {};
   a.x = x; a.wpk = wpk; a.scale = scale; a.bias = bias; a.residual = residual; a.y0 = y0; a.y1 = y1;
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin;
   a.Do = (D + 2 * pad - ksize) / stride + 1;

@@ -45,18 +45,36 @@ __device__ __forceinline__ int patch_of_row(int i) {
   return set * 16 + (g >> 1) * 4 + (i & 3);
 }
 
+// byte offset of the hi half of channel n inside a channels-last row in h2 storage (pw_h2.h); the lo half sits 16 bytes on
+__device__ __forceinline__ size_t h2_elem_off(int n) {
+  const int c = n & 31;
+  return (size_t)(n >> 5) * 128 + (size_t)((4 * ((c >> 3) & 1) + 2 * (c >> 4)) * 16 + 2 * (c & 7));
+}
+__device__ __forceinline__ void h2_store_elem(float* row, int n, float v) {
+  char* p = reinterpret_cast<char*>(row) + h2_elem_off(n);
+  v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  const _Float16 hi = (_Float16)v;
+  *reinterpret_cast<_Float16*>(p) = hi;
+  *reinterpret_cast<_Float16*>(p + 16) = (_Float16)(v - (float)hi);
+}
+__device__ __forceinline__ float h2_load_elem(const float* row, int n) {
+  const char* p = reinterpret_cast<const char*>(row) + h2_elem_off(n);
+  return (float)*reinterpret_cast<const _Float16*>(p) + (float)*reinterpret_cast<const _Float16*>(p + 16);
+}
+
 __device__ __forceinline__ void store_out(const ConvArgs& a, int n, size_t vox, float v) {
-  // n = packed output column
+  // n = packed output column; fmt_* = 0 (fp32) in the fp32 kernels (ConvArgs zero-initialised there)
   if (n < a.cout0) {
-    size_t o = vox * a.ld0 + n;
-    if (a.residual) v += a.residual[o];
+    if (a.residual) v += a.fmt_res ? h2_load_elem(a.residual + vox * a.ld0, n) : a.residual[vox * a.ld0 + n];
     if (a.relu0) v = fmaxf(v, 0.f);
-    a.y0[o] = v;
+    if (a.fmt_y0) h2_store_elem(a.y0 + vox * a.ld0, n, v);
+    else a.y0[vox * a.ld0 + n] = v;
   } else {
     int n1 = n - a.n1_start;
     if (a.y1 && n1 >= 0 && n1 < a.cout1) {
       if (a.relu1) v = fmaxf(v, 0.f);
-      a.y1[vox * a.ld1 + n1] = v;
+      if (a.fmt_y1) h2_store_elem(a.y1 + vox * a.ld1, n1, v);
+      else a.y1[vox * a.ld1 + n1] = v;
     }
   }
 }
@@ -435,6 +453,6 @@ static inline int choose_wd(int B, int Do, int Ho, int Wo, int ngroups) {
 
 // gather kernel launcher (pw_conv3d_gather.hip)
 int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, int stride, int algo, int Cin,
-                             long long n_out, hipStream_t st);
+                             long long n_out, hipStream_t st, bool f16 = false);
 
 #endif  // PW_CONV3D_COMMON_H_

@@ -44,8 +44,27 @@ __device__ __forceinline__ void gather_load(const GatherCtx<KS, MT>& c, int ch, 
   load_b<NT>(c.wr, wsoff + (unsigned)TAP * c.wstride, c.lane_off, bq);
 }
 
-template <int NT, int MT>
+typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
+
+// F16: x and weights in split-fp16 (h2) storage -- a lane's four 16-byte pieces are {hi, lo} x {k-step 0, 1} -- and the
+// product block is three v_mfma_f32_32x32x16_f16 (pw_h2.h); otherwise the exact-fp32 v_mfma_f32_32x32x2_f32
+template <int NT, int MT, bool F16>
 __device__ __forceinline__ void gather_mfma(const float4 (&aq)[MT][4], const float4 (&bq)[NT][4], f32x16 (&acc)[MT][NT]) {
+  if constexpr (F16) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int prod = 0; prod < 3; ++prod) {          // hi_x.hi_w, hi_x.lo_w, lo_x.hi_w
+        const int pw = prod == 1 ? 1 : 0, px = prod == 2 ? 1 : 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gh8, aq[mt][2 * ks + px]),
+                                                                 __builtin_bit_cast(gh8, bq[nt][2 * ks + pw]), acc[mt][nt], 0, 0, 0);
+      }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -63,7 +82,7 @@ __device__ __forceinline__ void gather_mfma(const float4 (&aq)[MT][4], const flo
 }
 
 // tap TAP computes from (ac, bc) while (an, bn) receive tap TAP+1 (or tap 0 of the next chunk)
-template <int NT, int KS, int MT, int TAP>
+template <int NT, int KS, int MT, int TAP, bool F16>
 __device__ __forceinline__ void gather_step(const GatherCtx<KS, MT>& c, int ch, int ch_step, bool more_chunks, unsigned wsoff,
                                             unsigned wsoff_next, float4 (&ac)[MT][4], float4 (&bc)[NT][4],
                                             float4 (&an)[MT][4], float4 (&bn)[NT][4], f32x16 (&acc)[MT][NT]) {
@@ -74,10 +93,10 @@ __device__ __forceinline__ void gather_step(const GatherCtx<KS, MT>& c, int ch, 
     if (more_chunks) gather_load<NT, KS, MT, 0>(c, ch + ch_step, wsoff_next, an, bn);
   }
   __builtin_amdgcn_sched_barrier(0);
-  gather_mfma<NT, MT>(ac, bc, acc);
+  gather_mfma<NT, MT, F16>(ac, bc, acc);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (TAP + 1 < TAPS)
-    gather_step<NT, KS, MT, TAP + 1>(c, ch, ch_step, more_chunks, wsoff, wsoff_next, an, bn, ac, bc, acc);
+    gather_step<NT, KS, MT, TAP + 1, F16>(c, ch, ch_step, more_chunks, wsoff, wsoff_next, an, bn, ac, bc, acc);
 }
 
 // MT = M-tiles (32 output voxels each) per wave (default 1, see the dispatch)
@@ -86,7 +105,7 @@ __device__ __forceinline__ void gather_step(const GatherCtx<KS, MT>& c, int ch, 
 // meet in LDS and partition 0 adds them in a fixed order (deterministic) before the epilogue.  Small
 // grids need this: with one (M-tile, N-group) per wave the 4x50x50 stage has ~1.2 waves of 1728-3456
 // MFMAs per SIMD, i.e. the slowest SIMD does 2 of them; split by 4 it is ~5 waves of 432.
-template <int NT, int KS, int STRIDE, int MT, int KSPL>
+template <int NT, int KS, int STRIDE, int MT, int KSPL, bool F16 = false>
 __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_out_vox) {
   constexpr int ksplit = KSPL;          // compile-time: the unsplit kernel keeps its straight-line code
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -140,7 +159,7 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
     for (int ch = kpart; ch < nchunk; ch += ksplit) {
       const unsigned wsoff = (unsigned)((ch * TAPS * ntiles_total + ng * NT) * 4096);
       const unsigned wsoff_next = (unsigned)(((ch + ksplit) * TAPS * ntiles_total + ng * NT) * 4096);
-      gather_step<NT, KS, MT, 0>(c, ch, ksplit, ch + ksplit < nchunk, wsoff, wsoff_next, a0, b0, a1, b1, acc);
+      gather_step<NT, KS, MT, 0, F16>(c, ch, ksplit, ch + ksplit < nchunk, wsoff, wsoff_next, a0, b0, a1, b1, acc);
       if constexpr (TAPS & 1) {             // an odd tap count leaves the next chunk's tap 0 in (a1, b1)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -194,11 +213,11 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
 }
 
 int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, int stride, int algo, int Cin,
-                             long long n_out, hipStream_t st) {
+                             long long n_out, hipStream_t st, bool f16) {
     // M-tiles per wave: 2 halves the weight loads per MFMA but measured slower (32->128 stride 2:
     // 199 us vs 180 us -- fewer waves to hide the L2 gather latency); PW_GATHER_MT=2 selects it
     const char* mte = getenv("PW_GATHER_MT");
-    const int MT = (mte && atoi(mte) == 2) ? 2 : 1;
+    const int MT = (!f16 && mte && atoi(mte) == 2) ? 2 : 1;
     const int nchunk = Cin / KC;
     int ksplit = 1;
     if (algo == 3) ksplit = (nchunk % 4 == 0) ? 4 : (nchunk % 2 == 0 ? 2 : 1);
@@ -215,6 +234,32 @@ int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, i
     hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, MTv, KSPv>), grid, dim3(256), red_bytes, st, a, n_out);   \
     pw_note_kernel("k_conv3d_gather<%d, %d, %d, %d, %d>", NTv, KSv, STv, MTv, KSPv);                             \
   } while (0)
+  if (f16) {          // split-fp16 operands (pw_conv3d_h2): k3 s2, k1 s1 and k3 s1 (tiny grids), one M-tile per wave
+#define PW_GATHER_F(NTv, KSv, STv, KSPv)                                                                              \
+  do {                                                                                                                \
+    hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1, KSPv, true>), grid, dim3(256), red_bytes, st, a, n_out);    \
+    pw_note_kernel("k_conv3d_gather<%d, %d, %d, 1, %d, true>", NTv, KSv, STv, KSPv);                                  \
+  } while (0)
+#define PW_GATHER_FK(NTv, KSv, STv)                      \
+  do {                                                   \
+    if (ksplit == 4) PW_GATHER_F(NTv, KSv, STv, 4);      \
+    else if (ksplit == 2) PW_GATHER_F(NTv, KSv, STv, 2); \
+    else PW_GATHER_F(NTv, KSv, STv, 1);                  \
+  } while (0)
+    if (ksize == 1 && stride == 1) {
+      if (NT == 2) PW_GATHER_FK(2, 1, 1); else PW_GATHER_FK(1, 1, 1);
+    } else if (ksize == 3 && stride == 1) {
+      if (NT == 2) PW_GATHER_FK(2, 3, 1); else PW_GATHER_FK(1, 3, 1);
+    } else if (ksize == 3 && stride == 2) {
+      if (NT == 2) PW_GATHER_FK(2, 3, 2); else PW_GATHER_FK(1, 3, 2);
+    } else {
+      pw_set_error("pw_conv3d_h2: no split-fp16 gather variant for ksize %d stride %d", ksize, stride);
+      return PW_EINVAL;
+    }
+#undef PW_GATHER_FK
+#undef PW_GATHER_F
+    return PW_OK;
+  }
 #define PW_GATHER(NTv, KSv, STv)                                        \
   do {                                                                  \
     if (ksplit == 4) PW_GATHER_L(NTv, KSv, STv, 1, 4);                  \

@@ -32,6 +32,7 @@ struct H2Ctx {
   bool has_next;
   PipeDma dm;
   int wave, lane;
+  long long* tap_probe;
 };
 
 template <int TAP>
@@ -82,23 +83,113 @@ template <int NT, int TAP>
 __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, const unsigned (&aaddr)[2][3][4],
                                         v4f (&ac)[2][4], v4f (&an)[2][4], v4f (&b0)[NT][4], v4f (&b1)[NT][4],
                                         v4f (&b2)[NT][4], f32x16 (&acc)[2][NT]) {
-  if (!(a.dma_stage & 1)) {
+  if (c.tap_probe) {                       // development aid: cycle counter at every tap of one stage
+    if (c.lane == 0) c.tap_probe[c.wave * 27 + TAP] = __builtin_readcyclecounter();
+  }
   if constexpr (TAP + 2 < 27) {
     h2_load_b<NT>(c.wr, c.wsoff + (unsigned)(TAP + 2) * c.wstride, c.lane_off, b2);
   } else {
     h2_load_b<NT>(c.wr, c.wsoff_next + (unsigned)(TAP + 2 - 27) * c.wstride, c.lane_off, b2);
   }
-  }
-  if (!(a.dma_stage & 4)) {
   if constexpr (TAP >= 1 && TAP <= PIPE_ROWS_PER_WAVE) pipe_dma_row<TAP - 1>(a, c.xr, c.lds3, c.dm, c.wave);
-  }
-  if (!(a.dma_stage & 2)) {
   if constexpr (TAP < 26) h2_read_a_tap<TAP + 1>(c.lds3, aaddr, an);
-  }
   __builtin_amdgcn_sched_barrier(0);
   h2_mfma<NT>(ac, b0, acc);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (TAP < 26) h2_step<NT, TAP + 1>(a, c, aaddr, an, ac, b1, b2, b0, acc);
+}
+
+// ---- epilogue shared by the kernels below: y = acc*scale + bias (+residual) (ReLU) through an LDS staging area.
+// The transposed accumulators (lane = voxel, 16 channels in groups of 4) are written as fp32 rows into `stg` (rows of
+// 8 voxels x 128 B, pitch 4 halo rows = 5120 B: the halo rows wave, wave+4, .. of a buffer no other wave touches), then read
+// back with 4 lanes per voxel (8 channels each): every global access is a 32-byte piece of a voxel row and a wave
+// instruction covers 16 complete 128-byte rows -- residual loads and stores fully coalesced (storing 8-byte pieces straight
+// from the accumulator layout cost 6.3 k cycles per stage, store-issue bound).
+template <int NT>
+__device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][NT], const float* sb, char* stg,
+                                            int b, int d0, int h0, int w0, int ng, int wave, int lane) {
+  const int od = d0 + wave;
+  const int half = lane >> 5, pj = patch_of_row(lane & 31);
+  const unsigned out_vox = (unsigned)((size_t)a.B * a.Do * a.Ho * a.Wo);
+  constexpr unsigned STG_ROW = 4 * TW * 128;                 // rows wave, wave+4, ...: 8 voxels x 128 B used of each
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n0 = (ng * NT + nt) * 32;
+    const bool to_y0 = n0 < a.cout0;
+    float* dst = to_y0 ? a.y0 : a.y1;
+    if (dst == nullptr) continue;
+    const int stride = to_y0 ? a.cout0 : a.cout1;
+    const int ld = to_y0 ? a.ld0 : a.ld1;
+    const int col0 = to_y0 ? n0 : n0 - a.n1_start;
+    if (col0 < 0 || col0 >= stride) continue;
+    const int fmt = to_y0 ? a.fmt_y0 : a.fmt_y1;
+    const float lo_clamp = (to_y0 ? a.relu0 : a.relu1) ? 0.f : -3.402823466e38f;
+    const bool has_res = to_y0 && a.residual != nullptr;
+    const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)ld * 4u);
+    const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)ld * 4u);
+    // phase A: scale / bias, fp32 rows to LDS (16-byte channel quads XOR-swizzled by the voxel index)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const v4f sc = *reinterpret_cast<const v4f*>(sb + n0 + 8 * g + 4 * half);
+      const v4f bi = *reinterpret_cast<const v4f*>(sb + H2_MAX_COUT + n0 + 8 * g + 4 * half);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int sv = mt * 32 + pj;
+        v4f v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * g + e] * sc[e] + bi[e];
+        *reinterpret_cast<v4f*>(stg + (sv >> 3) * STG_ROW + (sv & 7) * 128 + (((2 * g + half) ^ ((sv >> 1) & 7)) * 16)) = v;
+      }
+    }
+    // phase B: 4 passes of 16 voxels; lane = (voxel sv = 16 q + (lane >> 2), channel octet o = lane & 3)
+    const int o = lane & 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sv = 16 * q + (lane >> 2);
+      const int mt = sv >> 5, vr = (sv >> 3) & 3, vc = sv & 7;
+      const bool ok = od < a.Do && (h0 + mt * 4 + vr) < a.Ho && (w0 + vc) < a.Wo;
+      const unsigned soff = (unsigned)(((((b * a.Do + od) * a.Ho + h0) * a.Wo + w0) * ld) * 4);
+      const unsigned vox = (unsigned)(((mt * 4 + vr) * a.Wo + vc) * ld) * 4u + (unsigned)col0 * 4u;
+      const char* src = stg + (sv >> 3) * STG_ROW + (sv & 7) * 128;
+      const int sw = (sv >> 1) & 7;
+      const v4f lo4 = *reinterpret_cast<const v4f*>(src + (((2 * o) ^ sw) * 16));
+      const v4f hi4 = *reinterpret_cast<const v4f*>(src + (((2 * o + 1) ^ sw) * 16));
+      float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      const unsigned pos = (fmt == 0 ? (unsigned)(32 * o) : (unsigned)((4 * (o & 1) + 2 * (o >> 1)) * 16));
+      const unsigned rpos = (a.fmt_res == 0 ? (unsigned)(32 * o) : (unsigned)((4 * (o & 1) + 2 * (o >> 1)) * 16));
+      if (has_res) {
+        const unsigned base = ok ? vox + rpos : PIPE_OOB;
+        const float4 r0 = buf_load4(rr, base, soff), r1 = buf_load4(rr, ok ? base + 16u : PIPE_OOB, soff);
+        if (a.fmt_res == 0) {
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        } else {                                    // r0 = 8 hi halves, r1 = 8 lo halves of channels 8o .. 8o+7
+          const h8 rh = __builtin_bit_cast(h8, r0), rl = __builtin_bit_cast(h8, r1);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rh[e] + (float)rl[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], lo_clamp);
+      const unsigned obase = ok ? vox + pos : PIPE_OOB;
+      if (fmt == 0) {
+        const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
+        buf_store4(yr, obase, soff, va);
+        buf_store4(yr, ok ? obase + 16u : PIPE_OOB, soff, vb);
+      } else {
+        h8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = __builtin_amdgcn_fmed3f(v[e], -H2_MAX, H2_MAX);
+          oh[e] = (_Float16)x;
+          ol[e] = (_Float16)(x - (float)oh[e]);
+        }
+        const v4f wh = __builtin_bit_cast(v4f, oh), wl = __builtin_bit_cast(v4f, ol);
+        const float va[4] = {wh[0], wh[1], wh[2], wh[3]}, vb[4] = {wl[0], wl[1], wl[2], wl[3]};
+        buf_store4(yr, obase, soff, va);
+        buf_store4(yr, ok ? obase + 16u : PIPE_OOB, soff, vb);
+      }
+    }
+  }
 }
 
 template <int NT>
@@ -188,6 +279,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
           aaddr[khp][kw][q] = aaddr0[khp][kw][q] + bufoff;
           asm volatile("" : "+v"(aaddr[khp][kw][q]));       // one address register per variant, tap offset = immediate
         }
+    long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (a.probe) ts0 = __builtin_readcyclecounter();
     h2_read_a_tap<0>(c.lds3, aaddr, a0);
 
     // next stage: next chunk of this tile, else chunk 0 of the block's next item
@@ -203,83 +296,17 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     c.dm.b = tn.b; c.dm.d0 = tn.d0; c.dm.h0 = tn.h0; c.dm.wbase = tn.w0 > 0 ? tn.w0 - 1 : 0;
     c.dm.ch = chn; c.dm.ldsbuf = (unsigned)PIPE_BUF_BYTES - bufoff; c.dm.live = c.has_next;
 
+    c.tap_probe = (a.probe && blockIdx.x == 17 && stage == 3) ? a.probe + 256 * 8 * 16 * 4 : nullptr;
     h2_step<NT, 0>(a, c, aaddr, a0, a1, b0, b1, b2, acc);
+    if (a.probe) ts1 = __builtin_readcyclecounter();
 
     __builtin_amdgcn_s_waitcnt(0);     // my DMA rows of the next stage have landed
     __syncthreads();                   // everyone's have; everyone is done with this buffer
+    if (a.probe) ts2 = __builtin_readcyclecounter();
 
     if (ch == nchunk - 1) {
-      // ---- epilogue: y = acc*scale + bias (+residual) (ReLU); lane = one voxel per M-tile, 16 channels per N-tile
-      const int od = t.d0 + wave;
-      const unsigned out_vox = (unsigned)((size_t)a.B * a.Do * a.Ho * a.Wo);
-      const float* sb = lds + H2_SB_OFF / 4;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n0 = (t.ng * NT + nt) * 32;
-        const bool to_y0 = n0 < a.cout0;
-        float* dst = to_y0 ? a.y0 : a.y1;
-        if (dst == nullptr) continue;
-        const int stride = to_y0 ? a.cout0 : a.cout1;
-        const int ld = to_y0 ? a.ld0 : a.ld1;
-        const int col0 = to_y0 ? n0 : n0 - a.n1_start;
-        if (col0 < 0 || col0 >= stride) continue;
-        const int fmt = to_y0 ? a.fmt_y0 : a.fmt_y1;
-        const float lo_clamp = (to_y0 ? a.relu0 : a.relu1) ? 0.f : -3.402823466e38f;
-        const bool has_res = to_y0 && a.residual != nullptr;
-        const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)ld * 4u);
-        const rsrc_t rr = make_rsrc(has_res ? a.residual : dst, out_vox * (unsigned)ld * 4u);
-        v4f sc[4], bi[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          sc[g] = *reinterpret_cast<const v4f*>(sb + n0 + 8 * g + 4 * half);
-          bi[g] = *reinterpret_cast<const v4f*>(sb + H2_MAX_COUT + n0 + 8 * g + 4 * half);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const bool ok = od < a.Do && (t.h0 + mt * 4 + pr) < a.Ho && (t.w0 + pc) < a.Wo;
-          const unsigned soff = (unsigned)(((((t.b * a.Do + od) * a.Ho + (t.h0 + mt * 4)) * a.Wo + t.w0) * ld) * 4);
-          const unsigned vox = (unsigned)((pr * a.Wo + pc) * ld) * 4u + (unsigned)col0 * 4u;
-          // residual values first (fp32: 4 x 16 B; h2: 4 x (8 + 8) B), then the math, then the stores
-          float rv[4][4];
-          if (has_res) {
-            if (a.fmt_res == 0) {
-              const unsigned base = ok ? vox + (unsigned)(16 * half) : PIPE_OOB;
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const float4 r4 = buf_load4(rr, base + (unsigned)(32 * g), soff);
-                rv[g][0] = r4.x; rv[g][1] = r4.y; rv[g][2] = r4.z; rv[g][3] = r4.w;
-              }
-            } else {
-              const unsigned base = ok ? vox + (unsigned)(8 * half) : PIPE_OOB;
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const unsigned so = (unsigned)((4 * (g & 1) + 2 * (g >> 1)) * 16);
-                const u2 hi = buf_load2(rr, base + so, soff), lo = buf_load2(rr, base + so + 16u, soff);
-                h2_join4(hi, lo, rv[g]);
-              }
-            }
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = acc[mt][nt][4 * g + e] * sc[g][e] + bi[g][e];
-              if (has_res) v[e] += rv[g][e];
-              v[e] = fmaxf(v[e], lo_clamp);
-            }
-            if (fmt == 0) {
-              buf_store4(yr, ok ? vox + (unsigned)(16 * half + 32 * g) : PIPE_OOB, soff, v);
-            } else {
-              u2 hi, lo;
-              h2_split4(v, hi, lo);
-              const unsigned o = ok ? vox + (unsigned)(8 * half + (4 * (g & 1) + 2 * (g >> 1)) * 16) : PIPE_OOB;
-              buf_store2(yr, o, soff, hi);
-              buf_store2(yr, ok ? o + 16u : PIPE_OOB, soff, lo);
-            }
-          }
-        }
-      }
+      // ---- epilogue (staging rows = the halo rows of the consumed buffer this wave itself refills next stage)
+      h2_epilogue<NT>(a, acc, lds + H2_SB_OFF / 4, reinterpret_cast<char*>(lds) + bufoff + (unsigned)wave * (TW * 128), t.b, t.d0, t.h0, t.w0, t.ng, wave, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -287,8 +314,102 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     }
+    if (a.probe && lane == 0 && stage < 16) {   // {stage start, taps done, barrier passed, epilogue done}
+      long long* pp = a.probe + (((size_t)blockIdx.x * 8 + wave) * 16 + stage) * 4;
+      pp[0] = ts0; pp[1] = ts1; pp[2] = ts2; pp[3] = __builtin_readcyclecounter();
+    }
     if (!c.has_next) break;
     t = tn; ch = chn; item = itemn;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// tile-per-block variant: one 4x8x8 tile x N-group per 4-wave block, single 76.8 KB halo buffer -> TWO blocks per CU.
+// Nothing is pipelined inside a block (halo DMA burst -> wait -> 27 taps -> epilogue per chunk); the two resident
+// blocks drift apart so that one block's DMA wait / epilogue overlaps the other's MFMA phase (on the fp16 matrix
+// cores the sibling wave's VALU / VMEM instructions do issue beside an MFMA stream).
+// ------------------------------------------------------------------------------------
+template <int NT, int TAP>
+__device__ __forceinline__ void h2_tile_step(lds3_t lds3, rsrc_t wr, unsigned wsoff, unsigned wstride, unsigned lane_off,
+                                             const unsigned (&aaddr)[2][3][4], v4f (&ac)[2][4], v4f (&an)[2][4],
+                                             v4f (&b0)[NT][4], v4f (&b1)[NT][4], f32x16 (&acc)[2][NT]) {
+  if constexpr (TAP + 1 < 27) {
+    h2_load_b<NT>(wr, wsoff + (unsigned)(TAP + 1) * wstride, lane_off, b1);
+    h2_read_a_tap<TAP + 1>(lds3, aaddr, an);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  h2_mfma<NT>(ac, b0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TAP + 1 < 27) h2_tile_step<NT, TAP + 1>(lds3, wr, wsoff, wstride, lane_off, aaddr, an, ac, b1, b0, acc);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2) k_conv3d_h2_tile(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int half = lane >> 5, j = lane & 31;
+  const int ng = blockIdx.y;
+  const int pj = patch_of_row(j), pr = pj >> 3, pc = pj & 7;
+  const int ntiles_total = a.cout_total >> 5;
+  const int nchunk = a.Cin / KC;
+  unsigned aaddr[2][3][4];
+#pragma unroll
+  for (int khp = 0; khp < 2; ++khp)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ww = pc + kw;
+      const int f = ((ww >> 1) & 3) | (((pr + khp) & 1) << 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        aaddr[khp][kw][q] = (unsigned)((((wave * TH + pr) * TW + ww) * 8 + ((half * 4 + q) ^ f)) * 16);
+    }
+  const unsigned lane_off = (unsigned)lane * 64u;
+  const unsigned wstride = (unsigned)ntiles_total * 4096u;
+  const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
+  const rsrc_t wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 27 * ntiles_total * 4096));
+  const lds3_t lds3 = (lds3_t)lds;
+
+  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int tw = bid % a.tiles_w; bid /= a.tiles_w;
+  const int th = bid % a.tiles_h; bid /= a.tiles_h;
+  const int td = bid % a.tiles_d;
+  const int b = bid / a.tiles_d;
+  const int d0 = td * BD, h0 = th * BH, w0 = tw * BW;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (a.probe) ts0 = __builtin_readcyclecounter();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const unsigned wsoff = (unsigned)((ch * 27 * ntiles_total + ng * NT) * 4096);
+    v4f a0[2][4], a1[2][4], b0[NT][4], b1[NT][4];
+    h2_load_b<NT>(wr, wsoff, lane_off, b0);
+    stage_halo_chunk_dma(a, xr, lds, b, d0, h0, w0, ch, wave, lane);
+    if (a.probe && ch == 0) ts1 = __builtin_readcyclecounter();
+    h2_read_a_tap<0>(lds3, aaddr, a0);
+    h2_tile_step<NT, 0>(lds3, wr, wsoff, wstride, lane_off, aaddr, a0, a1, b0, b1, acc);
+  }
+  if (a.probe) ts2 = __builtin_readcyclecounter();
+
+  // every wave is done with the halo buffer; scale / bias go to the tail of it, the accumulators to this wave's rows
+  __syncthreads();
+  float* sb = lds + (PIPE_BUF_BYTES - 2 * H2_MAX_COUT * 4) / 4;      // rows 58, 59 (never staging rows: those end at 31)
+  for (int n = tid; n < a.cout_total; n += 256) {
+    sb[n] = a.scale ? a.scale[n] : 1.f;
+    sb[H2_MAX_COUT + n] = a.bias ? a.bias[n] : 0.f;
+  }
+  __syncthreads();
+  h2_epilogue<NT>(a, acc, sb, reinterpret_cast<char*>(lds) + (unsigned)wave * (TW * 128), b, d0, h0, w0, ng, wave, lane);
+  if (a.probe && lane == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+    long long* pp = a.probe + ((size_t)blockIdx.x * 4 + wave) * 4;
+    pp[0] = ts0; pp[1] = ts1; pp[2] = ts2; pp[3] = __builtin_readcyclecounter();
   }
 }
 
@@ -352,8 +473,11 @@ PW_API int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x
 // ------------------------------------------------------------------------------------ host entry
 PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* residual,
                         float* y0, float* y1, int B, int D, int H, int W, int Cin, int cout_total, int cout0, int cout1,
-                        int ld_y0, int ld_y1, int relu0, int relu1, int fmt_y0, int fmt_y1, int fmt_res, void* stream) {
+                        int ld_y0, int ld_y1, int ksize, int stride, int relu0, int relu1, int algo, int fmt_y0, int fmt_y1,
+                        int fmt_res, void* stream) {
   PW_CHECK_ARG(x && wpk && y0, "pw_conv3d_h2: null pointer");
+  PW_CHECK_ARG((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1),
+               "pw_conv3d_h2: 3x3x3 stride 1 / 2 and 1x1x1 stride 1 are built");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "pw_conv3d_h2: bad shape");
   PW_CHECK_ARG(Cin > 0 && Cin % KC == 0, "pw_conv3d_h2: Cin must be a multiple of 32 (got %d)", Cin);
   PW_CHECK_ARG(cout_total > 0 && cout_total % 32 == 0 && cout_total <= H2_MAX_COUT,
@@ -366,7 +490,9 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
   PW_CHECK_ARG((unsigned)fmt_y0 < 2 && (unsigned)fmt_y1 < 2 && (unsigned)fmt_res < 2, "pw_conv3d_h2: formats are 0 (fp32) or 1 (h2)");
   ConvArgs a = {};
   a.x = x; a.wpk = wpk; a.scale = scale; a.bias = bias; a.residual = residual; a.y0 = y0; a.y1 = y1;
-  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Do = D; a.Ho = H; a.Wo = W;
+  const int pad = (ksize - 1) / 2;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin;
+  a.Do = (D + 2 * pad - ksize) / stride + 1; a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
   a.cout_total = cout_total; a.cout0 = cout0; a.cout1 = cout1;
   a.ld0 = ld_y0 > 0 ? ld_y0 : cout0; a.ld1 = ld_y1 > 0 ? ld_y1 : cout1;
   PW_CHECK_ARG(a.ld0 >= cout0 && a.ld1 >= cout1 && a.ld0 % 32 == 0 && a.ld1 % 32 == 0,
@@ -374,18 +500,45 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
   a.n1_start = cout0;
   a.relu0 = relu0; a.relu1 = relu1;
   a.fmt_y0 = fmt_y0; a.fmt_y1 = fmt_y1; a.fmt_res = fmt_res;
-  if (const char* e = getenv("PW_H2_DEBUG")) a.dma_stage = atoi(e);     // TEMP sensitivity runs
-  a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
+  if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
+  a.tiles_d = (a.Do + BD - 1) / BD; a.tiles_h = (a.Ho + BH - 1) / BH; a.tiles_w = (a.Wo + BW - 1) / BW;
   PW_CHECK_ARG((size_t)B * D * H * W * Cin * 4 < (1ull << 32) &&
-                   (size_t)B * D * H * W * (a.ld0 > a.ld1 ? a.ld0 : a.ld1) * 4 < (1ull << 32),
+                   (size_t)B * a.Do * a.Ho * a.Wo * (a.ld0 > a.ld1 ? a.ld0 : a.ld1) * 4 < (1ull << 32),
                "pw_conv3d_h2: tensors must be < 4 GiB (32-bit buffer addressing)");
   const int ntiles = cout_total / 32;
   const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
+  if (!(ksize == 3 && stride == 1) || algo == 2 || algo == 3) {
+    // stride-2 / 1x1x1 (and, on request, tiny 3x3x3 grids): the gather kernel with split-fp16 operands
+    const int NTg = (ntiles % 2 == 0) ? 2 : 1;
+    const long long n_out = (long long)B * a.Do * a.Ho * a.Wo;
+    if (int rc = pw_launch_conv3d_gather(a, NTg, ntiles / NTg, ksize, stride, algo, Cin, n_out, pw_stream(stream), true)) return rc;
+    PW_CHECK_LAUNCH();
+    return PW_OK;
+  }
   // two N-tiles per wave (A fragments shared) when that still leaves every CU two or more work items
   int NT = (ntiles % 2 == 0 && nblk * (ntiles / 2) >= 2 * pw_num_cus()) ? 2 : 1;
   if (const char* e = getenv("PW_H2_NT")) {          // experiments only
     const int f = atoi(e);
     if ((f == 1 || f == 2) && ntiles % f == 0) NT = f;
+  }
+  if (const char* e = getenv("PW_H2_TILE")) {
+    if (atoi(e)) {
+      hipStream_t st = pw_stream(stream);
+      dim3 grid((unsigned)nblk, (unsigned)(ntiles / NT));
+      if (NT == 2) {
+        static int once = set_lds_limit(k_conv3d_h2_tile<2>, PIPE_BUF_BYTES);
+        if (once) return once;
+        hipLaunchKernelGGL(k_conv3d_h2_tile<2>, grid, dim3(256), PIPE_BUF_BYTES, st, a);
+        pw_note_kernel("k_conv3d_h2_tile<2>");
+      } else {
+        static int once = set_lds_limit(k_conv3d_h2_tile<1>, PIPE_BUF_BYTES);
+        if (once) return once;
+        hipLaunchKernelGGL(k_conv3d_h2_tile<1>, grid, dim3(256), PIPE_BUF_BYTES, st, a);
+        pw_note_kernel("k_conv3d_h2_tile<1>");
+      }
+      PW_CHECK_LAUNCH();
+      return PW_OK;
+    }
   }
   PipeArgs p;
   p.ngroups = ntiles / NT;

@@ -56,12 +56,23 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
       aq[q] = *reinterpret_cast<const float4*>(src + q * 4);
       bq[q] = *reinterpret_cast<const float4*>(wt + q * 4);
     }
+    if (a.dma_stage) {
+      // x8 and wpk8 in split-fp16 storage (pw_h2.h): the lane's four 16-byte pieces are {hi, lo} x {k-step 0, 1}
+      typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fh8, aq[2 * ks]), __builtin_bit_cast(fh8, bq[2 * ks]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fh8, aq[2 * ks]), __builtin_bit_cast(fh8, bq[2 * ks + 1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fh8, aq[2 * ks + 1]), __builtin_bit_cast(fh8, bq[2 * ks]), acc, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float av[4] = {aq[q].x, aq[q].y, aq[q].z, aq[q].w};
       const float bv[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+    }
     }
   }
   const float sc = a.scale ? a.scale[i] : 1.f;
@@ -125,7 +136,8 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
       v += lerp_w(c4, f.W4, sw4, wb4, ow0 + row);
       v = v * sc + bi;
       if (a.relu0) v = fmaxf(v, 0.f);
-      out[(unsigned)row * 32u] = v;
+      if (a.fmt_y0) h2_store_elem(a.y0 + (size_t)(m0 + row) * 32, i, v);
+      else out[(unsigned)row * 32u] = v;
     }
     return;
   }
@@ -147,7 +159,8 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
       v += trilerp_ac(f.y32, b, f.D4, f.H4, f.W4, sd4, sh4, sw4, od, oh, ow, i);
       v = v * sc + bi;
       if (a.relu0) v = fmaxf(v, 0.f);
-      a.y0[(size_t)vox * 32 + i] = v;
+      if (a.fmt_y0) h2_store_elem(a.y0 + (size_t)vox * 32, i, v);
+      else a.y0[(size_t)vox * 32 + i] = v;
     }
   }
 }
@@ -155,13 +168,15 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
 PW_API int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const float* y32,
                          const float* scale, const float* bias, float* out, int B, int D, int H,
                          int W, int Cin8, int D2, int H2, int W2, int D4, int H4, int W4, int relu,
-                         void* stream) {
+                         int x_h2, int out_h2, void* stream) {
   PW_CHECK_ARG(x8 && wpk8 && y16 && y32 && out, "pw_fpn3d_fuse: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin8 > 0 && Cin8 % 32 == 0, "pw_fpn3d_fuse: bad shape");
   PW_CHECK_ARG(D2 > 0 && H2 > 0 && W2 > 0 && D4 > 0 && H4 > 0 && W4 > 0, "pw_fpn3d_fuse: bad level shape");
   ConvArgs a = {};
   a.x = x8; a.wpk = wpk8; a.scale = scale; a.bias = bias; a.y0 = out;
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin8; a.relu0 = relu; a.cout_total = 32; a.cout0 = 32; a.ld0 = 32;
+  a.dma_stage = x_h2 ? 1 : 0;          // reused as the input-format flag: x8 and wpk8 are split-fp16
+  a.fmt_y0 = out_h2 ? 1 : 0;
   FpnArgs f = {y16, y32, D2, H2, W2, D4, H4, W4};
   const long long n = (long long)B * D * H * W;
   PW_CHECK_ARG(n < (1ll << 31), "pw_fpn3d_fuse: more than 2^31 voxels");

@@ -18,6 +18,7 @@
 //     with float4 gathers of feat, and writes the (Z,Y,X,C) row once (sum or zeros):
 //     coalesced 1 KiB per wave-store, no memset pass, no permute pass.
 #include "pw_common.h"
+#include "pw_h2.h"
 
 // ------------------------------------------------------------------------------------
 // camera matrices (closed-form 3x3 inverse, same op order as oracle inv3x3_f32)
@@ -532,13 +533,29 @@ __device__ __forceinline__ void fma4_nc(float4& acc, const float4& f, float d) {
 // coalesced go, then broadcast lane by lane so the sum keeps its sequential point order.
 constexpr int LONG_BLOCKS = 128;    // x 4 waves
 
+// one lane's 4 channels (quad `sub`) of voxel row v: fp32, or split-fp16 (h2, pw_h2.h) for the fp16-matrix-core encoder
+template <int LPV>
+__device__ __forceinline__ void pool_store(float4* __restrict__ out, int64_t v, int sub, const float4& acc, int out_h2) {
+  if (!out_h2) {
+    out[v * LPV + sub] = acc;
+  } else {
+    const float f[4] = {acc.x, acc.y, acc.z, acc.w};
+    u2 hi, lo;
+    h2_split4(f, hi, lo);
+    char* row = reinterpret_cast<char*>(out + v * LPV) + (sub >> 3) * 128;
+    const int c = (sub & 7) * 4;
+    *reinterpret_cast<u2*>(row + h2_group_off(c, 0)) = hi;
+    *reinterpret_cast<u2*>(row + h2_group_off(c, 1)) = lo;
+  }
+}
+
 template <int LPV>
 __global__ void __launch_bounds__(256)
 k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
              const int32_t* __restrict__ seg_start, const int32_t* __restrict__ order,
              const int32_t* __restrict__ order_feat, int64_t n_voxels, int long_threshold,
              const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
-             float4* __restrict__ out) {
+             float4* __restrict__ out, int out_h2) {
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPV;
   const int long_blocks = long_list ? LONG_BLOCKS : 0;
@@ -593,7 +610,7 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
           }
         }
       }
-      if (lane < LPV) out[v * LPV + sub] = acc;     // every lane group holds the same sums
+      if (lane < LPV) pool_store<LPV>(out, v, sub, acc, out_h2);     // every lane group holds the same sums
     }
     return;
   }
@@ -657,7 +674,7 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
           if (u < rc) fma4_nc(acc, feat[(int64_t)pf * LPV + sub], d);
         }
       }
-      out[v * LPV + sub] = acc;
+      pool_store<LPV>(out, v, sub, acc, out_h2);
     }
     v = vn; s = sn; e = en; my_pf = n_pf; my_o = n_o;
   }
@@ -746,9 +763,10 @@ static bool lpv_supported(int c) {
 PW_API int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_start,
                              const int32_t* order, const int32_t* order_feat, int64_t n_voxels,
                              int c, int long_threshold, const int32_t* long_list,
-                             const int32_t* n_long, float* out, void* stream) {
+                             const int32_t* n_long, float* out, int out_h2, void* stream) {
   PW_CHECK_ARG(depth && feat && seg_start && order && order_feat && out && n_voxels > 0 && c > 0,
                "pw_bev_pool_dense: bad arguments");
+  PW_CHECK_ARG(!out_h2 || (c % 32 == 0 && lpv_supported(c)), "pw_bev_pool_dense: h2 output needs C %% 32 == 0");
   PW_CHECK_ARG(!long_list || (n_long && long_threshold > 0), "pw_bev_pool_dense: long_list needs n_long");
   hipStream_t st = pw_stream(stream);
   if (lpv_supported(c) && ((uintptr_t)feat & 15) == 0 && ((uintptr_t)out & 15) == 0) {
@@ -759,7 +777,7 @@ PW_API int pw_bev_pool_dense(const float* depth, const float* feat, const int32_
     PW_DISPATCH_LPV(lpv, hipLaunchKernelGGL((k_pool_dense<L>), dim3(nb), dim3(256), 0, st, depth,
                                             (const float4*)feat, seg_start, order, order_feat,
                                             n_voxels, long_threshold, long_list, n_long,
-                                            (float4*)out));
+                                            (float4*)out, out_h2));
     pw_note_kernel("k_pool_dense<%d>", lpv);
   } else {
     hipLaunchKernelGGL(k_pool_dense_generic, dim3((unsigned)pw_cdiv(n_voxels * c, 256)), dim3(256),

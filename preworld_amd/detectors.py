@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import builder, ops
-from .modules import (ConvModule3d, DownScaleModule3DCustom, _PackedCache, to_channels_last_3d)
+from .modules import (ConvModule3d, DownScaleModule3DCustom, _PackedCache, as_f32, precision, to_channels_last_3d)
 
 
 class BEVStereo4DOCC(nn.Module):
@@ -147,7 +147,7 @@ class BEVStereo4DOCC(nn.Module):
     @torch.no_grad()
     def extract_img_feat(self, img_inputs, img_metas=None, **kwargs):
         frames = self.lift_inputs_from_images(img_inputs)
-        x_cl = self.extract_bev_feat_cl(frames)
+        x_cl = as_f32(self.extract_bev_feat_cl(frames))
         return [x_cl.permute(0, 4, 1, 2, 3)], frames[0]['depth']
 
     # ---- bevdet.py:139-175: the test-time entry the runner calls (`model(return_loss=False, **data)`)
@@ -173,53 +173,59 @@ class BEVStereo4DOCC(nn.Module):
                                   'register with inference_only=False to keep the reference class for training')
 
     # ---- bevdet.py:52-58
-    def bev_encoder_cl(self, x_cl):
-        return self.img_bev_encoder_neck.forward_cl(self.img_bev_encoder_backbone.forward_cl(x_cl))
+    def bev_encoder_cl(self, x_cl, out_h2=False):
+        h2 = precision() == 'h2'
+        feats = self.img_bev_encoder_backbone.forward_cl(x_cl, keep_h2=h2)
+        return self.img_bev_encoder_neck.forward_cl(feats, out_h2=out_h2)
 
     # ---- bevdet_occ.py:141-165 minus the image encoder / DepthNet
-    def lift_frame_cl(self, depth, tran_feat, sensor2keyego, intrin, post_rot, post_tran, bda, out=None):
+    def lift_frame_cl(self, depth, tran_feat, sensor2keyego, intrin, post_rot, post_tran, bda, out=None, out_h2=False):
+        """one frame: voxel pooling + pre_process_net -> channels-last (B,Z,Y,X,C) fp32 (or ops.H2 with out_h2), written
+        into `out` (a channel slice of the [adjacent, key] buffer) when given"""
         vt = self.img_view_transformer
         B, N = sensor2keyego.shape[:2]
         H, W = depth.shape[-2:]
         inp = [depth.new_empty(B, N, 1, H, W), sensor2keyego, None, intrin, post_rot, post_tran, bda]
-        keep = vt.collapse_z
-        vt.collapse_z = False
-        try:
-            bev, _ = vt.view_transform(inp, depth, tran_feat)
-        finally:
-            vt.collapse_z = keep
-        x = to_channels_last_3d(bev)
+        h2 = precision() == 'h2' and vt.out_channels % 32 == 0
+        x = vt.pool_cl(inp, depth, tran_feat, out_h2=h2)
         if self.pre_process:
-            x = self.pre_process_net.forward_cl(x, out_last=out)[0]
-        elif out is not None:
-            out.copy_(x)
-            x = out
-        return x
+            return self.pre_process_net.forward_cl(x, out_last=out, keep_h2=out_h2)[0]
+        if out is not None:
+            dst = out.buf if isinstance(out, ops.H2) else out
+            src = x if isinstance(x, ops.H2) == out_h2 else (ops.f32_to_h2(x) if out_h2 else as_f32(x))
+            dst.copy_(src.buf if isinstance(src, ops.H2) else src)
+            return ops.H2(dst) if out_h2 else dst
+        return x if isinstance(x, ops.H2) == out_h2 else (ops.f32_to_h2(x) if out_h2 else as_f32(x))
 
     # ---- bevdet_occ.py:167-269 (frame loop, [adj, key] concat, with_prev=False -> zeros)
-    def extract_bev_feat_cl(self, frames):
+    def extract_bev_feat_cl(self, frames, out_h2=False):
         """frames: list ordered [key, adj, ...] of dicts(depth, tran_feat, sensor2keyego, intrin,
         post_rot, post_tran, bda).  Returns the bev_encoder output, channels-last (B,Z,Y,X,C)."""
         # channel order [adjacent ..., key] (bevdet_occ.py:266): every frame's pre_process output is
-        # written straight into its channel slice of ONE buffer (row stride n*C), no torch.cat copy
+        # written straight into its channel slice of ONE buffer (row stride n*C), no torch.cat copy.
+        # In the 'h2' precision that buffer is in split-fp16 storage (an all-zero slice is zeros there too).
         f0 = frames[0]
         B = f0['sensor2keyego'].shape[0]
         _, _, size = self.img_view_transformer._grid()
         C = self.img_view_transformer.out_channels
         n = self.num_adj + 1
+        h2 = precision() == 'h2' and C % 32 == 0
         x = torch.empty(B, size[2], size[1], size[0], n * C, device=f0['depth'].device, dtype=torch.float32)
-        self.lift_frame_cl(out=x[..., (n - 1) * C:], **f0)
+
+        def sl(lo, hi):
+            return ops.H2(x[..., lo:hi]) if h2 else x[..., lo:hi]
+        self.lift_frame_cl(out=sl((n - 1) * C, n * C), out_h2=h2, **f0)
         for j in range(self.num_adj):                      # adjacent frame j+1 sits left of frame j
-            sl = x[..., (n - 2 - j) * C:(n - 1 - j) * C]
+            lo, hi = (n - 2 - j) * C, (n - 1 - j) * C
             if self.with_prev and len(frames) > 1 + j:
-                self.lift_frame_cl(out=sl, **frames[1 + j])
+                self.lift_frame_cl(out=sl(lo, hi), out_h2=h2, **frames[1 + j])
             else:
-                sl.zero_()
-        return self.bev_encoder_cl(x)
+                x[..., lo:hi].zero_()
+        return self.bev_encoder_cl(ops.H2(x) if h2 else x, out_h2=out_h2)
 
     def extract_voxel_feat_cl(self, frames):
         """... followed by final_conv: conv + bias + ReLU (preworld.py:72-79), channels-last (B,Z,Y,X,out_dim)."""
-        return self.final_conv.forward_cl(self.extract_bev_feat_cl(frames))
+        return self.final_conv.forward_cl(self.extract_bev_feat_cl(frames, out_h2=precision() == 'h2'))
 
     # ---- bevdet_occ.py:281-301: final_conv -> predicter MLP -> argmax(softmax) (softmax is monotone: argmax of logits)
     @torch.no_grad()

@@ -98,20 +98,27 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
     frames: their channel slice is zeros (bevdet_occ.py:243-258), exactly as in extract_bev_feat_cl.
     gather_on_host=True moves the 0.64 MB grids through host memory (for process groups that cannot all_gather device
     tensors: gloo in the tests; RCCL takes device tensors)."""
-    from . import parallel
+    from . import ops, parallel
+    from .modules import precision
     vt = net.img_view_transformer
     _, _, size = vt._grid()
     f0 = frames[0]
     B, C = f0['sensor2keyego'].shape[0], vt.out_channels
     n = net.num_adj + 1
     use = frames[:n] if net.with_prev else frames[:1]
-    lifted = parallel.lift_frames_sharded(use, lambda fr: net.lift_frame_cl(**fr),
-                                          (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device, group,
-                                          via_host=gather_on_host)
+    # same storage as the single-process path: in the 'h2' precision the exchanged features are the split-fp16 buffers
+    # themselves (same shape and byte count as fp32), so every rank continues with exactly the single-process bits
+    h2 = precision() == 'h2' and C % 32 == 0
+
+    def lift(fr):
+        y = net.lift_frame_cl(out_h2=h2, **fr)
+        return y.buf if h2 else y
+    lifted = parallel.lift_frames_sharded(use, lift, (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device,
+                                          group, via_host=gather_on_host)
     x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                       # [adjacent ..., key] (bevdet_occ.py:266)
     if len(lifted) < n:
         x = torch.cat([x.new_zeros(x.shape[:-1] + ((n - len(lifted)) * C,)), x], dim=-1)
-    v0 = net.final_conv.forward_cl(net.bev_encoder_cl(x))
+    v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.H2(x) if h2 else x, out_h2=h2))
 
     def decode(f):
         occ = net.occupancy_head.decode_cl(f, transposed=True)

@@ -146,7 +146,7 @@ class LSSViewTransformer(nn.Module):
                 bev = ops.bev_pool_v2(dep, feat, rd, rf, rb,
                                       (B, size[2], size[1], size[0], self.out_channels), st, ln)
         else:
-            out = ops.bev_pool_dense(dep, feat, vs)
+            out = ops.bev_pool_dense(dep, feat, vs, out_h2=getattr(self, '_pool_h2', False))
             bev = out.view(B, size[2], size[1], size[0], self.out_channels).permute(0, 4, 1, 2, 3)
         if self.collapse_z:
             bev = torch.cat(bev.unbind(dim=2), 1)
@@ -156,6 +156,20 @@ class LSSViewTransformer(nn.Module):
         if self.accelerate:
             self.pre_compute(input)
         return self.view_transform_core(input, depth, tran_feat)
+
+    def pool_cl(self, input, depth, tran_feat, out_h2=False):
+        """view_transform without the (B,C,Z,Y,X) view: the pooled channels-last (B,Z,Y,X,C) buffer itself, as fp32 or
+        (out_h2, inference, C % 32 == 0) as ops.H2 -- the same fp32 sums written in the split-fp16 storage the encoder's
+        first convolution consumes, so no conversion pass runs between pooling and pre_process."""
+        keep, self.collapse_z = self.collapse_z, False
+        self._pool_h2 = bool(out_h2) and not (torch.is_grad_enabled() and (depth.requires_grad or tran_feat.requires_grad))
+        try:
+            bev, _ = self.view_transform(input, depth, tran_feat)
+        finally:
+            self.collapse_z = keep
+            h2, self._pool_h2 = self._pool_h2, False
+        x = to_channels_last_3d(bev)
+        return ops.H2(x) if h2 else x
 
     def forward(self, input):
         x = input[0]
@@ -250,6 +264,24 @@ def from_channels_last_3d(y):
     return y.permute(0, 4, 1, 2, 3)
 
 
+def precision():
+    """'h2' (default): the voxel encoder's convolutions run on the fp16 matrix cores with split-fp16 operands
+    (ops.conv3d_h2: x = hi + lo, three MFMAs per product block, fp32 accumulate -- as accurate as an fp32 FMA chain,
+    DESIGN.md section 5.2) and activations travel between them in h2 storage; 'f32' (PW_PRECISION=f32): the exact-fp32
+    MFMA kernels (Winograd / direct) of round 1."""
+    import os
+    return os.environ.get('PW_PRECISION', 'h2')
+
+
+def as_h2(x):
+    """fp32 channels-last tensor or ops.H2 -> ops.H2 (one conversion pass if needed)"""
+    return x if isinstance(x, ops.H2) else ops.f32_to_h2(x.contiguous())
+
+
+def as_f32(x):
+    return ops.h2_to_f32(x) if isinstance(x, ops.H2) else x
+
+
 def _use_wino(x_cl, cout_total, ksize, stride):
     """3x3x3 stride-1 convs whose (4x8x8 tile, 32-column group) work items number >= 128 run on the Winograd
     F(2x2x2,3x3x3) kernel (pw_conv3d_wino: 3.4x fewer multiplies, 1.7-2.2x faster than the direct MFMA
@@ -320,14 +352,38 @@ class ConvModule3d(nn.Module):
             return wpk, ops._pad32(sc, 1.0), ops._pad32(bi, 0.0)
         return self._cache.get(params, build)
 
+    def folded_h2(self):
+        """(split-fp16 packed weight, scale * weight pre-scale, bias) for ops.conv3d_h2."""
+        params = [self.conv.weight, self.conv.bias]
+        if self.with_norm:
+            params += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        if not hasattr(self, '_h2cache'):
+            self._h2cache = _PackedCache()
+
+        def build():
+            _, sc, bi = self.folded()
+            wpk, inv = ops.pack_conv_weight_h2(self.conv.weight)
+            return wpk, (sc * inv).contiguous(), bi
+        return self._h2cache.get(params, build)
+
     def _check_eval(self):
         if self.training and self.with_norm:
             raise NotImplementedError('HIP voxel encoder runs BatchNorm in eval mode only '
                                       '(call .eval()); training-mode BN is not built yet')
 
-    def forward_cl(self, x_cl, residual=None, algo=0):
-        """channels-last in -> channels-last out"""
+    def forward_cl(self, x_cl, residual=None, algo=0, out_h2=False):
+        """channels-last in (fp32 tensor or ops.H2) -> channels-last out (fp32, or ops.H2 with out_h2)"""
         self._check_eval()
+        if precision() == 'h2' and self.kernel_size in (1, 3) and self.out_channels % 32 == 0 and algo in (0, 2, 3):
+            wpk, sc, bi = self.folded_h2()
+            return ops.conv3d_h2(as_h2(x_cl), wpk, sc, bi, residual=residual, cout0=self.out_channels,
+                                 relu0=self.with_activation, ksize=self.kernel_size, stride=self.stride, algo=algo,
+                                 out_h2=(out_h2, out_h2))
+        x_cl, residual = as_f32(x_cl), (as_f32(residual) if residual is not None else None)
+        y = self._forward_cl_f32(x_cl, residual, algo)
+        return as_h2(y) if out_h2 else y
+
+    def _forward_cl_f32(self, x_cl, residual=None, algo=0):
         wpk, sc, bi = self.folded()
         if algo == 0 and _use_wino(x_cl, sc.numel(), self.kernel_size, self.stride):
             uw = self._wcache.get([self.conv.weight], lambda: ops.pack_conv_weight_wino(self.conv.weight))
@@ -356,9 +412,60 @@ class BasicBlock3D(nn.Module):
         self.downsample = downsample
         self._cache = _PackedCache()
 
-    def forward_cl(self, x, out=None):
-        """out: optional destination (a channel slice of a wider channels-last buffer is fine); the
-        downsample branch is then written there first and conv2 adds onto it in place."""
+    def forward_cl(self, x, out=None, out_h2=False):
+        """x: fp32 channels-last tensor or ops.H2.  out: optional destination (a channel slice of a wider channels-last
+        buffer is fine; an ops.H2 when out_h2); the downsample branch is then written there first and conv2 adds onto it
+        in place.  Returns fp32, or ops.H2 with out_h2."""
+        if precision() == 'h2':
+            return self._forward_cl_h2(x, out, out_h2)
+        x = as_f32(x)
+        if out_h2:
+            return as_h2(self._forward_cl_f32(x, None)) if out is None else self._forward_f32_into_h2(x, out)
+        return self._forward_cl_f32(x, out.buf if isinstance(out, ops.H2) else out)
+
+    def _forward_f32_into_h2(self, x, out):
+        y = self._forward_cl_f32(x, None)
+        ops.f32_to_h2(y, out=out.buf)
+        return out
+
+    def _forward_cl_h2(self, x, out, out_h2):
+        """split-fp16 path: conv1 + downsample as ONE pass over x (N = 2 x Cout), everything between the convs in h2"""
+        c1, c2, ds = self.conv1, self.conv2, self.downsample
+        c1._check_eval()
+        x = as_h2(x)
+        dst = out.buf if isinstance(out, ops.H2) else out
+        if ds is not None:
+            params = [c1.conv.weight, c1.bn.weight, c1.bn.bias, c1.bn.running_mean, c1.bn.running_var,
+                      ds.conv.weight, ds.bn.weight, ds.bn.bias, ds.bn.running_mean, ds.bn.running_var]
+            if not hasattr(self, '_h2cache'):
+                self._h2cache = _PackedCache()
+
+            def build():
+                w1, s1, b1 = c1.folded_h2()
+                wd, sd, bd = ds.folded_h2()
+                return (torch.cat([w1, wd], dim=2).contiguous(), torch.cat([s1, sd]).contiguous(),
+                        torch.cat([b1, bd]).contiguous())
+            wpk, sc, bi = self._h2cache.get(params, build)
+            y, identity = ops.conv3d_h2(x, wpk, sc, bi, cout0=c1.out_channels, cout1=ds.out_channels, relu0=True, relu1=False,
+                                        out1=dst, ksize=3, stride=c1.stride, out_h2=(True, out_h2))
+        else:
+            w1, s1, b1 = c1.folded_h2()
+            y = ops.conv3d_h2(x, w1, s1, b1, cout0=c1.out_channels, relu0=True, ksize=3, stride=c1.stride, out_h2=(True, True))
+            w2, s2, b2 = c2.folded_h2()
+            if dst is None:                                   # identity = the block input itself, result in a new buffer
+                return ops.conv3d_h2(y, w2, s2, b2, residual=x, cout0=c2.out_channels, relu0=True, out_h2=(out_h2, out_h2))
+            if out_h2:
+                dst.copy_(x.buf)
+            else:
+                ops.h2_to_f32(x, out=dst)
+            identity = ops.H2(dst) if out_h2 else dst
+        w2, s2, b2 = c2.folded_h2()
+        idb = identity.buf if isinstance(identity, ops.H2) else identity
+        return ops.conv3d_h2(y, w2, s2, b2, residual=identity, cout0=c2.out_channels, relu0=True, out0=idb,
+                             out_h2=(out_h2, out_h2))
+
+    def _forward_cl_f32(self, x, out=None):
+        """exact-fp32 path (PW_PRECISION=f32): Winograd / direct MFMA kernels"""
         c1, c2, ds = self.conv1, self.conv2, self.downsample
         c1._check_eval()
         if ds is not None:
@@ -384,7 +491,7 @@ class BasicBlock3D(nn.Module):
                                                relu0=True, relu1=False, out1=out)
         else:
             identity = x
-            y = c1.forward_cl(x)
+            y = c1._forward_cl_f32(x)
         w2, s2, b2 = c2.folded()
         if out is not None and ds is None:
             out.copy_(identity)
@@ -424,17 +531,21 @@ class CustomResNet3D(nn.Module):
         self.layers = nn.Sequential(*layers)
         self.with_cp = with_cp
 
-    def forward_cl(self, x, out_last=None):
-        """out_last: optional destination of the LAST block's output (see BasicBlock3D.forward_cl)."""
+    def forward_cl(self, x, out_last=None, keep_h2=False):
+        """x: fp32 channels-last tensor or ops.H2.  out_last: optional destination of the LAST block's output (see
+        BasicBlock3D.forward_cl).  keep_h2: return the stage outputs as ops.H2 (what the next split-fp16 kernel consumes)
+        instead of fp32 tensors.  In the default 'h2' precision every block-to-block tensor stays in h2 storage."""
         feats = []
         n_layers = len(self.layers)
+        h2 = precision() == 'h2'
         for lid, layer in enumerate(self.layers):
             for bid, blk in enumerate(layer):
                 last = out_last is not None and lid == n_layers - 1 and bid == len(layer) - 1
-                x = blk.forward_cl(x, out=out_last) if last else blk.forward_cl(x)
+                x = blk.forward_cl(x, out=out_last if last else None,
+                                   out_h2=isinstance(out_last, ops.H2) if last else h2)
             if lid in self.backbone_output_ids:
                 feats.append(x)
-        return feats
+        return [as_h2(f) if keep_h2 else as_f32(f) for f in feats]
 
     def forward(self, x):
         return [from_channels_last_3d(f) for f in self.forward_cl(to_channels_last_3d(x))]
@@ -456,25 +567,44 @@ class LSSFPN3D(nn.Module):
         self.with_cp = with_cp
         self._cache = _PackedCache()
 
-    def forward_cl(self, feats):
+    def forward_cl(self, feats, out_h2=False):
+        """feats: fp32 channels-last tensors or ops.H2 -> fp32 tensor (or ops.H2 with out_h2)"""
         x8, x16, x32 = feats
         c8, c16, c32 = x8.shape[-1], x16.shape[-1], x32.shape[-1]
         cm = self.conv
         cm._check_eval()
         params = [cm.conv.weight, cm.bn.weight, cm.bn.bias, cm.bn.running_mean, cm.bn.running_var]
+        w = cm.conv.weight
+        assert w.shape[1] == c8 + c16 + c32
+        if precision() == 'h2':
+            if not hasattr(self, '_h2cache'):
+                self._h2cache = _PackedCache()
+
+            def build_h2():
+                sc, bi = ops.fold_bn(cm.bn.weight, cm.bn.bias, cm.bn.running_mean, cm.bn.running_var, cm.bn.eps)
+                w8, i8 = ops.pack_conv_weight_h2(w[:, :c8].contiguous())
+                w16, i16 = ops.pack_conv_weight_h2(w[:, c8:c8 + c16].contiguous())
+                w32, i32 = ops.pack_conv_weight_h2(w[:, c8 + c16:].contiguous())
+                # the three partial sums share ONE BN scale: y16 / y32 are scaled by inv16 / inv8 and inv32 / inv8 so that
+                # the fused kernel can apply scale * inv8 to the sum (all factors are powers of two: exact)
+                return w8, w16, w32, (i16 / i8).contiguous(), (i32 / i8).contiguous(), (sc * i8).contiguous(), bi
+            w8, w16, w32, r16, r32, sc8, bi = self._h2cache.get(params, build_h2)
+            y16 = ops.conv3d_h2(as_h2(x16), w16, r16, ksize=1, out_h2=(False, False))
+            y32 = ops.conv3d_h2(as_h2(x32), w32, r32, ksize=1, out_h2=(False, False))
+            return ops.fpn3d_fuse(as_h2(x8), w8, y16, y32, sc8, bi, relu=True, out_h2=out_h2)
 
         def build():
-            w = cm.conv.weight
-            assert w.shape[1] == c8 + c16 + c32
             sc, bi = ops.fold_bn(cm.bn.weight, cm.bn.bias, cm.bn.running_mean, cm.bn.running_var,
                                  cm.bn.eps)
             return (ops.pack_conv_weight(w[:, :c8].contiguous()),
                     ops.pack_conv_weight(w[:, c8:c8 + c16].contiguous()),
                     ops.pack_conv_weight(w[:, c8 + c16:].contiguous()), sc, bi)
         w8, w16, w32, sc, bi = self._cache.get(params, build)
+        x8, x16, x32 = as_f32(x8), as_f32(x16), as_f32(x32)
         y16 = ops.conv3d_ndhwc(x16, w16, ksize=1)
         y32 = ops.conv3d_ndhwc(x32, w32, ksize=1)
-        return ops.fpn3d_fuse(x8, w8, y16, y32, sc, bi, relu=True)
+        y = ops.fpn3d_fuse(x8, w8, y16, y32, sc, bi, relu=True)
+        return as_h2(y) if out_h2 else y
 
     def forward(self, feats):
         return from_channels_last_3d(self.forward_cl([to_channels_last_3d(f) for f in feats]))

@@ -135,9 +135,10 @@ def lss_ranks(seg_start, order, n_voxels, D, HW):
     return rb[:kept], rd[:kept], rf[:kept], st[:ni], ln[:ni]
 
 
-def bev_pool_dense(depth, feat, vs, out=None):
+def bev_pool_dense(depth, feat, vs, out=None, out_h2=False):
     """Write-once dense pooling.  depth (B,N,D,H,W) flat, feat (B,N,H,W,C), vs = VoxelSort built
-    with aux_div=D*H*W, aux_mod=H*W  ->  (n_voxels, C)."""
+    with aux_div=D*H*W, aux_mod=H*W  ->  (n_voxels, C) fp32, or the same sums in split-fp16 storage (out_h2=True:
+    returns the float32-typed buffer; wrap it in ops.H2)."""
     C = feat.shape[-1]
     if vs.order_feat is None:
         raise _lib.PreworldHipError('bev_pool_dense needs a VoxelSort built with aux_div/aux_mod')
@@ -147,7 +148,7 @@ def bev_pool_dense(depth, feat, vs, out=None):
               _chk(vs.seg_start, _i32, 'seg_start'), _chk(vs.order, _i32, 'order'),
               _chk(vs.order_feat, _i32, 'order_feat'), vs.n_keys, C,
               LONG_SEGMENT if vs.long_list is not None else 0, _p(vs.long_list), _p(vs.n_long),
-              _chk(out, _f32, 'out'), _stream())
+              _chk(out, _f32, 'out'), int(bool(out_h2)), _stream())
     return out
 
 
@@ -479,7 +480,7 @@ def pack_conv_weights_h2_concat(ws):
 
 
 def conv3d_h2(x, wpk, scale, bias=None, residual=None, cout0=None, cout1=0, relu0=False, relu1=False, out0=None,
-              out1=None, out_h2=(True, True)):
+              out1=None, out_h2=(True, True), ksize=3, stride=1, algo=0):
     """3x3x3 stride-1 pad-1 conv on the fp16 matrix cores with split-fp16 operands (pw_conv3d_h2).
     x: H2 (B,D,H,W,Cin); wpk from pack_conv_weight_h2; scale (cout_total,) MUST already contain the packer's
     inv_scale (scale = bn_scale * inv_scale).  residual: H2 or fp32 tensor with y0's layout (may be out0 itself).
@@ -489,8 +490,11 @@ def conv3d_h2(x, wpk, scale, bias=None, residual=None, cout0=None, cout1=0, relu
     B, D, H, W, Cin = x.shape
     nch, taps, nt = wpk.shape[:3]
     cout_total = nt * 32
-    if nch * 32 != Cin or taps != 27:
-        raise _lib.PreworldHipError('packed h2 weight does not match Cin / 3x3x3')
+    if nch * 32 != Cin or taps != ksize ** 3:
+        raise _lib.PreworldHipError('packed h2 weight does not match Cin / ksize')
+    pad = (ksize - 1) // 2
+    D, H, W = [(v + 2 * pad - ksize) // stride + 1 for v in (D, H, W)]      # output grid from here on
+    Din, Hin, Win = x.shape[1:4]
     if cout0 is None:
         cout0 = cout_total
     fm0, fm1 = int(bool(out_h2[0])), int(bool(out_h2[1]))
@@ -511,29 +515,34 @@ def conv3d_h2(x, wpk, scale, bias=None, residual=None, cout0=None, cout1=0, relu
         res = residual.buf if fmr else residual
         if _row_stride(res, (B, D, H, W, cout0), 'residual') != ld0:
             raise _lib.PreworldHipError('residual must have the same row stride as y0')
-    if scale is None or scale.numel() != cout_total or (bias is not None and bias.numel() != cout_total):
+    if scale is None:
+        raise _lib.PreworldHipError('conv3d_h2 needs scale = (BN scale or 1) * inv_scale of pack_conv_weight_h2')
+    if scale.numel() != cout_total or (bias is not None and bias.numel() != cout_total):
         raise _lib.PreworldHipError('scale (with the weight pre-scale folded in) / bias must have cout_total=%d entries' % cout_total)
     xb = x.buf
     if not xb.is_contiguous():
         raise _lib.PreworldHipError('x must be dense')
-    _lib.call('pw_conv3d_h2', _p(xb), _chk(wpk, _f32, 'wpk'), _p(scale), _p(bias), _p(res), _p(y0), _p(y1), B, D, H, W,
-              Cin, cout_total, cout0, cout1, ld0, ld1, int(relu0), int(relu1), fm0, fm1, fmr, _stream())
+    _lib.call('pw_conv3d_h2', _p(xb), _chk(wpk, _f32, 'wpk'), _p(scale), _p(bias), _p(res), _p(y0), _p(y1), B, Din, Hin, Win,
+              Cin, cout_total, cout0, cout1, ld0, ld1, ksize, stride, int(relu0), int(relu1), algo, fm0, fm1, fmr, _stream())
     r0 = H2(y0) if fm0 else y0
     if cout1:
         return r0, (H2(y1) if fm1 else y1)
     return r0
 
 
-def fpn3d_fuse(x8, wpk8, y16, y32, scale, bias, relu=True, out=None):
-    """LSSFPN3D tail: ReLU(BN(W8 x8 + up2(y16) + up4(y32))) -- lss_fpn.py:132-148."""
-    B, D, H, W, C8 = x8.shape
+def fpn3d_fuse(x8, wpk8, y16, y32, scale, bias, relu=True, out=None, out_h2=False):
+    """LSSFPN3D tail: ReLU(BN(W8 x8 + up2(y16) + up4(y32))) -- lss_fpn.py:132-148.  x8: fp32 tensor (wpk8 from
+    pack_conv_weight) or ops.H2 (wpk8 from pack_conv_weight_h2, its inv_scale folded into scale); out_h2: return ops.H2."""
+    x_h2 = isinstance(x8, H2)
+    xb = x8.buf if x_h2 else x8
+    B, D, H, W, C8 = xb.shape
     if out is None:
-        out = torch.empty(B, D, H, W, 32, device=x8.device, dtype=_f32)
-    _lib.call('pw_fpn3d_fuse', _chk(x8, _f32, 'x8'), _chk(wpk8, _f32, 'wpk8'), _chk(y16, _f32, 'y16'),
+        out = torch.empty(B, D, H, W, 32, device=xb.device, dtype=_f32)
+    _lib.call('pw_fpn3d_fuse', _chk(xb, _f32, 'x8'), _chk(wpk8, _f32, 'wpk8'), _chk(y16, _f32, 'y16'),
               _chk(y32, _f32, 'y32'), _p(scale), _p(bias), _chk(out, _f32, 'out'), B, D, H, W, C8,
               y16.shape[1], y16.shape[2], y16.shape[3], y32.shape[1], y32.shape[2], y32.shape[3],
-              int(relu), _stream())
-    return out
+              int(relu), int(x_h2), int(bool(out_h2)), _stream())
+    return H2(out) if out_h2 else out
 
 
 def pack_conv_weight16(w):

@@ -251,15 +251,21 @@ def test_module_dispatch_wino_matches_direct():
     x = T(rs.standard_normal((1, 16, 48, 56, 32)).astype(np.float32))
     assert M._use_wino(x, 64, 3, 1) and not M._use_wino(x[:, :2, :8, :8], 64, 3, 1) and M._use_wino(x, 128, 3, 1) and not M._use_wino(x, 48, 3, 1)
     with torch.no_grad():
-        a = blk.forward_cl(x)
-        os.environ['PW_CONV_WINO'] = '0'
+        h = blk.forward_cl(x)                               # default precision: split-fp16 kernels
+        os.environ['PW_PRECISION'] = 'f32'
         try:
+            a = blk.forward_cl(x)
+            os.environ['PW_CONV_WINO'] = '0'
             assert not M._use_wino(x, 64, 3, 1)
             b = blk.forward_cl(x)
         finally:
             os.environ.pop('PW_CONV_WINO', None)
+            os.environ.pop('PW_PRECISION', None)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), **WINO_TOL)
     assert not torch.equal(a, b)
+    # the three implementations (h2 on the fp16 cores, Winograd fp32, direct fp32) agree; h2 sits with the direct sum
+    np.testing.assert_allclose(h.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert not torch.equal(h, b)
 
 
 def test_conv3d_bad_arguments_raise():
@@ -571,3 +577,61 @@ def test_conv3d_h2_two_outputs_strided_inplace_residual():
     # separate fp32-output run of the same conv agrees with the decoded h2 result to the format's resolution
     f = ops.conv3d_h2(y0, wp1, sc[:32].contiguous() / inv[:32] * inv1, bi[:32].contiguous(), residual=y1, relu0=True, out_h2=(False, False))
     np.testing.assert_allclose(ops.h2_to_f32(dense).cpu().numpy(), f.cpu().numpy(), rtol=5e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize('shape,cout', [((1, 32, 8, 12, 12), 64), ((2, 64, 5, 9, 7), 128), ((1, 32, 16, 20, 20), 64)])
+def test_conv3d_h2_stride2_and_1x1(shape, cout):
+    """split-fp16 gather kernel: 3x3x3 stride 2 (encoder stage transitions), 1x1x1 (FPN laterals), and the chunk-split
+    variant for tiny 3x3x3 grids, fp32 and h2 outputs, against the oracle."""
+    from _parity import check_close
+    rs = np.random.RandomState(7)
+    x = rs.standard_normal(shape).astype(np.float32)
+    xh = ops.f32_to_h2(cl(x))
+    w = _rand_conv(rs, cout, shape[1], 3)
+    wpk, inv = ops.pack_conv_weight_h2(T(w))
+    got = ops.conv3d_h2(xh, wpk, inv, cout0=cout, ksize=3, stride=2, out_h2=(True, True))
+    check_close('conv3d_h2 k3 s2 %s' % (shape,), ncdhw(ops.h2_to_f32(got)), O.conv3d(x, w, None, 2, 1), 3e-6, atol=1e-6)
+    got = ops.conv3d_h2(xh, wpk, inv, cout0=cout, ksize=3, stride=1, algo=3 if (shape[1] // 32) % 2 == 0 else 2, out_h2=(False, False))
+    check_close('conv3d_h2 k3 s1 gather %s' % (shape,), ncdhw(got), O.conv3d(x, w, None, 1, 1), 3e-6, atol=1e-6)
+    w1 = _rand_conv(rs, 32, shape[1], 1)
+    b1 = rs.standard_normal(32).astype(np.float32)
+    wp1, inv1 = ops.pack_conv_weight_h2(T(w1))
+    got = ops.conv3d_h2(xh, wp1, inv1, T(b1), cout0=32, ksize=1, out_h2=(False, False))
+    check_close('conv3d_h2 k1 %s' % (shape,), ncdhw(got), O.conv3d(x, w1, b1, 1, 0), 3e-6, atol=1e-6)
+
+
+def test_pool_h2_and_fpn_h2():
+    """voxel pooling with h2 output = the fp32 pooled sums split (bit-identical to converting the fp32 result); the fused
+    neck with h2 input / output against its exact-fp32 self."""
+    from test_gpu_lss import _prepare, vsort
+    from _parity import check_close
+    gc = S.GRID_CONFIG_C1
+    rig = S.synthetic_rig(1)
+    fr, lower, interval, size, vox, _ = _prepare(gc, S.INPUT_SIZE, S.DOWNSAMPLE, rig, 1, 1)
+    D, H, W = fr.shape[:3]
+    vs = vsort(vox, size[0] * size[1] * size[2], D, H * W)
+    depth, feat = S.lift_inputs(7, B=1, N=1)
+    d_t, f_t = T(depth), T(np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2)))
+    ref = ops.bev_pool_dense(d_t, f_t, vs)
+    h = ops.bev_pool_dense(d_t, f_t, vs, out_h2=True)
+    assert torch.equal(h, ops.f32_to_h2(ref).buf)
+    # neck: x8 (32 ch), x16 (64 ch at 1/2), x32 (128 ch at 1/4)
+    rs = np.random.RandomState(2)
+    neck = M.LSSFPN3D(in_channels=224, out_channels=32).to(DEV).eval()
+    with torch.no_grad():
+        neck.conv.bn.running_var.uniform_(0.5, 1.5); neck.conv.bn.running_mean.normal_(0, 0.1)
+        neck.conv.bn.weight.uniform_(0.5, 1.5); neck.conv.bn.bias.normal_(0, 0.1)
+    feats = [T(rs.standard_normal((1, 8, 16, 24, 32)).astype(np.float32)), T(rs.standard_normal((1, 4, 8, 12, 64)).astype(np.float32)),
+             T(rs.standard_normal((1, 2, 4, 6, 128)).astype(np.float32))]
+    import os
+    os.environ['PW_PRECISION'] = 'f32'
+    try:
+        with torch.no_grad():
+            want = neck.forward_cl(feats)
+    finally:
+        os.environ.pop('PW_PRECISION')
+    with torch.no_grad():
+        got = neck.forward_cl(feats)
+        got_h2 = neck.forward_cl([ops.f32_to_h2(f) for f in feats], out_h2=True)
+    check_close('fpn3d h2 vs f32 path', got, want.cpu().numpy(), 3e-6, atol=1e-6)
+    check_close('fpn3d h2 in/out', ops.h2_to_f32(got_h2), want.cpu().numpy(), 3e-6, atol=1e-6)

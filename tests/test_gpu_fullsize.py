@@ -100,6 +100,9 @@ def _gpu_stages(net, frames):
         feats = net.img_bev_encoder_backbone.forward_cl(x)
         neck = net.img_bev_encoder_neck.forward_cl(feats)
         fc = net.final_conv.forward_cl(neck)
+    # (the composed path keeps these tensors in split-fp16 storage end to end; here every stage hands out fp32 = hi + lo
+    # and the next one splits it again -- the same VALUES, but a value that sits exactly between two fp16 neighbours can
+    # come back as the other (hi, lo) pair, which moves the dropped lo.lo product: last-bit differences, checked below)
     return pools, pres, feats, neck, fc
 
 
@@ -133,11 +136,12 @@ def test_c2_single_frame_with_prev_false_fullsize():
     net = harness.build_model(harness.model_cfg(GC, with_prev=False, detector='PreWorld'), sd, DEV)
     assert type(net).__name__ == 'PreWorld' and not net.with_prev
     frames = harness.lifted_frames(5, 6, DEV, n_frames=2)             # the adjacent frame is supplied and must be ignored
+    TAG = 'C2'
     ovf, fc = _encoder_checks('C2', net, frames[:1], sd, False, 5)
     with torch.no_grad():
         res = net.simple_test_from_lift(frames, want_logits=True)
     assert sorted(k for k in res if 'occ' in k) == ['geo_occ', 'semantic_occ']
-    assert torch.equal(res['voxel_feats'][0], fc), 'composed path differs from the staged path'
+    _cmp('%s composed vs staged final_conv' % TAG, res['voxel_feats'][0], fc.cpu().numpy(), 6e-6)
     occ_o, logits_o = O.occ_decode(ovf, sd)
     lerr = _cmp('C2 logits', res['logits'][0][0].permute(2, 1, 0, 3), logits_o, RTOL['logits'])
     _cmp_states('C2 semantic_occ', res['semantic_occ'][0], occ_o, logits_o, lerr)
@@ -153,10 +157,11 @@ def test_c3_seven_states_fullsize():
     net = harness.build_model(harness.model_cfg(GC), sd, DEV)
     frames = harness.lifted_frames(6, 6, DEV, n_frames=2)
     ego = torch.from_numpy(S.ego_state(6)).to(DEV)
+    TAG = 'C3'
     ovf, fc = _encoder_checks('C3', net, frames, sd, True, 6)
     with torch.no_grad():
         res = net.simple_test_from_lift(frames, ego, n_steps=6, want_logits=True)
-    assert torch.equal(res['voxel_feats'][0], fc), 'composed path differs from the staged path'
+    _cmp('%s composed vs staged final_conv' % TAG, res['voxel_feats'][0], fc.cpu().numpy(), 6e-6)
     e = O.plan_head(S.ego_state(6).reshape(1, -1).astype(np.float32), sd)[0]
     v = ovf
     for k in range(7):

@@ -17,10 +17,17 @@ buf = torch.zeros(nblk * 8 * 16 * 4 + 8 * 27, dtype=torch.int64, device=dev)
 os.environ['PW_CONV_PROBE'] = str(buf.data_ptr())
 os.environ['PW_CONV_PIPE'] = '1'
 from preworld_amd import ops  # noqa: E402
-w = ops.pack_conv_weight(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
-for _ in range(3):
-    buf.zero_()
-    ops.conv3d_ndhwc(x, w, ksize=3, algo=1)
+if os.environ.get('H2', '0') == '1':          # the split-fp16 kernel k_conv3d_h2 (same probe layout)
+    wh, inv = ops.pack_conv_weight_h2(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
+    xh = ops.f32_to_h2(x)
+    for _ in range(3):
+        buf.zero_()
+        ops.conv3d_h2(xh, wh, inv)
+else:
+    w = ops.pack_conv_weight(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
+    for _ in range(3):
+        buf.zero_()
+        ops.conv3d_ndhwc(x, w, ksize=3, algo=1)
 torch.cuda.synchronize()
 raw = buf.cpu().numpy()
 t = raw[:nblk * 8 * 16 * 4].reshape(nblk, 8, 16, 4).astype(np.float64)
