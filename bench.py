@@ -70,8 +70,8 @@ class KernelProbe:
     """Times every hot launch of one eager step with HIP events recorded on the launch stream (torch's current stream ==
     the stream passed through the C ABI) and asks the library which kernel it picked (pw_last_kernel)."""
 
-    OPS = ('conv3d_ndhwc', 'conv3d_wino', 'occ_head_fused', 'forecast_steps', 'fpn3d_fuse', 'bev_pool_dense',
-           'segment_sort', 'lss_voxel_index')
+    OPS = ('conv3d_ndhwc', 'conv3d_wino', 'conv3d_h2', 'occ_head_fused', 'forecast_steps', 'forecast_steps_h2', 'fpn3d_fuse', 'bev_pool_dense',
+           'segment_sort', 'lss_voxel_index', 'f32_to_h2', 'h2_to_f32')
 
     def __init__(self):
         self.records = []
@@ -123,6 +123,20 @@ class KernelProbe:
             fl = 2.0 * nv * 27 * Cin * cout
             w.update(label='conv3d k3 s1 %dx%dx%d %d->%d' % (D, H, W, Cin, cout), flops=fl, exec_flops=fl * 8 / 27,
                      bytes=4.0 * (x.numel() + nv * cout + uw.numel()))
+        elif name == 'conv3d_h2':
+            # split-fp16 operands on the fp16 matrix cores: three MFMA products per direct-form multiply
+            x, wpk = args[0].buf, args[1]
+            B, D, H, W, Cin = x.shape
+            taps, nt = wpk.shape[1], wpk.shape[2]
+            ks, st = kw.get('ksize', 3), kw.get('stride', 1)
+            nv = B * (D // st) * (H // st) * (W // st)
+            cout = (kw.get('cout0') or nt * 32) + (kw.get('cout1') or 0)
+            fl = 2.0 * nv * taps * Cin * cout
+            w.update(label='conv3d k%d s%d %dx%dx%d %d->%d' % (ks, st, D, H, W, Cin, cout), flops=fl, exec_flops=3.0 * fl,
+                     mfma='f16', bytes=4.0 * (x.numel() + nv * cout + wpk.numel()))
+        elif name in ('f32_to_h2', 'h2_to_f32'):
+            t = args[0].buf if hasattr(args[0], 'buf') else args[0]
+            w.update(label=name, mfma=None, bytes=8.0 * t.numel())
         elif name == 'occ_head_fused':
             x = args[0]
             nv = x.numel() // x.shape[-1]
@@ -132,13 +146,15 @@ class KernelProbe:
             w.update(label='occ_head 32->16->8->18 + argmax', flops=conv + tail,
                      exec_flops=(conv * 8 / 27 if wino else conv) + tail, bytes=4.0 * x.numel() + 2.0 * nv,
                      units=int(x.shape[0]))
-        elif name == 'forecast_steps':
-            v0, n_steps = args[0], args[6]
+        elif name in ('forecast_steps', 'forecast_steps_h2'):
+            v0, n_steps = args[0], (args[6] if name == 'forecast_steps' else args[5])
             nv = v0.numel() // 32
             fl = 2.0 * nv * n_steps * (32 * 128 + 128 * 32)
-            w.update(label='forecast %d steps' % n_steps, flops=fl, exec_flops=fl, bytes=4.0 * v0.numel() * (1 + n_steps))
+            h2 = name.endswith('h2')
+            w.update(label='forecast %d steps' % n_steps, flops=fl, exec_flops=3.0 * fl if h2 else fl,
+                     mfma='f16' if h2 else 'f32', bytes=4.0 * v0.numel() * (1 + n_steps))
         elif name == 'fpn3d_fuse':
-            x = args[0]
+            x = args[0].buf if hasattr(args[0], 'buf') else args[0]
             fl = 2.0 * (x.numel() // 32) * 32 * 32
             w.update(label='fpn3d_fuse', flops=fl, exec_flops=fl, bytes=8.0 * x.numel())
         elif name == 'bev_pool_dense':

@@ -227,6 +227,12 @@ int pw_forecast_prologue(const float* ego, int n_samples, int ego_dim, const flo
 int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
                       const float* w2p, const float* c1p, const float* fusion_b2, int n_steps,
                       float* states, void* stream);
+/* pw_forecast_steps on the fp16 matrix cores with split-fp16 operands (see pw_conv3d_h2): w1p / w2p are the split weights
+ * float[4 tiles][2 k-blocks][2 planes][64 lanes][4] built by preworld_amd.ops.forecast_pack_h2 with power-of-two pre-scales
+ * whose inverses are inv1 / inv2; everything else as pw_forecast_steps (fp32 states in and out). */
+int pw_forecast_steps_h2(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
+                         const float* w2p, float inv1, float inv2, const float* c1p, const float* fusion_b2,
+                         int n_steps, float* states, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A14/A16/A17  render ops with the reference's semantics on compacted point arrays

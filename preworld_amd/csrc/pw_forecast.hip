@@ -237,6 +237,138 @@ PW_API int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_sa
 }
 
 // ------------------------------------------------------------------------------------
+// The same recursion on the fp16 matrix cores with split-fp16 operands (pw_h2.h: x = hi + lo, three
+// v_mfma_f32_32x32x16_f16 per product block, fp32 accumulate -- as accurate as an fp32 FMA chain at 5.3x the MFMA rate).
+// Same transposed chain: block ks of the next GEMM's K index = accumulator registers 8 ks .. 8 ks + 7 of both lane
+// halves, so a lane splits ITS OWN 8 registers into the 8 hi / 8 lo halves of its B fragment -- no LDS round trip, no
+// shuffles.  Weights (A operand) are split and packed on the host (preworld_amd.ops.forecast_pack_h2):
+//   w1p[t][ks][p][lane][e] = plane p of S1 * W1[t*32 + (lane&31)][row_of(8 ks + e, lane>>5)]
+//   w2p[t][kb][p][lane][e] = plane p of S2 * W2[lane&31][t*32 + row_of(8 kb + e, lane>>5)]
+// with power-of-two S1, S2 undone by inv1 / inv2 here.  With the MFMA time cut to ~1/5 the kernel is bound by its
+// VALU work (softplus: 128 values per voxel and step, plus the splits).
+// ------------------------------------------------------------------------------------
+typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
+typedef float fv4 __attribute__((ext_vector_type(4)));
+constexpr int WH2 = 4 * 2 * 2 * 64 * 4;     // floats per packed split matrix (16 KB)
+
+// registers r0 .. r0+7 of an accumulator -> (8 hi halves, 8 lo halves)
+__device__ __forceinline__ void split8(const float* x, fh8& hi, fh8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float c = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f);
+    hi[e] = (_Float16)c;
+    lo[e] = (_Float16)(c - (float)hi[e]);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_samples, const float* __restrict__ w1p,
+              const float* __restrict__ w2p, float inv1, float inv2, const float* __restrict__ c1p,
+              const float* __restrict__ fb2, int n_steps, float* __restrict__ states) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* l_w1 = lds;
+  float* l_w2 = lds + WH2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  for (int k = tid; k < WH2 / 4; k += 256) {
+    reinterpret_cast<float4*>(l_w1)[k] = reinterpret_cast<const float4*>(w1p)[k];
+    reinterpret_cast<float4*>(l_w2)[k] = reinterpret_cast<const float4*>(w2p)[k];
+  }
+  __syncthreads();
+  const long long n_total = n_vox_per_sample * n_samples;
+  const long long n_tiles = (n_total + 31) / 32;
+  float b2r[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) b2r[s] = fb2[row_of(s, h)];
+  // A fragment (t, k-block, plane) of this lane: 16 bytes at ((t*2 + kb)*2 + p)*1024 + lane*16
+  const char* a1 = reinterpret_cast<const char*>(l_w1) + lane * 16;
+  const char* a2 = reinterpret_cast<const char*>(l_w2) + lane * 16;
+
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+    const long long m0 = tile * 32;
+    long long m = m0 + j;
+    const bool valid = m < n_total;
+    if (!valid) m = n_total - 1;
+    const int sample = (int)(m / n_vox_per_sample);
+    const float* c1s = c1p + (size_t)sample * HID + h * 64;
+    float v[16];
+    const float* src = v0 + (size_t)m * C + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 t4 = *reinterpret_cast<const float4*>(src + 8 * q);
+      v[4 * q + 0] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+    }
+    for (int step = 0; step < n_steps; ++step) {
+      fh8 vh[2], vl[2];
+      split8(v, vh[0], vl[0]);
+      split8(v + 8, vh[1], vl[1]);
+      f32x16 o;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) o[s] = 0.f;
+#pragma unroll 1
+      for (int t = 0; t < 4; ++t) {
+        f32x16 hid;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) hid[s] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const fh8 wh = __builtin_bit_cast(fh8, *reinterpret_cast<const fv4*>(a1 + ((t * 2 + ks) * 2 + 0) * 1024));
+          const fh8 wl = __builtin_bit_cast(fh8, *reinterpret_cast<const fv4*>(a1 + ((t * 2 + ks) * 2 + 1) * 1024));
+          hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, vh[ks], hid, 0, 0, 0);
+          hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, vh[ks], hid, 0, 0, 0);
+          hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, vl[ks], hid, 0, 0, 0);
+        }
+        float hs[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 c4 = *reinterpret_cast<const float4*>(c1s + t * 16 + q * 4);
+          hs[4 * q + 0] = softplus_t20(fmaf(hid[4 * q + 0], inv1, c4.x));
+          hs[4 * q + 1] = softplus_t20(fmaf(hid[4 * q + 1], inv1, c4.y));
+          hs[4 * q + 2] = softplus_t20(fmaf(hid[4 * q + 2], inv1, c4.z));
+          hs[4 * q + 3] = softplus_t20(fmaf(hid[4 * q + 3], inv1, c4.w));
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          fh8 hh, hl;
+          split8(hs + 8 * kb, hh, hl);
+          const fh8 wh = __builtin_bit_cast(fh8, *reinterpret_cast<const fv4*>(a2 + ((t * 2 + kb) * 2 + 0) * 1024));
+          const fh8 wl = __builtin_bit_cast(fh8, *reinterpret_cast<const fv4*>(a2 + ((t * 2 + kb) * 2 + 1) * 1024));
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl, o, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) v[s] = fmaf(o[s], inv2, b2r[s]) + v[s];   // + b2, residual connection (:342)
+      if (valid) {
+        float* dst = states + ((size_t)step * n_total + m) * C + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      }
+    }
+  }
+}
+
+PW_API int pw_forecast_steps_h2(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
+                                const float* w2p, float inv1, float inv2, const float* c1p, const float* fusion_b2,
+                                int n_steps, float* states, void* stream) {
+  PW_CHECK_ARG(v0 && w1p && w2p && c1p && fusion_b2 && states, "pw_forecast_steps_h2: null pointer");
+  PW_CHECK_ARG(n_vox_per_sample > 0 && n_samples > 0 && n_steps > 0, "pw_forecast_steps_h2: bad sizes");
+  PW_CHECK_ARG((((uintptr_t)v0 | (uintptr_t)states | (uintptr_t)w1p | (uintptr_t)w2p) & 15) == 0,
+               "pw_forecast_steps_h2: pointers must be 16-B aligned");
+  const size_t lds_bytes = (size_t)2 * WH2 * 4;   // 32 KB
+  long long n_tiles = (n_vox_per_sample * n_samples + 31) / 32;
+  long long want = (n_tiles + 3) / 4;
+  unsigned nb = (unsigned)(want < 1024 ? want : 1024);   // 4 blocks x 256 CUs, grid-stride
+  hipLaunchKernelGGL(k_forecast_h2, dim3(nb), dim3(256), lds_bytes, pw_stream(stream), v0, (long long)n_vox_per_sample,
+                     n_samples, w1p, w2p, inv1, inv2, c1p, fusion_b2, n_steps, states);
+  pw_note_kernel("k_forecast_h2");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // A12  attribute projection: density_mlp / semantic_mlp / color_mlp
 // (mmdet3d/models/detectors/preworld_temporal_traj.py:81-104, used at :231-250 and in
 // forward_train before the render head).  The three 32 -> 64 Softplus -> {2,17,3} MLPs run as

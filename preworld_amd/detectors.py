@@ -394,6 +394,12 @@ class PreWorld4DTraj(_PreWorldCommon):
         plan = [(ph[0].weight.contiguous(), ph[0].bias), (ph[2].weight.contiguous(), ph[2].bias),
                 (ph[4].weight.contiguous(), ph[4].bias)]
         ef, _, c1p = ops.forecast_prologue(ego, plan, fh[0].weight.contiguous(), fh[0].bias)
+        if precision() == 'h2':
+            if not hasattr(self, '_fc_h2cache'):
+                self._fc_h2cache = _PackedCache()
+            packed = self._fc_h2cache.get([fh[0].weight, fh[2].weight],
+                                          lambda: ops.forecast_pack_h2(fh[0].weight.float(), fh[2].weight.float()))
+            return ops.forecast_steps_h2(v_cl, B, packed, c1p, fh[2].bias, n_steps), ef
         w1p, w2p = self._forecast_weights()
         states = ops.forecast_steps(v_cl, B, w1p, w2p, c1p, fh[2].bias, n_steps)
         return states, ef

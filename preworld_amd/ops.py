@@ -609,6 +609,50 @@ def forecast_steps(v0, n_samples, w1p, w2p, c1p, fusion_b2, n_steps, states=None
     return states
 
 
+def _split_planes(w):
+    """float64 tensor -> (power-of-two scale S, fp16 hi, fp16 lo) of S * w, largest |S w| in [512, 1024)"""
+    S = float(2.0 ** torch.floor(torch.log2(1023.0 / w.abs().max().clamp_min(1e-30))))
+    ws = w * S
+    hi = ws.to(torch.float16)
+    return S, hi, (ws - hi.double()).to(torch.float16)
+
+
+def forecast_pack_h2(fusion_w1, fusion_w2):
+    """fusion_head.{0,2}.weight ([128][64], [32][128]) -> (w1p, w2p, inv1, inv2): split-fp16 MFMA A operands in the order
+    pw_forecast_steps_h2 documents (include/preworld_hip.h) and the inverses of their power-of-two pre-scales."""
+    import numpy as np
+    dev = fusion_w1.device
+    lane = np.arange(64)
+    i, h = lane & 31, lane >> 5
+    e = np.arange(8)
+    # row_of(8 kb + e, h) = ((8kb+e) & 3) + 8 * ((8kb+e) >> 2) + 4 h
+    t, kb, ln, ee = np.meshgrid(np.arange(4), np.arange(2), lane, e, indexing='ij')
+    r = 8 * kb + ee
+    k = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5)
+    row = ln & 31
+    T = lambda a: torch.from_numpy(a.reshape(-1)).to(dev)                      # noqa: E731
+    S1, h1, l1 = _split_planes(fusion_w1[:, :32].double())                     # voxel part of W1 (128, 32)
+    S2, h2_, l2 = _split_planes(fusion_w2.double())                            # (32, 128)
+    idx1 = (T(t) * 32 + T(row), T(k))
+    idx2 = (T(row), T(t) * 32 + T(k))
+    w1p = torch.stack([h1[idx1].view(4, 2, 64, 8), l1[idx1].view(4, 2, 64, 8)], dim=2)     # (t, kb, p, lane, e)
+    w2p = torch.stack([h2_[idx2].view(4, 2, 64, 8), l2[idx2].view(4, 2, 64, 8)], dim=2)
+    return (w1p.contiguous().view(torch.float32).contiguous(), w2p.contiguous().view(torch.float32).contiguous(),
+            1.0 / S1, 1.0 / S2)
+
+
+def forecast_steps_h2(v0, n_samples, packed, c1p, fusion_b2, n_steps, states=None):
+    """forecast_steps on the fp16 matrix cores with split-fp16 operands; packed = forecast_pack_h2(...)."""
+    w1p, w2p, inv1, inv2 = packed
+    n_total = v0.numel() // 32
+    if states is None:
+        states = torch.empty((n_steps,) + tuple(v0.shape), device=v0.device, dtype=_f32)
+    _lib.call('pw_forecast_steps_h2', _chk(v0, _f32, 'v0'), n_total // n_samples, n_samples, _chk(w1p, _f32, 'w1p'),
+              _chk(w2p, _f32, 'w2p'), float(inv1), float(inv2), _chk(c1p, _f32, 'c1p'), _chk(fusion_b2, _f32, 'fb2'),
+              n_steps, _chk(states, _f32, 'states'), _stream())
+    return states
+
+
 def softplus(x):
     y = torch.empty_like(x)
     _lib.call('pw_softplus', _chk(x, _f32, 'x'), _p(y), x.numel(), _stream())
