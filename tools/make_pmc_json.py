@@ -1,0 +1,37 @@
+"""gpurun_out/<V>/pmc_{FETCH,WRITE}_SIZE.md (tools/rocpd_pmc.py tables, KB per dispatch) -> profiles/<round>_pmc_traffic.json
+{'by_kernel': {rocprof kernel name: {fetch_bytes, write_bytes, fetch_reported_bytes, dispatches}}} -- what bench.py reads for
+`roofline.traffic`.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of wide (16 B/lane)
+streaming reads, so kernels whose reads are dwordx4 / `buffer_load ... lds` are doubled (WIDE below); WRITE_SIZE is exact on
+this box (81.92 MB fill = 80 000 KB)."""
+import json
+import re
+import sys
+
+WIDE = ('k_conv3d_h2', 'k_conv3d_gather', 'k_occ_head', 'k_forecast', 'k_conv3d_wino', 'k_conv3d_k3s1')
+
+
+def table(path):
+    out = {}
+    for line in open(path):
+        m = re.match(r'\| `(.+?)` \| (\w+) \| (\d+) \| ([\d.e+-]+) \|', line)
+        if m:
+            out[m.group(1)] = (int(m.group(3)), float(m.group(4)) * 1024.0)
+    return out
+
+
+def main(vdir, dst):
+    f, w = table(vdir + '/pmc_FETCH_SIZE.md'), table(vdir + '/pmc_WRITE_SIZE.md')
+    by = {}
+    for k in sorted(set(f) | set(w)):
+        if not k.startswith('k_'):
+            continue
+        fr = f.get(k, (0, 0.0))[1]
+        by[k] = dict(fetch_reported_bytes=int(fr), fetch_bytes=int(fr * (2 if k.startswith(WIDE) else 1)),
+                     write_bytes=int(w.get(k, (0, 0.0))[1]), dispatches=f.get(k, w.get(k))[0],
+                     fetch_doubled=bool(k.startswith(WIDE)))
+    json.dump({'_note': __doc__, 'source': vdir, 'by_kernel': by}, open(dst, 'w'), indent=1)
+    print('wrote', dst, len(by), 'kernels')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])

@@ -1,0 +1,32 @@
+# round-2 profile set in ONE gpurun call:  V=r02a bash tools/run_profiles_r02.sh
+#   bench lines (default, serial, 3 / 4 in flight), rocprofv3 --kernel-trace --stats of the bench (default + serial),
+#   and separate PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) over an eager, strictly serial run of the same step
+set -x
+V=${V:-r02a}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+R=$PWD
+O=$R/gpurun_out/$V
+mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --in-flight 1 --no-cpu-baseline > $O/bench_serial.json 2>> $O/bench.err
+python bench.py --in-flight 3 --no-cpu-baseline > $O/bench_if3.json 2>> $O/bench.err
+python bench.py --in-flight 4 --no-cpu-baseline > $O/bench_if4.json 2>> $O/bench.err
+python bench.py --config C2 --no-cpu-baseline > $O/bench_c2.json 2>> $O/bench.err
+python bench.py --mode sharded --steps 30 --no-cpu-baseline > $O/bench_sharded_w1.json 2>> $O/bench.err
+python tools/bench_h2.py > $O/layers_h2.txt 2>&1
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/prof -o r1 -- python $R/bench.py --steps 6 --warmup 2 --settle-s 0.2 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err
+rocprofv3 --kernel-trace --stats -d $O/prof_serial -o r1 -- python $R/bench.py --in-flight 1 --steps 20 --warmup 2 --settle-s 0.5 --no-cpu-baseline > $O/prof_bench_serial.json 2>> $O/prof.err
+EAGER="python $R/bench.py --no-graph --in-flight 1 --steps 4 --warmup 1 --settle-s 0.0 --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_FETCH_SIZE -o p -- $EAGER > /dev/null 2>> $O/prof.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_WRITE_SIZE -o p -- $EAGER > /dev/null 2>> $O/prof.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_MFMA -o p -- $EAGER > /dev/null 2>> $O/prof.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/pmc_SQ -o p -- $EAGER > /dev/null 2>> $O/prof.err
+cd $R
+python tools/rocpd_stats.py $(find $O/prof -name '*.db' | head -1) > $O/kernel_stats.md 2>&1
+python tools/rocpd_stats.py $(find $O/prof_serial -name '*.db' | head -1) > $O/kernel_stats_serial.md 2>&1
+for c in FETCH_SIZE WRITE_SIZE MFMA SQ; do python tools/rocpd_pmc.py $(find $O/pmc_$c -name '*.db' | head -1) > $O/pmc_$c.md 2>&1; done
+find $O -name '*.db' -delete
+rm -rf $O/prof $O/prof_serial $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA $O/pmc_SQ
+ls -la $O
