@@ -23,6 +23,138 @@ constexpr int H2_MAX_COUT = 256;
 constexpr int H2_LDS = H2_SB_OFF + 2 * H2_MAX_COUT * 4;
 }  // namespace
 
+// ---- software-pipelined epilogue of the persistent kernel (EPI > 0).
+// The tile that finished in stage s is written out DURING stage s+1.  At the end of stage s every wave only parks its raw
+// accumulators in LDS (h2_epi_park: 8 ds_write_b128 per N-tile).  The 4 NT passes that turn them into
+// scale / bias / residual / ReLU / fp16 split / coalesced stores are BRANCH-FREE straight-line code placed in the same
+// scheduling region as the 12 NT MFMAs of taps 2 .. 4 NT + 1 of the next stage (their LDS / residual loads one tap earlier),
+// so that they issue in the ~5 free slots a single wave has per 32-cycle MFMA: a separate epilogue phase cost 4.9 k of a
+// 22.9 k-cycle stage, and the same passes placed before the MFMAs (branchy version) simply moved those cycles into the taps.
+// Being branch-free means the variant is a template parameter:
+//   EPI 1: y0 (and y1) in h2 storage, no residual      EPI 2: y0 h2 + h2 residual (no y1)      EPI 3: fp32, no residual
+//   EPI 0: anything else -- the generic epilogue phase (h2_epilogue) at the end of the stage.
+// A stage with nothing parked runs the same code with every lane's offset out of range (loads return 0, stores are dropped).
+// Parking area = this wave's own halo rows (wave + 4 K, K < 7 / 13 for NT 1 / 2) of the buffer the stage just consumed: those
+// rows are refilled only by this wave's own DMA instructions, which are issued after the passes (other rows first).
+struct EpiTile { int b, d0, h0, w0, ng; unsigned bufoff; bool pending; };
+struct EpiRegs { v4f x0, x1, s0, s1, b0, b1; float4 r0, r1; unsigned vbase, soff; };
+
+__device__ __forceinline__ unsigned epi_slot_off(int u) {          // parked voxel row u (128 B): 10 per halo row
+  const int row = (int)(((unsigned)u * 205u) >> 11);               // u / 10 for u < 1024
+  return (unsigned)(row * (4 * TW * 128) + (u - row * 10) * 128);
+}
+
+template <int NT>
+__device__ __forceinline__ void h2_epi_park(const f32x16 (&acc)[2][NT], char* stg, int lane) {
+  const int half = lane >> 5, pj = patch_of_row(lane & 31);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int u = nt * 64 + mt * 32 + pj;
+      char* dst = stg + epi_slot_off(u);
+      const int sw = (u >> 1) & 7;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v4f v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * g + e];
+        *reinterpret_cast<v4f*>(dst + (((2 * g + half) ^ sw) * 16)) = v;
+      }
+    }
+}
+
+// pass P of 4 NT covers 16 parked voxel rows; lane = (row u = 16 P + (lane >> 2), channel octet o = lane & 3)
+template <int NT, int EPI, int P>
+__device__ __forceinline__ void h2_epi_load(const ConvArgs& a, const EpiTile& t, const char* stg, const float* sb, int wave,
+                                            int lane, EpiRegs& r) {
+  constexpr int nt = P >> 2;
+  const int n0 = (t.ng * NT + nt) * 32;
+  const bool to_y0 = n0 < a.cout0;
+  const int ld = to_y0 ? a.ld0 : a.ld1;
+  const int col0 = to_y0 ? n0 : n0 - a.n1_start;
+  const int od = t.d0 + wave;
+  const int o = lane & 3;
+  const int u = 16 * P + (lane >> 2), sv = u & 63;
+  const int mt = sv >> 5, vr = (sv >> 3) & 3, vc = sv & 7;
+  const bool ok = t.pending && od < a.Do && (t.h0 + mt * 4 + vr) < a.Ho && (t.w0 + vc) < a.Wo;
+  r.soff = (unsigned)(((((t.b * a.Do + od) * a.Ho + t.h0) * a.Wo + t.w0) * ld) * 4);
+  const unsigned pos = (EPI == 3 ? (unsigned)(32 * o) : (unsigned)((4 * (o & 1) + 2 * (o >> 1)) * 16));
+  r.vbase = ok ? (unsigned)(((mt * 4 + vr) * a.Wo + vc) * ld) * 4u + (unsigned)col0 * 4u + pos : PIPE_OOB;
+  const char* src = stg + epi_slot_off(u);
+  const int sw = (u >> 1) & 7;
+  r.x0 = *reinterpret_cast<const v4f*>(src + (((2 * o) ^ sw) * 16));
+  r.x1 = *reinterpret_cast<const v4f*>(src + (((2 * o + 1) ^ sw) * 16));
+  r.s0 = *reinterpret_cast<const v4f*>(sb + n0 + 8 * o);
+  r.s1 = *reinterpret_cast<const v4f*>(sb + n0 + 8 * o + 4);
+  r.b0 = *reinterpret_cast<const v4f*>(sb + H2_MAX_COUT + n0 + 8 * o);
+  r.b1 = *reinterpret_cast<const v4f*>(sb + H2_MAX_COUT + n0 + 8 * o + 4);
+  if constexpr (EPI == 2) {
+    const unsigned out_vox = (unsigned)((size_t)a.B * a.Do * a.Ho * a.Wo);
+    const rsrc_t rr = make_rsrc(a.residual, out_vox * (unsigned)ld * 4u);
+    r.r0 = buf_load4(rr, r.vbase, r.soff);
+    r.r1 = buf_load4(rr, r.vbase == PIPE_OOB ? PIPE_OOB : r.vbase + 16u, r.soff);
+  }
+}
+
+template <int NT, int EPI, int P>
+__device__ __forceinline__ void h2_epi_compute(const ConvArgs& a, const EpiTile& t, const EpiRegs& r) {
+  constexpr int nt = P >> 2;
+  const int n0 = (t.ng * NT + nt) * 32;
+  const bool to_y0 = n0 < a.cout0;
+  float* dst = to_y0 ? a.y0 : a.y1;
+  const int ld = to_y0 ? a.ld0 : a.ld1;
+  const float lo_clamp = (to_y0 ? a.relu0 : a.relu1) ? 0.f : -3.402823466e38f;
+  const unsigned out_vox = (unsigned)((size_t)a.B * a.Do * a.Ho * a.Wo);
+  const rsrc_t yr = make_rsrc(dst, out_vox * (unsigned)ld * 4u);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = fmaf(r.x0[e], r.s0[e], r.b0[e]); v[4 + e] = fmaf(r.x1[e], r.s1[e], r.b1[e]); }
+  if constexpr (EPI == 2) {                         // r0 = 8 hi halves, r1 = 8 lo halves of channels 8o .. 8o+7
+    const h8 rh = __builtin_bit_cast(h8, r.r0), rl = __builtin_bit_cast(h8, r.r1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)rh[e] + (float)rl[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], lo_clamp);
+  const unsigned second = r.vbase == PIPE_OOB ? PIPE_OOB : r.vbase + 16u;
+  if constexpr (EPI == 3) {
+    const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
+    buf_store4(yr, r.vbase, r.soff, va);
+    buf_store4(yr, second, r.soff, vb);
+  } else {
+    h8 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = __builtin_amdgcn_fmed3f(v[e], -H2_MAX, H2_MAX);
+      oh[e] = (_Float16)x;
+      ol[e] = (_Float16)(x - (float)oh[e]);
+    }
+    const v4f wh = __builtin_bit_cast(v4f, oh), wl = __builtin_bit_cast(v4f, ol);
+    const float va[4] = {wh[0], wh[1], wh[2], wh[3]}, vb[4] = {wl[0], wl[1], wl[2], wl[3]};
+    buf_store4(yr, r.vbase, r.soff, va);
+    buf_store4(yr, second, r.soff, vb);
+  }
+}
+
+template <int NT, int EPI, int P>
+__device__ __forceinline__ void h2_epi_rest(const ConvArgs& a, const EpiTile& t, const char* stg, const float* sb, int wave,
+                                            int lane) {
+  if constexpr (P < 4 * NT) {
+    EpiRegs r;
+    h2_epi_load<NT, EPI, P>(a, t, stg, sb, wave, lane, r);
+    h2_epi_compute<NT, EPI, P>(a, t, r);
+    h2_epi_rest<NT, EPI, P + 1>(a, t, stg, sb, wave, lane);
+  }
+}
+
+// halo row this wave's DMA issues at tap TAP of a stage (or -1): parking rows (< S) go out after the epilogue passes
+template <int NT, int TAP>
+__device__ __forceinline__ constexpr int h2_dma_row_of_tap() {
+  if constexpr (NT == 1) return (TAP >= 1 && TAP <= 8) ? TAP + 6 : ((TAP >= 9 && TAP <= 15) ? TAP - 9 : -1);
+  else return (TAP >= 1 && TAP <= 2) ? TAP + 12 : ((TAP >= 10 && TAP <= 22) ? TAP - 10 : -1);
+}
+
 template <int NT>
 struct H2Ctx {
   lds3_t lds3;
@@ -33,6 +165,8 @@ struct H2Ctx {
   PipeDma dm;
   int wave, lane;
   long long* tap_probe;
+  EpiTile epi;                 // tile parked by the previous stage, written out during this one
+  const char* ldsg;            // generic pointer to the LDS base (the parked rows are read through it)
 };
 
 template <int TAP>
@@ -79,10 +213,10 @@ __device__ __forceinline__ void h2_mfma(const v4f (&aq)[2][4], const v4f (&b)[NT
   }
 }
 
-template <int NT, int TAP>
+template <int NT, int EPI, int TAP>
 __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, const unsigned (&aaddr)[2][3][4],
                                         v4f (&ac)[2][4], v4f (&an)[2][4], v4f (&b0)[NT][4], v4f (&b1)[NT][4],
-                                        v4f (&b2)[NT][4], f32x16 (&acc)[2][NT]) {
+                                        v4f (&b2)[NT][4], f32x16 (&acc)[2][NT], EpiRegs& er) {
   if (c.tap_probe) {                       // development aid: cycle counter at every tap of one stage
     if (c.lane == 0) c.tap_probe[c.wave * 27 + TAP] = __builtin_readcyclecounter();
   }
@@ -91,12 +225,26 @@ __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, c
   } else {
     h2_load_b<NT>(c.wr, c.wsoff_next + (unsigned)(TAP + 2 - 27) * c.wstride, c.lane_off, b2);
   }
-  if constexpr (TAP >= 1 && TAP <= PIPE_ROWS_PER_WAVE) pipe_dma_row<TAP - 1>(a, c.xr, c.lds3, c.dm, c.wave);
+  if constexpr (h2_dma_row_of_tap<NT, TAP>() >= 0) pipe_dma_row<h2_dma_row_of_tap<NT, TAP>()>(a, c.xr, c.lds3, c.dm, c.wave);
   if constexpr (TAP < 26) h2_read_a_tap<TAP + 1>(c.lds3, aaddr, an);
   __builtin_amdgcn_sched_barrier(0);
+  constexpr bool epi_tap = EPI > 0 && TAP >= 2 && TAP <= 4 * NT + 1;
+  if constexpr (epi_tap) h2_epi_compute<NT, EPI, TAP - 2>(a, c.epi, er);      // pass TAP-2 of the previous tile (loaded last tap)
   h2_mfma<NT>(ac, b0, acc);
+  if constexpr (epi_tap) {
+    // interleave: one MFMA, then a handful of the pass's VALU instructions in its shadow; the two stores last
+#pragma unroll
+    for (int i = 0; i < 12 * NT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NT == 1 ? 6 : 3, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+  }
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (TAP < 26) h2_step<NT, TAP + 1>(a, c, aaddr, an, ac, b1, b2, b0, acc);
+  if constexpr (EPI > 0 && TAP >= 1 && TAP <= 4 * NT)
+    h2_epi_load<NT, EPI, TAP - 1>(a, c.epi, c.ldsg + c.epi.bufoff + (unsigned)c.wave * (TW * 128),
+                                  reinterpret_cast<const float*>(c.ldsg + H2_SB_OFF), c.wave, c.lane, er);
+  if constexpr (TAP < 26) h2_step<NT, EPI, TAP + 1>(a, c, aaddr, an, ac, b1, b2, b0, acc, er);
 }
 
 // ---- epilogue shared by the kernels below: y = acc*scale + bias (+residual) (ReLU) through an LDS staging area.
@@ -137,7 +285,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&ac
         const int sv = mt * 32 + pj;
         v4f v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * g + e] * sc[e] + bi[e];
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[mt][nt][4 * g + e], sc[e], bi[e]);
         *reinterpret_cast<v4f*>(stg + (sv >> 3) * STG_ROW + (sv & 7) * 128 + (((2 * g + half) ^ ((sv >> 1) & 7)) * 16)) = v;
       }
     }
@@ -192,7 +340,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&ac
   }
 }
 
-template <int NT>
+template <int NT, int EPI>
 __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -236,10 +384,13 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   c.lane_off = (unsigned)lane * 64u;
   c.wstride = (unsigned)ntiles_total * 4096u;
   c.wave = wave; c.lane = lane;
+  c.ldsg = reinterpret_cast<const char*>(lds);
+  c.epi.pending = false; c.epi.b = c.epi.d0 = c.epi.h0 = c.epi.w0 = c.epi.ng = 0; c.epi.bufoff = 0;
 
   PipeTile t = pipe_decode(a, p, item);
   int ch = 0;
   v4f a0[2][4], a1[2][4], b0[NT][4], b1[NT][4], b2[NT][4];
+  EpiRegs er = {};
   f32x16 acc[2][NT];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -297,16 +448,25 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     c.dm.ch = chn; c.dm.ldsbuf = (unsigned)PIPE_BUF_BYTES - bufoff; c.dm.live = c.has_next;
 
     c.tap_probe = (a.probe && blockIdx.x == 17 && stage == 3) ? a.probe + 256 * 8 * 16 * 4 : nullptr;
-    h2_step<NT, 0>(a, c, aaddr, a0, a1, b0, b1, b2, acc);
+    h2_step<NT, EPI, 0>(a, c, aaddr, a0, a1, b0, b1, b2, acc, er);
     if (a.probe) ts1 = __builtin_readcyclecounter();
 
     __builtin_amdgcn_s_waitcnt(0);     // my DMA rows of the next stage have landed
     __syncthreads();                   // everyone's have; everyone is done with this buffer
     if (a.probe) ts2 = __builtin_readcyclecounter();
 
+    c.epi.pending = false;               // its passes ran inside this stage's taps
     if (ch == nchunk - 1) {
-      // ---- epilogue (staging rows = the halo rows of the consumed buffer this wave itself refills next stage)
-      h2_epilogue<NT>(a, acc, lds + H2_SB_OFF / 4, reinterpret_cast<char*>(lds) + bufoff + (unsigned)wave * (TW * 128), t.b, t.d0, t.h0, t.w0, t.ng, wave, lane);
+      char* stg = reinterpret_cast<char*>(lds) + bufoff + (unsigned)wave * (TW * 128);
+      if constexpr (EPI == 0) {
+        // generic epilogue phase (any mix of formats / residual): parks, reads back and stores before the next stage
+        h2_epilogue<NT>(a, acc, lds + H2_SB_OFF / 4, stg, t.b, t.d0, t.h0, t.w0, t.ng, wave, lane);
+      } else {
+        // first half of the pipelined epilogue: park the raw accumulators in this wave's rows of the consumed buffer
+        h2_epi_park<NT>(acc, stg, lane);
+        c.epi.b = t.b; c.epi.d0 = t.d0; c.epi.h0 = t.h0; c.epi.w0 = t.w0; c.epi.ng = t.ng; c.epi.bufoff = bufoff;
+        c.epi.pending = true;
+      }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -320,6 +480,12 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     }
     if (!c.has_next) break;
     t = tn; ch = chn; item = itemn;
+  }
+  // the last tile of this block has no next stage to ride on
+  if constexpr (EPI > 0) {
+    if (c.epi.pending)
+      h2_epi_rest<NT, EPI, 0>(a, c.epi, reinterpret_cast<const char*>(lds) + c.epi.bufoff + (unsigned)wave * (TW * 128),
+                              lds + H2_SB_OFF / 4, wave, lane);
   }
 }
 
@@ -547,17 +713,26 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
   p.m_ng = magic_of(p.ngroups); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
   const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
   hipStream_t st = pw_stream(stream);
+  // epilogue variant (see "software-pipelined epilogue"): the branch-free in-tap passes need uniform formats
+  int epi = 0;
+  const bool y1_h2 = cout1 == 0 || fmt_y1 == 1, y1_f32 = cout1 == 0 || fmt_y1 == 0;
+  if (fmt_y0 == 1 && y1_h2 && !residual) epi = 1;
+  else if (fmt_y0 == 1 && cout1 == 0 && residual && fmt_res == 1) epi = 2;
+  else if (fmt_y0 == 0 && y1_f32 && !residual) epi = 3;
+  if (const char* e = getenv("PW_H2_EPI")) { if (atoi(e) == 0) epi = 0; }      // A/B runs and tests of the generic phase
+#define PW_H2_LAUNCH(NTv, EPIv)                                                          \
+  do {                                                                                   \
+    static int once = set_lds_limit(k_conv3d_h2<NTv, EPIv>, H2_LDS);                      \
+    if (once) return once;                                                               \
+    hipLaunchKernelGGL((k_conv3d_h2<NTv, EPIv>), dim3(nb), dim3(256), H2_LDS, st, a, p);  \
+    pw_note_kernel("k_conv3d_h2<%d, %d>", NTv, EPIv);                                     \
+  } while (0)
   if (NT == 2) {
-    static int once = set_lds_limit(k_conv3d_h2<2>, H2_LDS);
-    if (once) return once;
-    hipLaunchKernelGGL(k_conv3d_h2<2>, dim3(nb), dim3(256), H2_LDS, st, a, p);
-    pw_note_kernel("k_conv3d_h2<2>");
+    if (epi == 1) PW_H2_LAUNCH(2, 1); else if (epi == 2) PW_H2_LAUNCH(2, 2); else if (epi == 3) PW_H2_LAUNCH(2, 3); else PW_H2_LAUNCH(2, 0);
   } else {
-    static int once = set_lds_limit(k_conv3d_h2<1>, H2_LDS);
-    if (once) return once;
-    hipLaunchKernelGGL(k_conv3d_h2<1>, dim3(nb), dim3(256), H2_LDS, st, a, p);
-    pw_note_kernel("k_conv3d_h2<1>");
+    if (epi == 1) PW_H2_LAUNCH(1, 1); else if (epi == 2) PW_H2_LAUNCH(1, 2); else if (epi == 3) PW_H2_LAUNCH(1, 3); else PW_H2_LAUNCH(1, 0);
   }
+#undef PW_H2_LAUNCH
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

@@ -576,7 +576,7 @@ def test_conv3d_h2_two_outputs_strided_inplace_residual():
     assert torch.equal(buf[..., 64:96], dense.buf)
     # separate fp32-output run of the same conv agrees with the decoded h2 result to the format's resolution
     f = ops.conv3d_h2(y0, wp1, sc[:32].contiguous() / inv[:32] * inv1, bi[:32].contiguous(), residual=y1, relu0=True, out_h2=(False, False))
-    np.testing.assert_allclose(ops.h2_to_f32(dense).cpu().numpy(), f.cpu().numpy(), rtol=5e-7, atol=1e-7)
+    np.testing.assert_allclose(ops.h2_to_f32(dense).cpu().numpy(), f.cpu().numpy(), rtol=5e-7, atol=5e-7)
 
 
 @pytest.mark.parametrize('shape,cout', [((1, 32, 8, 12, 12), 64), ((2, 64, 5, 9, 7), 128), ((1, 32, 16, 20, 20), 64)])
