@@ -275,6 +275,18 @@ int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, const f
                    float* out_depth, float* out_sem, float* out_rgb, float* out_last,
                    int32_t* out_counts, float* out_weights, uint8_t* out_mask, void* stream);
 
+/* Backward of pw_render_rays in ONE kernel (reference: torch autograd through nerf_head.py:211-225 grid_sample, utils.py:37-68
+ * Raw2Alpha / Alphas2Weights with render_utils_kernel.cu:507-517,654-677, and the three segment sums :331-353): the same
+ * per-ray march (identical masks / compactions / early stop), the reverse transmittance scan, and the trilinear corner
+ * scatter-adds into grad_grid (Z,Y,X,grid_channels) -- ACCUMULATED with float atomics, zero it first.
+ * g_depth (R), g_sem (R,n_sem), g_rgb (R,3), g_last (R) = d loss / d {depth, semantic, color, alphainv_last};
+ * g_weights (R,n_samples) = d loss / d out_weights (the dense per-sample weights) or NULL. */
+int pw_render_rays_backward(const float* rays_o, const float* rays_d, int n_rays, const float* t, int n_samples,
+                            const float* grid, int X, int Y, int Z, int grid_channels, int c_sigma, int c_sem,
+                            int n_sem, int c_rgb, const float* consts_host, const float* g_depth, const float* g_sem,
+                            const float* g_rgb, const float* g_last, const float* g_weights, float* grad_grid,
+                            void* stream);
+
 /* A12  attribute projection (preworld_temporal_traj.py:81-104): density/semantic/color MLPs
  * (each 32 -> 64 Softplus -> {2,17,3}) fused; v0 (n_vox,32) channels-last; out (n_vox,24) packed
  * {density_prob[2], semantic[17], color[3], 0, 0}.  w1p/w2p: float[6144] per-lane MFMA operand

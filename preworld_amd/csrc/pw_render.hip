@@ -211,6 +211,13 @@ struct RenderArgs {
   int* out_counts;         // (R, 3): #masked, #alpha>thr, #weight>thr  (or null)
   float* out_weights;      // (R, S) dense per-sample weights, 0 where culled (or null)
   uint8_t* out_mask;       // (R, S) inner|cumdist sample mask (or null)
+  // backward (k_render_rays<NP, true>): upstream gradients and the gradient of the packed grid
+  const float* g_depth;    // (R)
+  const float* g_sem;      // (R, n_sem)
+  const float* g_rgb;      // (R, 3)
+  const float* g_last;     // (R)   d loss / d alphainv_last
+  const float* g_w;        // (R, S) d loss / d dense weights, or null
+  float* grad_grid;        // (Z,Y,X,GC), ACCUMULATED into (zero it first)
 };
 
 constexpr int RPASS = 7;   // 7 x 64 = 448 >= 417 samples per ray
@@ -264,7 +271,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Where the time goes (38 400 rays x 417 samples: 1.36 ms): the two order-dependent scans (cumdist
 // reset scan, transmittance product with early stop) run as wave-uniform VALU chains, ~12 k
 // instructions per ray; hoisting the corner gathers out of their bounds tests changed nothing.
-template <int NP>
+// BWD = true: the same march (identical masks, compactions and early stop by construction), then the reverse pass of
+// mmdet3d/models/nerf/utils.py:37-68 + render_utils_kernel.cu:507-517,654-677 + grid_sample's backward in the same wave:
+//   d loss / d w_i      = g_depth s_i radius + g_sem . sem_i + g_rgb . rgb_i (+ g_w[i])        for samples with w_i > thres
+//   d loss / d alpha_i  = gw_i T_i - back_cum / (1 - alpha_i + 1e-10),  back_cum += gw_i w_i   (reverse over the scanned samples)
+//   d loss / d sigma_i  = min(e, 1e10) (1 + e)^(-interval-1) interval d alpha_i
+// and the trilinear corner scatter-adds of (w_i g_sem, w_i g_rgb, d sigma_i) into the packed (Z,Y,X,24) gradient grid with
+// hardware float atomics (summation order across rays is not deterministic, like the reference's grid_sample backward).
+template <int NP, bool BWD>
 __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -355,26 +369,29 @@ __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
     }
   }
   // ---- A15/A16 density gather + raw2alpha on masked samples
-  float alpha[NP];
+  float alpha[NP], eq[NP];
   int n_mask = 0;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const bool m = (maskbits[p] >> lane) & 1ull;
     n_mask += __popcll(maskbits[p]);
-    float al = 0.f;
+    float al = 0.f, ee = 0.f;
     if (m) {
       const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
       float sig = 0.f;
       PW_FOR_CORNERS(t3, { if (inb) sig += a.grid[cbase + a.c_sigma] * wgt; })
       const float e = expf(sig + a.act_shift);
       al = 1.f - powf(1.f + e, -a.interval);
+      ee = e;
     }
     alpha[p] = al;
+    eq[p] = ee;
   }
   // ---- A17 alpha2weight (render_utils_kernel.cu:577-605) over samples with alpha > thres
-  float w[NP];
+  float w[NP], Tq[NP];
+  unsigned long long proc[NP];                 // samples the transmittance scan visited (up to and including the stopper)
 #pragma unroll
-  for (int p = 0; p < NP; ++p) w[p] = 0.f;
+  for (int p = 0; p < NP; ++p) { w[p] = 0.f; Tq[p] = 1.f; proc[p] = 0ull; }
   float T_cum = 1.f;
   int n_alpha = 0;
   bool stopped = false;
@@ -388,10 +405,72 @@ __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
       rem &= rem - 1;
       const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha[p]), l));
       const float wq = T_cum * al;
-      if (lane == l) w[p] = wq;
+      if (lane == l) { w[p] = wq; Tq[p] = T_cum; }
+      proc[p] |= 1ull << l;
       T_cum = (float)((double)T_cum * (1. - (double)al));
       if ((double)T_cum < 1e-3) stopped = true;
     }
+  }
+  if constexpr (BWD) {
+    // ---- reverse pass
+    float gsem[17], grgb[3];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) gsem[k] = a.g_sem[(size_t)ray * a.n_sem + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) grgb[k] = a.g_rgb[(size_t)ray * 3 + k];
+    const float gdep = a.g_depth[ray] * a.depth_scale;
+    float gw[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      gw[p] = 0.f;
+      const bool keep = w[p] > a.fast_thres;
+      if (keep) {
+        const float sdist = 1.f - 1.f / (1.f + tt[p]);
+        const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
+        float acc = gdep * sdist;
+        if (a.g_w) acc += a.g_w[(size_t)ray * S + p * 64 + lane];
+        PW_FOR_CORNERS(t3, {
+          if (inb) {
+            const float* g = a.grid + cbase;
+            float* gg = a.grad_grid + cbase;
+            const float ww = w[p] * wgt;
+            for (int k = 0; k < 17; ++k) { acc += gsem[k] * (g[a.c_sem + k] * wgt); unsafeAtomicAdd(gg + a.c_sem + k, ww * gsem[k]); }
+            for (int k = 0; k < 3; ++k) { acc += grgb[k] * (g[a.c_rgb + k] * wgt); unsafeAtomicAdd(gg + a.c_rgb + k, ww * grgb[k]); }
+          }
+        })
+        gw[p] = acc;
+      }
+    }
+    float back_cum = a.g_last[ray] * T_cum;               // grad_last * alphainv_last (render_utils_kernel.cu:671)
+    float galpha[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) galpha[p] = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      const int p = NP - 1 - pp;
+      unsigned long long rem = proc[p];
+      while (rem) {
+        const int l = 63 - __builtin_clzll(rem);
+        rem &= ~(1ull << l);
+        const float gwl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw[p]), l));
+        const float Tl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tq[p]), l));
+        const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha[p]), l));
+        const float wl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[p]), l));
+        const float g = (float)((double)(gwl * Tl) - (double)back_cum / (1. - (double)al + 1e-10));
+        if (lane == l) galpha[p] = g;
+        back_cum += gwl * wl;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if ((proc[p] >> lane) & 1ull) {
+        const double m = (double)eq[p] < 1e10 ? (double)eq[p] : 1e10;
+        const float gsig = (float)(m * (double)powf(1.f + eq[p], -a.interval - 1.f) * (double)a.interval * (double)galpha[p]);
+        const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
+        PW_FOR_CORNERS(t3, { if (inb) unsafeAtomicAdd(a.grad_grid + cbase + a.c_sigma, gsig * wgt); })
+      }
+    }
+    return;
   }
   // ---- A18 render_depth/semantic/color over samples with weight > thres
   float acc_d = 0.f, acc_rgb[3] = {0.f, 0.f, 0.f};
@@ -482,9 +561,41 @@ PW_API int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, 
   a.out_depth = out_depth; a.out_sem = out_sem; a.out_rgb = out_rgb; a.out_last = out_last;
   a.out_counts = out_counts; a.out_weights = out_weights; a.out_mask = out_mask;
   const dim3 grid_dim((unsigned)pw_cdiv(n_rays, 4));
-  if (n_samples <= 128) hipLaunchKernelGGL(k_render_rays<2>, grid_dim, dim3(256), 0, pw_stream(stream), a);
-  else if (n_samples <= 256) hipLaunchKernelGGL(k_render_rays<4>, grid_dim, dim3(256), 0, pw_stream(stream), a);
-  else hipLaunchKernelGGL(k_render_rays<RPASS>, grid_dim, dim3(256), 0, pw_stream(stream), a);
+  if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  else hipLaunchKernelGGL((k_render_rays<RPASS, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  pw_note_kernel("k_render_rays<%d, false>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS));
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_render_rays_backward(const float* rays_o, const float* rays_d, int n_rays, const float* t, int n_samples,
+                                   const float* grid, int X, int Y, int Z, int grid_channels, int c_sigma, int c_sem,
+                                   int n_sem, int c_rgb, const float* consts_host, const float* g_depth, const float* g_sem,
+                                   const float* g_rgb, const float* g_last, const float* g_weights, float* grad_grid,
+                                   void* stream) {
+  if (n_rays == 0) return PW_OK;
+  PW_CHECK_ARG(rays_o && rays_d && t && grid && consts_host && g_depth && g_sem && g_rgb && g_last && grad_grid,
+               "pw_render_rays_backward: null pointer");
+  PW_CHECK_ARG(n_rays > 0 && n_samples > 1 && n_samples <= RPASS * 64, "pw_render_rays_backward: n_samples must be in [2, %d]", RPASS * 64);
+  PW_CHECK_ARG(X > 1 && Y > 1 && Z > 1 && grid_channels > 0 && n_sem == 17, "pw_render_rays_backward: bad grid / n_sem");
+  PW_CHECK_ARG(c_sigma >= 0 && c_sigma < grid_channels && c_sem >= 0 && c_sem + n_sem <= grid_channels && c_rgb >= 0 &&
+                   c_rgb + 3 <= grid_channels, "pw_render_rays_backward: channel offsets outside the packed grid");
+  RenderArgs a = {};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.grid = grid;
+  const float* c = consts_host;
+  for (int i = 0; i < 3; ++i) { a.center[i] = c[i]; a.radius[i] = c[3 + i]; a.xyz_min[i] = c[15 + i]; a.xyz_max[i] = c[18 + i]; }
+  for (int i = 0; i < 9; ++i) a.bda[i] = c[6 + i];
+  a.bg_len = c[21]; a.act_shift = c[22]; a.interval = c[23]; a.dist_thres = c[24]; a.fast_thres = c[25];
+  a.depth_scale = c[26];
+  a.R = n_rays; a.S = n_samples; a.X = X; a.Y = Y; a.Z = Z; a.GC = grid_channels;
+  a.c_sigma = c_sigma; a.c_sem = c_sem; a.n_sem = n_sem; a.c_rgb = c_rgb;
+  a.g_depth = g_depth; a.g_sem = g_sem; a.g_rgb = g_rgb; a.g_last = g_last; a.g_w = g_weights; a.grad_grid = grad_grid;
+  const dim3 grid_dim((unsigned)pw_cdiv(n_rays, 4));
+  if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  else hipLaunchKernelGGL((k_render_rays<RPASS, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  pw_note_kernel("k_render_rays<%d, true>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS));
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

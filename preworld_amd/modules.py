@@ -767,9 +767,9 @@ class NerfHead(nn.Module):
 
     The forward pass of render_one_scene + render_depth/semantic/color is one HIP kernel
     (pw_render_rays, one wavefront per ray); the scalar losses on the (n_rays,) outputs are a
-    handful of torch reductions.  Forward/eval only in this round: gradients w.r.t. the
-    attribute grids are not built (ops.Raw2Alpha / ops.Alphas2Weights expose the reference's
-    autograd ops for composing one)."""
+    handful of torch reductions.  With gradients enabled the render runs through ops.RenderRays, whose backward is
+    ONE kernel as well (pw_render_rays_backward: reverse transmittance scan + trilinear corner scatter-adds into the packed
+    grid); ops.Raw2Alpha / ops.Alphas2Weights keep the reference's op-level autograd interface."""
 
     def __init__(self, point_cloud_range, voxel_size, scene_center=None, radius=39, step_size=0.5,
                  use_depth_sup=True, balance_cls_weight=True, weight_depth=1.0, weight_semantic=1.0,
@@ -863,19 +863,24 @@ class NerfHead(nn.Module):
         """Same signature as nerf_head.py:361-420.  density (B,X,Y,Z), semantic (B,X,Y,Z,17),
         color (B,X,Y,Z,3), rays (B,R,16), bda (B,3,3) -> dict of scalar losses."""
         assert dataset_type == 'Nuscenes'
-        if torch.is_grad_enabled() and (density.requires_grad or semantic.requires_grad):
-            raise NotImplementedError('NerfHead HIP path is forward-only in this build')
         losses = {}
         suffix = '_%ds' % int(interval) if if_temporal else ''
+        need_grad = torch.is_grad_enabled() and (density.requires_grad or semantic.requires_grad or color.requires_grad)
         for b in range(rays.shape[0]):
             gt_depth = rays[b, :, 2]
             gt_depth[gt_depth > 52] = 0                          # in-place, like :379
             mask = gt_depth > 0
             grid = pack_attribute_grid(density[b].float(), semantic[b].float(), color[b].float())
-            out = ops.render_rays(rays[b, :, 4:7][mask].float().contiguous(),
-                                  rays[b, :, 7:10][mask].float().contiguous(),
-                                  self.t_table(grid.device), grid, self.consts(bda[b].cpu()),
-                                  want_debug=self.weight_distortion > 0)
+            ro, rd = rays[b, :, 4:7][mask].float().contiguous(), rays[b, :, 7:10][mask].float().contiguous()
+            if need_grad:
+                # training: the fused forward + ONE backward kernel (reverse transmittance scan + corner scatter-adds)
+                d_, s_, c_, l_, w_ = ops.RenderRays.apply(grid, ro, rd, self.t_table(grid.device), self.consts(bda[b].cpu()))
+                out = dict(depth=d_, semantic=s_, color=c_, alphainv_last=l_)
+                if self.weight_distortion > 0:
+                    out['weights'] = w_
+            else:
+                out = ops.render_rays(ro, rd, self.t_table(grid.device), grid, self.consts(bda[b].cpu()),
+                                      want_debug=self.weight_distortion > 0)
             single = self.compute_loss(out, gt_depth[mask], rays[b, :, 3][mask], rays[b, :, 13:16][mask],
                                        suffix)
             for k, v in single.items():

@@ -939,6 +939,45 @@ def render_rays(rays_o, rays_d, t, grid, consts, c_sigma=0, c_sem=2, n_sem=17, c
     return out
 
 
+def render_rays_backward(rays_o, rays_d, t, grid, consts, g_depth, g_sem, g_rgb, g_last, g_weights=None, c_sigma=0, c_sem=2,
+                         n_sem=17, c_rgb=19, grad_grid=None):
+    """Backward of render_rays in one kernel (pw_render_rays_backward): gradient of the packed (Z,Y,X,GC) grid given the
+    gradients of depth (R), semantic (R,17), color (R,3), alphainv_last (R) [and of the dense weights (R,S)]."""
+    R, S = rays_o.shape[0], t.numel()
+    Z, Y, X, GC = grid.shape
+    if grad_grid is None:
+        grad_grid = torch.zeros_like(grid)
+    ch = (ctypes.c_float * 27)(*[float(v) for v in consts])
+    gw = _chk(g_weights.contiguous(), _f32, 'g_weights') if g_weights is not None else None
+    _lib.call('pw_render_rays_backward', _chk(rays_o.contiguous(), _f32, 'rays_o'), _chk(rays_d.contiguous(), _f32, 'rays_d'), R,
+              _chk(t, _f32, 't'), S, _chk(grid, _f32, 'grid'), X, Y, Z, GC, c_sigma, c_sem, n_sem, c_rgb, ch,
+              _chk(g_depth.contiguous(), _f32, 'g_depth'), _chk(g_sem.contiguous(), _f32, 'g_sem'),
+              _chk(g_rgb.contiguous(), _f32, 'g_rgb'), _chk(g_last.contiguous(), _f32, 'g_last'), gw,
+              _chk(grad_grid, _f32, 'grad_grid'), _stream())
+    return grad_grid
+
+
+class RenderRays(torch.autograd.Function):
+    """Differentiable fused render head: forward = pw_render_rays, backward = pw_render_rays_backward.  Replaces the autograd
+    graph the reference builds through 3x F.grid_sample, Raw2Alpha, Alphas2Weights and 3x segment_coo
+    (nerf_head.py:165-269,331-353; utils.py:26-68).  Returns (depth, semantic, color, alphainv_last, weights (R,S) dense)."""
+
+    @staticmethod
+    def forward(ctx, grid, rays_o, rays_d, t, consts):
+        grid = grid.contiguous()
+        out = render_rays(rays_o, rays_d, t, grid, consts, want_debug=True)
+        ctx.save_for_backward(grid, rays_o, rays_d, t)
+        ctx.consts = tuple(float(v) for v in consts)
+        return out['depth'], out['semantic'], out['color'], out['alphainv_last'], out['weights']
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_depth, g_sem, g_rgb, g_last, g_w):
+        grid, rays_o, rays_d, t = ctx.saved_tensors
+        gg = render_rays_backward(rays_o, rays_d, t, grid, ctx.consts, g_depth, g_sem, g_rgb, g_last, g_w)
+        return gg, None, None, None, None
+
+
 def confusion_hist(pred, gt, mask, n_cl, hist):
     """hist (n_cl,n_cl) int64 += bincount(n_cl*gt + pred) over (masked) voxels -- occ_metrics.py:82-105."""
     p = pred.contiguous().view(-1)

@@ -654,6 +654,49 @@ def gen_render(nh):
          scene_center=head.scene_center.numpy())
 
 
+def gen_render_grad(nh):
+    """Gradients of the render head w.r.t. the density / semantic / color grids: the imported reference NerfHead under torch
+    autograd (grid_sample backward, Raw2Alpha / Alphas2Weights backward through the bound C restatements) against the
+    differentiable checker oracle/torch_render.py, same inputs; the fixture keeps the reference's gradients at sampled
+    voxels plus their sums."""
+    from oracle import torch_render as TR
+    head = nh.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4, scene_center=[0, 0, 2.2], radius=39,
+                       use_depth_sup=True, weight_depth=1.0, weight_semantic=1.0, weight_color=1.0)
+    R, S_ = 48, 417
+    density, semantic, color = [torch.from_numpy(a).requires_grad_() for a in S.render_grids(23)]
+    o_np, d_np = S.rays(24, R)
+    bda_np = np.array([[0.98, 0.05, 0.0], [-0.05, 0.98, 0.0], [0.0, 0.0, 1.0]], np.float32)
+    coef = TR.objective_coefficients(25, R, S_)
+    res = head.render_one_scene(torch.from_numpy(o_np), torch.from_numpy(d_np), torch.from_numpy(bda_np), density, semantic,
+                                color, mask=None)
+    res['N_ray'] = R
+    # dense (R, S) weights need the step ids, which render_one_scene does not return: recover them from t (strictly
+    # increasing sample table) -- pure indexing, no arithmetic on the reference's values
+    t_tab = torch.from_numpy(O.NerfConsts().t_table())
+    step_id = torch.searchsorted(t_tab, res['t'])
+    out = dict(depth=head.render_depth(res), semantic=head.render_semantic(res), color=head.render_color(res),
+               alphainv_last=res['alphainv_last'],
+               weights=torch.zeros(R, S_).index_put((res['ray_id'], step_id), res['weights']))
+    TR.scalar_objective(out, coef).backward()
+    ref = [density.grad.clone(), semantic.grad.clone(), color.grad.clone()]
+    d2, s2, c2 = [torch.from_numpy(a).requires_grad_() for a in S.render_grids(23)]
+    out2 = TR.render(o_np, d_np, bda_np, d2, s2, c2)
+    for k in out:
+        np.testing.assert_allclose(out2[k].detach().numpy(), out[k].detach().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+    TR.scalar_objective(out2, coef).backward()
+    for a, b, name in zip(ref, (d2.grad, s2.grad, c2.grad), ('density', 'semantic', 'color')):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=1e-5, atol=1e-7, err_msg=name)
+    rng = np.random.RandomState(26)
+    nz = torch.nonzero(ref[0].abs() > 0).numpy()
+    pick = nz[rng.choice(len(nz), 4096, replace=False)]
+    ix = tuple(torch.from_numpy(pick[:, i]) for i in range(3))
+    save('render_grad_small.npz', seed_grid=np.int64(23), seed_rays=np.int64(24), seed_coef=np.int64(25), R=np.int64(R),
+         bda=bda_np, voxels=pick.astype(np.int32), g_density=ref[0][ix].numpy(), g_semantic=ref[1][ix].numpy(),
+         g_color=ref[2][ix].numpy(), sum_density=np.float64(ref[0].double().sum()), sum_semantic=ref[1].double().sum((0, 1, 2)).numpy(),
+         sum_color=ref[2].double().sum((0, 1, 2)).numpy(), abs_density=np.float64(ref[0].double().abs().sum()),
+         n_nonzero=np.int64(len(nz)), depth=out['depth'].detach().numpy(), alphainv_last=out['alphainv_last'].detach().numpy())
+
+
 def gen_metric(om):
     """G8: Metric_mIoU on seeded random labels."""
     rng = np.random.RandomState(4)
@@ -816,6 +859,8 @@ def main():
         gen_bevdepth(vtm)
     if want('metric_temporal'):
         gen_metric_temporal(om)
+    if want('render_grad'):
+        gen_render_grad(nh)
     if only:
         return
     gen_kat(bp)
