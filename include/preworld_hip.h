@@ -268,12 +268,13 @@ int pw_cumdist_thres(const float* dist, float thres, int n_rays, int n_pts, uint
  *   outputs: out_depth (n_rays), out_sem (n_rays,17), out_rgb (n_rays,3), out_last (n_rays) =
  *   alphainv_last; optional out_counts int32 (n_rays,3) = #samples after each of the reference's
  *   three compactions, out_weights (n_rays,n_samples) dense weights (0 where culled), out_mask
- *   uint8 (n_rays,n_samples) the inner|cumdist mask. */
+ *   uint8 (n_rays,n_samples) the inner|cumdist mask.  *   grid_bf16 != 0: `grid` points at bfloat16 values (same (Z,Y,X,grid_channels) layout, half the bytes per trilinear corner;
+ *   BASELINE configs[4] "bf16 storage"): widened to fp32 on load, fp32 arithmetic and accumulation throughout. */
 int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, const float* t,
                    int n_samples, const float* grid, int X, int Y, int Z, int grid_channels,
                    int c_sigma, int c_sem, int n_sem, int c_rgb, const float* consts_host,
                    float* out_depth, float* out_sem, float* out_rgb, float* out_last,
-                   int32_t* out_counts, float* out_weights, uint8_t* out_mask, void* stream);
+                   int32_t* out_counts, float* out_weights, uint8_t* out_mask, int grid_bf16, void* stream);
 
 /* Backward of pw_render_rays in ONE kernel (reference: torch autograd through nerf_head.py:211-225 grid_sample, utils.py:37-68
  * Raw2Alpha / Alphas2Weights with render_utils_kernel.cu:507-517,654-677, and the three segment sums :331-353): the same

@@ -278,7 +278,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   d loss / d sigma_i  = min(e, 1e10) (1 + e)^(-interval-1) interval d alpha_i
 // and the trilinear corner scatter-adds of (w_i g_sem, w_i g_rgb, d sigma_i) into the packed (Z,Y,X,24) gradient grid with
 // hardware float atomics (summation order across rays is not deterministic, like the reference's grid_sample backward).
-template <int NP, bool BWD>
+// BF16 = true: the packed grid is stored as bfloat16 (48 B per trilinear corner instead of 96: BASELINE.json configs[4] /
+// north_star "bf16 storage, fp32 accumulate"); every value is widened to fp32 on load, all arithmetic stays fp32.
+template <bool BF16>
+__device__ __forceinline__ float grid_at(const float* grid, size_t idx) {
+  if constexpr (BF16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(grid)[idx] << 16);
+  else return grid[idx];
+}
+
+template <int NP, bool BWD, bool BF16 = false>
 __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -379,7 +387,7 @@ __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
     if (m) {
       const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
       float sig = 0.f;
-      PW_FOR_CORNERS(t3, { if (inb) sig += a.grid[cbase + a.c_sigma] * wgt; })
+      PW_FOR_CORNERS(t3, { if (inb) sig += grid_at<BF16>(a.grid, cbase + a.c_sigma) * wgt; })
       const float e = expf(sig + a.act_shift);
       al = 1.f - powf(1.f + e, -a.interval);
       ee = e;
@@ -494,9 +502,8 @@ __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
       rgb[0] = rgb[1] = rgb[2] = 0.f;
       PW_FOR_CORNERS(t3, {
         if (inb) {
-          const float* g = a.grid + cbase;
-          for (int k = 0; k < 17; ++k) sem[k] += g[a.c_sem + k] * wgt;
-          for (int k = 0; k < 3; ++k) rgb[k] += g[a.c_rgb + k] * wgt;
+          for (int k = 0; k < 17; ++k) sem[k] += grid_at<BF16>(a.grid, cbase + a.c_sem + k) * wgt;
+          for (int k = 0; k < 3; ++k) rgb[k] += grid_at<BF16>(a.grid, cbase + a.c_rgb + k) * wgt;
         }
       })
 #pragma unroll
@@ -537,7 +544,7 @@ PW_API int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, 
                           const float* consts_host /* 3 center, 3 radius, 9 bda, 3 xyz_min, 3 xyz_max,
                           bg_len, act_shift, interval, dist_thres, fast_thres, depth_scale = 27 floats */,
                           float* out_depth, float* out_sem, float* out_rgb, float* out_last,
-                          int32_t* out_counts, float* out_weights, uint8_t* out_mask, void* stream) {
+                          int32_t* out_counts, float* out_weights, uint8_t* out_mask, int grid_bf16, void* stream) {
   if (n_rays == 0) return PW_OK;
   PW_CHECK_ARG(rays_o && rays_d && t && grid && consts_host && out_depth && out_sem && out_rgb &&
                    out_last,
@@ -561,10 +568,16 @@ PW_API int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, 
   a.out_depth = out_depth; a.out_sem = out_sem; a.out_rgb = out_rgb; a.out_last = out_last;
   a.out_counts = out_counts; a.out_weights = out_weights; a.out_mask = out_mask;
   const dim3 grid_dim((unsigned)pw_cdiv(n_rays, 4));
-  if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-  else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-  else hipLaunchKernelGGL((k_render_rays<RPASS, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-  pw_note_kernel("k_render_rays<%d, false>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS));
+  if (grid_bf16) {
+    if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, false, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, false, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    else hipLaunchKernelGGL((k_render_rays<RPASS, false, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  } else {
+    if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    else hipLaunchKernelGGL((k_render_rays<RPASS, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  }
+  pw_note_kernel("k_render_rays<%d, false, %s>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS), grid_bf16 ? "true" : "false");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

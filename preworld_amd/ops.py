@@ -921,6 +921,11 @@ def render_rays(rays_o, rays_d, t, grid, consts, c_sigma=0, c_sem=2, n_sem=17, c
     R, S = rays_o.shape[0], t.numel()
     Z, Y, X, GC = grid.shape
     dev = rays_o.device
+    bf16 = grid.dtype == torch.bfloat16           # bf16 STORAGE of the packed grid (grid.to(torch.bfloat16)); fp32 arithmetic
+    if not bf16 and grid.dtype != _f32:
+        raise _lib.PreworldHipError('grid must be float32 or bfloat16')
+    if not grid.is_cuda or not grid.is_contiguous():
+        raise _lib.PreworldHipError('grid must be a contiguous device tensor')
     depth = torch.empty(R, device=dev, dtype=_f32)
     sem = torch.empty(R, n_sem, device=dev, dtype=_f32)
     rgb = torch.empty(R, 3, device=dev, dtype=_f32)
@@ -931,8 +936,8 @@ def render_rays(rays_o, rays_d, t, grid, consts, c_sigma=0, c_sem=2, n_sem=17, c
     ch = (ctypes.c_float * 27)(*[float(v) for v in consts])
     _lib.call('pw_render_rays', _chk(rays_o.contiguous(), _f32, 'rays_o'),
               _chk(rays_d.contiguous(), _f32, 'rays_d'), R, _chk(t, _f32, 't'), S,
-              _chk(grid, _f32, 'grid'), X, Y, Z, GC, c_sigma, c_sem, n_sem, c_rgb, ch, _p(depth),
-              _p(sem), _p(rgb), _p(last), _p(counts), _p(weights), _p(mask), _stream())
+              _p(grid), X, Y, Z, GC, c_sigma, c_sem, n_sem, c_rgb, ch, _p(depth),
+              _p(sem), _p(rgb), _p(last), _p(counts), _p(weights), _p(mask), int(bf16), _stream())
     out = dict(depth=depth, semantic=sem, color=rgb, alphainv_last=last)
     if want_debug:
         out.update(counts=counts, weights=weights, mask=mask.bool())

@@ -337,3 +337,24 @@ def test_nerf_head_forward_is_differentiable():
     from _parity import check_close
     for name, a, b in zip(('density', 'semantic', 'color'), g, cg):
         check_close('NerfHead d loss / d %s' % name, a.grad[0], b.grad.numpy(), 5e-5, atol=1e-8)
+
+
+def test_render_bf16_grid_storage():
+    """BASELINE configs[4] "bf16": the packed sigma / semantic / color grid stored as bfloat16 (48 B per corner), fp32 arithmetic.
+    Exactness: identical to the fp32 kernel run on the bf16-ROUNDED grid (the only difference is the storage format);
+    stated tolerance against the fp32 grid: the bf16 rounding of the inputs (2^-9 relative per value) propagated."""
+    from _parity import check_close
+    head = _head()
+    density, semantic, color = S.render_grids(31)
+    o, d = S.rays(77, 300)
+    grid = M.pack_attribute_grid(T(density), T(semantic), T(color))
+    g16 = grid.to(torch.bfloat16)
+    c = head.consts(torch.eye(3))
+    t = head.t_table(DEV)
+    out16 = ops.render_rays(T(o), T(d), t, g16, c, want_debug=True)
+    outr = ops.render_rays(T(o), T(d), t, g16.float(), c, want_debug=True)            # fp32 kernel on the rounded grid
+    for k in ('depth', 'semantic', 'color', 'alphainv_last', 'weights'):
+        assert torch.equal(out16[k], outr[k]), k
+    out32 = ops.render_rays(T(o), T(d), t, grid, c)
+    for k, tol in (('depth', 2e-2), ('semantic', 3e-2), ('color', 3e-2), ('alphainv_last', 1e-2)):
+        check_close('bf16-stored grid vs fp32 grid: %s' % k, out16[k], out32[k].cpu().numpy(), tol)
