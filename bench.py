@@ -46,6 +46,7 @@ from preworld_amd import _lib  # noqa: E402
 from preworld_amd import harness  # noqa: E402
 from preworld_amd import ops  # noqa: E402
 from preworld_amd import synth as S  # noqa: E402
+from preworld_amd.modules import precision  # noqa: E402
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks and HBM3E
 PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0}
@@ -432,7 +433,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong' if sharded else 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'f32' if precision() == 'f32' else 'f32 as hi+lo f16 (3 MFMA per product block, f32 accumulate)',
             'data': 'synthetic',
             'config': {
                 'workload': workload,
@@ -448,6 +449,13 @@ def main():
                 'replicas x%d (independent samples, no data-path collective)' % world,
                 'note': ' OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else None,
                 'excluded': 'image backbone + DepthNet (stay on PyTorch, SURVEY 8a)',
+                'arithmetic': ('PW_PRECISION=%s: ' % precision()) + (
+                    'every value is fp32; conv / forecast products run as exact-fp32 MFMA (Winograd / direct kernels)'
+                    if precision() == 'f32' else
+                    'activations and weights are fp32 values stored as fp16 hi + fp16 lo (same 4 bytes); each product block is '
+                    'hi.hi + lo_w.hi_x + hi_w.lo_x on v_mfma_f32_32x32x16_f16 with fp32 accumulation (K = 1728 dot product: '
+                    '5.8e-6 max error vs 5.6e-6 for an fp32 fma chain, profiles/r02_hw_probes.md); pooling, FPN interpolation, '
+                    'OccHead, softplus, argmax in fp32; roofline priced against the fp16 dense peak'),
             },
             'roofline': roofline,
         }

@@ -27,30 +27,35 @@ def timeit(fn, secs=0.4):
     return s.elapsed_time(e) / n * 1e3
 
 
-for (B, D, H, W), cin, cout in SHAPES:
-    torch.manual_seed(0)
-    x = torch.randn(B, D, H, W, cin, device=DEV)
-    w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
-    sc = torch.ones(cout, device=DEV); bi = torch.zeros(cout, device=DEV)
-    xh = ops.f32_to_h2(x)
-    wpk, inv = ops.pack_conv_weight_h2(w)
-    y = torch.empty(B, D, H, W, cout, device=DEV)
-    uw = ops.pack_conv_weight_wino(w)
-    gf = 2.0 * B * D * H * W * 27 * cin * cout / 1e9
-    res = {}
-    for fmt in (True, False):
-        t = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(fmt, fmt)))
-        res['h2->h2' if fmt else 'h2->f32'] = t
-    kern = _lib.lib().pw_last_kernel().decode()
-    os.environ['PW_H2_TILE'] = '1'
-    res['tile h2->h2'] = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(True, True)))
-    for nt in ('1', '2'):
-        if cout >= 64:
-            os.environ['PW_H2_NT'] = nt
-            res['tile NT=%s' % nt] = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(True, True)))
-    os.environ.pop('PW_H2_NT', None)
-    os.environ.pop('PW_H2_TILE')
-    t = timeit(lambda: ops.conv3d_wino(x, uw, sc, bi, relu0=True, out0=y))
-    res['wino f32'] = t
-    print('%dx%dx%dx%d %d->%d %6.1f GF  %s' % (B, D, H, W, cin, cout, gf, kern),
-          '  '.join('%s %.1f us (%.0f TF direct)' % (k, v, gf / v * 1e3) for k, v in res.items()), flush=True)
+def main():
+  for (B, D, H, W), cin, cout in SHAPES:
+      torch.manual_seed(0)
+      x = torch.randn(B, D, H, W, cin, device=DEV)
+      w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
+      sc = torch.ones(cout, device=DEV); bi = torch.zeros(cout, device=DEV)
+      xh = ops.f32_to_h2(x)
+      wpk, inv = ops.pack_conv_weight_h2(w)
+      y = torch.empty(B, D, H, W, cout, device=DEV)
+      uw = ops.pack_conv_weight_wino(w)
+      gf = 2.0 * B * D * H * W * 27 * cin * cout / 1e9
+      res = {}
+      for fmt in (True, False):
+          t = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(fmt, fmt)))
+          res['h2->h2' if fmt else 'h2->f32'] = t
+      kern = _lib.lib().pw_last_kernel().decode()
+      os.environ['PW_H2_TILE'] = '1'
+      res['tile h2->h2'] = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(True, True)))
+      for nt in ('1', '2'):
+          if cout >= 64:
+              os.environ['PW_H2_NT'] = nt
+              res['tile NT=%s' % nt] = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(True, True)))
+      os.environ.pop('PW_H2_NT', None)
+      os.environ.pop('PW_H2_TILE')
+      t = timeit(lambda: ops.conv3d_wino(x, uw, sc, bi, relu0=True, out0=y))
+      res['wino f32'] = t
+      print('%dx%dx%dx%d %d->%d %6.1f GF  %s' % (B, D, H, W, cin, cout, gf, kern),
+            '  '.join('%s %.1f us (%.0f TF direct)' % (k, v, gf / v * 1e3) for k, v in res.items()), flush=True)
+
+
+if __name__ == '__main__':
+    main()
