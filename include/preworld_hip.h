@@ -208,6 +208,20 @@ int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, cons
                       uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H,
                       int W, int Cin, int n_mid, int n_hid, int n_cls, int wpk_layout, void* stream);
 
+/* A11 on the fp16 matrix cores (split-fp16 operands, pw_h2 storage; same reference lines as pw_occ_head_fused):
+ * x (B,D,H,W,32) in h2 storage; wpk = 27 taps x {hi, lo} x 64 lanes x 8 fp16 (55 296 bytes):
+ *   wpk[tap][p][g*16 + j][e] = plane p of S_j * w[j][16*(g>>1) + 8*(g&1) + e][tap], S_j the per-output-channel power of two
+ *   that puts max |w[j]| in [512, 1024); scale [16] = folded BN scale / S_j, bias [16];
+ * tailpk = 800 floats (preworld_amd.ops.pack_occ_tail_h2): six fragments [64 lanes][4 fp16] = {hi, lo} of S1 * W1 (rows = 8
+ *   hidden channels padded to 16, lane (row = l & 15, k = 4 (l >> 4) + e)), {hi, lo} of S2 * W2 rows 0..15 and rows 16..17
+ *   (k = hidden channel, padded to 16), then s1 / S1 and b1 padded to 16 floats each (folded BN of occ_pred_conv.1);
+ *   inv2 = 1 / S2 rescales the logits output.  Outputs as pw_occ_head_fused.
+ * Kernel k_occ_head_h2<LOGITS>: v_mfma_f32_16x16x32_f16 with all conv weights register-resident; the tail runs on
+ * v_mfma_f32_16x16x16_f16 inside the next tile's tap loop. */
+int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* tailpk, float inv2,
+                   uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H, int W, int Cin, int n_mid,
+                   int n_hid, int n_cls, void* stream);
+
 /* A10  state-conditioned forecast (mmdet3d/models/detectors/preworld_temporal_traj.py:329-368).
  * pw_forecast_pack: fusion_head.{0,2}.weight ([128][64], [32][128]) -> per-lane MFMA operand
  *   order, w1p/w2p float[4096] each (once per weight update).
@@ -229,10 +243,12 @@ int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_samples, 
                       float* states, void* stream);
 /* pw_forecast_steps on the fp16 matrix cores with split-fp16 operands (see pw_conv3d_h2): w1p / w2p are the split weights
  * float[4 tiles][2 k-blocks][2 planes][64 lanes][4] built by preworld_amd.ops.forecast_pack_h2 with power-of-two pre-scales
- * whose inverses are inv1 / inv2; everything else as pw_forecast_steps (fp32 states in and out). */
+ * whose inverses are inv1 / inv2; everything else as pw_forecast_steps.  v0_h2 / out_h2 != 0: v0 is read / the states are
+ * written in h2 storage (same 4 bytes per element, see pw_f32_to_h2) instead of fp32 -- what pw_conv3d_h2 writes and
+ * pw_occ_head_h2 reads. */
 int pw_forecast_steps_h2(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
                          const float* w2p, float inv1, float inv2, const float* c1p, const float* fusion_b2,
-                         int n_steps, float* states, void* stream);
+                         int n_steps, float* states, int v0_h2, int out_h2, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A14/A16/A17  render ops with the reference's semantics on compacted point arrays

@@ -248,6 +248,7 @@ PW_API int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_sa
 // VALU work (softplus: 128 values per voxel and step, plus the splits).
 // ------------------------------------------------------------------------------------
 typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fh4 __attribute__((ext_vector_type(4)));
 typedef float fv4 __attribute__((ext_vector_type(4)));
 constexpr int WH2 = 4 * 2 * 2 * 64 * 4;     // floats per packed split matrix (16 KB)
 
@@ -264,7 +265,7 @@ __device__ __forceinline__ void split8(const float* x, fh8& hi, fh8& lo) {
 __global__ void __launch_bounds__(256, 2)
 k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_samples, const float* __restrict__ w1p,
               const float* __restrict__ w2p, float inv1, float inv2, const float* __restrict__ c1p,
-              const float* __restrict__ fb2, int n_steps, float* __restrict__ states) {
+              const float* __restrict__ fb2, int n_steps, float* __restrict__ states, int v0_h2, int out_h2) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* l_w1 = lds;
   float* l_w2 = lds + WH2;
@@ -292,11 +293,23 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
     const int sample = (int)(m / n_vox_per_sample);
     const float* c1s = c1p + (size_t)sample * HID + h * 64;
     float v[16];
-    const float* src = v0 + (size_t)m * C + 4 * h;
+    if (v0_h2) {
+      // h2 storage (pw_h2.h): channels 8 q + 4 h + 0..3 = the 8-byte group at slot 4 (q & 1) + 2 (q >> 1) + plane, byte 8 h
+      const char* src = reinterpret_cast<const char*>(v0 + (size_t)m * C) + 8 * h;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 t4 = *reinterpret_cast<const float4*>(src + 8 * q);
-      v[4 * q + 0] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+      for (int q = 0; q < 4; ++q) {
+        const int off = (4 * (q & 1) + 2 * (q >> 1)) * 16;
+        const fh4 hi4 = *reinterpret_cast<const fh4*>(src + off), lo4 = *reinterpret_cast<const fh4*>(src + off + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = (float)hi4[e] + (float)lo4[e];
+      }
+    } else {
+      const float* src = v0 + (size_t)m * C + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 t4 = *reinterpret_cast<const float4*>(src + 8 * q);
+        v[4 * q + 0] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+      }
     }
     for (int step = 0; step < n_steps; ++step) {
       fh8 vh[2], vl[2];
@@ -341,10 +354,27 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
 #pragma unroll
       for (int s = 0; s < 16; ++s) v[s] = fmaf(o[s], inv2, b2r[s]) + v[s];   // + b2, residual connection (:342)
       if (valid) {
-        float* dst = states + ((size_t)step * n_total + m) * C + 4 * h;
+        if (out_h2) {
+          char* dst = reinterpret_cast<char*>(states + ((size_t)step * n_total + m) * C) + 8 * h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          for (int q = 0; q < 4; ++q) {
+            const int off = (4 * (q & 1) + 2 * (q >> 1)) * 16;
+            fh4 hi4, lo4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = __builtin_amdgcn_fmed3f(v[4 * q + e], -65504.f, 65504.f);
+              hi4[e] = (_Float16)x;
+              lo4[e] = (_Float16)(x - (float)hi4[e]);
+            }
+            *reinterpret_cast<fh4*>(dst + off) = hi4;
+            *reinterpret_cast<fh4*>(dst + off + 16) = lo4;
+          }
+        } else {
+          float* dst = states + ((size_t)step * n_total + m) * C + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
       }
     }
   }
@@ -352,7 +382,7 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
 
 PW_API int pw_forecast_steps_h2(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
                                 const float* w2p, float inv1, float inv2, const float* c1p, const float* fusion_b2,
-                                int n_steps, float* states, void* stream) {
+                                int n_steps, float* states, int v0_h2, int out_h2, void* stream) {
   PW_CHECK_ARG(v0 && w1p && w2p && c1p && fusion_b2 && states, "pw_forecast_steps_h2: null pointer");
   PW_CHECK_ARG(n_vox_per_sample > 0 && n_samples > 0 && n_steps > 0, "pw_forecast_steps_h2: bad sizes");
   PW_CHECK_ARG((((uintptr_t)v0 | (uintptr_t)states | (uintptr_t)w1p | (uintptr_t)w2p) & 15) == 0,
@@ -362,7 +392,7 @@ PW_API int pw_forecast_steps_h2(const float* v0, int64_t n_vox_per_sample, int n
   long long want = (n_tiles + 3) / 4;
   unsigned nb = (unsigned)(want < 1024 ? want : 1024);   // 4 blocks x 256 CUs, grid-stride
   hipLaunchKernelGGL(k_forecast_h2, dim3(nb), dim3(256), lds_bytes, pw_stream(stream), v0, (long long)n_vox_per_sample,
-                     n_samples, w1p, w2p, inv1, inv2, c1p, fusion_b2, n_steps, states);
+                     n_samples, w1p, w2p, inv1, inv2, c1p, fusion_b2, n_steps, states, v0_h2, out_h2);
   pw_note_kernel("k_forecast_h2");
   PW_CHECK_LAUNCH();
   return PW_OK;

@@ -1,5 +1,6 @@
 // Fused OccHead kernels (A11) -- entry point pw_occ_head_fused in include/preworld_hip.h.
 #include "pw_wino_common.h"
+#include "pw_occ_tail.h"
 
 // ------------------------------------------------------------------------------------
 // OccHead on v_mfma_f32_16x16x4_f32: the head's 3x3x3 conv has only 16 output channels, which
@@ -13,18 +14,6 @@
 // voxel runs 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18 and argmax -> uint8 inside the epilogue; the
 // 46 MB logits tensor is only written on request.
 // ------------------------------------------------------------------------------------
-struct OccTail {
-  const float* w1;      // [8][16]  occ_pred_conv.0.weight
-  const float* s1;      // [8]      folded BN scale
-  const float* b1;      // [8]      folded BN bias
-  const float* w2;      // [18][8]  occ_pred_conv.3.weight
-  uint8_t* occ;         // [B*D*H*W] argmax class
-  float* logits;        // [B*D*H*W][18] or null
-  uint8_t* geo;         // [B*D*H*W] geo_occ or null
-  int empty_idx;
-  int n_mid, n_hid, n_cls;
-};
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void load_b16(rsrc_t wr, unsigned wsoff, unsigned lane_off, float4 (&b)[2]) {

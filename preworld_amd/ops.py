@@ -397,6 +397,10 @@ class H2:
     def shape(self):
         return self.buf.shape
 
+    @property
+    def device(self):
+        return self.buf.device
+
     def __getitem__(self, idx):
         return H2(self.buf[idx])
 
@@ -575,6 +579,67 @@ def occ_head_fused(x, wpk, scale, bias, w1, s1, b1, w2, want_logits=False, occ=N
     return out if len(out) > 1 else occ
 
 
+def pack_occ_weight_h2(w):
+    """OccHead conv weight (16, 32, 3,3,3) -> (wpk, inv_scale (16,)) for pw_occ_head_h2 (include/preworld_hip.h):
+    wpk[tap][plane][g*16 + j][e] = plane of S_j * w[j][16*(g>>1) + 8*(g&1) + e][tap] as a float32-typed (27, 2, 64, 4) tensor."""
+    Cout, Cin = w.shape[:2]
+    if (Cout, Cin) != (16, 32) or tuple(w.shape[2:]) != (3, 3, 3):
+        raise _lib.PreworldHipError('pack_occ_weight_h2 expects a (16, 32, 3, 3, 3) weight')
+    wf = w.reshape(Cout, -1).double()
+    S = torch.exp2(torch.floor(torch.log2(1023.0 / wf.abs().amax(dim=1).clamp_min(1e-30))))
+    ws = (wf * S[:, None]).view(Cout, Cin, 27)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.double()).to(torch.float16)
+    t = torch.stack([hi, lo], 0).view(2, 16, 2, 2, 8, 27)                          # (p, j, ks, half, e, tap): c = 16 ks + 8 half + e
+    t = t.permute(5, 0, 2, 3, 1, 4).contiguous()                                   # (tap, p, ks, half, j, e): g = 2 ks + half
+    wpk = t.view(27, 2, 64, 8).view(torch.float32).view(27, 2, 64, 4).contiguous()
+    return wpk, (1.0 / S).float()
+
+
+def pack_occ_tail_h2(w1, s1, b1, w2):
+    """The 16 -> 8 (+BN+ReLU) -> 18 tail of OccHead as operands of pw_occ_head_h2: w1 (8,16), s1 / b1 (8,) folded BN, w2 (18,8)
+    -> (tailpk float32 (800,), inv2).  One power-of-two pre-scale per matrix (argmax must see one common scale)."""
+    dev = w1.device
+    S1, h1, l1 = _split_planes(w1.double())
+    S2, h2_, l2 = _split_planes(w2.double())
+    lane = torch.arange(64, device=dev)
+    row, kg = lane & 15, lane >> 4
+    k = (4 * kg)[:, None] + torch.arange(4, device=dev)[None, :]                    # (64, 4): k = 4 g + e
+
+    def frag(plane, nrow, ncol, row0=0):
+        full = torch.zeros(32, 16, dtype=torch.float16, device=dev)
+        full[:nrow, :ncol] = plane
+        return full[(row0 + row)[:, None], k]                                       # (64, 4) fp16
+
+    frags = [frag(h1, 8, 16), frag(l1, 8, 16), frag(h2_, 18, 8), frag(l2, 18, 8), frag(h2_, 18, 8, 16), frag(l2, 18, 8, 16)]
+    pk = torch.stack(frags, 0).contiguous().view(torch.float32).reshape(-1)        # 6 * 64 * 2 floats
+    s1p = torch.zeros(16, dtype=_f32, device=dev)
+    b1p = torch.zeros(16, dtype=_f32, device=dev)
+    s1p[:8] = (s1.double() / S1).float()
+    b1p[:8] = b1.float()
+    return torch.cat([pk, s1p, b1p]).contiguous(), 1.0 / S2
+
+
+def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, want_logits=False, occ=None, want_geo=False, empty_idx=17):
+    """OccHead (occupancy_head.py:124-177) on the fp16 matrix cores: x = ops.H2 (B,D,H,W,32); wpk from pack_occ_weight_h2;
+    scale (16,) MUST already contain the packer's inv_scale; (tailpk, inv2) from pack_occ_tail_h2.
+    Returns like occ_head_fused."""
+    if not isinstance(x, H2):
+        raise _lib.PreworldHipError('occ_head_h2 takes an ops.H2 input (ops.f32_to_h2)')
+    B, D, H, W, Cin = x.shape
+    if occ is None:
+        occ = torch.empty(B, D, H, W, device=x.device, dtype=torch.uint8)
+    logits = torch.empty(B, D, H, W, 18, device=x.device, dtype=_f32) if want_logits else None
+    geo = torch.empty(B, D, H, W, device=x.device, dtype=torch.uint8) if want_geo else None
+    if tailpk.numel() != 800 or scale.numel() < 16 or bias.numel() < 16:
+        raise _lib.PreworldHipError('occ_head_h2: tailpk (800,), scale / bias (16,) expected')
+    _lib.call('pw_occ_head_h2', _chk(x.buf, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
+              _chk(bias, _f32, 'bias'), _chk(tailpk, _f32, 'tailpk'), float(inv2), _p(occ), _p(logits), _p(geo),
+              int(empty_idx), B, D, H, W, Cin, 16, 8, 18, _stream())
+    out = (occ,) + ((logits,) if want_logits else ()) + ((geo,) if want_geo else ())
+    return out if len(out) > 1 else occ
+
+
 def forecast_pack(fusion_w1, fusion_w2):
     w1p = torch.empty(4096, device=fusion_w1.device, dtype=_f32)
     w2p = torch.empty(4096, device=fusion_w1.device, dtype=_f32)
@@ -641,16 +706,21 @@ def forecast_pack_h2(fusion_w1, fusion_w2):
             1.0 / S1, 1.0 / S2)
 
 
-def forecast_steps_h2(v0, n_samples, packed, c1p, fusion_b2, n_steps, states=None):
-    """forecast_steps on the fp16 matrix cores with split-fp16 operands; packed = forecast_pack_h2(...)."""
+def forecast_steps_h2(v0, n_samples, packed, c1p, fusion_b2, n_steps, states=None, out_h2=False):
+    """forecast_steps on the fp16 matrix cores with split-fp16 operands; packed = forecast_pack_h2(...).
+    v0: fp32 tensor or ops.H2; out_h2=True returns the states as ONE ops.H2 of shape (n_steps, *v0.shape)."""
     w1p, w2p, inv1, inv2 = packed
-    n_total = v0.numel() // 32
+    v0_h2 = isinstance(v0, H2)
+    vbuf = v0.buf if v0_h2 else v0
+    n_total = vbuf.numel() // 32
     if states is None:
-        states = torch.empty((n_steps,) + tuple(v0.shape), device=v0.device, dtype=_f32)
-    _lib.call('pw_forecast_steps_h2', _chk(v0, _f32, 'v0'), n_total // n_samples, n_samples, _chk(w1p, _f32, 'w1p'),
+        states = torch.empty((n_steps,) + tuple(vbuf.shape), device=vbuf.device, dtype=_f32)
+    elif isinstance(states, H2):
+        states = states.buf
+    _lib.call('pw_forecast_steps_h2', _chk(vbuf, _f32, 'v0'), n_total // n_samples, n_samples, _chk(w1p, _f32, 'w1p'),
               _chk(w2p, _f32, 'w2p'), float(inv1), float(inv2), _chk(c1p, _f32, 'c1p'), _chk(fusion_b2, _f32, 'fb2'),
-              n_steps, _chk(states, _f32, 'states'), _stream())
-    return states
+              n_steps, _chk(states, _f32, 'states'), int(v0_h2), int(bool(out_h2)), _stream())
+    return H2(states) if out_h2 else states
 
 
 def softplus(x):

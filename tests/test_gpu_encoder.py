@@ -392,6 +392,61 @@ def test_occ_head_wino_matches_direct_and_oracle(shape):
     np.testing.assert_allclose(got[sl], want[sl], rtol=5e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize('shape', [(1, 16, 200, 200), (2, 5, 19, 27), (1, 4, 8, 8), (1, 16, 96, 104), (3, 2, 9, 7)])
+def test_occ_head_h2_matches_direct_and_oracle(shape):
+    """k_occ_head_h2 (split-fp16 16x16x32 MFMA, register-resident weights, scalar-operand tail) against the direct fp32
+    16x16x4 MFMA kernel: logits to split-fp16 accuracy, occupancy = argmax of its own logits (first maximum), geo_occ
+    consistent, ragged grids (partial tiles in every axis); on a corner crop the logits against the oracle."""
+    B, D, H, W = shape
+    rs = np.random.RandomState(23)
+    x = T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32))
+    w0 = T(_rand_conv(rs, 16, 32, 3))
+    s0 = T(rs.uniform(0.5, 1.5, 16).astype(np.float32)); b0 = T((rs.standard_normal(16) * 0.3).astype(np.float32))
+    w1 = T((rs.standard_normal((8, 16)) * 0.4).astype(np.float32))
+    s1 = T(rs.uniform(0.5, 1.5, 8).astype(np.float32)); b1 = T((rs.standard_normal(8) * 0.3).astype(np.float32))
+    w2 = T((rs.standard_normal((18, 8)) * 0.5).astype(np.float32))
+    occ_d, lg_d, geo_d = ops.occ_head_fused(x, ops.pack_conv_weight16(w0), ops._pad32(s0, 1.0), ops._pad32(b0, 0.0), w1, s1, b1,
+                                            w2, want_logits=True, want_geo=True)
+    wpk, inv = ops.pack_occ_weight_h2(w0)
+    hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_h2(w1, s1, b1, w2)
+    xh = ops.f32_to_h2(x)
+    occ_h, lg_h, geo_h = ops.occ_head_h2(xh, wpk, *hargs, want_logits=True, want_geo=True)
+    from _parity import check_argmax, check_close
+    check_close('occ_head h2 logits vs direct fp32 %s' % (shape,), lg_h, lg_d, 2e-5)
+    assert torch.equal(occ_h.long(), lg_h.argmax(-1))
+    check_argmax('occ_head h2 vs direct %s' % (shape,), occ_h, occ_d, lg_d, 2e-4)
+    np.testing.assert_array_equal(geo_h.cpu().numpy(), np.where(occ_h.cpu().numpy() != 17, 0, 17).astype(np.uint8))
+    occ_only = ops.occ_head_h2(xh, wpk, *hargs)
+    assert torch.equal(occ_only, occ_h)                      # deterministic, logits optional
+    d1, h1, w1_ = min(D, 6), min(H, 12), min(W, 12)
+    xc = x[:1, :d1, :h1, :w1_].permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
+    mid = np.maximum(O.conv3d(xc, w0.cpu().numpy()) * s0.cpu().numpy()[None, :, None, None, None]
+                     + b0.cpu().numpy()[None, :, None, None, None], 0)
+    hid = np.maximum(np.einsum('oc,bcdhw->bodhw', w1.cpu().numpy(), mid) * s1.cpu().numpy()[None, :, None, None, None]
+                     + b1.cpu().numpy()[None, :, None, None, None], 0)
+    want = np.einsum('oc,bcdhw->bdhwo', w2.cpu().numpy(), hid)
+    got = lg_h[:1, :d1, :h1, :w1_].cpu().numpy()
+    sl = (slice(None), slice(0, d1 if d1 == D else d1 - 1), slice(0, h1 if h1 == H else h1 - 1),
+          slice(0, w1_ if w1_ == W else w1_ - 1))
+    check_close('occ_head h2 logits vs oracle crop %s' % (shape,), got[sl], want[sl], 2e-5)
+
+
+def test_forecast_h2_storage_in_and_out():
+    """pw_forecast_steps_h2 with v0 read from / states written in h2 storage equals the fp32-I/O run of the same kernel
+    up to the storage rounding (2^-22 relative per value)."""
+    rs = np.random.RandomState(5)
+    v0 = T(rs.standard_normal((1, 4, 10, 12, 32)).astype(np.float32))
+    fw1 = T((rs.standard_normal((128, 64)) * 0.2).astype(np.float32)); fw2 = T((rs.standard_normal((32, 128)) * 0.2).astype(np.float32))
+    fb2 = T((rs.standard_normal(32) * 0.1).astype(np.float32))
+    c1p = T((rs.standard_normal((1, 128)) * 0.3).astype(np.float32))
+    packed = ops.forecast_pack_h2(fw1, fw2)
+    ref = ops.forecast_steps_h2(v0, 1, packed, c1p, fb2, 3)
+    out = ops.forecast_steps_h2(ops.f32_to_h2(v0), 1, packed, c1p, fb2, 3, out_h2=True)
+    assert isinstance(out, ops.H2) and tuple(out.shape) == (3,) + tuple(v0.shape)
+    from _parity import check_close
+    check_close('forecast h2 storage I/O', ops.h2_to_f32(out), ref, 2e-6)
+
+
 @pytest.mark.parametrize('shape', [(1, 8, 40, 72), (2, 4, 12, 200), (1, 16, 200, 200), (1, 4, 8, 24)])
 def test_fpn3d_fuse_vs_torch_interpolate(shape):
     """k_fpn3d_fuse against ReLU(BN(conv1x1(x8) + up2(y16) + up4(y32))) built from torch's own trilinear

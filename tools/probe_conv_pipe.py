@@ -17,7 +17,20 @@ buf = torch.zeros(nblk * 8 * 16 * 4 + 8 * 27, dtype=torch.int64, device=dev)
 os.environ['PW_CONV_PROBE'] = str(buf.data_ptr())
 os.environ['PW_CONV_PIPE'] = '1'
 from preworld_amd import ops  # noqa: E402
-if os.environ.get('H2', '0') == '1':          # the split-fp16 kernel k_conv3d_h2 (same probe layout)
+if os.environ.get('OCC', '0') == '1':         # k_occ_head_h2 (same probe layout; no per-tap table)
+    import numpy as _np
+    rs = _np.random.RandomState(0)
+    T = lambda a: torch.from_numpy(_np.ascontiguousarray(a)).to(dev)
+    w0 = T((rs.standard_normal((16, 32, 3, 3, 3)) * 0.05).astype(_np.float32))
+    wpk, inv = ops.pack_occ_weight_h2(w0)
+    hargs = (inv.contiguous(), T(_np.zeros(16, _np.float32))) + ops.pack_occ_tail_h2(
+        T(rs.standard_normal((8, 16)).astype(_np.float32)), T(_np.ones(8, _np.float32)), T(_np.zeros(8, _np.float32)),
+        T(rs.standard_normal((18, 8)).astype(_np.float32)))
+    xh = ops.f32_to_h2(x)
+    for _ in range(3):
+        buf.zero_()
+        ops.occ_head_h2(xh, wpk, *hargs, want_geo=True)
+elif os.environ.get('H2', '0') == '1':        # the split-fp16 kernel k_conv3d_h2 (same probe layout)
     wh, inv = ops.pack_conv_weight_h2(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
     xh = ops.f32_to_h2(x)
     for _ in range(3):
@@ -49,15 +62,20 @@ for st in range(0, 10):
     if m.any():
         print('stage %2d: taps %8.0f  wait %7.0f  epi %7.0f' % (st, (t[:, :, st, 1] - t[:, :, st, 0])[m].mean(),
               (t[:, :, st, 2] - t[:, :, st, 1])[m].mean(), (t[:, :, st, 3] - t[:, :, st, 2])[m].mean()))
-span = t[..., 3][valid].max() - t[..., 0][valid].min()
-print('kernel span (cycles of the 100 MHz counter x?) %.0f' % span)
+# per block (the counters of different XCDs are not synchronised): first stage start -> last stage end
+spans = [t[b, :, :, 3][valid[b]].max() - t[b, :, :, 0][valid[b]].min() for b in range(nblk) if valid[b].any()]
+print('block span (cycles): mean %.0f  max %.0f   (x stages/16 recorded)' % (np.mean(spans), np.max(spans)))
 for w in range(8):
     m = valid[:, w, 1:9]
+    if not m.any():
+        continue
     print('wave %d: taps mean %8.0f  p10 %8.0f p90 %8.0f   wait mean %7.0f' % (
         w, (t[:, w, 1:9, 1] - t[:, w, 1:9, 0])[m].mean(), np.percentile((t[:, w, 1:9, 1] - t[:, w, 1:9, 0])[m], 10),
         np.percentile((t[:, w, 1:9, 1] - t[:, w, 1:9, 0])[m], 90), (t[:, w, 1:9, 2] - t[:, w, 1:9, 1])[m].mean()))
 # one block, one stage: per-wave absolute times relative to stage start of wave 0
 b = 17
+if os.environ.get('OCC', '0') == '1':
+    sys.exit(0)
 for st in (3, 4):
     base = t[b, :, st, 0].min()
     print('block %d stage %d:' % (b, st), ' '.join('w%d[%.0f..%.0f]' % (w, t[b, w, st, 0] - base, t[b, w, st, 1] - base) for w in range(8)))
