@@ -71,7 +71,7 @@ class KernelProbe:
     """Times every hot launch of one eager step with HIP events recorded on the launch stream (torch's current stream ==
     the stream passed through the C ABI) and asks the library which kernel it picked (pw_last_kernel)."""
 
-    OPS = ('conv3d_ndhwc', 'conv3d_wino', 'conv3d_h2', 'occ_head_fused', 'forecast_steps', 'forecast_steps_h2', 'fpn3d_fuse', 'bev_pool_dense',
+    OPS = ('conv3d_ndhwc', 'conv3d_wino', 'conv3d_h2', 'occ_head_fused', 'occ_head_h2', 'forecast_steps', 'forecast_steps_h2', 'fpn3d_fuse', 'bev_pool_dense',
            'segment_sort', 'lss_voxel_index', 'f32_to_h2', 'h2_to_f32')
 
     def __init__(self):
@@ -147,8 +147,15 @@ class KernelProbe:
             w.update(label='occ_head 32->16->8->18 + argmax', flops=conv + tail,
                      exec_flops=(conv * 8 / 27 if wino else conv) + tail, bytes=4.0 * x.numel() + 2.0 * nv,
                      units=int(x.shape[0]))
+        elif name == 'occ_head_h2':
+            x = args[0].buf
+            nv = x.numel() // x.shape[-1]
+            fl = 2.0 * nv * (27 * 32 * 16 + 16 * 8 + 8 * 18)
+            w.update(label='occ_head 32->16->8->18 + argmax', flops=fl, exec_flops=3.0 * fl, mfma='f16',
+                     bytes=4.0 * x.numel() + 2.0 * nv, units=int(x.shape[0]))
         elif name in ('forecast_steps', 'forecast_steps_h2'):
             v0, n_steps = args[0], (args[6] if name == 'forecast_steps' else args[5])
+            v0 = v0.buf if hasattr(v0, 'buf') else v0
             nv = v0.numel() // 32
             fl = 2.0 * nv * n_steps * (32 * 128 + 128 * 32)
             h2 = name.endswith('h2')

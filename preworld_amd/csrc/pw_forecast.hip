@@ -311,10 +311,10 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
         v[4 * q + 0] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
       }
     }
+    fh8 vh[2], vl[2];                        // split of the current state: GEMM operand of this step AND the h2 output of the last
+    split8(v, vh[0], vl[0]);
+    split8(v + 8, vh[1], vl[1]);
     for (int step = 0; step < n_steps; ++step) {
-      fh8 vh[2], vl[2];
-      split8(v, vh[0], vl[0]);
-      split8(v + 8, vh[1], vl[1]);
       f32x16 o;
 #pragma unroll
       for (int s = 0; s < 16; ++s) o[s] = 0.f;
@@ -353,22 +353,35 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) v[s] = fmaf(o[s], inv2, b2r[s]) + v[s];   // + b2, residual connection (:342)
+      split8(v, vh[0], vl[0]);
+      split8(v + 8, vh[1], vl[1]);
       if (valid) {
         if (out_h2) {
-          char* dst = reinterpret_cast<char*>(states + ((size_t)step * n_total + m) * C) + 8 * h;
+          // h2 storage: a 16-byte slot holds 8 channels of one plane, but this lane has only 4 of them (8 q + 4 h + e) and its
+          // partner lane (l ^ 32, same voxel) the other 4.  One v_permlane32_swap per dword trades the pieces so that lane half
+          // h ends up with both pieces of the slots of q = 2 h, 2 h + 1: four 16-byte stores like the fp32 layout.
+          fh4 hi4[4], lo4[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int off = (4 * (q & 1) + 2 * (q >> 1)) * 16;
-            fh4 hi4, lo4;
+          for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float x = __builtin_amdgcn_fmed3f(v[4 * q + e], -65504.f, 65504.f);
-              hi4[e] = (_Float16)x;
-              lo4[e] = (_Float16)(x - (float)hi4[e]);
+              hi4[q][e] = vh[q >> 1][4 * (q & 1) + e];
+              lo4[q][e] = vl[q >> 1][4 * (q & 1) + e];
             }
-            *reinterpret_cast<fh4*>(dst + off) = hi4;
-            *reinterpret_cast<fh4*>(dst + off + 16) = lo4;
-          }
+          char* dst = reinterpret_cast<char*>(states + ((size_t)step * n_total + m) * C);
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              typedef unsigned fu2 __attribute__((ext_vector_type(2)));
+              typedef unsigned fu4 __attribute__((ext_vector_type(4)));
+              const fu2 a = __builtin_bit_cast(fu2, p ? lo4[qq] : hi4[qq]), b = __builtin_bit_cast(fu2, p ? lo4[qq + 2] : hi4[qq + 2]);
+              const auto s0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+              const auto s1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+              fu4 slot;
+              slot[0] = s0[0]; slot[1] = s1[0]; slot[2] = s0[1]; slot[3] = s1[1];      // channels +0..3 | +4..7
+              *reinterpret_cast<fu4*>(dst + (4 * qq + 2 * h + p) * 16) = slot;
+            }
         } else {
           float* dst = states + ((size_t)step * n_total + m) * C + 4 * h;
 #pragma unroll

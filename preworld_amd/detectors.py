@@ -223,9 +223,11 @@ class BEVStereo4DOCC(nn.Module):
                 x[..., lo:hi].zero_()
         return self.bev_encoder_cl(ops.H2(x) if h2 else x, out_h2=out_h2)
 
-    def extract_voxel_feat_cl(self, frames):
-        """... followed by final_conv: conv + bias + ReLU (preworld.py:72-79), channels-last (B,Z,Y,X,out_dim)."""
-        return self.final_conv.forward_cl(self.extract_bev_feat_cl(frames, out_h2=precision() == 'h2'))
+    def extract_voxel_feat_cl(self, frames, out_h2=False):
+        """... followed by final_conv: conv + bias + ReLU (preworld.py:72-79), channels-last (B,Z,Y,X,out_dim); out_h2: keep
+        the result in h2 storage (ops.H2) for the split-fp16 forecast / OccHead kernels."""
+        return self.final_conv.forward_cl(self.extract_bev_feat_cl(frames, out_h2=precision() == 'h2'),
+                                          out_h2=out_h2 and precision() == 'h2')
 
     # ---- bevdet_occ.py:281-301: final_conv -> predicter MLP -> argmax(softmax) (softmax is monotone: argmax of logits)
     @torch.no_grad()
@@ -313,7 +315,7 @@ class PreWorld(_PreWorldCommon):
 
     @torch.no_grad()
     def simple_test_from_lift(self, frames, want_logits=False, **kwargs):
-        v0 = self.extract_voxel_feat_cl(frames)                       # (B,Z,Y,X,C)
+        v0 = self.extract_voxel_feat_cl(frames, out_h2=self.if_post_finetune)   # (B,Z,Y,X,C); ops.H2 on the split-fp16 path
         res = {'voxel_feats': [v0]}
         if not self.if_post_finetune:
             occ = self.attribute_decode(self.attributes_cl(v0)).permute(0, 3, 2, 1)
@@ -385,9 +387,9 @@ class PreWorld4DTraj(_PreWorldCommon):
                                                             fh[2].weight.float().contiguous()))
 
     # ---- preworld_temporal_traj.py:329-368: all recursion steps in one kernel
-    def forecast_cl(self, v_cl, ego_states, n_steps=6):
-        """v_cl (B,Z,Y,X,C); ego_states (B,1,21) (always temporal_ego_states[0], :331).
-        Returns states (n_steps,B,Z,Y,X,C) and the ego feature (B,32)."""
+    def forecast_cl(self, v_cl, ego_states, n_steps=6, out_h2=False):
+        """v_cl (B,Z,Y,X,C), fp32 tensor or ops.H2; ego_states (B,1,21) (always temporal_ego_states[0], :331).
+        Returns states (n_steps,B,Z,Y,X,C) (ops.H2 with out_h2 on the split-fp16 path) and the ego feature (B,32)."""
         ph, fh = self.plan_head, self.fusion_head
         B = v_cl.shape[0]
         ego = ego_states.reshape(B, -1).float().contiguous()
@@ -399,7 +401,9 @@ class PreWorld4DTraj(_PreWorldCommon):
                 self._fc_h2cache = _PackedCache()
             packed = self._fc_h2cache.get([fh[0].weight, fh[2].weight],
                                           lambda: ops.forecast_pack_h2(fh[0].weight.float(), fh[2].weight.float()))
-            return ops.forecast_steps_h2(v_cl, B, packed, c1p, fh[2].bias, n_steps), ef
+            return ops.forecast_steps_h2(v_cl, B, packed, c1p, fh[2].bias, n_steps, out_h2=out_h2), ef
+        if isinstance(v_cl, ops.H2):
+            v_cl = ops.h2_to_f32(v_cl)
         w1p, w2p = self._forecast_weights()
         states = ops.forecast_steps(v_cl, B, w1p, w2p, c1p, fh[2].bias, n_steps)
         return states, ef
@@ -407,7 +411,8 @@ class PreWorld4DTraj(_PreWorldCommon):
     # ---- preworld_temporal_traj.py:212-370 (post-finetune branch) from lifted inputs
     @torch.no_grad()
     def simple_test_from_lift(self, frames, temporal_ego_states, n_steps=6, want_logits=False):
-        v0 = self.extract_voxel_feat_cl(frames)                       # (B,Z,Y,X,C)
+        # post-finetune decode: final_conv -> forecast -> OccHead stay in h2 storage end to end on the split-fp16 path
+        v0 = self.extract_voxel_feat_cl(frames, out_h2=self.if_post_finetune)      # (B,Z,Y,X,C)
         if not self.if_post_finetune:
             return self._simple_test_attributes(v0, temporal_ego_states, n_steps)
         res = {}
@@ -417,7 +422,7 @@ class PreWorld4DTraj(_PreWorldCommon):
         # buffer): one persistent-kernel prologue and one partial last round of tiles instead of n_steps of each
         outs = [self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True)]
         if n_steps > 0:
-            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps)
+            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps, out_h2=isinstance(v0, ops.H2))
             feats += [states[k] for k in range(n_steps)]
             o = self.occupancy_head.decode_cl(states.view((n_steps * B,) + tuple(v0.shape[1:])), want_logits=want_logits,
                                               transposed=True, want_geo=True)

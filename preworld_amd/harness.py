@@ -118,12 +118,14 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
     x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                       # [adjacent ..., key] (bevdet_occ.py:266)
     if len(lifted) < n:
         x = torch.cat([x.new_zeros(x.shape[:-1] + ((n - len(lifted)) * C,)), x], dim=-1)
-    v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.H2(x) if h2 else x, out_h2=h2))
+    # final_conv -> forecast -> OccHead keep h2 storage like simple_test_from_lift (post-finetune decode)
+    v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.H2(x) if h2 else x, out_h2=h2), out_h2=h2)
 
     def decode(f):
         occ = net.occupancy_head.decode_cl(f, transposed=True)
         occ = occ.permute(0, 3, 2, 1)[0].contiguous()                          # batch element 0, (X,Y,Z) (:306)
         return occ.cpu() if gather_on_host else occ
 
-    grids = parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k)[0][k - 1], decode, n_steps + 1, group)
+    grids = parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k, out_h2=h2)[0][k - 1], decode, n_steps + 1,
+                                           group)
     return {'semantic_occ_%ds' % k: [g] for k, g in enumerate(grids)}

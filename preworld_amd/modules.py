@@ -669,18 +669,50 @@ class OccHead(nn.Module):
         wpk, uwpk, s0, b0, w1, s1, b1, w2 = self._cache.get(params, build)
         return (uwpk if wino else wpk)[1 if transposed else 0], s0, b0, w1, s1, b1, w2
 
+    def _folded_h2(self, transposed=False):
+        """operands of ops.occ_head_h2: split-fp16 conv weights (both tap orders), folded BN with the weights' pre-scale
+        divided out, the packed 16->8->18 tail"""
+        c0, bn0 = self.occ_convs[0][0], self.occ_convs[0][1]
+        c1, bn1, c2 = self.occ_pred_conv[0], self.occ_pred_conv[1], self.occ_pred_conv[3]
+        params = [c0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, c1.weight,
+                  bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, c2.weight]
+
+        def build():
+            s0, b0 = ops.fold_bn(bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, bn0.eps)
+            s1, b1 = ops.fold_bn(bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps)
+            packs = []
+            for w in (c0.weight, c0.weight.permute(0, 1, 4, 3, 2).contiguous()):
+                wpk, inv = ops.pack_occ_weight_h2(w.float())
+                packs.append((wpk, (s0 * inv).contiguous()))
+            tailpk, inv2 = ops.pack_occ_tail_h2(c1.weight.reshape(c1.weight.shape[0], -1).float(), s1, b1,
+                                                c2.weight.reshape(c2.weight.shape[0], -1).float())
+            return packs, b0.contiguous(), tailpk, inv2
+        if not hasattr(self, '_cache_h2'):
+            self._cache_h2 = _PackedCache()
+        packs, b0, tailpk, inv2 = self._cache_h2.get(params, build)
+        wpk, s0 = packs[1 if transposed else 0]
+        return wpk, s0, b0, tailpk, inv2
+
     def decode_cl(self, x_cl, want_logits=False, transposed=False, want_geo=False):
-        """x_cl (B,D,H,W,C) channels-last -> uint8 argmax (B,D,H,W) [, logits (B,D,H,W,18)].
+        """x_cl (B,D,H,W,C) channels-last (fp32 tensor or ops.H2) -> uint8 argmax (B,D,H,W) [, logits (B,D,H,W,18)].
         The reference feeds (1,C,X,Y,Z), i.e. kernel axes (kD,kH,kW) <-> (X,Y,Z).  With
         transposed=True, x_cl is the encoder's native (B,Z,Y,X,C) buffer and the kernel taps are
         permuted instead of the 82 MB activation; the result is then the
         (Z,Y,X) array whose .permute(0,3,2,1) view is the reference's (X,Y,Z) output."""
         if self.training:
             raise NotImplementedError('OccHead HIP path is eval-only')
-        # the 32->16 conv runs as Winograd F(2x2x2,3x3x3) (k_occ_head_wino) on grids with enough 4x8x8 tiles to
-        # keep the persistent blocks busy; PW_OCC_WINO=0 keeps the direct 16x16x4 MFMA kernel
         import os
         B, D, H, W, C = x_cl.shape
+        is_h2 = isinstance(x_cl, ops.H2)
+        if C == 32 and (is_h2 or precision() == 'h2') and os.environ.get('PW_OCC_H2', '1') != '0':
+            # split-fp16 kernel (k_occ_head_h2); an fp32 input is converted first (30 us at 16x200x200, still ahead)
+            wpk, s0, b0, tailpk, inv2 = self._folded_h2(transposed)
+            return ops.occ_head_h2(x_cl if is_h2 else ops.f32_to_h2(x_cl.contiguous()), wpk, s0, b0, tailpk, inv2,
+                                   want_logits=want_logits, want_geo=want_geo, empty_idx=self.empty_idx)
+        if is_h2:
+            x_cl = ops.h2_to_f32(x_cl)
+        # fp32: the 32->16 conv runs as Winograd F(2x2x2,3x3x3) (k_occ_head_wino) on grids with enough 4x8x8 tiles to
+        # keep the persistent blocks busy; PW_OCC_WINO=0 keeps the direct 16x16x4 MFMA kernel
         wino = (C == 32 and B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) >= 256
                 and os.environ.get('PW_OCC_WINO', '1') != '0')
         wpk, s0, b0, w1, s1, b1, w2 = self._folded(transposed, wino)

@@ -404,6 +404,9 @@ class H2:
     def __getitem__(self, idx):
         return H2(self.buf[idx])
 
+    def view(self, *shape):
+        return H2(self.buf.view(*shape))
+
 
 def _rows(t, name):
     """(n_vox, C, ld) of a channels-last tensor that is dense or a channel slice of a dense buffer."""

@@ -141,7 +141,7 @@ def test_c2_single_frame_with_prev_false_fullsize():
     with torch.no_grad():
         res = net.simple_test_from_lift(frames, want_logits=True)
     assert sorted(k for k in res if 'occ' in k) == ['geo_occ', 'semantic_occ']
-    _cmp('%s composed vs staged final_conv' % TAG, res['voxel_feats'][0], fc.cpu().numpy(), 6e-6)
+    _cmp('%s composed vs staged final_conv' % TAG, M.as_f32(res['voxel_feats'][0]), fc.cpu().numpy(), 6e-6)
     occ_o, logits_o = O.occ_decode(ovf, sd)
     lerr = _cmp('C2 logits', res['logits'][0][0].permute(2, 1, 0, 3), logits_o, RTOL['logits'])
     _cmp_states('C2 semantic_occ', res['semantic_occ'][0], occ_o, logits_o, lerr)
@@ -161,13 +161,13 @@ def test_c3_seven_states_fullsize():
     ovf, fc = _encoder_checks('C3', net, frames, sd, True, 6)
     with torch.no_grad():
         res = net.simple_test_from_lift(frames, ego, n_steps=6, want_logits=True)
-    _cmp('%s composed vs staged final_conv' % TAG, res['voxel_feats'][0], fc.cpu().numpy(), 6e-6)
+    _cmp('%s composed vs staged final_conv' % TAG, M.as_f32(res['voxel_feats'][0]), fc.cpu().numpy(), 6e-6)
     e = O.plan_head(S.ego_state(6).reshape(1, -1).astype(np.float32), sd)[0]
     v = ovf
     for k in range(7):
         if k:
             v = O.forecast_step(v, e, sd)
-            _cmp('C3 state %d features' % k, res['voxel_feats'][k], np.ascontiguousarray(v.transpose(0, 3, 2, 1, 4)), RTOL['state'])
+            _cmp('C3 state %d features' % k, M.as_f32(res['voxel_feats'][k]), np.ascontiguousarray(v.transpose(0, 3, 2, 1, 4)), RTOL['state'])
         occ_o, logits_o = O.occ_decode(v, sd)
         lerr = _cmp('C3 logits %ds' % k, res['logits'][k][0].permute(2, 1, 0, 3), logits_o, RTOL['logits'])
         _cmp_states('C3 semantic_occ_%ds' % k, res['semantic_occ_%ds' % k][0], occ_o, logits_o, lerr)
