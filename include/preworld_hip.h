@@ -446,6 +446,37 @@ int pw_lovasz_softmax(const float* probas, const uint8_t* target, const uint8_t*
                       int ignore_index, void* workspace, size_t workspace_bytes, float* loss,
                       float* inv_present, float* dprob, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Training side of the voxel encoder (what torch autograd runs behind mmdet3d/models/backbones/resnet.py:88-184 in
+ * forward_train): conv3d weight / data gradients and BatchNorm3d with batch statistics.  fp32, channels-last.
+ * ------------------------------------------------------------------------------------- */
+/* dW of a Conv3d(bias=False, kernel ksize in {1,3}, stride in {1,2}, padding ksize/2): x (B,D,H,W,Cin), dy (B,Do,Ho,Wo,Cout),
+ * dw float[Cout][Cin][k][k][k] (torch's layout).  fp32 MFMA with K = voxels, per-chunk partial tiles in `workspace`
+ * (pw_conv3d_wgrad_workspace_bytes) summed in a fixed order: deterministic. */
+size_t pw_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int ksize, int stride);
+int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int B, int D, int H,
+                    int W, int Cin, int Cout, int ksize, int stride, void* stream);
+/* dX of Conv3d(k=3, stride=2, padding=1): dy (B,Do,Ho,Wo,Cout) with Do = (D-1)/2+1 .., wt float[3][3][3][Cout][Cin] (torch's
+ * weight.permute(2,3,4,0,1)), dx (B,D,H,W,Cin), Cin % 4 == 0.  (Stride-1 and 1x1x1 data gradients are forward convolutions
+ * with flipped / transposed weights: pw_conv3d_ndhwc.) */
+int pw_conv3d_dgrad_s2(const float* dy, const float* wt, float* dx, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+/* BatchNorm3d, training mode, on channels-last rows x (N, C), 256 % C == 0:
+ *   pw_bn_stats       mean[c], var[c] (biased), rstd[c] = 1/sqrt(var + eps)              (double accumulation, deterministic)
+ *   pw_bn_apply       y = (x - mean) rstd gamma + beta (+ residual) (ReLU if relu)
+ *   pw_bn_bwd_reduce  dz = dy (masked by y > 0 if relu);  sum_dz[c] = sum dz,  sum_dz_xhat[c] = sum dz x_hat
+ *   pw_bn_bwd_apply   dx = gamma rstd (dz - sum_dz / N - x_hat sum_dz_xhat / N);  dres = dz (or NULL)
+ * d gamma = sum_dz_xhat, d beta = sum_dz.  workspace: pw_bn_workspace_bytes(C). */
+size_t pw_bn_workspace_bytes(int C);
+int pw_bn_stats(const float* x, int64_t N, int C, float eps, void* workspace, size_t workspace_bytes, float* mean, float* var,
+                float* rstd, void* stream);
+int pw_bn_apply(const float* x, int64_t N, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                const float* residual, int relu, float* y, void* stream);
+int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean, const float* rstd,
+                     int relu, void* workspace, size_t workspace_bytes, float* sum_dz, float* sum_dz_xhat, void* stream);
+int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean, const float* rstd,
+                    const float* gamma, const float* sum_dz, const float* sum_dz_xhat, int relu, float* dx, float* dres,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

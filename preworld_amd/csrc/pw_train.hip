@@ -1,0 +1,392 @@
+// Training-side kernels of the voxel encoder: what torch autograd runs behind the reference's BasicBlock3D / CustomResNet3D
+// (mmdet3d/models/backbones/resnet.py:88-184: Conv3d(bias=False) -> BatchNorm3d (batch statistics) -> ReLU, residual add) when
+// the detector's forward_train calls them.  Entry points (include/preworld_hip.h):
+//   pw_conv3d_wgrad      dW[co][ci][tap] = sum_vox dY[vox][co] X[vox*s + tap - pad][ci]       (fp32 MFMA, K = voxels)
+//   pw_conv3d_dgrad_s2   dX of a 3x3x3 stride-2 pad-1 conv (the stride-1 / 1x1x1 dgrads are forward convs with the weights
+//                        flipped / transposed and run on the forward kernels: preworld_amd/train.py)
+//   pw_bn_stats / pw_bn_apply / pw_bn_bwd_reduce / pw_bn_bwd_apply   BatchNorm3d in training mode on channels-last rows
+// Channels-last fp32 everywhere: x (B, D, H, W, Cin), dy (B, Do, Ho, Wo, Cout).
+#include "pw_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------
+// wgrad.  One wave accumulates ONE 32 x 32 block (co0.., ci0..) of ONE tap over a slice of output rows (b, od, oh):
+// v_mfma_f32_32x32x2_f32 with K = two consecutive output voxels of the row.  Lane (i = l & 31, k = l >> 5) feeds
+//   A[i][k] = dY[row, ow + k][co0 + i]          B[k][j] = X[input row of the tap, (ow + k) s + kw - pad][ci0 + j]
+// straight from global memory: consecutive lanes read consecutive channels of a voxel row (128-byte segments), the validity of
+// the tap's input row is wave-uniform and the w range is clipped once per row, so the inner loop is 2 loads + 1 MFMA with no
+// predicate.  The four waves of a block take interleaved rows of the block's chunk and add their tiles through LDS; a second
+// kernel sums the per-chunk partial tiles in a fixed order (deterministic, no atomics) into torch's [Cout][Cin][kd][kh][kw].
+// ------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* partial;        // [n_chunks][taps][co_blocks][ci_blocks][32][32]
+  int B, D, H, W, Cin, Do, Ho, Wo, Cout;
+  int ks, stride, pad, taps;
+  int co_blocks, ci_blocks, n_chunks, rows_per_chunk, n_rows;
+};
+
+__global__ void __launch_bounds__(256) k_conv3d_wgrad(WgradArgs a) {
+  __shared__ float red[3][64 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, k = lane >> 5;
+  int bid = blockIdx.x;
+  const int cib = bid % a.ci_blocks; bid /= a.ci_blocks;
+  const int cob = bid % a.co_blocks; bid /= a.co_blocks;
+  const int tap = bid;
+  const int chunk = blockIdx.y;
+  const int kw = tap % a.ks, kh = (tap / a.ks) % a.ks, kd = tap / (a.ks * a.ks);
+  const int co = cob * 32 + i, ci = cib * 32 + i;
+  const bool co_ok = co < a.Cout, ci_ok = ci < a.Cin;
+  // clipped w range: 0 <= ow * s + kw - pad < W
+  const int ow_lo = max(0, (a.pad - kw + a.stride - 1) / a.stride);
+  const int ow_hi = min(a.Wo, (a.W - 1 + a.pad - kw) / a.stride + 1);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int r0 = chunk * a.rows_per_chunk, r1 = min(a.n_rows, r0 + a.rows_per_chunk);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const int oh = row % a.Ho, t = row / a.Ho;
+    const int od = t % a.Do, b = t / a.Do;
+    const int id = od * a.stride + kd - a.pad, ih = oh * a.stride + kh - a.pad;
+    if ((unsigned)id >= (unsigned)a.D || (unsigned)ih >= (unsigned)a.H) continue;     // wave-uniform
+    const float* dyr = a.dy + ((size_t)row * a.Wo) * a.Cout + co;
+    const float* xr = a.x + ((((size_t)b * a.D + id) * a.H + ih) * a.W + (kw - a.pad)) * a.Cin + ci;
+    int ow = ow_lo;
+    for (; ow + 8 <= ow_hi; ow += 8) {                   // 4 MFMAs, 8 loads in flight
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = ow + 2 * u + k;
+        av[u] = co_ok ? dyr[(size_t)o * a.Cout] : 0.f;
+        bv[u] = ci_ok ? xr[(size_t)o * a.stride * a.Cin] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; ow < ow_hi; ow += 2) {
+      const int o = ow + k;
+      const bool ok = o < ow_hi;
+      const float av = (ok && co_ok) ? dyr[(size_t)o * a.Cout] : 0.f;
+      const float bv = (ok && ci_ok) ? xr[(size_t)o * a.stride * a.Cin] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  // block reduction of the four waves' tiles (fixed order: wave 0 + 1 + 2 + 3)
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r * 64 + lane]) + red[1][r * 64 + lane]) + red[2][r * 64 + lane];
+    float* dst = a.partial + ((((size_t)chunk * a.taps + tap) * a.co_blocks + cob) * a.ci_blocks + cib) * 1024;
+    // D row (co) = (r & 3) + 8 (r >> 2) + 4 k, column (ci) = i
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * k) * 32 + i] = acc[r];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int n_chunks,
+                                                      int taps, int co_blocks, int ci_blocks, int Cout, int Cin) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // over [tap][cob][cib][32][32]
+  const size_t per_chunk = (size_t)taps * co_blocks * ci_blocks * 1024;
+  if (idx >= per_chunk) return;
+  float s = 0.f;
+  for (int c = 0; c < n_chunks; ++c) s += partial[(size_t)c * per_chunk + idx];
+  const int j = (int)(idx & 31), i = (int)((idx >> 5) & 31);
+  size_t t = idx >> 10;
+  const int cib = (int)(t % ci_blocks); t /= ci_blocks;
+  const int cob = (int)(t % co_blocks); t /= co_blocks;
+  const int tap = (int)t;
+  const int co = cob * 32 + i, ci = cib * 32 + j;
+  if (co < Cout && ci < Cin) dw[((size_t)co * Cin + ci) * taps + tap] = s;
+}
+
+PW_API size_t pw_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  const int pad = ksize / 2;
+  const int Do = (D + 2 * pad - ksize) / stride + 1, Ho = (H + 2 * pad - ksize) / stride + 1;
+  const int n_rows = B * Do * Ho;
+  int n_chunks = n_rows / 32;
+  n_chunks = n_chunks < 1 ? 1 : (n_chunks > 64 ? 64 : n_chunks);
+  const size_t tiles = (size_t)ksize * ksize * ksize * ((Cout + 31) / 32) * ((Cin + 31) / 32);
+  return (size_t)n_chunks * tiles * 1024 * 4;
+}
+
+PW_API int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int B, int D,
+                           int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+  PW_CHECK_ARG(x && dy && dw && workspace, "pw_conv3d_wgrad: null pointer");
+  PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "pw_conv3d_wgrad: bad shape");
+  PW_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "pw_conv3d_wgrad: ksize 1 | 3, stride 1 | 2");
+  PW_CHECK_ARG(workspace_bytes >= pw_conv3d_wgrad_workspace_bytes(B, D, H, W, Cin, Cout, ksize, stride),
+               "pw_conv3d_wgrad: workspace too small");
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.partial = (float*)workspace;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.ks = ksize; a.stride = stride; a.pad = ksize / 2; a.taps = ksize * ksize * ksize;
+  a.Do = (D + 2 * a.pad - ksize) / stride + 1; a.Ho = (H + 2 * a.pad - ksize) / stride + 1; a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+  a.co_blocks = (Cout + 31) / 32; a.ci_blocks = (Cin + 31) / 32;
+  a.n_rows = B * a.Do * a.Ho;
+  int n_chunks = a.n_rows / 32;
+  a.n_chunks = n_chunks < 1 ? 1 : (n_chunks > 64 ? 64 : n_chunks);
+  a.rows_per_chunk = (a.n_rows + a.n_chunks - 1) / a.n_chunks;
+  hipStream_t st = pw_stream(stream);
+  hipLaunchKernelGGL(k_conv3d_wgrad, dim3((unsigned)(a.taps * a.co_blocks * a.ci_blocks), (unsigned)a.n_chunks), dim3(256), 0, st, a);
+  const size_t per_chunk = (size_t)a.taps * a.co_blocks * a.ci_blocks * 1024;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)pw_cdiv((int64_t)per_chunk, 256)), dim3(256), 0, st, a.partial, dw, a.n_chunks,
+                     a.taps, a.co_blocks, a.ci_blocks, Cout, Cin);
+  pw_note_kernel("k_conv3d_wgrad");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// dgrad of the 3x3x3 stride-2 pad-1 conv (the two down-sampling stages of CustomResNet3D): a thread owns 4 consecutive input
+// channels of one input voxel and walks the taps whose output coordinate is integral ((i + 1 - k) even: one tap on even
+// coordinates, two on odd ones, 1..8 taps per voxel).  wt: the weights as [kd][kh][kw][Cout][Cin] (w.permute(2,3,4,0,1)), so the
+// 8 lanes of a voxel read one 128-byte row per (tap, co).  Small layers (8.8 + 4.4 GFLOP at the C3 shape): plain fp32 FMAs.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_conv3d_dgrad_s2(const float* __restrict__ dy, const float* __restrict__ w,
+                                                        float* __restrict__ dx, int B, int D, int H, int W, int Cin, int Do,
+                                                        int Ho, int Wo, int Cout) {
+  const int cq = Cin / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * D * H * W * cq;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % cq) * 4;
+  size_t v = idx / cq;
+  const int iw = (int)(v % W); v /= W;
+  const int ih = (int)(v % H); v /= H;
+  const int id = (int)(v % D);
+  const int b = (int)(v / D);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kd = (id + 1) & 1; kd < 3; kd += 2) {
+    const int od = (id + 1 - kd) >> 1;
+    if ((unsigned)od >= (unsigned)Do) continue;
+    for (int kh = (ih + 1) & 1; kh < 3; kh += 2) {
+      const int oh = (ih + 1 - kh) >> 1;
+      if ((unsigned)oh >= (unsigned)Ho) continue;
+      for (int kw = (iw + 1) & 1; kw < 3; kw += 2) {
+        const int ow = (iw + 1 - kw) >> 1;
+        if ((unsigned)ow >= (unsigned)Wo) continue;
+        const float* dyr = dy + ((((size_t)b * Do + od) * Ho + oh) * Wo + ow) * Cout;
+        const int tap = (kd * 3 + kh) * 3 + kw;
+        const float4* wr = reinterpret_cast<const float4*>(w + ((size_t)tap * Cout) * Cin + c4);      // [tap][co][ci]
+        const int cq4 = Cin / 4;
+#pragma unroll 4
+        for (int co = 0; co < Cout; ++co) {
+          const float g = dyr[co];
+          const float4 wv = wr[(size_t)co * cq4];
+          acc[0] = fmaf(g, wv.x, acc[0]); acc[1] = fmaf(g, wv.y, acc[1]);
+          acc[2] = fmaf(g, wv.z, acc[2]); acc[3] = fmaf(g, wv.w, acc[3]);
+        }
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(dx + idx * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+PW_API int pw_conv3d_dgrad_s2(const float* dy, const float* wt, float* dx, int B, int D, int H, int W, int Cin, int Cout,
+                              void* stream) {
+  PW_CHECK_ARG(dy && wt && dx, "pw_conv3d_dgrad_s2: null pointer");
+  PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 4 == 0 && Cout > 0, "pw_conv3d_dgrad_s2: bad shape (Cin %% 4)");
+  PW_CHECK_ARG((((uintptr_t)dx | (uintptr_t)wt) & 15) == 0, "pw_conv3d_dgrad_s2: dx / wt must be 16-byte aligned");
+  const int Do = (D - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const size_t total = (size_t)B * D * H * W * (Cin / 4);
+  hipLaunchKernelGGL(k_conv3d_dgrad_s2, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, pw_stream(stream), dy, wt, dx, B,
+                     D, H, W, Cin, Do, Ho, Wo, Cout);
+  pw_note_kernel("k_conv3d_dgrad_s2");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// BatchNorm3d in training mode on channels-last rows x (N, C), C in {32, 64, 128, 256} (256 % C == 0).
+// Sums are accumulated in double per thread (rows strided over the block), reduced through LDS and over blocks in a fixed
+// order: deterministic, and closer to the exact mean / variance than a float cascade.
+//   stats:      mean[c], var[c] (biased, what normalisation uses), rstd[c] = 1 / sqrt(var + eps)
+//   apply:      y = x_hat gamma + beta (+ residual) (ReLU)
+//   bwd_reduce: dz = dy (y > 0 if ReLU);  sum_dz[c], sum_dz_xhat[c]
+//   bwd_apply:  dx = gamma rstd (dz - sum_dz / N - x_hat sum_dz_xhat / N);  dres = dz (optional)
+// ------------------------------------------------------------------------------------
+constexpr int BN_BLOCKS = 512;
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   const float* __restrict__ y, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, int64_t N, int C, int relu,
+                                                   double* __restrict__ partial /* [blocks][2][C] */) {
+  __shared__ double red[2][256];
+  const int c = threadIdx.x % C, rsub = threadIdx.x / C, rstep = 256 / C;
+  const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < N ? r0 + per : N;
+  double s0 = 0.0, s1 = 0.0;
+  float m = 0.f, rs = 0.f;
+  if (BWD) { m = mean[c]; rs = rstd[c]; }
+  for (int64_t r = r0 + rsub; r < r1; r += rstep) {
+    const float xv = x[r * C + c];
+    if (BWD) {
+      float dz = dy[r * C + c];
+      if (relu && !(y[r * C + c] > 0.f)) dz = 0.f;
+      s0 += (double)dz;
+      s1 += (double)dz * (double)((xv - m) * rs);
+    } else {
+      s0 += (double)xv;
+      s1 += (double)xv * (double)xv;
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int q = 0; q < rstep; ++q) { a0 += red[0][q * C + threadIdx.x]; a1 += red[1][q * C + threadIdx.x]; }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a0;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = a1;
+  }
+}
+
+// out0 / out1: (mean, var) + rstd for the forward statistics, (sum_dz, sum_dz_xhat) for the backward sums
+__global__ void __launch_bounds__(256) k_bn_finish(const double* __restrict__ partial, int blocks, int C, int64_t N, float eps,
+                                                   int fwd, float* __restrict__ out0, float* __restrict__ out1,
+                                                   float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a0 = 0.0, a1 = 0.0;
+  for (int b = 0; b < blocks; ++b) { a0 += partial[((size_t)b * 2 + 0) * C + c]; a1 += partial[((size_t)b * 2 + 1) * C + c]; }
+  if (fwd) {
+    const double mu = a0 / (double)N;
+    double var = a1 / (double)N - mu * mu;
+    if (var < 0.0) var = 0.0;
+    out0[c] = (float)mu;
+    out1[c] = (float)var;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    out0[c] = (float)a0;
+    out1[c] = (float)a1;
+  }
+}
+
+PW_API size_t pw_bn_workspace_bytes(int C) { return (size_t)BN_BLOCKS * 2 * C * sizeof(double); }
+
+static int bn_check(int64_t N, int C, const void* ws, size_t ws_bytes, const char* who) {
+  if (!(N > 0 && C > 0 && C <= 256 && 256 % C == 0 && C % 4 == 0)) {
+    pw_set_error("%s: C must divide 256 and be a multiple of 4 (got N=%lld C=%d)", who, (long long)N, C);
+    return PW_EINVAL;
+  }
+  if (!ws || ws_bytes < pw_bn_workspace_bytes(C)) {
+    pw_set_error("%s: workspace too small", who);
+    return PW_ENOSPC;
+  }
+  return PW_OK;
+}
+
+PW_API int pw_bn_stats(const float* x, int64_t N, int C, float eps, void* workspace, size_t workspace_bytes, float* mean,
+                       float* var, float* rstd, void* stream) {
+  PW_CHECK_ARG(x && mean && var && rstd, "pw_bn_stats: null pointer");
+  if (int rc = bn_check(N, C, workspace, workspace_bytes, "pw_bn_stats")) return rc;
+  const int blocks = (int)(N < BN_BLOCKS ? N : BN_BLOCKS);
+  hipStream_t st = pw_stream(stream);
+  hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, N, C, 0, (double*)workspace);
+  hipLaunchKernelGGL(k_bn_finish, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)workspace, blocks, C, N, eps, 1, mean, var,
+                     rstd);
+  pw_note_kernel("k_bn_reduce<false>");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+__global__ void __launch_bounds__(256) k_bn_apply(const float4* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float4* __restrict__ residual,
+                                                  int64_t n4, int C, int relu, float4* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  const float4 v = x[i];
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (o[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e];
+  if (residual) {
+    const float4 r = residual[i];
+    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+  }
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+  }
+  y[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+PW_API int pw_bn_apply(const float* x, int64_t N, int C, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* residual, int relu, float* y, void* stream) {
+  PW_CHECK_ARG(x && mean && rstd && gamma && beta && y && N > 0 && C > 0 && C % 4 == 0, "pw_bn_apply: bad arguments");
+  PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, "pw_bn_apply: tensors must be 16-byte aligned");
+  const int64_t n4 = N * C / 4;
+  hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)pw_cdiv(n4, 256)), dim3(256), 0, pw_stream(stream), (const float4*)x, mean, rstd,
+                     gamma, beta, (const float4*)residual, n4, C, relu, (float4*)y);
+  pw_note_kernel("k_bn_apply");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean,
+                            const float* rstd, int relu, void* workspace, size_t workspace_bytes, float* sum_dz,
+                            float* sum_dz_xhat, void* stream) {
+  PW_CHECK_ARG(x && dy && mean && rstd && sum_dz && sum_dz_xhat && (!relu || y), "pw_bn_bwd_reduce: null pointer");
+  if (int rc = bn_check(N, C, workspace, workspace_bytes, "pw_bn_bwd_reduce")) return rc;
+  const int blocks = (int)(N < BN_BLOCKS ? N : BN_BLOCKS);
+  hipStream_t st = pw_stream(stream);
+  hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, st, x, dy, y, mean, rstd, N, C, relu, (double*)workspace);
+  hipLaunchKernelGGL(k_bn_finish, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)workspace, blocks, C, N, 0.f, 0, sum_dz,
+                     sum_dz_xhat, (float*)nullptr);
+  pw_note_kernel("k_bn_reduce<true>");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4* __restrict__ x, const float4* __restrict__ dy,
+                                                      const float4* __restrict__ y, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ sum_dz, const float* __restrict__ sum_dz_xhat,
+                                                      int64_t n4, int C, float inv_n, int relu, float4* __restrict__ dx,
+                                                      float4* __restrict__ dres) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  const float4 xv = x[i], gv = dy[i];
+  float xe[4] = {xv.x, xv.y, xv.z, xv.w}, dz[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
+  if (relu) {
+    const float4 yv = y[i];
+    const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (!(ye[e] > 0.f)) dz[e] = 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float xh = (xe[e] - mean[c + e]) * rstd[c + e];
+    o[e] = gamma[c + e] * rstd[c + e] * (dz[e] - sum_dz[c + e] * inv_n - xh * sum_dz_xhat[c + e] * inv_n);
+  }
+  dx[i] = make_float4(o[0], o[1], o[2], o[3]);
+  if (dres) dres[i] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+}
+
+PW_API int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean,
+                           const float* rstd, const float* gamma, const float* sum_dz, const float* sum_dz_xhat, int relu,
+                           float* dx, float* dres, void* stream) {
+  PW_CHECK_ARG(x && dy && mean && rstd && gamma && sum_dz && sum_dz_xhat && dx && (!relu || y) && N > 0 && C > 0 && C % 4 == 0,
+               "pw_bn_bwd_apply: bad arguments");
+  PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0,
+               "pw_bn_bwd_apply: tensors must be 16-byte aligned");
+  const int64_t n4 = N * C / 4;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)pw_cdiv(n4, 256)), dim3(256), 0, pw_stream(stream), (const float4*)x,
+                     (const float4*)dy, (const float4*)y, mean, rstd, gamma, sum_dz, sum_dz_xhat, n4, C, 1.f / (float)N, relu,
+                     (float4*)dx, (float4*)dres);
+  pw_note_kernel("k_bn_bwd_apply");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

@@ -368,11 +368,15 @@ class ConvModule3d(nn.Module):
 
     def _check_eval(self):
         if self.training and self.with_norm:
-            raise NotImplementedError('HIP voxel encoder runs BatchNorm in eval mode only '
-                                      '(call .eval()); training-mode BN is not built yet')
+            raise NotImplementedError('this fused HIP path folds BatchNorm (eval mode); training mode goes through '
+                                      'preworld_amd.train (ConvModule3d.forward_cl / BasicBlock3D.forward_cl dispatch there)')
 
     def forward_cl(self, x_cl, residual=None, algo=0, out_h2=False):
-        """channels-last in (fp32 tensor or ops.H2) -> channels-last out (fp32, or ops.H2 with out_h2)"""
+        """channels-last in (fp32 tensor or ops.H2) -> channels-last out (fp32, or ops.H2 with out_h2).
+        In training mode (BatchNorm with batch statistics, autograd): preworld_amd.train, fp32."""
+        if self.training and self.with_norm:                # fp32 tensors under autograd (out_h2 does not apply)
+            from . import train
+            return train.conv_module_forward(self, as_f32(x_cl), residual=as_f32(residual) if residual is not None else None)
         self._check_eval()
         if precision() == 'h2' and self.kernel_size in (1, 3) and self.out_channels % 32 == 0 and algo in (0, 2, 3):
             wpk, sc, bi = self.folded_h2()
@@ -415,7 +419,12 @@ class BasicBlock3D(nn.Module):
     def forward_cl(self, x, out=None, out_h2=False):
         """x: fp32 channels-last tensor or ops.H2.  out: optional destination (a channel slice of a wider channels-last
         buffer is fine; an ops.H2 when out_h2); the downsample branch is then written there first and conv2 adds onto it
-        in place.  Returns fp32, or ops.H2 with out_h2."""
+        in place.  Returns fp32, or ops.H2 with out_h2.  Training mode: preworld_amd.train (fp32, autograd)."""
+        if self.training:                                  # fp32 tensors under autograd; h2 storage is an inference format
+            from . import train
+            if out is not None:
+                raise NotImplementedError('BasicBlock3D training path returns a new fp32 tensor (no preallocated destination)')
+            return train.basic_block_forward(self, as_f32(x))
         if precision() == 'h2':
             return self._forward_cl_h2(x, out, out_h2)
         x = as_f32(x)
@@ -537,7 +546,7 @@ class CustomResNet3D(nn.Module):
         instead of fp32 tensors.  In the default 'h2' precision every block-to-block tensor stays in h2 storage."""
         feats = []
         n_layers = len(self.layers)
-        h2 = precision() == 'h2'
+        h2 = precision() == 'h2' and not self.training
         for lid, layer in enumerate(self.layers):
             for bid, blk in enumerate(layer):
                 last = out_last is not None and lid == n_layers - 1 and bid == len(layer) - 1
@@ -545,7 +554,7 @@ class CustomResNet3D(nn.Module):
                                    out_h2=isinstance(out_last, ops.H2) if last else h2)
             if lid in self.backbone_output_ids:
                 feats.append(x)
-        return [as_h2(f) if keep_h2 else as_f32(f) for f in feats]
+        return [as_h2(f) if (keep_h2 and not self.training) else as_f32(f) for f in feats]
 
     def forward(self, x):
         return [from_channels_last_3d(f) for f in self.forward_cl(to_channels_last_3d(x))]

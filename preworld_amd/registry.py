@@ -21,8 +21,10 @@ the registry objects as arguments and is unit-tested against a minimal stand-in 
 
 The drop-ins are INFERENCE classes (eval-mode BatchNorm folded into the convs, no conv backward): `register()` therefore
 defaults to `inference_only=True` semantics -- it replaces the classes for `tools/test*.py` runs; for a training run call
-`register(..., training=True)`, which leaves every class that cannot train (conv stack, OccHead, NerfHead, detectors)
-on the reference implementation and swaps only the pieces that have a backward (`CustomFocalLoss`)."""
+`register(..., training=True)`, which leaves every class that cannot train (FPN, OccHead, detectors, view transformers)
+on the reference implementation and swaps only the pieces that have a backward: `CustomFocalLoss` and `CustomResNet3D`
+(the voxel encoder backbone and `pre_process_net`: batch-statistics BatchNorm, conv dgrad / wgrad on the HIP kernels of
+csrc/pw_train.hip, preworld_amd/train.py)."""
 from . import builder
 
 # reference type name -> (registry, can it train?)
@@ -30,7 +32,7 @@ REGISTRY_OF = {
     'LSSViewTransformer': ('mmdet3d.NECKS', False),
     'LSSViewTransformerBEVDepth': ('mmdet3d.NECKS', False),
     'LSSViewTransformerBEVStereo': ('mmdet3d.NECKS', False),
-    'CustomResNet3D': ('mmdet.BACKBONES', False),
+    'CustomResNet3D': ('mmdet.BACKBONES', True),       # .train(): batch-stat BN + conv dgrad / wgrad (preworld_amd/train.py)
     'LSSFPN3D': ('mmdet.NECKS', False),
     'OccHead': ('mmdet.HEADS', False),
     'NerfHead': ('mmdet.HEADS', False),

@@ -63,10 +63,12 @@ def test_force_reregistration_and_build_from_reference_cfg():
 
 
 def test_training_registration_keeps_inference_only_classes_on_the_reference():
-    """the conv stack / heads / detectors have no backward, so a training run must not get them."""
+    """classes without a backward must not reach a training run.  training=True swaps only what can train: the focal
+    loss and the voxel encoder backbone (batch-statistics BatchNorm + conv dgrad / wgrad, tests/test_gpu_train.py); FPN, heads,
+    view transformers and detectors stay on the reference implementation."""
     regs = {k: FakeRegistry() for k in ALL_REGS}
     done = R.register(regs, training=True)
-    assert done == [('mmdet.LOSSES', 'CustomFocalLoss')]
+    assert sorted(done) == [('mmdet.BACKBONES', 'CustomResNet3D'), ('mmdet.LOSSES', 'CustomFocalLoss')]
     done = R.register(regs)
     assert {n for _, n in done} == set(R.REGISTRY_OF)
 

@@ -826,6 +826,46 @@ def gen_metric_temporal(om):
          iou_1s=iu1, mious=np.array(mious), ious=np.array(ious), cnt=np.int64(m.cnt))
 
 
+def gen_encoder_train(res):
+    """A6/A7 in TRAINING mode (forward_train's use of the encoder): the reference CustomResNet3D with batch-statistics BatchNorm,
+    one forward + backward of a fixed scalar objective through torch autograd on the CPU.  Stored: the three stage outputs, d loss /
+    d input, the gradient of every parameter and the running statistics after the step.  Inputs / weights / objective
+    coefficients are regenerated from the seeds by the test."""
+    sd = S.synth_state_dict(21)
+    enc = res.CustomResNet3D(numC_input=64, num_layer=[1, 2, 2], with_cp=False, num_channels=[32, 64, 128], stride=[1, 2, 2],
+                             backbone_output_ids=[0, 1, 2])
+    own = enc.state_dict()
+    with torch.no_grad():
+        for k in own:
+            if 'num_batches_tracked' not in k and ('img_bev_encoder_backbone.' + k) in sd:
+                own[k].copy_(torch.from_numpy(sd['img_bev_encoder_backbone.' + k]))
+    enc.train()
+    B, Z, Y, X = 2, 6, 10, 12
+    rs = np.random.RandomState(22)
+    x = torch.from_numpy(rs.standard_normal((B, 64, Z, Y, X)).astype(np.float32)).requires_grad_(True)
+    feats = enc(x)
+    coef = [torch.from_numpy(rs.standard_normal(tuple(f.shape)).astype(np.float32)) for f in feats]
+    loss = sum((f * c).sum() for f, c in zip(feats, coef))
+    loss.backward()
+    out = dict(seed_sd=np.int64(21), seed_in=np.int64(22), shape=np.array([B, Z, Y, X]), loss=np.float64(loss.item()),
+               dx=x.grad.numpy())
+    for i, f in enumerate(feats):
+        out['feat%d' % i] = f.detach().numpy()
+    # conv weight gradients: in full for stage 0, as 8 seeded random projections per output channel for the larger layers
+    # (keeps the fixture at ~1 MB; tests/test_gpu_train.py projects its own gradient with the same matrix)
+    for k, p_ in enc.named_parameters():
+        g = p_.grad.numpy()
+        if g.ndim == 5 and not k.startswith('layers.0.'):
+            R = np.random.RandomState(23).standard_normal((g[0].size, 8)).astype(np.float64)
+            out['gradproj.' + k] = g.reshape(g.shape[0], -1).astype(np.float64) @ R
+        else:
+            out['grad.' + k] = g
+    for k, b_ in enc.named_buffers():
+        if 'num_batches_tracked' not in k:
+            out['buf.' + k] = b_.detach().numpy().copy()
+    save('encoder_train_small.npz', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shim()
@@ -861,6 +901,8 @@ def main():
         gen_metric_temporal(om)
     if want('render_grad'):
         gen_render_grad(nh)
+    if want('encoder_train'):
+        gen_encoder_train(res)
     if only:
         return
     gen_kat(bp)
