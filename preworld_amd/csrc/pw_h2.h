@@ -69,7 +69,7 @@ __device__ __forceinline__ void buf_store4(rsrc_t r, unsigned voff, unsigned sof
 #pragma unroll
   for (int e = 0; e < 4; ++e) t[e] = __float_as_uint(v[e]);
   __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
-  // gfx950 hazard (found the hard way, tools/dbg_epi*.py): a 128-bit buffer store reads its data VGPRs over several cycles;
+  // gfx950 hazard (found as wrong channels c & 7 in {2,3} of one epilogue variant): a 128-bit buffer store reads its data VGPRs over several cycles;
   // hipcc (ROCm 7.2) scheduled a v_pk_add_f32 that overwrites two of them ONE instruction after the store and lanes 12-15 of
   // every 16 stored the new value of dword 1.  Keeping the four registers live across two wait states closes the window.
   asm volatile("s_nop 1" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
