@@ -64,3 +64,48 @@ def test_images_to_occupancy_wiring():
         res = net.simple_test_from_lift(frames, T(S.ego_state(1)), n_steps=2)
     occ = res['semantic_occ_0s'][0]
     assert tuple(occ.shape) == (100, 100, 8) and occ.dtype == torch.uint8 and int(occ.max()) <= 17
+
+
+def test_detector_entry_point_from_images():
+    """The call the reference's runner makes (apis/test.py: `model(return_loss=False, **data)`, bevdet.py:139-175): the
+    PreWorld4DTraj drop-in built from a config dict WITH its image side (toy-width Swin + FPN_LSS, the real
+    LSSViewTransformerBEVStereo / DepthNet interface), fed stacked images + poses the way `prepare_inputs` expects them
+    (bevdet_occ.py:88-139), must return the reference's result dict as numpy uint8 (X,Y,Z) grids -- and the same grids
+    as lifting the frames by hand and calling simple_test_from_lift."""
+    cfg = harness.model_cfg(S.GRID_CONFIG_C1)
+    cfg['img_backbone'] = dict(type='SwinTransformer', **dict(S.small_swin_cfg(), window_size=4))
+    cfg['img_neck'] = dict(type='FPN_LSS', in_channels=64 + 128, out_channels=48, extra_upsample=None, input_feature_index=(0, 1),
+                           scale_factor=2)
+    cfg['img_view_transformer']['in_channels'] = 48
+    torch.manual_seed(1)
+    from preworld_amd import builder
+    net = builder.build(cfg, 'PreWorld4DTraj')
+    sd = {k: torch.from_numpy(v) for k, v in S.synth_state_dict(0).items()}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(any(t in k for t in ('depth_net', 'img_backbone', 'img_neck', 'num_batches_tracked')) for k in missing)
+    net = net.to(DEV).eval()
+    n_cams, T_ = 1, net.num_frame                                   # key + adjacent + extra stereo reference frame
+    rigs = [S.synthetic_rig(n_cams, dx=-2.5 * f) for f in range(T_)]
+    imgs = torch.randn(1, n_cams * T_, 3, 512, 1408, device=DEV)    # camera-major / frame-minor (bevdet_occ.py:93-96)
+
+    def cat(key):
+        return torch.cat([T(r[key]) for r in rigs], 1)              # frame-major (B, T*N, ...)
+    e2g = torch.eye(4, device=DEV).view(1, 1, 4, 4).repeat(1, n_cams * T_, 1, 1).clone()
+    for f in range(T_):
+        e2g[:, f * n_cams:(f + 1) * n_cams, 0, 3] = -0.4 * f
+    img_inputs = [imgs, cat('sensor2ego'), e2g, cat('intrin'), cat('post_rot'), cat('post_tran'), T(rigs[0]['bda'])]
+    ego = T(S.ego_state(1))
+    with torch.no_grad():
+        out = net(return_loss=False, img_inputs=[img_inputs], img_metas=[[dict()]], points=None,
+                  temporal_ego_states=[ego.unsqueeze(0)])
+        frames = net.lift_inputs_from_images(net.prepare_inputs(img_inputs, stereo=True))
+        ref = net.simple_test_from_lift(frames, ego)
+    assert sorted(out) == sorted(['%s_occ_%ds' % (p, k) for p in ('semantic', 'geo') for k in range(7)])
+    for k in range(7):
+        a = out['semantic_occ_%ds' % k][0]
+        assert isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.shape == (100, 100, 8)
+        assert np.array_equal(a, ref['semantic_occ_%ds' % k][0].cpu().numpy())
+        g = out['geo_occ_%ds' % k][0]
+        assert np.array_equal(g, np.where(a != 17, 0, 17).astype(np.uint8))
+    with pytest.raises(NotImplementedError):
+        net(return_loss=True)
