@@ -288,6 +288,83 @@ def cpu_baseline(sd, seed=100):
 
 
 # ------------------------------------------------------------------------------ main
+def bench_c5(args):
+    """Extra, non-headline line (BASELINE.json configs[4]): the volume-rendering attribute head at the literal C5 shape
+    -- 6 cameras x 512 rays x 96 uniform samples through the packed (200,200,16,24) sigma / semantic / colour grid -- forward
+    (pw_render_rays) and forward + backward (pw_render_rays_backward, corner scatter-add of the gradient grid), one GPU, a
+    scene-like grid (ground slab + a ring of occupied blocks, rays terminate after a few occupied samples).  `value` = rays/s
+    of forward + backward; the fp32-grid forward, the bf16-grid forward and the reference's own 38 400 x 417 shape are in config."""
+    from preworld_amd import modules as M
+    dev = 'cuda:0'
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                                   # noqa: E731
+    head = M.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4, scene_center=[0, 0, 2.2], radius=39).to(dev)
+    _, semantic, color = S.render_grids(41)
+    xs, ys, zs = np.meshgrid(np.arange(200), np.arange(200), np.arange(16), indexing='ij')
+    rr = np.hypot(xs - 100, ys - 100)
+    dens = np.where((zs < 2) | ((rr > 40) & (rr < 60) & ((xs // 8 + ys // 8) % 2 == 0)), 4.0, -8.0).astype(np.float32)
+    grid = M.pack_attribute_grid(T(dens), T(semantic), T(color))
+    g16 = grid.to(torch.bfloat16)
+    consts = head.consts(torch.eye(3))
+
+    def shape(R, t):
+        o, d = S.rays(7, R)
+        ro, rd = T(o), T(d)
+        gd, gs, gc, gl = (torch.randn(R, device=dev), torch.randn(R, 17, device=dev), torch.randn(R, 3, device=dev),
+                          torch.randn(R, device=dev))
+        gg = torch.zeros_like(grid)
+
+        def fwd():
+            ops.render_rays(ro, rd, t, grid, consts)
+
+        def fwd_bwd():
+            ops.render_rays(ro, rd, t, grid, consts)
+            gg.zero_()
+            ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, grad_grid=gg)
+        return fwd, fwd_bwd, (lambda: ops.render_rays(ro, rd, t, g16, consts))
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    b = torch.linspace(0, 2, 97)
+    t96 = ((b[1:] + b[:-1]) * 0.5).to(dev).contiguous()
+    R = 3072
+    fwd, fwd_bwd, fwd16 = shape(R, t96)
+    t_end = time.perf_counter() + args.settle_s
+    while time.perf_counter() < t_end:
+        fwd_bwd()
+    steps = max(args.steps, 20)
+    t_fb = timed(fwd_bwd, steps, args.warmup)
+    t_f, t_f16 = timed(fwd, steps, args.warmup), timed(fwd16, steps, args.warmup)
+    rf, rfb, _ = shape(38400, head.t_table(dev))
+    t_rf, t_rfb = timed(rf, 10, 2), timed(rfb, 5, 1)
+    grid_bytes = grid.numel() * 4
+    res = {
+        'metric': 'rays/sec (render head forward + backward, 6 cams x 512 rays x 96 samples)', 'value': round(R / t_fb, 1),
+        'unit': 'rays/s', 'n_gpus': 1, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': round(t_fb * 1e3, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {
+            'workload': 'C5: NerfHead render, 3072 rays x 96 uniform samples, packed (200,200,16,24) fp32 grid, scene-like occupancy; '
+                        'a step = forward + zero-fill of the gradient grid + backward',
+            'forward_ms': round(t_f * 1e3, 4), 'forward_bf16_grid_ms': round(t_f16 * 1e3, 4),
+            'forward_samples_per_s': round(R * 96 / t_f, 0), 'fwd_bwd_samples_per_s': round(R * 96 / t_fb, 0),
+            'reference_shape_38400x417': {'forward_ms': round(t_rf * 1e3, 3), 'fwd_bwd_ms': round(t_rfb * 1e3, 3),
+                                          'forward_samples_per_s': round(38400 * 417 / t_rf, 0)},
+            'note': 'extra, non-headline entry; the headline metric is --config C3'},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_render_rays', 'achieved': round(grid_bytes / t_f / 1e9, 1), 'peak': PEAK_HBM_GBPS,
+                     'unit': 'GB/s', 'frac': round(grid_bytes / t_f / 1e9 / PEAK_HBM_GBPS, 4), 'traffic': None,
+                     'note': 'algorithmic bytes = the 61 MB packed grid read once per forward (SURVEY 8d); the kernel is bound by the '
+                             'per-ray scan and gather latency, not by HBM (profiles/r02_render_c5.txt)'},
+    }
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -298,12 +375,15 @@ def main():
                          'its idle clock state (measured: 304 us vs 278 us for the same conv launch)')
     ap.add_argument('--in-flight', type=int, default=2,
                     help='independent samples in flight per GPU (one hipGraph + HIP stream each); 1 = strictly serial')
-    ap.add_argument('--config', default='C3', choices=['C3', 'C2'])
+    ap.add_argument('--config', default='C3', choices=['C3', 'C2', 'C5'],
+                    help='C3 (headline) / C2 = the occupancy forward pass; C5 = the pre-train render head (extra, non-headline line)')
     ap.add_argument('--mode', default='replicas', choices=['replicas', 'sharded'])
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-d2h', action='store_true', help='leave the occupancy grids on the device (no host payload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.config == 'C5':
+        return bench_c5(args)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))

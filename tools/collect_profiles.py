@@ -38,6 +38,8 @@ def main(v, what):
             o.write('## %s\n%s\n' % (c, rd('pmc_%s.md' % c)))
     shutil.copy(os.path.join(src, 'layers_h2.txt'), os.path.join(dst, v + '_layers_h2.txt'))
     shutil.copy(os.path.join(src, 'bench.json'), os.path.join(dst, v + '_bench.json'))
+    if os.path.exists(os.path.join(src, 'bench_c5.json')):
+        shutil.copy(os.path.join(src, 'bench_c5.json'), os.path.join(dst, v + '_bench_c5.json'))
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'make_pmc_json.py'), src, os.path.join(dst, 'r02_pmc_traffic.json')])
 
 

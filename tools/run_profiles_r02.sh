@@ -13,6 +13,7 @@ python bench.py --in-flight 3 --no-cpu-baseline > $O/bench_if3.json 2>> $O/bench
 python bench.py --in-flight 4 --no-cpu-baseline > $O/bench_if4.json 2>> $O/bench.err
 python bench.py --config C2 --no-cpu-baseline > $O/bench_c2.json 2>> $O/bench.err
 python bench.py --mode sharded --steps 30 --no-cpu-baseline > $O/bench_sharded_w1.json 2>> $O/bench.err
+python bench.py --config C5 > $O/bench_c5.json 2>> $O/bench.err
 python tools/bench_h2.py > $O/layers_h2.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
