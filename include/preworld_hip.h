@@ -477,6 +477,14 @@ int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t N, 
                     const float* gamma, const float* sum_dz, const float* sum_dz_xhat, int relu, float* dx, float* dres,
                     void* stream);
 
+/* Trilinear up-sampling with align_corners=True (torch's upsample_trilinear3d index / weight rule) of a channels-last map
+ * lo (B,Dl,Hl,Wl,C) to hi (B,Dh,Hh,Wh,C), C % 4 == 0: hi = up(lo) or hi += up(lo) (accumulate != 0); and its adjoint
+ * dlo = up^T(dhi), computed as a gather (deterministic).  Training side of LSSFPN3D (necks/lss_fpn.py:132-148). */
+int pw_upsample_trilinear_add(const float* lo, float* hi, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C,
+                              int accumulate, void* stream);
+int pw_upsample_trilinear_adjoint(const float* dhi, float* dlo, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

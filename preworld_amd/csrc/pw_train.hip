@@ -390,3 +390,147 @@ PW_API int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int6
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Trilinear up-sampling (align_corners=True) of a channels-last map and its adjoint -- the LSSFPN3D of
+// mmdet3d/models/necks/lss_fpn.py:132-148 in training: with the 1x1x1 conv commuted below the up-sampling only the
+// 32-channel maps are interpolated.  Source index / weights exactly as torch's upsample_trilinear3d: src = dst (in-1)/(out-1).
+//   pw_upsample_trilinear_add      hi (+)= up(lo)                        one thread per (hi voxel, 4 channels)
+//   pw_upsample_trilinear_adjoint  dlo = up^T(dhi)                        one thread per (lo voxel, 4 channels) GATHERS the hi
+//                                  voxels whose two corners along each axis include it (deterministic, no atomics)
+// ------------------------------------------------------------------------------------
+struct UpArgs {
+  const float* src;
+  float* dst;
+  int B, Dl, Hl, Wl, Dh, Hh, Wh, C;
+  float sd, sh, sw;                 // (in - 1) / (out - 1), 0 when out == 1
+  int accumulate;
+};
+
+__device__ __forceinline__ void up_axis(int d, float s, int n_in, int& i0, int& i1, float& l0, float& l1) {
+  const float src = s * (float)d;
+  i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ void __launch_bounds__(256) k_upsample_add(UpArgs a) {
+  const int cq = a.C / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)a.B * a.Dh * a.Hh * a.Wh * cq;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % cq);
+  size_t v = idx / cq;
+  const int x = (int)(v % a.Wh); v /= a.Wh;
+  const int y = (int)(v % a.Hh); v /= a.Hh;
+  const int z = (int)(v % a.Dh);
+  const int b = (int)(v / a.Dh);
+  int z0, z1, y0, y1, x0, x1;
+  float lz0, lz1, ly0, ly1, lx0, lx1;
+  up_axis(z, a.sd, a.Dl, z0, z1, lz0, lz1);
+  up_axis(y, a.sh, a.Hl, y0, y1, ly0, ly1);
+  up_axis(x, a.sw, a.Wl, x0, x1, lx0, lx1);
+  const float4* lo = reinterpret_cast<const float4*>(a.src) + (size_t)b * a.Dl * a.Hl * a.Wl * cq + c4;
+  auto at = [&](int zz, int yy, int xx) { return lo[(((size_t)zz * a.Hl + yy) * a.Wl + xx) * cq]; };
+  const float4 p000 = at(z0, y0, x0), p001 = at(z0, y0, x1), p010 = at(z0, y1, x0), p011 = at(z0, y1, x1);
+  const float4 p100 = at(z1, y0, x0), p101 = at(z1, y0, x1), p110 = at(z1, y1, x0), p111 = at(z1, y1, x1);
+  float4* out = reinterpret_cast<float4*>(a.dst) + idx;
+  float4 o = a.accumulate ? *out : make_float4(0.f, 0.f, 0.f, 0.f);
+#define PW_TRI(f) (lz0 * (ly0 * (lx0 * p000.f + lx1 * p001.f) + ly1 * (lx0 * p010.f + lx1 * p011.f)) + \
+                   lz1 * (ly0 * (lx0 * p100.f + lx1 * p101.f) + ly1 * (lx0 * p110.f + lx1 * p111.f)))
+  o.x += PW_TRI(x); o.y += PW_TRI(y); o.z += PW_TRI(z); o.w += PW_TRI(w);
+#undef PW_TRI
+  *out = o;
+}
+
+// hi-index range whose corners can include lo index j: floor(s d) in {j - 1, j}
+__device__ __forceinline__ void adj_range(int j, float s, int n_out, int& lo, int& hi) {
+  if (s <= 0.f) { lo = 0; hi = n_out - 1; return; }
+  lo = (int)floorf((float)(j - 1) / s) - 1;
+  hi = (int)ceilf((float)(j + 1) / s) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > n_out - 1) hi = n_out - 1;
+}
+__device__ __forceinline__ float adj_weight(int d, int j, float s, int n_in) {
+  int i0, i1;
+  float l0, l1;
+  up_axis(d, s, n_in, i0, i1, l0, l1);
+  return (i0 == j ? l0 : 0.f) + (i1 == j ? l1 : 0.f);
+}
+
+__global__ void __launch_bounds__(256) k_upsample_adjoint(UpArgs a) {      // src = d hi, dst = d lo
+  const int cq = a.C / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)a.B * a.Dl * a.Hl * a.Wl * cq;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % cq);
+  size_t v = idx / cq;
+  const int xl = (int)(v % a.Wl); v /= a.Wl;
+  const int yl = (int)(v % a.Hl); v /= a.Hl;
+  const int zl = (int)(v % a.Dl);
+  const int b = (int)(v / a.Dl);
+  int zlo, zhi, ylo, yhi, xlo, xhi;
+  adj_range(zl, a.sd, a.Dh, zlo, zhi);
+  adj_range(yl, a.sh, a.Hh, ylo, yhi);
+  adj_range(xl, a.sw, a.Wh, xlo, xhi);
+  const float4* hi = reinterpret_cast<const float4*>(a.src) + (size_t)b * a.Dh * a.Hh * a.Wh * cq + c4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = zlo; z <= zhi; ++z) {
+    const float wz = adj_weight(z, zl, a.sd, a.Dl);
+    if (wz == 0.f) continue;
+    for (int y = ylo; y <= yhi; ++y) {
+      const float wy = adj_weight(y, yl, a.sh, a.Hl) * wz;
+      if (wy == 0.f) continue;
+      for (int x = xlo; x <= xhi; ++x) {
+        const float w = adj_weight(x, xl, a.sw, a.Wl) * wy;
+        if (w == 0.f) continue;
+        const float4 g = hi[(((size_t)z * a.Hh + y) * a.Wh + x) * cq];
+        acc.x = fmaf(w, g.x, acc.x); acc.y = fmaf(w, g.y, acc.y); acc.z = fmaf(w, g.z, acc.z); acc.w = fmaf(w, g.w, acc.w);
+      }
+    }
+  }
+  reinterpret_cast<float4*>(a.dst)[idx] = acc;
+}
+
+static int up_args(UpArgs& a, const float* src, float* dst, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C,
+                   const char* who) {
+  if (!(src && dst && B > 0 && Dl > 0 && Hl > 0 && Wl > 0 && Dh >= Dl && Hh >= Hl && Wh >= Wl && C > 0 && C % 4 == 0)) {
+    pw_set_error("%s: bad arguments", who);
+    return PW_EINVAL;
+  }
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0) {
+    pw_set_error("%s: tensors must be 16-byte aligned", who);
+    return PW_EINVAL;
+  }
+  a.src = src; a.dst = dst; a.B = B; a.Dl = Dl; a.Hl = Hl; a.Wl = Wl; a.Dh = Dh; a.Hh = Hh; a.Wh = Wh; a.C = C;
+  a.sd = Dh > 1 ? (float)(Dl - 1) / (float)(Dh - 1) : 0.f;
+  a.sh = Hh > 1 ? (float)(Hl - 1) / (float)(Hh - 1) : 0.f;
+  a.sw = Wh > 1 ? (float)(Wl - 1) / (float)(Wh - 1) : 0.f;
+  a.accumulate = 0;
+  return PW_OK;
+}
+
+PW_API int pw_upsample_trilinear_add(const float* lo, float* hi, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C,
+                                     int accumulate, void* stream) {
+  UpArgs a;
+  if (int rc = up_args(a, lo, hi, B, Dl, Hl, Wl, Dh, Hh, Wh, C, "pw_upsample_trilinear_add")) return rc;
+  a.accumulate = accumulate;
+  const size_t total = (size_t)B * Dh * Hh * Wh * (C / 4);
+  hipLaunchKernelGGL(k_upsample_add, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, pw_stream(stream), a);
+  pw_note_kernel("k_upsample_add");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+PW_API int pw_upsample_trilinear_adjoint(const float* dhi, float* dlo, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh,
+                                         int C, void* stream) {
+  UpArgs a;
+  if (int rc = up_args(a, dhi, dlo, B, Dl, Hl, Wl, Dh, Hh, Wh, C, "pw_upsample_trilinear_adjoint")) return rc;
+  const size_t total = (size_t)B * Dl * Hl * Wl * (C / 4);
+  hipLaunchKernelGGL(k_upsample_adjoint, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, pw_stream(stream), a);
+  pw_note_kernel("k_upsample_adjoint");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

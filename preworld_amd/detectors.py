@@ -7,14 +7,21 @@ signature and result dicts as the reference.
 Everything downstream of the image-view features runs on libpreworld_hip.so (channels-last, no permute copies); the
 image backbone / neck / DepthNet are plain PyTorch-ROCm modules (image_encoder.py), as north_star prescribes.
 `img_backbone` / `img_neck` are optional: the benchmarks and most parity tests start from the lifted inputs
-(`simple_test_from_lift`) and need no 88 M-parameter Swin-B.  Inference only: `forward_train` is not built
-(SURVEY 8a scopes the path to the forward pass)."""
+(`simple_test_from_lift`) and need no 88 M-parameter Swin-B.  `PreWorld.forward_train` (the single-time-step detector of the
+fine-tune / pre-train configs) runs the voxel side on the HIP training kernels (preworld_amd/train.py); the temporal
+`PreWorld4DTraj.forward_train` (forecast + trajectory losses) is not built."""
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import builder, ops
 from .modules import (ConvModule3d, DownScaleModule3DCustom, _PackedCache, as_f32, precision, to_channels_last_3d)
+
+
+# occ3d-nuScenes voxel counts per class (mmdet3d/models/detectors/preworld.py:19-21): class weights 1 / log(freq)
+NUSC_CLASS_FREQUENCIES = np.array([1163161, 2309034, 188743, 2997643, 20317180, 852476, 243808, 2457947, 497017, 2731022,
+                                   7224789, 214411435, 5565043, 63191967, 76098082, 128860031, 141625221, 2307405309],
+                                  dtype=np.float64)
 
 
 class BEVStereo4DOCC(nn.Module):
@@ -300,6 +307,84 @@ class _PreWorldCommon(BEVStereo4DOCC):
         occ = torch.where(dens > self.test_threshold, sem, torch.full_like(sem, self.num_classes - 1))
         return occ.to(torch.uint8)
 
+    # ---- preworld.py:229-309: the training step of the fine-tune / pre-train configs, voxel side on the HIP training kernels
+    def _bev_feat_train(self, img_inputs):
+        """bevdet_occ.py:167-269 in training: the frame loop of extract_img_feat with the KEY frame under autograd and the
+        adjacent / stereo-reference frames under no_grad (:229-238), each frame through image encoder -> DepthNet -> voxel
+        pooling (ops.bev_pool_v2, backward = pw_bev_pool_v2_backward) -> pre_process_net; [adjacent, key] concat; encoder +
+        neck.  Returns (channels-last (B,Z,Y,X,C) features, depth of the key frame)."""
+        imgs, sensor2keyegos, ego2globals, intrins, post_rots, post_trans, bda, curr2adjsensor = img_inputs
+        vt = self.img_view_transformer
+        feats, depth_key, feat_prev_iv = [], None, None
+        for fid in range(self.num_frame - 1, -1, -1):
+            key_frame = fid == 0
+            extra_ref_frame = fid == self.num_frame - self.extra_ref_frames
+            if not (key_frame or self.with_prev):
+                continue
+            with torch.enable_grad() if key_frame else torch.no_grad():
+                if extra_ref_frame:
+                    feat_prev_iv = self.extract_stereo_ref_feat(imgs[fid])
+                    continue
+                mlp_input = vt.get_mlp_input(sensor2keyegos[0], ego2globals[0], intrins[fid], post_rots[fid], post_trans[fid], bda)
+                x, stereo_feat = self.image_encoder(imgs[fid], stereo=True)
+                metas = dict(k2s_sensor=curr2adjsensor[fid], intrins=intrins[fid], post_rots=post_rots[fid],
+                             post_trans=post_trans[fid], frustum=vt.cv_frustum.to(x), cv_downsample=4, downsample=vt.downsample,
+                             grid_config=vt.grid_config, cv_feat_list=[feat_prev_iv, stereo_feat])
+                bev, depth = vt([x, sensor2keyegos[fid], ego2globals[fid], intrins[fid], post_rots[fid], post_trans[fid], bda,
+                                 mlp_input], metas)
+                bev_cl = to_channels_last_3d(bev)
+                if self.pre_process:
+                    bev_cl = as_f32(self.pre_process_net.forward_cl(bev_cl)[0])
+                feats.append(bev_cl)
+                if key_frame:
+                    depth_key = depth
+                feat_prev_iv = stereo_feat
+        key = feats[-1]
+        if not self.with_prev:
+            feats = [key.new_zeros(key.shape[:-1] + (key.shape[-1] * self.num_adj,)), key]
+        x = torch.cat(feats, dim=-1)                                  # [adjacent ..., key] (:266), channels-last
+        return as_f32(self.bev_encoder_cl(x)), depth_key
+
+    def _voxel_losses_train(self, voxel_feats_cl, **kwargs):
+        """preworld.py:237-303 from the final_conv output: OccHead per batch element, loss_voxel / the zero-weight `loss_sup_*`
+        terms, optional render losses.  voxel_feats_cl: (B,Z,Y,X,C) channels-last."""
+        from . import losses as L, train
+        head = self.occupancy_head
+        logits = torch.cat([train.occ_head_forward(head, voxel_feats_cl[b:b + 1], transposed=True)
+                            for b in range(voxel_feats_cl.shape[0])], 0)           # (B,Z,Y,X,18)
+        occ_preds = logits.permute(0, 4, 3, 2, 1)                                   # (B,18,X,Y,Z) view, as :240-247 stacks them
+        vf_xyz = voxel_feats_cl.permute(0, 3, 2, 1, 4)                              # (B,X,Y,Z,C) view (:238)
+        density_prob = self.density_mlp(vf_xyz)
+        density, semantic, color = density_prob[..., 0], self.semantic_mlp(vf_xyz), self.color_mlp(vf_xyz)
+        out = {}
+        voxel_semantics = kwargs['voxel_semantics']
+        cw17 = torch.from_numpy(1.0 / np.log(NUSC_CLASS_FREQUENCIES[:17] + 0.001)).float()
+        if self.if_post_finetune:
+            out.update(L.loss_voxel(occ_preds, voxel_semantics, cw17, camera_mask=None, empty_idx=self.empty_idx,
+                                    use_focal_loss=self.use_focal_loss, weight_voxel_ce=self.weight_voxel_ce,
+                                    weight_voxel_sem_scal=self.weight_voxel_sem_scal,
+                                    weight_voxel_geo_scal=self.weight_voxel_geo_scal, weight_voxel_lovasz=self.weight_voxel_lovasz,
+                                    focal_loss=getattr(self, 'focal_loss', None)))
+        else:
+            cw = torch.cat([cw17, torch.zeros(1)]).to(occ_preds)
+            out['loss_sup_voxel'] = L.CE_ssc_loss(occ_preds, voxel_semantics, cw, 255) * 0.
+        ce = nn.CrossEntropyLoss(reduction='mean')
+        if self.if_render:
+            out.update(self.nerf_head(density, semantic, color, if_pretrain=self.if_pretrain, dataset_type=self.dataset_type,
+                                      rays=kwargs['rays'], bda=kwargs.get('bda')))
+        else:                                                         # loss_sup (:120-127): zero weight, keeps the MLPs in the graph
+            for pred, tag, n in ((semantic, 'semantic', self.num_classes - 1), (color, 'color', 3), (density, 'density', 1)):
+                out['loss_sup_%s' % tag] = ce(pred.reshape(-1, n), torch.ones_like(pred).reshape(-1, n)) * 0.
+        if self.if_pretrain:
+            n = self.num_classes - 1
+            out['loss_sup_semantic'] = ce(semantic.reshape(-1, n), torch.ones_like(semantic).reshape(-1, n)) * 0.
+        return out
+
+    def forward_train_from_feats(self, bev_feat_cl, **kwargs):
+        """final_conv -> OccHead -> losses (preworld.py:237-309) from the neck output (B,Z,Y,X,C); what a test without the image
+        side drives."""
+        return self._voxel_losses_train(as_f32(self.final_conv.forward_cl(bev_feat_cl)), **kwargs)
+
     @staticmethod
     def _to_numpy(res):
         """the reference's payload: every grid a numpy uint8 (X,Y,Z) array (one D2H copy for all of them)"""
@@ -332,6 +417,19 @@ class PreWorld(_PreWorldCommon):
     def simple_test(self, points, img_metas, img=None, rescale=False, **kwargs):
         frames = self.lift_inputs_from_images(self.prepare_inputs(img, stereo=True))
         return self._to_numpy(self.simple_test_from_lift(frames))
+
+    def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
+        """preworld.py:229-309 for the released nuScenes configs (module in .train()): image side in PyTorch under autograd, the
+        voxel side -- pooling backward, pre_process / encoder / neck / final_conv / OccHead with batch-statistics BatchNorm, the
+        voxel losses -- on the HIP training kernels (preworld_amd/train.py, losses.py).  Returns the reference's loss dict."""
+        if not self.training:
+            raise RuntimeError('forward_train expects the module in training mode (model.train())')
+        prepared = self.prepare_inputs(img_inputs, stereo=True)
+        feat_cl, depth = self._bev_feat_train(prepared)
+        out = self.forward_train_from_feats(feat_cl, bda=prepared[6], **kwargs)
+        if self.use_lss_depth_loss:
+            out['loss_lss_depth'] = self.img_view_transformer.get_depth_loss(kwargs['gt_depth'], depth)
+        return out
 
 
 class PreWorld4DTraj(_PreWorldCommon):

@@ -377,6 +377,9 @@ class ConvModule3d(nn.Module):
         if self.training and self.with_norm:                # fp32 tensors under autograd (out_h2 does not apply)
             from . import train
             return train.conv_module_forward(self, as_f32(x_cl), residual=as_f32(residual) if residual is not None else None)
+        if self.training and torch.is_grad_enabled() and residual is None:     # conv + bias + act without norm (final_conv)
+            from . import train
+            return train.conv_bias_act_forward(self, as_f32(x_cl))
         self._check_eval()
         if precision() == 'h2' and self.kernel_size in (1, 3) and self.out_channels % 32 == 0 and algo in (0, 2, 3):
             wpk, sc, bi = self.folded_h2()
@@ -578,6 +581,9 @@ class LSSFPN3D(nn.Module):
 
     def forward_cl(self, feats, out_h2=False):
         """feats: fp32 channels-last tensors or ops.H2 -> fp32 tensor (or ops.H2 with out_h2)"""
+        if self.training:                                  # fp32 under autograd (preworld_amd.train)
+            from . import train
+            return train.fpn_forward(self, [as_f32(f) for f in feats])
         x8, x16, x32 = feats
         c8, c16, c32 = x8.shape[-1], x16.shape[-1], x32.shape[-1]
         cm = self.conv
@@ -730,6 +736,10 @@ class OccHead(nn.Module):
 
     def forward(self, voxel_feats, **kwargs):
         assert type(voxel_feats) is list and len(voxel_feats) == self.num_level
+        if self.training:                                  # batch-statistics BN, autograd (preworld_amd.train)
+            from . import train
+            logits = train.occ_head_forward(self, to_channels_last_3d(voxel_feats[0]).float(), transposed=False)
+            return {'output_voxels': [from_channels_last_3d(logits)]}
         _, logits = self.decode_cl(to_channels_last_3d(voxel_feats[0]), want_logits=True)
         return {'output_voxels': [from_channels_last_3d(logits)]}
 

@@ -21,25 +21,26 @@ the registry objects as arguments and is unit-tested against a minimal stand-in 
 
 The drop-ins are INFERENCE classes (eval-mode BatchNorm folded into the convs, no conv backward): `register()` therefore
 defaults to `inference_only=True` semantics -- it replaces the classes for `tools/test*.py` runs; for a training run call
-`register(..., training=True)`, which leaves every class that cannot train (FPN, OccHead, detectors, view transformers)
-on the reference implementation and swaps only the pieces that have a backward: `CustomFocalLoss` and `CustomResNet3D`
-(the voxel encoder backbone and `pre_process_net`: batch-statistics BatchNorm, conv dgrad / wgrad on the HIP kernels of
-csrc/pw_train.hip, preworld_amd/train.py)."""
+`register(..., training=True)`, which leaves every class that cannot train (the `BEVStereo4DOCC` and `PreWorld4DTraj`
+detectors: their `forward_train` is not built) on the reference implementation and swaps the ones that have a backward on the
+HIP kernels: view transformers, `CustomResNet3D`, `LSSFPN3D`, `OccHead`, `NerfHead`, `CustomFocalLoss` and the `PreWorld`
+detector (csrc/pw_train.hip, preworld_amd/train.py)."""
 from . import builder
 
-# reference type name -> (registry, can it train?)
+# reference type name -> (registry, can it train?)   -- "can train" = forward under autograd + backward on HIP kernels, pinned by
+# gradient fixtures of the imported reference module (tests/test_gpu_train.py, test_gpu_render.py, test_gpu_lss.py)
 REGISTRY_OF = {
-    'LSSViewTransformer': ('mmdet3d.NECKS', False),
-    'LSSViewTransformerBEVDepth': ('mmdet3d.NECKS', False),
-    'LSSViewTransformerBEVStereo': ('mmdet3d.NECKS', False),
-    'CustomResNet3D': ('mmdet.BACKBONES', True),       # .train(): batch-stat BN + conv dgrad / wgrad (preworld_amd/train.py)
-    'LSSFPN3D': ('mmdet.NECKS', False),
-    'OccHead': ('mmdet.HEADS', False),
-    'NerfHead': ('mmdet.HEADS', False),
+    'LSSViewTransformer': ('mmdet3d.NECKS', True),            # pooling through ops.bev_pool_v2 (pw_bev_pool_v2_backward)
+    'LSSViewTransformerBEVDepth': ('mmdet3d.NECKS', True),    # + DepthNet (PyTorch) and get_depth_loss
+    'LSSViewTransformerBEVStereo': ('mmdet3d.NECKS', True),
+    'CustomResNet3D': ('mmdet.BACKBONES', True),              # batch-stat BN + conv dgrad / wgrad (preworld_amd/train.py)
+    'LSSFPN3D': ('mmdet.NECKS', True),                        # per-level 1x1x1 conv + trilinear up-sampling adjoint + BN
+    'OccHead': ('mmdet.HEADS', True),                         # conv / BN on HIP kernels, the 16 -> 8 -> 18 layers as library GEMMs
+    'NerfHead': ('mmdet.HEADS', True),                        # fused render forward + backward (ops.RenderRays)
     'CustomFocalLoss': ('mmdet.LOSSES', True),
-    'BEVStereo4DOCC': ('mmdet.DETECTORS', False),
-    'PreWorld': ('mmdet.DETECTORS', False),
-    'PreWorld4DTraj': ('mmdet.DETECTORS', False),
+    'BEVStereo4DOCC': ('mmdet.DETECTORS', False),             # forward_train (loss_occ on the predicter MLP) not built
+    'PreWorld': ('mmdet.DETECTORS', True),                    # forward_train of the fine-tune / pre-train configs
+    'PreWorld4DTraj': ('mmdet.DETECTORS', False),             # temporal forward_train (forecast + trajectory losses) not built
 }
 
 

@@ -167,3 +167,115 @@ def basic_block_forward(blk, x):
     identity = conv_module_forward(blk.downsample, x) if blk.downsample is not None else x
     y = conv_module_forward(blk.conv1, x)
     return conv_module_forward(blk.conv2, y, residual=identity.contiguous(), relu=True)
+
+
+# ------------------------------------------------------------------------------ FPN / final_conv / OccHead in training mode
+def upsample_add(lo, hi, accumulate):
+    """hi (B,Dh,Hh,Wh,C) (+)= trilinear(lo (B,Dl,Hl,Wl,C)), align_corners=True (torch's index rule)"""
+    B, Dl, Hl, Wl, C = lo.shape
+    _lib.call('pw_upsample_trilinear_add', ops._p(_cl(lo, 'lo')), ops._p(_cl(hi, 'hi')), B, Dl, Hl, Wl, hi.shape[1], hi.shape[2],
+              hi.shape[3], C, int(accumulate), ops._stream())
+    return hi
+
+
+def upsample_adjoint(dhi, lo_shape):
+    B, Dl, Hl, Wl, C = lo_shape
+    dlo = torch.empty(tuple(lo_shape), device=dhi.device, dtype=_f32)
+    _lib.call('pw_upsample_trilinear_adjoint', ops._p(_cl(dhi, 'dhi')), ops._p(dlo), B, Dl, Hl, Wl, dhi.shape[1], dhi.shape[2],
+              dhi.shape[3], C, ops._stream())
+    return dlo
+
+
+class UpsampleSumCL(torch.autograd.Function):
+    """base + up(a) + up(b): the three per-level 1x1x1 conv outputs of LSSFPN3D summed at full resolution"""
+
+    @staticmethod
+    def forward(ctx, base, a, b):
+        ctx.shapes = (tuple(a.shape), tuple(b.shape))
+        out = base.clone()
+        upsample_add(a.contiguous(), out, True)
+        upsample_add(b.contiguous(), out, True)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        sa, sb = ctx.shapes
+        return (dy if ctx.needs_input_grad[0] else None, upsample_adjoint(dy, sa) if ctx.needs_input_grad[1] else None,
+                upsample_adjoint(dy, sb) if ctx.needs_input_grad[2] else None)
+
+
+class BiasReLUCL(torch.autograd.Function):
+    """relu(x + bias) on channels-last rows, through the BatchNorm kernels with mean 0 / rstd 1 / gamma 1"""
+
+    @staticmethod
+    def forward(ctx, x, bias, relu):
+        C = x.shape[-1]
+        zero, one = torch.zeros(C, device=x.device, dtype=_f32), torch.ones(C, device=x.device, dtype=_f32)
+        y = bn_apply(x, zero, one, one, bias.detach().float().contiguous(), None, relu)
+        ctx.save_for_backward(x, y, zero, one)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, zero, one = ctx.saved_tensors
+        _, _, dbias, dz = bn_backward(x, dy.contiguous(), y, zero, one, one, ctx.relu, True)
+        return dz, dbias, None
+
+
+def fpn_forward(neck, feats):
+    """LSSFPN3D in training mode (lss_fpn.py:132-148).  The bias-free 1x1x1 conv commutes with the trilinear up-sampling, so
+    each level is convolved at its own resolution with its slice of the 224-column weight and only 32-channel maps are
+    up-sampled; BatchNorm (batch statistics) + ReLU follow on the sum -- the same function as upsample -> concat -> conv."""
+    x8, x16, x32 = [f.contiguous() for f in feats]
+    cm = neck.conv
+    w = cm.conv.weight
+    c8, c16 = x8.shape[-1], x16.shape[-1]
+    y8 = Conv3dCL.apply(x8, w[:, :c8], 1)
+    y16 = Conv3dCL.apply(x16, w[:, c8:c8 + c16], 1)
+    y32 = Conv3dCL.apply(x32, w[:, c8 + c16:], 1)
+    pre = UpsampleSumCL.apply(y8, y16, y32)
+    out, mean, var = BatchNormCL.apply(pre, cm.bn.weight, cm.bn.bias, None, cm.bn.eps, cm.with_activation)
+    _update_running(cm.bn, mean, var, float(pre.numel() // pre.shape[-1]))
+    return out
+
+
+def conv_bias_act_forward(m, x):
+    """ConvModule3d without norm (final_conv: conv + bias + ReLU, preworld.py:72-79) in training mode"""
+    y = Conv3dCL.apply(x.contiguous(), m.conv.weight, m.stride)
+    if m.conv.bias is None and not m.with_activation:
+        return y
+    bias = m.conv.bias if m.conv.bias is not None else torch.zeros(y.shape[-1], device=y.device, dtype=_f32)
+    return BiasReLUCL.apply(y, bias, m.with_activation)
+
+
+def _bn_cl(bn, x, relu):
+    out, mean, var = BatchNormCL.apply(x.contiguous(), bn.weight, bn.bias, None, bn.eps, relu)
+    _update_running(bn, mean, var, float(x.numel() // x.shape[-1]))
+    return out
+
+
+def occ_head_forward(head, x_cl, transposed=True):
+    """OccHead.forward_coarse_voxel (occupancy_head.py:124-161) in training mode on channels-last x (B,Z,Y,X,32) -> logits
+    (B,Z,Y,X,18).  transposed: x is the encoder's native (Z,Y,X) buffer while the reference convolves (X,Y,Z): the taps are
+    permuted instead of the activation.  3x3x3 conv 32 -> 16 on the MFMA kernels (output columns zero-padded to 32 so that
+    dgrad runs on them too), batch-statistics BatchNorm on the HIP kernels; the per-voxel 16 -> 8 -> 18 layers (and the soft-weight
+    branch) are plain library GEMMs (torch.matmul)."""
+    c0, bn0 = head.occ_convs[0][0], head.occ_convs[0][1]
+    c1, bn1, c2 = head.occ_pred_conv[0], head.occ_pred_conv[1], head.occ_pred_conv[3]
+    w0 = c0.weight.permute(0, 1, 4, 3, 2) if transposed else c0.weight
+    pad = 32 - w0.shape[0]
+    w0p = torch.cat([w0, w0.new_zeros((pad,) + tuple(w0.shape[1:]))], 0) if pad else w0
+    mid = Conv3dCL.apply(x_cl.contiguous(), w0p.contiguous(), 1)[..., :w0.shape[0]]
+    mid = _bn_cl(bn0, mid, True)
+    if head.soft_weights:
+        # occupancy_head.py:141-151 with num_level = 1: softmax over ONE channel == 1, so the features are unchanged and the branch
+        # receives exactly zero gradients -- but its BatchNorm sees the batch (running statistics move) and its parameters get
+        # zero-valued .grad tensors (weight decay applies to them), so it is evaluated, not skipped
+        s0, sbn, s3 = head.voxel_soft_weights[0], head.voxel_soft_weights[1], head.voxel_soft_weights[3]
+        sw = _bn_cl(sbn, torch.matmul(mid, s0.weight.reshape(s0.weight.shape[0], -1).t()), True)
+        sw = torch.softmax(torch.matmul(sw, s3.weight.reshape(s3.weight.shape[0], -1).t()), dim=-1)
+        mid = mid * sw
+    hid = _bn_cl(bn1, torch.matmul(mid, c1.weight.reshape(c1.weight.shape[0], -1).t()), True)
+    return torch.matmul(hid, c2.weight.reshape(c2.weight.shape[0], -1).t())

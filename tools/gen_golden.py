@@ -866,6 +866,46 @@ def gen_encoder_train(res):
     save('encoder_train_small.npz', **out)
 
 
+def gen_neck_head_train(fpn, occ):
+    """A8 / A9 / A11 in TRAINING mode, composed the way forward_train does (preworld.py:237-247): LSSFPN3D -> final_conv
+    (ConvModule with bias, default ReLU) -> permute to (X,Y,Z) -> OccHead, every BatchNorm on batch statistics; one forward +
+    backward of a fixed scalar objective through torch autograd on the CPU."""
+    sd = S.synth_state_dict(31)
+    neck = fpn.LSSFPN3D(in_channels=224, out_channels=32)
+    head = occ.OccHead(with_cp=False, use_deblock=False, norm_cfg=dict(type='SyncBN', requires_grad=True), soft_weights=True,
+                       final_occ_size=[200, 200, 16], empty_idx=17, num_level=1, in_channels=[32], out_channel=18,
+                       point_cloud_range=[-40, -40, -1, 40, 40, 5.4])
+    fconv = _ConvModule(32, 32, kernel_size=3, stride=1, padding=1, bias=True, conv_cfg=dict(type='Conv3d'))
+    with torch.no_grad():
+        load_sd(neck, sd, 'img_bev_encoder_neck.')
+        load_sd(head, sd, 'occupancy_head.')
+        load_sd(fconv, sd, 'final_conv.')
+    neck.train(); head.train(); fconv.train()
+    Z, Y, X = 8, 16, 12
+    rs = np.random.RandomState(32)
+    feats = [torch.from_numpy(rs.standard_normal((2, c, Z // d, Y // d, X // d)).astype(np.float32)).requires_grad_(True)
+             for c, d in ((32, 1), (64, 2), (128, 4))]
+    nk = neck(feats)
+    vf = fconv(nk).permute(0, 4, 3, 2, 1)                            # (B,X,Y,Z,C)  preworld.py:238
+    logits = torch.stack([head([vf[b].permute(3, 0, 1, 2).unsqueeze(0)])['output_voxels'][0].squeeze(0)
+                          for b in range(vf.shape[0])], 0)          # (B,18,X,Y,Z): per batch element, like :240-247
+    coef = torch.from_numpy(rs.standard_normal(tuple(logits.shape)).astype(np.float32))
+    loss = (logits * coef).sum()
+    loss.backward()
+    out = dict(seed_sd=np.int64(31), seed_in=np.int64(32), shape=np.array([2, Z, Y, X]), loss=np.float64(loss.item()),
+               neck=nk.detach().numpy(), logits=logits.detach().numpy())
+    for i, f in enumerate(feats):
+        out['dfeat%d' % i] = f.grad.numpy()
+    for name, mod in (('neck', neck), ('final_conv', fconv), ('head', head)):
+        for k, p_ in mod.named_parameters():
+            if p_.grad is not None:
+                out['grad.%s.%s' % (name, k)] = p_.grad.numpy()
+        for k, b_ in mod.named_buffers():
+            if 'num_batches_tracked' not in k:
+                out['buf.%s.%s' % (name, k)] = b_.detach().numpy().copy()
+    save('neck_head_train_small.npz', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shim()
@@ -903,6 +943,8 @@ def main():
         gen_render_grad(nh)
     if want('encoder_train'):
         gen_encoder_train(res)
+    if want('neck_head_train'):
+        gen_neck_head_train(fpn, occ)
     if only:
         return
     gen_kat(bp)
