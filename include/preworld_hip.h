@@ -450,7 +450,7 @@ int pw_lovasz_softmax(const float* probas, const uint8_t* target, const uint8_t*
  * Training side of the voxel encoder (what torch autograd runs behind mmdet3d/models/backbones/resnet.py:88-184 in
  * forward_train): conv3d weight / data gradients and BatchNorm3d with batch statistics.  fp32, channels-last.
  * ------------------------------------------------------------------------------------- */
-/* dW of a Conv3d(bias=False, kernel ksize in {1,3}, stride in {1,2}, padding ksize/2): x (B,D,H,W,Cin), dy (B,Do,Ho,Wo,Cout),
+/* dW of a Conv3d(kernel ksize in {1,3}, stride in {1,2}, padding ksize/2; or ksize 2, stride 2, no padding): x (B,D,H,W,Cin), dy (B,Do,Ho,Wo,Cout),
  * dw float[Cout][Cin][k][k][k] (torch's layout).  fp32 MFMA with K = voxels, per-chunk partial tiles in `workspace`
  * (pw_conv3d_wgrad_workspace_bytes) summed in a fixed order: deterministic. */
 size_t pw_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int ksize, int stride);
@@ -460,6 +460,9 @@ int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* workspace,
  * weight.permute(2,3,4,0,1)), dx (B,D,H,W,Cin), Cin % 4 == 0.  (Stride-1 and 1x1x1 data gradients are forward convolutions
  * with flipped / transposed weights: pw_conv3d_ndhwc.) */
 int pw_conv3d_dgrad_s2(const float* dy, const float* wt, float* dx, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+/* dX of the unpadded Conv3d(k=2, stride=2) of the trajectory branch (heads/occupancy_head.py:180-200): dy (B,D/2,H/2,W/2,Cout),
+ * wt float[2][2][2][Cout][Cin], dx (B,D,H,W,Cin).  pw_conv3d_wgrad takes ksize 2 / stride 2 for the matching dW. */
+int pw_conv3d_dgrad_k2s2(const float* dy, const float* wt, float* dx, int B, int D, int H, int W, int Cin, int Cout, void* stream);
 /* BatchNorm3d, training mode, on channels-last rows x (N, C), 256 % C == 0:
  *   pw_bn_stats       mean[c], var[c] (biased), rstd[c] = 1/sqrt(var + eps)              (double accumulation, deterministic)
  *   pw_bn_apply       y = (x - mean) rstd gamma + beta (+ residual) (ReLU if relu)

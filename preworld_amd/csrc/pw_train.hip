@@ -106,8 +106,10 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
   if (co < Cout && ci < Cin) dw[((size_t)co * Cin + ci) * taps + tap] = s;
 }
 
+static inline int wgrad_pad(int ksize) { return ksize == 2 ? 0 : ksize / 2; }   // 2x2x2 stride-2 convs (trajectory branch) are unpadded
+
 PW_API size_t pw_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int ksize, int stride) {
-  const int pad = ksize / 2;
+  const int pad = wgrad_pad(ksize);
   const int Do = (D + 2 * pad - ksize) / stride + 1, Ho = (H + 2 * pad - ksize) / stride + 1;
   const int n_rows = B * Do * Ho;
   int n_chunks = n_rows / 32;
@@ -120,13 +122,14 @@ PW_API int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* wor
                            int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
   PW_CHECK_ARG(x && dy && dw && workspace, "pw_conv3d_wgrad: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "pw_conv3d_wgrad: bad shape");
-  PW_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "pw_conv3d_wgrad: ksize 1 | 3, stride 1 | 2");
+  PW_CHECK_ARG(((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2)) || (ksize == 2 && stride == 2),
+               "pw_conv3d_wgrad: ksize 1 | 3 with stride 1 | 2 (padding ksize / 2), or ksize 2 with stride 2 (no padding)");
   PW_CHECK_ARG(workspace_bytes >= pw_conv3d_wgrad_workspace_bytes(B, D, H, W, Cin, Cout, ksize, stride),
                "pw_conv3d_wgrad: workspace too small");
   WgradArgs a;
   a.x = x; a.dy = dy; a.partial = (float*)workspace;
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-  a.ks = ksize; a.stride = stride; a.pad = ksize / 2; a.taps = ksize * ksize * ksize;
+  a.ks = ksize; a.stride = stride; a.pad = wgrad_pad(ksize); a.taps = ksize * ksize * ksize;
   a.Do = (D + 2 * a.pad - ksize) / stride + 1; a.Ho = (H + 2 * a.pad - ksize) / stride + 1; a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
   a.co_blocks = (Cout + 31) / 32; a.ci_blocks = (Cin + 31) / 32;
   a.n_rows = B * a.Do * a.Ho;
@@ -199,6 +202,51 @@ PW_API int pw_conv3d_dgrad_s2(const float* dy, const float* wt, float* dx, int B
   hipLaunchKernelGGL(k_conv3d_dgrad_s2, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, pw_stream(stream), dy, wt, dx, B,
                      D, H, W, Cin, Do, Ho, Wo, Cout);
   pw_note_kernel("k_conv3d_dgrad_s2");
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// dgrad of the unpadded 2x2x2 stride-2 convs of the trajectory branch (heads/occupancy_head.py:180-200): every input voxel feeds
+// exactly one output voxel through exactly one tap.  wt: [2][2][2][Cout][Cin].  Input voxels beyond 2 * (D / 2) etc. get 0.
+__global__ void __launch_bounds__(256) k_conv3d_dgrad_k2s2(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int B, int D, int H, int W, int Cin, int Do,
+                                                          int Ho, int Wo, int Cout) {
+  const int cq = Cin / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * D * H * W * cq;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % cq) * 4;
+  size_t v = idx / cq;
+  const int iw = (int)(v % W); v /= W;
+  const int ih = (int)(v % H); v /= H;
+  const int id = (int)(v % D);
+  const int b = (int)(v / D);
+  const int od = id >> 1, oh = ih >> 1, ow = iw >> 1;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (od < Do && oh < Ho && ow < Wo) {
+    const float* dyr = dy + ((((size_t)b * Do + od) * Ho + oh) * Wo + ow) * Cout;
+    const int tap = ((id & 1) * 2 + (ih & 1)) * 2 + (iw & 1);
+    const float4* wr = reinterpret_cast<const float4*>(w + ((size_t)tap * Cout) * Cin + c4);
+#pragma unroll 4
+    for (int co = 0; co < Cout; ++co) {
+      const float g = dyr[co];
+      const float4 wv = wr[(size_t)co * cq];
+      acc[0] = fmaf(g, wv.x, acc[0]); acc[1] = fmaf(g, wv.y, acc[1]);
+      acc[2] = fmaf(g, wv.z, acc[2]); acc[3] = fmaf(g, wv.w, acc[3]);
+    }
+  }
+  *reinterpret_cast<float4*>(dx + idx * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+PW_API int pw_conv3d_dgrad_k2s2(const float* dy, const float* wt, float* dx, int B, int D, int H, int W, int Cin, int Cout,
+                                void* stream) {
+  PW_CHECK_ARG(dy && wt && dx, "pw_conv3d_dgrad_k2s2: null pointer");
+  PW_CHECK_ARG(B > 0 && D > 1 && H > 1 && W > 1 && Cin > 0 && Cin % 4 == 0 && Cout > 0, "pw_conv3d_dgrad_k2s2: bad shape (Cin %% 4)");
+  PW_CHECK_ARG((((uintptr_t)dx | (uintptr_t)wt) & 15) == 0, "pw_conv3d_dgrad_k2s2: dx / wt must be 16-byte aligned");
+  const size_t total = (size_t)B * D * H * W * (Cin / 4);
+  hipLaunchKernelGGL(k_conv3d_dgrad_k2s2, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, pw_stream(stream), dy, wt, dx,
+                     B, D, H, W, Cin, D / 2, H / 2, W / 2, Cout);
+  pw_note_kernel("k_conv3d_dgrad_k2s2");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

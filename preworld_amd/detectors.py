@@ -7,9 +7,9 @@ signature and result dicts as the reference.
 Everything downstream of the image-view features runs on libpreworld_hip.so (channels-last, no permute copies); the
 image backbone / neck / DepthNet are plain PyTorch-ROCm modules (image_encoder.py), as north_star prescribes.
 `img_backbone` / `img_neck` are optional: the benchmarks and most parity tests start from the lifted inputs
-(`simple_test_from_lift`) and need no 88 M-parameter Swin-B.  `PreWorld.forward_train` (the single-time-step detector of the
-fine-tune / pre-train configs) runs the voxel side on the HIP training kernels (preworld_amd/train.py); the temporal
-`PreWorld4DTraj.forward_train` (forecast + trajectory losses) is not built."""
+(`simple_test_from_lift`) and need no 88 M-parameter Swin-B.  `PreWorld.forward_train` and `PreWorld4DTraj.forward_train` run the
+voxel side of the training step on the HIP training kernels (preworld_amd/train.py); `BEVStereo4DOCC.forward_train` is not
+built."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -345,10 +345,13 @@ class _PreWorldCommon(BEVStereo4DOCC):
         x = torch.cat(feats, dim=-1)                                  # [adjacent ..., key] (:266), channels-last
         return as_f32(self.bev_encoder_cl(x)), depth_key
 
-    def _voxel_losses_train(self, voxel_feats_cl, **kwargs):
-        """preworld.py:237-303 from the final_conv output: OccHead per batch element, loss_voxel / the zero-weight `loss_sup_*`
-        terms, optional render losses.  voxel_feats_cl: (B,Z,Y,X,C) channels-last."""
+    def _voxel_losses_train(self, voxel_feats_cl, interval=None, voxel_semantics=None, rays=None, **kwargs):
+        """preworld.py:237-303 / preworld_temporal_traj.py:392-434 from a state's features: OccHead per batch element, loss_voxel /
+        the zero-weight `loss_sup_*` terms, optional render losses.  voxel_feats_cl: (B,Z,Y,X,C) channels-last.  interval: None
+        for the single-time-step detector, else the state index (keys get the reference's `_{k}s` suffix)."""
         from . import losses as L, train
+        sfx = '' if interval is None else '_%ds' % interval
+        voxel_semantics = kwargs['voxel_semantics'] if voxel_semantics is None else voxel_semantics
         head = self.occupancy_head
         logits = torch.cat([train.occ_head_forward(head, voxel_feats_cl[b:b + 1], transposed=True)
                             for b in range(voxel_feats_cl.shape[0])], 0)           # (B,Z,Y,X,18)
@@ -357,25 +360,25 @@ class _PreWorldCommon(BEVStereo4DOCC):
         density_prob = self.density_mlp(vf_xyz)
         density, semantic, color = density_prob[..., 0], self.semantic_mlp(vf_xyz), self.color_mlp(vf_xyz)
         out = {}
-        voxel_semantics = kwargs['voxel_semantics']
         cw17 = torch.from_numpy(1.0 / np.log(NUSC_CLASS_FREQUENCIES[:17] + 0.001)).float()
         if self.if_post_finetune:
-            out.update(L.loss_voxel(occ_preds, voxel_semantics, cw17, camera_mask=None, empty_idx=self.empty_idx,
-                                    use_focal_loss=self.use_focal_loss, weight_voxel_ce=self.weight_voxel_ce,
-                                    weight_voxel_sem_scal=self.weight_voxel_sem_scal,
-                                    weight_voxel_geo_scal=self.weight_voxel_geo_scal, weight_voxel_lovasz=self.weight_voxel_lovasz,
-                                    focal_loss=getattr(self, 'focal_loss', None)))
+            lv = L.loss_voxel(occ_preds, voxel_semantics, cw17, camera_mask=None, empty_idx=self.empty_idx,
+                              use_focal_loss=self.use_focal_loss, weight_voxel_ce=self.weight_voxel_ce,
+                              weight_voxel_sem_scal=self.weight_voxel_sem_scal, weight_voxel_geo_scal=self.weight_voxel_geo_scal,
+                              weight_voxel_lovasz=self.weight_voxel_lovasz, focal_loss=getattr(self, 'focal_loss', None))
+            out.update({k + sfx: v for k, v in lv.items()})
         else:
             cw = torch.cat([cw17, torch.zeros(1)]).to(occ_preds)
-            out['loss_sup_voxel'] = L.CE_ssc_loss(occ_preds, voxel_semantics, cw, 255) * 0.
+            out['loss_sup_voxel' + sfx] = L.CE_ssc_loss(occ_preds, voxel_semantics, cw, 255) * 0.
         ce = nn.CrossEntropyLoss(reduction='mean')
         if self.if_render:
+            extra = {} if interval is None else dict(if_temporal=True, interval=interval)
             out.update(self.nerf_head(density, semantic, color, if_pretrain=self.if_pretrain, dataset_type=self.dataset_type,
-                                      rays=kwargs['rays'], bda=kwargs.get('bda')))
+                                      rays=kwargs['rays'] if rays is None else rays, bda=kwargs.get('bda'), **extra))
         else:                                                         # loss_sup (:120-127): zero weight, keeps the MLPs in the graph
             for pred, tag, n in ((semantic, 'semantic', self.num_classes - 1), (color, 'color', 3), (density, 'density', 1)):
-                out['loss_sup_%s' % tag] = ce(pred.reshape(-1, n), torch.ones_like(pred).reshape(-1, n)) * 0.
-        if self.if_pretrain:
+                out['loss_sup_%s%s' % (tag, sfx)] = ce(pred.reshape(-1, n), torch.ones_like(pred).reshape(-1, n)) * 0.
+        if self.if_pretrain and interval is None:                      # preworld.py:305-307 (the temporal detector has no such term)
             n = self.num_classes - 1
             out['loss_sup_semantic'] = ce(semantic.reshape(-1, n), torch.ones_like(semantic).reshape(-1, n)) * 0.
         return out
@@ -559,6 +562,50 @@ class PreWorld4DTraj(_PreWorldCommon):
         return res
 
     # ---- preworld_temporal_traj.py:212-370 with the reference's signature: images + kwargs['temporal_ego_states']
+    def set_epoch(self, epoch):                                         # :150-151, called by the reference's epoch hook
+        self.curr_epoch = epoch
+
+    def future_intervals(self):
+        """:436-446: how many forecast steps are supervised grows with the epoch"""
+        ep = getattr(self, 'curr_epoch', 0)
+        if self.if_render:
+            return [0, 1] if ep <= 2 else list(range(0, min(ep - 1, 6)))
+        return [0, 1] if ep <= 4 else list(range(0, min(int((ep - 3) // 2) + 1, 6)))
+
+    def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
+        """preworld_temporal_traj.py:372-530 (module in .train()): the current state's losses, then for every supervised future
+        interval one state-conditioned forecast step, the trajectory branch, OccHead + losses on the forecast state -- voxel side
+        on the HIP training kernels (preworld_amd/train.py), per-voxel / per-sample MLPs as library GEMMs under torch autograd.
+        Returns the reference's loss dict (keys `..._{k}s`)."""
+        from . import train
+        if not self.training:
+            raise RuntimeError('forward_train expects the module in training mode (model.train())')
+        prepared = self.prepare_inputs(img_inputs, stereo=True)
+        feat_cl, depth = self._bev_feat_train(prepared)
+        v = as_f32(self.final_conv.forward_cl(feat_cl))                 # (B,Z,Y,X,C)
+        losses = {}
+        if self.use_lss_depth_loss:
+            losses['loss_lss_depth'] = self.img_view_transformer.get_depth_loss(kwargs['gt_depth'], depth)
+        bda = prepared[6]
+        losses.update(self._voxel_losses_train(v, interval=0, voxel_semantics=kwargs['voxel_semantics'],
+                                               rays=kwargs.get('rays'), bda=bda))
+        for ego_interval in self.future_intervals():
+            ego = kwargs['temporal_ego_states'][0]
+            ego = ego.reshape(ego.shape[0], ego.shape[-1]).float()
+            identity = self.plan_head(ego)                              # (B, out_dim)
+            fused = train.fusion_step(self.fusion_head, v, identity)
+            down = train.downscale_forward(self.downscale, fused)       # (B, 4 out_dim)
+            fused_ego = identity + self.ego_fusion_head(torch.cat([identity, down], dim=-1))
+            pred_traj = self.traj_head(fused_ego)
+            k = ego_interval + 1
+            sem = kwargs['temporal_semantics'][k]['voxel_semantics'] if self.if_post_finetune else kwargs['voxel_semantics']
+            rays = kwargs['temporal_rays'][k] if self.if_render else None
+            losses.update(self._voxel_losses_train(fused, interval=k, voxel_semantics=sem, rays=rays, bda=bda))
+            gt = kwargs['temporal_trajs'][:, k - 1, :]
+            losses['loss_traj_%ds' % k] = torch.sum(torch.mean(torch.abs(pred_traj - gt) ** 2, dim=0))        # loss.py:125-131
+            v = fused                                                   # recursive (:528)
+        return losses
+
     def simple_test(self, points, img_metas, img=None, rescale=False, **kwargs):
         temporal_ego_states = kwargs['temporal_ego_states'][0]          # (:228,:304)
         frames = self.lift_inputs_from_images(self.prepare_inputs(img, stereo=True))

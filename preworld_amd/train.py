@@ -29,6 +29,8 @@ def conv3d_raw(x, w, stride=1):
     """Conv3d(bias=False, padding=k//2) of channels-last x (B,D,H,W,Cin) with torch-layout w (Cout,Cin,k,k,k) -> (B,Do,Ho,Wo,Cout);
     fp32 MFMA kernels of the inference path, no scale / bias / activation."""
     k = w.shape[2]
+    if k == 2 and stride != 2:
+        raise _lib.PreworldHipError('2x2x2 convs are built for stride 2 (the trajectory branch)')
     return ops.conv3d_ndhwc(_cl(x, 'x'), ops.pack_conv_weight(w.detach()), cout0=w.shape[0], ksize=k, stride=stride)
 
 
@@ -42,10 +44,10 @@ def conv3d_dgrad(dy, w, x_shape, stride=1):
             raise _lib.PreworldHipError('conv3d_dgrad: Cout %% 32 == 0 expected (encoder layers)')
         wt = w.detach().flip(2, 3, 4).transpose(0, 1).contiguous() if k == 3 else w.detach().transpose(0, 1).contiguous()
         return ops.conv3d_ndhwc(_cl(dy, 'dy'), ops.pack_conv_weight(wt), cout0=Cin, ksize=k, stride=1)
-    if k != 3 or stride != 2:
-        raise _lib.PreworldHipError('conv3d_dgrad: only stride 1 (k 1 | 3) and 3x3x3 stride 2 are built')
+    if stride != 2 or k not in (2, 3):
+        raise _lib.PreworldHipError('conv3d_dgrad: only stride 1 (k 1 | 3), 3x3x3 stride 2 and 2x2x2 stride 2 are built')
     dx = torch.empty(B, D, H, W, Cin, device=dy.device, dtype=_f32)
-    _lib.call('pw_conv3d_dgrad_s2', ops._p(_cl(dy, 'dy')), ops._p(_cl(w.detach().permute(2, 3, 4, 0, 1).contiguous(), 'w')), ops._p(dx), B, D, H, W, Cin,
+    _lib.call('pw_conv3d_dgrad_s2' if k == 3 else 'pw_conv3d_dgrad_k2s2', ops._p(_cl(dy, 'dy')), ops._p(_cl(w.detach().permute(2, 3, 4, 0, 1).contiguous(), 'w')), ops._p(dx), B, D, H, W, Cin,
               Cout, ops._stream())
     return dx
 
@@ -279,3 +281,22 @@ def occ_head_forward(head, x_cl, transposed=True):
         mid = mid * sw
     hid = _bn_cl(bn1, torch.matmul(mid, c1.weight.reshape(c1.weight.shape[0], -1).t()), True)
     return torch.matmul(hid, c2.weight.reshape(c2.weight.shape[0], -1).t())
+
+
+def downscale_forward(mod, v_cl):
+    """DownScaleModule3DCustom (heads/occupancy_head.py:180-200) in training mode on channels-last v (B,Z,Y,X,C) -> (B, 4C): three
+    unpadded 2x2x2 stride-2 convs with bias (taps permuted for the (Z,Y,X) buffer, like the inference path) and the global average."""
+    x = v_cl.contiguous()
+    for conv in (mod.downscale1, mod.downscale2, mod.downscale3):
+        y = Conv3dCL.apply(x, conv.weight.permute(0, 1, 4, 3, 2).contiguous(), 2)
+        x = BiasReLUCL.apply(y, conv.bias, False)
+    return x.mean(dim=(1, 2, 3))
+
+
+def fusion_step(fusion_head, v_cl, ego_feat):
+    """One state-conditioned forecast step (preworld_temporal_traj.py:452-455) under autograd: v + W2 softplus(W1 [v, e] + b1) + b2
+    with the ego half of W1 applied once per sample instead of on a repeat_interleave'd copy (same function; plain library GEMMs)."""
+    l0, l2 = fusion_head[0], fusion_head[2]
+    C = v_cl.shape[-1]
+    hid = torch.nn.functional.linear(v_cl, l0.weight[:, :C]) + torch.nn.functional.linear(ego_feat, l0.weight[:, C:], l0.bias)[:, None, None, None, :]
+    return v_cl + torch.nn.functional.linear(fusion_head[1](hid), l2.weight, l2.bias)

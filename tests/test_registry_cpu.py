@@ -64,12 +64,12 @@ def test_force_reregistration_and_build_from_reference_cfg():
 
 def test_training_registration_keeps_inference_only_classes_on_the_reference():
     """classes without a backward must not reach a training run.  training=True swaps only what can train (forward
-    under autograd + HIP backward, pinned by gradient fixtures: tests/test_gpu_train.py); the two detectors whose forward_train
-    is not built stay on the reference implementation."""
+    under autograd + HIP backward, pinned by gradient fixtures: tests/test_gpu_train.py); the base detector whose forward_train
+    is not built stays on the reference implementation."""
     regs = {k: FakeRegistry() for k in ALL_REGS}
     done = R.register(regs, training=True)
-    assert {n for _, n in done} == set(R.REGISTRY_OF) - {'BEVStereo4DOCC', 'PreWorld4DTraj'}
-    assert 'PreWorld4DTraj' not in regs['mmdet.DETECTORS'].module_dict and 'PreWorld' in regs['mmdet.DETECTORS'].module_dict
+    assert {n for _, n in done} == set(R.REGISTRY_OF) - {'BEVStereo4DOCC'}
+    assert 'BEVStereo4DOCC' not in regs['mmdet.DETECTORS'].module_dict and 'PreWorld4DTraj' in regs['mmdet.DETECTORS'].module_dict
     regs = {k: FakeRegistry() for k in ALL_REGS}
     done = R.register(regs)
     assert {n for _, n in done} == set(R.REGISTRY_OF)
@@ -130,10 +130,10 @@ def test_every_preworld_config_builds_through_the_registry():
             assert ('downscale.downscale3.weight' in keys) == has_traj
         else:
             assert 'predicter.2.weight' in det.state_dict()
-        if model['type'] == 'PreWorld':            # the single-time-step detector has a training step (tests/test_gpu_train.py)
+        if model['type'] in ('PreWorld', 'PreWorld4DTraj'):       # both have a training step (tests/test_gpu_train.py)
             with pytest.raises(RuntimeError, match='training mode'):
                 det.eval().forward_train()
-        else:                                      # BEVStereo4DOCC / PreWorld4DTraj: not built, and they say so
+        else:                                      # BEVStereo4DOCC: not built, and it says so
             with pytest.raises(NotImplementedError):
                 det.forward_train()
 
