@@ -227,6 +227,7 @@ k_scan_sums(int32_t* __restrict__ sums, int nb) {
   }
 }
 
+// third pass of the 3-pass form (kept for reference sizes beyond SCAN_FUSED_MAX_BLOCKS tiles)
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_scan_apply(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ sums,
              int32_t* __restrict__ out) {
@@ -248,6 +249,34 @@ k_scan_apply(const int32_t* __restrict__ in, int64_t n, const int32_t* __restric
   }
 }
 
+// two-pass form: every block of the apply pass adds up the totals of the tiles before it (nb <= a few thousand ints, L2-resident)
+// instead of waiting for a one-block scan of the totals -- one launch and one dependent round trip less
+constexpr int SCAN_FUSED_MAX_BLOCKS = 4096;
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_apply_fused(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ tile_sums,
+                   int32_t* __restrict__ out) {
+  __shared__ int lds[4];
+  int carry_part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS) carry_part += tile_sums[i];
+  int carry;
+  block_exclusive_scan(carry_part, lds, &carry);
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = base + k < n ? in[base + k] : 0;
+    s += v[k];
+  }
+  int tot;
+  int ex = block_exclusive_scan(s, lds, &tot) + carry;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < n) out[base + k] = ex;
+    ex += v[k];
+  }
+}
+
 static size_t scan_ws_bytes(int64_t n) { return pw_align_up((size_t)pw_cdiv(n, SCAN_TILE) * 4, 256); }
 
 // out may alias in
@@ -255,8 +284,12 @@ static int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_
                               hipStream_t st) {
   int nb = (int)pw_cdiv(n, SCAN_TILE);
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nb);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums, out);
+  if (nb <= SCAN_FUSED_MAX_BLOCKS) {
+    hipLaunchKernelGGL(k_scan_apply_fused, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums, out);
+  } else {
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums, out);
+  }
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
@@ -274,8 +307,9 @@ static int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_
 // run length issued by its first lane; the other lanes take base + offset in the run.
 __global__ void __launch_bounds__(256)
 k_hist(const int32_t* __restrict__ keys, int64_t n, int32_t* __restrict__ count,
-       int32_t* __restrict__ rank) {
+       int32_t* __restrict__ rank, int32_t* __restrict__ n_long) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_long && i == 0) *n_long = 0;                 // consumed by k_scatter, two launches later
   const int lane = threadIdx.x & 63;
   const int k = i < n ? keys[i] : -1;
   const int kprev = __shfl_up(k, 1, 64);
@@ -351,13 +385,12 @@ __device__ __forceinline__ int count_smaller_lds(const int32_t* ids, int m16, in
   return r;
 }
 
-__global__ void __launch_bounds__(256)
-k_sort_long(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ tmp,
-            const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
-            int32_t* __restrict__ order, int aux_div, int aux_mod, int32_t* __restrict__ order_aux) {
-  extern __shared__ __attribute__((aligned(16))) int32_t ids[];
+__device__ __forceinline__ void sort_long_blocks(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ tmp,
+                                                 const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
+                                                 int32_t* __restrict__ order, int aux_div, int aux_mod,
+                                                 int32_t* __restrict__ order_aux, int32_t* ids, int first, int stride) {
   const int nl = *n_long;
-  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+  for (int li = first; li < nl; li += stride) {
     const int k = long_list[li];
     const int s = seg_start[k], n = seg_start[k + 1] - s;
     if (n <= SORT_LDS_MAX) {                              // the segment fits: stage once
@@ -386,6 +419,38 @@ k_sort_long(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ t
     }
     __syncthreads();
   }
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_long(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ tmp,
+            const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
+            int32_t* __restrict__ order, int aux_div, int aux_mod, int32_t* __restrict__ order_aux) {
+  extern __shared__ __attribute__((aligned(16))) int32_t ids[];
+  sort_long_blocks(seg_start, tmp, long_list, n_long, order, aux_div, aux_mod, order_aux, ids, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// k_ranksort and k_sort_long in ONE launch (they are independent: short segments by one thread per point, long ones by the first
+// SORT_LONG_BLOCKS blocks through LDS): one launch and one drain / fill of the GPU less per frame
+constexpr int SORT_LONG_BLOCKS = 512;
+__global__ void __launch_bounds__(256)
+k_ranksort_all(const int32_t* __restrict__ keys, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ tmp,
+               const int32_t* __restrict__ kept_ptr, const int32_t* __restrict__ long_list,
+               const int32_t* __restrict__ n_long, int32_t* __restrict__ order, int aux_div, int aux_mod,
+               int32_t* __restrict__ order_aux) {
+  extern __shared__ __attribute__((aligned(16))) int32_t ids[];
+  if ((int)blockIdx.x < SORT_LONG_BLOCKS) {
+    sort_long_blocks(seg_start, tmp, long_list, n_long, order, aux_div, aux_mod, order_aux, ids, (int)blockIdx.x, SORT_LONG_BLOCKS);
+    return;
+  }
+  const int64_t pos = (int64_t)(blockIdx.x - SORT_LONG_BLOCKS) * blockDim.x + threadIdx.x;
+  if (pos >= *kept_ptr) return;
+  const int id = tmp[pos];
+  const int k = keys[id];
+  const int s = seg_start[k], e = seg_start[k + 1];
+  if (e - s > SORT_LONG) return;
+  int r = 0;
+  for (int j = s; j < e; ++j) r += tmp[j] < id;
+  emit_sorted(order, order_aux, s + r, id, aux_div, aux_mod);
 }
 
 // zero-fill by a kernel, not hipMemsetAsync: a hipGraph that contains memset nodes faulted on replay
@@ -429,21 +494,22 @@ PW_API int pw_segment_sort(int64_t n, int64_t n_keys, const int32_t* keys, void*
   ws += pw_align_up((size_t)n * 4, 256);
   int32_t* sums = (int32_t*)ws;
   hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)pw_cdiv(n_keys + 1, 256)), dim3(256), 0, st, count, n_keys + 1);
-  if (long_list) hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(256), 0, st, n_long, (int64_t)1);
   unsigned nbk = (unsigned)pw_cdiv(n, 256);
-  hipLaunchKernelGGL(k_hist, dim3(nbk), dim3(256), 0, st, keys, n, count, rank);
+  hipLaunchKernelGGL(k_hist, dim3(nbk), dim3(256), 0, st, keys, n, count, rank, long_list ? n_long : (int32_t*)nullptr);
   int rc = scan_exclusive_i32(count, seg_start, n_keys + 1, sums, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_scatter, dim3(nbk), dim3(256), 0, st, keys, n, seg_start, rank, tmp,
                      long_threshold, long_list, n_long);
   // with a long list (threshold must be SORT_LONG) the long segments go to the LDS block sort
   const int split = (long_list && long_threshold == SORT_LONG) ? 1 : 0;
-  hipLaunchKernelGGL(k_ranksort, dim3(nbk), dim3(256), 0, st, keys, seg_start, tmp,
-                     seg_start + n_keys, order, aux_div, aux_mod, order_aux, split);
-  if (split)
-    hipLaunchKernelGGL(k_sort_long, dim3(1024), dim3(256), SORT_LDS_MAX * 4, st, seg_start, tmp,
-                       long_list, n_long, order, aux_div, aux_mod, order_aux);
-  pw_note_kernel("k_hist + 3 scan + k_scatter + k_ranksort + k_sort_long");
+  if (split) {
+    hipLaunchKernelGGL(k_ranksort_all, dim3(nbk + SORT_LONG_BLOCKS), dim3(256), SORT_LDS_MAX * 4, st, keys, seg_start, tmp,
+                       seg_start + n_keys, long_list, n_long, order, aux_div, aux_mod, order_aux);
+  } else {
+    hipLaunchKernelGGL(k_ranksort, dim3(nbk), dim3(256), 0, st, keys, seg_start, tmp,
+                       seg_start + n_keys, order, aux_div, aux_mod, order_aux, split);
+  }
+  pw_note_kernel("k_zero + k_hist + 2 scan + k_scatter + k_ranksort_all");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
