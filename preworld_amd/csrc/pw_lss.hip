@@ -598,6 +598,9 @@ __device__ __forceinline__ void fma4_nc(float4& acc, const float4& f, float d) {
 // start first and run under the bulk sweep: 64 (pixel, depth) pairs are fetched in one
 // coalesced go, then broadcast lane by lane so the sum keeps its sequential point order.
 constexpr int LONG_BLOCKS = 128;    // x 4 waves
+#ifndef PW_POOL_WAVES
+#define PW_POOL_WAVES 5
+#endif
 
 // one lane's 4 channels (quad `sub`) of voxel row v: fp32, or split-fp16 (h2, pw_h2.h) for the fp16-matrix-core encoder
 template <int LPV>
@@ -616,7 +619,7 @@ __device__ __forceinline__ void pool_store(float4* __restrict__ out, int64_t v, 
 }
 
 template <int LPV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_POOL_WAVES, 8)))
 k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
              const int32_t* __restrict__ seg_start, const int32_t* __restrict__ order,
              const int32_t* __restrict__ order_feat, int64_t n_voxels, int long_threshold,
@@ -658,20 +661,22 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
           my_pf = order_feat[idx];
           my_d = depth[order[idx]];
         }
+        {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
+          for (int u = 0; u < NU; ++u) {
 #pragma unroll
-          for (int g = 0; g < GROUPS; ++g) {
-            const int pidx = u * GROUPS + g;                // compile-time
-            if (pidx < n) {                                // wave-uniform
-              const int src = g * LPV + sub;
-              float4 fv;
-              fv.x = __shfl(f[u].x, src, 64);
-              fv.y = __shfl(f[u].y, src, 64);
-              fv.z = __shfl(f[u].z, src, 64);
-              fv.w = __shfl(f[u].w, src, 64);
-              const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_d), pidx));
-              fma4_nc(acc, fv, d);
+            for (int g = 0; g < GROUPS; ++g) {
+              const int pidx = u * GROUPS + g;                // compile-time
+              if (pidx < n) {                                // wave-uniform
+                const int src = g * LPV + sub;
+                float4 fv;
+                fv.x = __shfl(f[u].x, src, 64);
+                fv.y = __shfl(f[u].y, src, 64);
+                fv.z = __shfl(f[u].z, src, 64);
+                fv.w = __shfl(f[u].w, src, 64);
+                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_d), pidx));
+                fma4_nc(acc, fv, d);
+              }
             }
           }
         }
@@ -683,16 +688,19 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
   // Dense sweep, software-pipelined over the voxels of one lane group.  A voxel costs a chain of
   // dependent loads (segment bounds -> point ids -> depth / feature row); run back to back that
   // chain (~3 memory latencies) times ~10 voxels per group was the whole kernel time.  Here the
-  // bounds and the first LPV point ids of voxel v+stride are requested while voxel v gathers, so
-  // one memory latency per voxel stays exposed.  Lane `sub` holds the (pixel, point id) pair of
+  // bounds and the first LPV point ids of later voxels are requested while voxel v gathers (see
+  // the pipeline note below), so one memory latency per voxel stays exposed.  Lane `sub` holds the (pixel, point id) pair of
   // point s+sub (one coalesced load per array per group instead of LPV clamped ones); pairs are
   // broadcast inside the lane group and only points that exist gather their feature row.
   // The sum order is still point order, one non-contracted multiply-add at a time (bit-exact).
   const int64_t gid = (int64_t)(blockIdx.x - long_blocks) * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)(gridDim.x - long_blocks) * blockDim.x / LPV;
   const int gbase = lane - sub;                     // first lane of this voxel's lane group
+  // three-stage pipeline over the group's voxels v, v + stride, v + 2 stride: bounds are requested TWO voxels ahead, point ids ONE
+  // voxel ahead (their bounds arrived an iteration ago), so an iteration exposes one memory latency (its gathers) instead of two
+  // (bounds -> ids were back to back inside the iteration before)
   int64_t v = gid / LPV;
-  int s = 0, e = 0, my_pf = 0, my_o = 0;
+  int s = 0, e = 0, my_pf = 0, my_o = 0, sn = 0, en = 0;
   if (v < n_voxels) {
     s = seg_start[v];
     e = seg_start[v + 1];
@@ -701,29 +709,36 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
       my_pf = order_feat[j];
       my_o = order[j];
     }
+    if (v + stride < n_voxels) { sn = seg_start[v + stride]; en = seg_start[v + stride + 1]; }
   }
   while (v < n_voxels) {
-    const int64_t vn = v + stride;
-    int sn = 0, en = 0;
-    if (vn < n_voxels) { sn = seg_start[vn]; en = seg_start[vn + 1]; }
-    const bool skip = long_list && e - s > long_threshold;   // summed by the long-segment blocks
-    const int cnt = skip ? 0 : min(LPV, e - s);
-    const float my_d = cnt > 0 ? depth[my_o] : 0.f;
-    float4 f[LPV];
-#pragma unroll
-    for (int u = 0; u < LPV; ++u) {
-      const int pf = __shfl(my_pf, gbase + u, 64);
-      f[u] = u < cnt ? feat[(int64_t)pf * LPV + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    const int64_t vn = v + stride, v2 = vn + stride;
+    int s2 = 0, e2 = 0;
+    if (v2 < n_voxels) { s2 = seg_start[v2]; e2 = seg_start[v2 + 1]; }
     int n_pf = 0, n_o = 0;
     if (en > sn) {
       const int j = min(sn + sub, en - 1);
       n_pf = order_feat[j];
       n_o = order[j];
     }
+    const bool skip = long_list && e - s > long_threshold;   // summed by the long-segment blocks
+    const int cnt = skip ? 0 : min(LPV, e - s);
+    const float my_d = cnt > 0 ? depth[my_o] : 0.f;
+    // most voxels hold 0-3 points: stop the unrolled per-point work at the largest count among the wave's voxels
+    // (wave-uniform test; skipped iterations would only have shuffled and predicated-off)
+    float4 f[LPV];
+#pragma unroll
+    for (int u = 0; u < LPV; ++u) f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < LPV; ++u) {
+      if (__ballot(u < cnt) == 0ull) break;
+      const int pf = __shfl(my_pf, gbase + u, 64);
+      if (u < cnt) f[u] = feat[(int64_t)pf * LPV + sub];
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < LPV; ++u) {
+      if (__ballot(u < cnt) == 0ull) break;
       const float d = __shfl(my_d, gbase + u, 64);
       if (u < cnt) fma4_nc(acc, f[u], d);
     }
@@ -742,7 +757,7 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
       }
       pool_store<LPV>(out, v, sub, acc, out_h2);
     }
-    v = vn; s = sn; e = en; my_pf = n_pf; my_o = n_o;
+    v = vn; s = sn; e = en; my_pf = n_pf; my_o = n_o; sn = s2; en = e2;
   }
 }
 

@@ -35,3 +35,8 @@ alg = 4.0 * (640000 * 32 + d_t.numel() + f_t.numel() + 640001 + 2 * kept)
 print('%s: voxel_index %.1f us | sort %.1f us | pool fp32 %.1f us (%.2f TB/s) | pool h2 %.1f us (%.2f TB/s) | frame total %.1f us' % (
     ' '.join('%s=%s' % (k, v) for k, v in os.environ.items() if k.startswith('PW_')) or 'default',
     t_idx, t_sort, t_pool, alg / t_pool * 1e-6, t_pool_h2, alg / t_pool_h2 * 1e-6, t_idx + t_sort + t_pool_h2), flush=True)
+# where does the pooling time go: the dense sweep alone (long segments walked by their lane group) vs with the long-segment blocks
+vs0 = ops.VoxelSort(vs.seg_start, vs.order, vs.order_feat, None, None, vs.n_keys)
+t0 = timeit(lambda: ops.bev_pool_dense(d_t, f_t, vs0, out=out))
+print('pool fp32 without the long-segment blocks (same result, long segments inside the sweep): %.1f us; long segments: %d' % (
+    t0, int(vs.n_long.item())), flush=True)
