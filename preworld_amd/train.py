@@ -1,16 +1,24 @@
-"""Training-mode forward + backward of the voxel encoder blocks on the HIP kernels of csrc/pw_train.hip.
+"""Training side of the voxel path: forward under torch autograd + backward on the HIP kernels of csrc/pw_train.hip.
 
-What torch autograd runs behind the reference's `BasicBlock3D` / `CustomResNet3D` (mmdet3d/models/backbones/resnet.py:88-184:
-Conv3d(bias=False) -> BatchNorm3d with batch statistics -> ReLU, residual add) when `forward_train` calls them:
+What torch autograd runs behind the reference's modules when `forward_train` (preworld.py:229-309,
+preworld_temporal_traj.py:372-530) calls them:
+  * BasicBlock3D / CustomResNet3D (backbones/resnet.py:88-184): Conv3d(bias=False) -> BatchNorm3d (batch statistics) -> ReLU,
+    residual add                                                   conv_module_forward / basic_block_forward
+  * LSSFPN3D (necks/lss_fpn.py:132-148)                            fpn_forward (per-level 1x1x1 convs, trilinear up-sampling + adjoint)
+  * final_conv (conv + bias + ReLU)                                conv_bias_act_forward
+  * OccHead.forward_coarse_voxel (heads/occupancy_head.py:124-161) occ_head_forward
+  * the forecast step and the trajectory branch (:448-470)         fusion_step / downscale_forward
+Kernels:
   * conv forward   : the fp32 MFMA kernels of the inference path with unit scale / zero bias (raw conv output)
   * conv dgrad     : stride 1 (3x3x3 and 1x1x1) = a forward conv with the weights flipped and transposed, on the same kernels;
-                     3x3x3 stride 2 = pw_conv3d_dgrad_s2
+                     3x3x3 stride 2 = pw_conv3d_dgrad_s2; 2x2x2 stride 2 = pw_conv3d_dgrad_k2s2
   * conv wgrad     : pw_conv3d_wgrad (fp32 MFMA, K = voxels, deterministic two-stage reduction)
   * BatchNorm3d    : pw_bn_stats / pw_bn_apply / pw_bn_bwd_reduce / pw_bn_bwd_apply (batch statistics in double, running
                      statistics updated like nn.BatchNorm3d: momentum, unbiased variance, num_batches_tracked)
-Everything is fp32 channels-last (B, D, H, W, C).  `ConvModule3d.forward_cl`, `BasicBlock3D.forward_cl` and therefore
-`CustomResNet3D.forward_cl` / `.forward` dispatch here when the module is in training mode.  The rest of `forward_train`
-(FPN, final_conv, OccHead, forecast backward) is not built."""
+  * up-sampling    : pw_upsample_trilinear_add / pw_upsample_trilinear_adjoint
+Everything is fp32 channels-last (B, D, H, W, C); the per-voxel / per-sample dense layers are library GEMMs (torch.matmul /
+F.linear).  `ConvModule3d.forward_cl`, `BasicBlock3D.forward_cl`, `CustomResNet3D`, `LSSFPN3D`, `OccHead.forward` dispatch here
+when the module is in training mode; `PreWorld.forward_train` / `PreWorld4DTraj.forward_train` (detectors.py) compose them."""
 import torch
 
 from . import _lib, ops

@@ -1,5 +1,5 @@
 """Training step of the voxel encoder at the C3 shape: CustomResNet3D [1,2,4] on (1,64,16,200,200), forward with batch-statistics
-BatchNorm + backward (conv dgrad / wgrad, BN backward) through preworld_amd.train.  Development aid / profiles/r02_train_encoder.txt."""
+BatchNorm + backward (conv dgrad / wgrad, BN backward) through preworld_amd.train.  Development aid / profiles/r02_train.txt."""
 import os
 import sys
 import time
@@ -69,3 +69,47 @@ for (D, H, W), cin, cout, s in (((16, 200, 200), 32, 32, 1), ((16, 200, 200), 64
     td = t(lambda: train.conv3d_dgrad(g, w, xx.shape, s))
     print('%dx%dx%d %d->%d s%d  %.1f GF: wgrad %.0f us (%.0f TF)  dgrad %.0f us (%.0f TF)' % (D, H, W, cin, cout, s, gf, tw, gf / tw * 1e3,
                                                                                     td, gf / td * 1e3), flush=True)
+
+# ---- the whole voxel side of PreWorld.forward_train at the C3 shape, from lifted inputs (image side excluded): pooling with
+# backward -> pre_process (key frame under autograd, adjacent under no_grad) -> encoder -> neck -> final_conv -> OccHead -> loss_voxel
+from preworld_amd import harness  # noqa: E402
+from preworld_amd.modules import to_channels_last_3d  # noqa: E402
+cfg = harness.model_cfg(S.GRID_CONFIG_FULL, detector='PreWorld')
+cfg.update(if_render=False, if_post_finetune=True, use_lss_depth_loss=False, weight_voxel_ce=1.0, weight_voxel_sem_scal=1.0,
+           weight_voxel_geo_scal=1.0, weight_voxel_lovasz=1.0)
+net = harness.build_model(cfg, sd, dev).train()
+frames = harness.lifted_frames(0, 6, dev, n_frames=2)
+sem = torch.randint(0, 18, (1, 200, 200, 16), device=dev)
+vt = net.img_view_transformer
+
+
+def lift(fr, grad):
+    d, f = fr['depth'].detach().requires_grad_(grad), fr['tran_feat'].detach().requires_grad_(grad)
+    B, N = fr['sensor2keyego'].shape[:2]
+    inp = [d.new_empty(B, N, 1, d.shape[-2], d.shape[-1]), fr['sensor2keyego'], None, fr['intrin'], fr['post_rot'], fr['post_tran'],
+           fr['bda']]
+    x = to_channels_last_3d(vt.view_transform(inp, d, f)[0]).float()
+    return net.pre_process_net.forward_cl(x)[0], d
+
+
+def train_step():
+    net.zero_grad(set_to_none=True)
+    key, d = lift(frames[0], True)
+    with torch.no_grad():
+        adj, _ = lift(frames[1], False)
+    feat = net.bev_encoder_cl(torch.cat([adj, key], -1))
+    losses = net.forward_train_from_feats(feat, voxel_semantics=sem)
+    sum(losses.values()).backward()
+    return losses
+
+
+for _ in range(2):
+    out = train_step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 5
+for _ in range(n):
+    train_step()
+torch.cuda.synchronize()
+print('PreWorld.forward_train voxel side, C3 shape (6 cams, 2 frames, 200x200x16), forward + backward: %.1f ms per step   losses: %s' % (
+    (time.perf_counter() - t0) / n * 1e3, ', '.join('%s %.3f' % (k, float(v)) for k, v in out.items() if 'sup' not in k)), flush=True)
