@@ -33,13 +33,25 @@ def _cl(t, name):
 
 
 # ------------------------------------------------------------------------------ raw ops
+def _conv_fwd(x, w, stride):
+    """bias-free conv of channels-last x with torch-layout w on the fp32 inference kernels: Winograd F(2x2x2,3x3x3) where the
+    module stack uses it (3x3x3 stride 1, enough tiles; PW_CONV_WINO=0 / PW_TRAIN_WINO=0 keep the direct MFMA kernel), else direct"""
+    import os
+    from .modules import _use_wino
+    k, cout = w.shape[2], w.shape[0]
+    cout_total = (cout + 31) // 32 * 32
+    if os.environ.get('PW_TRAIN_WINO', '1') != '0' and _use_wino(x, cout_total, k, stride):
+        return ops.conv3d_wino(x, ops.pack_conv_weight_wino(w), cout0=cout)
+    return ops.conv3d_ndhwc(x, ops.pack_conv_weight(w), cout0=cout, ksize=k, stride=stride)
+
+
 def conv3d_raw(x, w, stride=1):
     """Conv3d(bias=False, padding=k//2) of channels-last x (B,D,H,W,Cin) with torch-layout w (Cout,Cin,k,k,k) -> (B,Do,Ho,Wo,Cout);
     fp32 MFMA kernels of the inference path, no scale / bias / activation."""
     k = w.shape[2]
     if k == 2 and stride != 2:
         raise _lib.PreworldHipError('2x2x2 convs are built for stride 2 (the trajectory branch)')
-    return ops.conv3d_ndhwc(_cl(x, 'x'), ops.pack_conv_weight(w.detach()), cout0=w.shape[0], ksize=k, stride=stride)
+    return _conv_fwd(_cl(x, 'x'), w.detach(), stride)
 
 
 def conv3d_dgrad(dy, w, x_shape, stride=1):
@@ -51,12 +63,12 @@ def conv3d_dgrad(dy, w, x_shape, stride=1):
         if Cout % 32:
             raise _lib.PreworldHipError('conv3d_dgrad: Cout %% 32 == 0 expected (encoder layers)')
         wt = w.detach().flip(2, 3, 4).transpose(0, 1).contiguous() if k == 3 else w.detach().transpose(0, 1).contiguous()
-        return ops.conv3d_ndhwc(_cl(dy, 'dy'), ops.pack_conv_weight(wt), cout0=Cin, ksize=k, stride=1)
+        return _conv_fwd(_cl(dy, 'dy'), wt, 1)
     if stride != 2 or k not in (2, 3):
         raise _lib.PreworldHipError('conv3d_dgrad: only stride 1 (k 1 | 3), 3x3x3 stride 2 and 2x2x2 stride 2 are built')
     dx = torch.empty(B, D, H, W, Cin, device=dy.device, dtype=_f32)
-    _lib.call('pw_conv3d_dgrad_s2' if k == 3 else 'pw_conv3d_dgrad_k2s2', ops._p(_cl(dy, 'dy')), ops._p(_cl(w.detach().permute(2, 3, 4, 0, 1).contiguous(), 'w')), ops._p(dx), B, D, H, W, Cin,
-              Cout, ops._stream())
+    _lib.call('pw_conv3d_dgrad_s2' if k == 3 else 'pw_conv3d_dgrad_k2s2', ops._p(_cl(dy, 'dy')),
+              ops._p(_cl(w.detach().permute(2, 3, 4, 0, 1).contiguous(), 'w')), ops._p(dx), B, D, H, W, Cin, Cout, ops._stream())
     return dx
 
 
