@@ -107,5 +107,5 @@ def test_detector_entry_point_from_images():
         assert np.array_equal(a, ref['semantic_occ_%ds' % k][0].cpu().numpy())
         g = out['geo_occ_%ds' % k][0]
         assert np.array_equal(g, np.where(a != 17, 0, 17).astype(np.uint8))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match='training mode'):        # the training step exists (tests/test_gpu_train.py) but the module is in eval()
         net(return_loss=True)
