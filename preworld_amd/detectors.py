@@ -8,8 +8,8 @@ Everything downstream of the image-view features runs on libpreworld_hip.so (cha
 image backbone / neck / DepthNet are plain PyTorch-ROCm modules (image_encoder.py), as north_star prescribes.
 `img_backbone` / `img_neck` are optional: the benchmarks and most parity tests start from the lifted inputs
 (`simple_test_from_lift`) and need no 88 M-parameter Swin-B.  `PreWorld.forward_train` and `PreWorld4DTraj.forward_train` run the
-voxel side of the training step on the HIP training kernels (preworld_amd/train.py); `BEVStereo4DOCC.forward_train` is not
-built."""
+voxel side of the training step on the HIP training kernels (preworld_amd/train.py), and so does `BEVStereo4DOCC.forward_train`
+(depth loss + softmax cross entropy on the predicter's logits)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -175,9 +175,64 @@ class BEVStereo4DOCC(nn.Module):
             return self.forward_train(**kwargs)
         return self.forward_test(**kwargs)
 
-    def forward_train(self, **kwargs):
-        raise NotImplementedError('preworld_amd detectors are inference drop-ins (forward pass only, SURVEY 8a); '
-                                  'register with inference_only=False to keep the reference class for training')
+    def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
+        """bevdet_occ.py:303-327 (module in .train()): depth loss + `loss_occ` on the predicter's logits.  `loss_occ` is built by
+        mmdet's registry in the reference (third-party, not in the tree); the configs use
+        dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0) = mean softmax cross entropy x loss_weight, which is what
+        is implemented here (anything else raises)."""
+        if not self.training:
+            raise RuntimeError('forward_train expects the module in training mode (model.train())')
+        cfg = dict(self.loss_occ_cfg or dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+        if cfg.get('type') != 'CrossEntropyLoss' or cfg.get('use_sigmoid', False) or cfg.get('class_weight') is not None:
+            raise NotImplementedError('loss_occ=%r: only the plain softmax CrossEntropyLoss of the released configs is built' % (cfg,))
+        prepared = self.prepare_inputs(img_inputs, stereo=True)
+        feat_cl, depth = self._bev_feat_train(prepared)
+        losses = {'loss_depth': self.img_view_transformer.get_depth_loss(kwargs['gt_depth'], depth)}
+        v = as_f32(self.final_conv.forward_cl(feat_cl)).permute(0, 3, 2, 1, 4)      # (B,X,Y,Z,C) view (:318)
+        occ_pred = self.predicter(v) if self.use_predicter else v
+        sem = kwargs['voxel_semantics'].long().reshape(-1)
+        losses['loss_occ'] = float(cfg.get('loss_weight', 1.0)) * nn.functional.cross_entropy(
+            occ_pred.reshape(-1, self.num_classes), sem, reduction='mean')
+        return losses
+
+    # ---- the frame loop of the training step (shared by the three detectors)
+    def _bev_feat_train(self, img_inputs):
+        """bevdet_occ.py:167-269 in training: the frame loop of extract_img_feat with the KEY frame under autograd and the
+        adjacent / stereo-reference frames under no_grad (:229-238), each frame through image encoder -> DepthNet -> voxel
+        pooling (ops.bev_pool_v2, backward = pw_bev_pool_v2_backward) -> pre_process_net; [adjacent, key] concat; encoder +
+        neck.  Returns (channels-last (B,Z,Y,X,C) features, depth of the key frame)."""
+        imgs, sensor2keyegos, ego2globals, intrins, post_rots, post_trans, bda, curr2adjsensor = img_inputs
+        vt = self.img_view_transformer
+        feats, depth_key, feat_prev_iv = [], None, None
+        for fid in range(self.num_frame - 1, -1, -1):
+            key_frame = fid == 0
+            extra_ref_frame = fid == self.num_frame - self.extra_ref_frames
+            if not (key_frame or self.with_prev):
+                continue
+            with torch.enable_grad() if key_frame else torch.no_grad():
+                if extra_ref_frame:
+                    feat_prev_iv = self.extract_stereo_ref_feat(imgs[fid])
+                    continue
+                mlp_input = vt.get_mlp_input(sensor2keyegos[0], ego2globals[0], intrins[fid], post_rots[fid], post_trans[fid], bda)
+                x, stereo_feat = self.image_encoder(imgs[fid], stereo=True)
+                metas = dict(k2s_sensor=curr2adjsensor[fid], intrins=intrins[fid], post_rots=post_rots[fid],
+                             post_trans=post_trans[fid], frustum=vt.cv_frustum.to(x), cv_downsample=4, downsample=vt.downsample,
+                             grid_config=vt.grid_config, cv_feat_list=[feat_prev_iv, stereo_feat])
+                bev, depth = vt([x, sensor2keyegos[fid], ego2globals[fid], intrins[fid], post_rots[fid], post_trans[fid], bda,
+                                 mlp_input], metas)
+                bev_cl = to_channels_last_3d(bev)
+                if self.pre_process:
+                    bev_cl = as_f32(self.pre_process_net.forward_cl(bev_cl)[0])
+                feats.append(bev_cl)
+                if key_frame:
+                    depth_key = depth
+                feat_prev_iv = stereo_feat
+        key = feats[-1]
+        if not self.with_prev:
+            feats = [key.new_zeros(key.shape[:-1] + (key.shape[-1] * self.num_adj,)), key]
+        x = torch.cat(feats, dim=-1)                                  # [adjacent ..., key] (:266), channels-last
+        return as_f32(self.bev_encoder_cl(x)), depth_key
+
 
     # ---- bevdet.py:52-58
     def bev_encoder_cl(self, x_cl, out_h2=False):
@@ -306,44 +361,6 @@ class _PreWorldCommon(BEVStereo4DOCC):
         sem = grid[..., 2:19].argmax(-1)
         occ = torch.where(dens > self.test_threshold, sem, torch.full_like(sem, self.num_classes - 1))
         return occ.to(torch.uint8)
-
-    # ---- preworld.py:229-309: the training step of the fine-tune / pre-train configs, voxel side on the HIP training kernels
-    def _bev_feat_train(self, img_inputs):
-        """bevdet_occ.py:167-269 in training: the frame loop of extract_img_feat with the KEY frame under autograd and the
-        adjacent / stereo-reference frames under no_grad (:229-238), each frame through image encoder -> DepthNet -> voxel
-        pooling (ops.bev_pool_v2, backward = pw_bev_pool_v2_backward) -> pre_process_net; [adjacent, key] concat; encoder +
-        neck.  Returns (channels-last (B,Z,Y,X,C) features, depth of the key frame)."""
-        imgs, sensor2keyegos, ego2globals, intrins, post_rots, post_trans, bda, curr2adjsensor = img_inputs
-        vt = self.img_view_transformer
-        feats, depth_key, feat_prev_iv = [], None, None
-        for fid in range(self.num_frame - 1, -1, -1):
-            key_frame = fid == 0
-            extra_ref_frame = fid == self.num_frame - self.extra_ref_frames
-            if not (key_frame or self.with_prev):
-                continue
-            with torch.enable_grad() if key_frame else torch.no_grad():
-                if extra_ref_frame:
-                    feat_prev_iv = self.extract_stereo_ref_feat(imgs[fid])
-                    continue
-                mlp_input = vt.get_mlp_input(sensor2keyegos[0], ego2globals[0], intrins[fid], post_rots[fid], post_trans[fid], bda)
-                x, stereo_feat = self.image_encoder(imgs[fid], stereo=True)
-                metas = dict(k2s_sensor=curr2adjsensor[fid], intrins=intrins[fid], post_rots=post_rots[fid],
-                             post_trans=post_trans[fid], frustum=vt.cv_frustum.to(x), cv_downsample=4, downsample=vt.downsample,
-                             grid_config=vt.grid_config, cv_feat_list=[feat_prev_iv, stereo_feat])
-                bev, depth = vt([x, sensor2keyegos[fid], ego2globals[fid], intrins[fid], post_rots[fid], post_trans[fid], bda,
-                                 mlp_input], metas)
-                bev_cl = to_channels_last_3d(bev)
-                if self.pre_process:
-                    bev_cl = as_f32(self.pre_process_net.forward_cl(bev_cl)[0])
-                feats.append(bev_cl)
-                if key_frame:
-                    depth_key = depth
-                feat_prev_iv = stereo_feat
-        key = feats[-1]
-        if not self.with_prev:
-            feats = [key.new_zeros(key.shape[:-1] + (key.shape[-1] * self.num_adj,)), key]
-        x = torch.cat(feats, dim=-1)                                  # [adjacent ..., key] (:266), channels-last
-        return as_f32(self.bev_encoder_cl(x)), depth_key
 
     def _voxel_losses_train(self, voxel_feats_cl, interval=None, voxel_semantics=None, rays=None, **kwargs):
         """preworld.py:237-303 / preworld_temporal_traj.py:392-434 from a state's features: OccHead per batch element, loss_voxel /

@@ -21,10 +21,9 @@ the registry objects as arguments and is unit-tested against a minimal stand-in 
 
 The drop-ins are INFERENCE classes (eval-mode BatchNorm folded into the convs, no conv backward): `register()` therefore
 defaults to `inference_only=True` semantics -- it replaces the classes for `tools/test*.py` runs; for a training run call
-`register(..., training=True)`, which leaves the one class that cannot train (the `BEVStereo4DOCC` base detector: its
-`forward_train` is not built) on the reference implementation and swaps the ones that have a backward on the HIP kernels: view
-transformers, `CustomResNet3D`, `LSSFPN3D`, `OccHead`, `NerfHead`, `CustomFocalLoss` and the `PreWorld` / `PreWorld4DTraj`
-detectors (csrc/pw_train.hip, preworld_amd/train.py)."""
+`register(..., training=True)`, which swaps only classes whose REGISTRY_OF entry says they have a backward on the HIP kernels --
+as of round 2 all of them: view transformers, `CustomResNet3D`, `LSSFPN3D`, `OccHead`, `NerfHead`, `CustomFocalLoss` and the three
+detectors with their `forward_train` (csrc/pw_train.hip, preworld_amd/train.py)."""
 from . import builder
 
 # reference type name -> (registry, can it train?)   -- "can train" = forward under autograd + backward on HIP kernels, pinned by
@@ -38,7 +37,7 @@ REGISTRY_OF = {
     'OccHead': ('mmdet.HEADS', True),                         # conv / BN on HIP kernels, the 16 -> 8 -> 18 layers as library GEMMs
     'NerfHead': ('mmdet.HEADS', True),                        # fused render forward + backward (ops.RenderRays)
     'CustomFocalLoss': ('mmdet.LOSSES', True),
-    'BEVStereo4DOCC': ('mmdet.DETECTORS', False),             # forward_train (loss_occ on the predicter MLP) not built
+    'BEVStereo4DOCC': ('mmdet.DETECTORS', True),              # forward_train: depth loss + softmax CE on the predicter MLP
     'PreWorld': ('mmdet.DETECTORS', True),                    # forward_train of the fine-tune / pre-train configs
     'PreWorld4DTraj': ('mmdet.DETECTORS', True),              # temporal forward_train: forecast steps, trajectory branch, per-state losses
 }

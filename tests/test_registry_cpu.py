@@ -64,12 +64,11 @@ def test_force_reregistration_and_build_from_reference_cfg():
 
 def test_training_registration_keeps_inference_only_classes_on_the_reference():
     """classes without a backward must not reach a training run.  training=True swaps only what can train (forward
-    under autograd + HIP backward, pinned by gradient fixtures: tests/test_gpu_train.py); the base detector whose forward_train
-    is not built stays on the reference implementation."""
+    under autograd + HIP backward, pinned by gradient fixtures: tests/test_gpu_train.py) -- the REGISTRY_OF flag is what gates it."""
     regs = {k: FakeRegistry() for k in ALL_REGS}
     done = R.register(regs, training=True)
-    assert {n for _, n in done} == set(R.REGISTRY_OF) - {'BEVStereo4DOCC'}
-    assert 'BEVStereo4DOCC' not in regs['mmdet.DETECTORS'].module_dict and 'PreWorld4DTraj' in regs['mmdet.DETECTORS'].module_dict
+    assert all(can_train for _, can_train in R.REGISTRY_OF.values())       # round 2: every drop-in has a training path
+    assert {n for _, n in done} == set(R.REGISTRY_OF)
     regs = {k: FakeRegistry() for k in ALL_REGS}
     done = R.register(regs)
     assert {n for _, n in done} == set(R.REGISTRY_OF)
@@ -130,12 +129,8 @@ def test_every_preworld_config_builds_through_the_registry():
             assert ('downscale.downscale3.weight' in keys) == has_traj
         else:
             assert 'predicter.2.weight' in det.state_dict()
-        if model['type'] in ('PreWorld', 'PreWorld4DTraj'):       # both have a training step (tests/test_gpu_train.py)
-            with pytest.raises(RuntimeError, match='training mode'):
-                det.eval().forward_train()
-        else:                                      # BEVStereo4DOCC: not built, and it says so
-            with pytest.raises(NotImplementedError):
-                det.forward_train()
+        with pytest.raises(RuntimeError, match='training mode'):          # every detector has a training step (tests/test_gpu_train.py)
+            det.eval().forward_train()
 
 
 def test_bevdepth_host_methods_match_reference(golden):
