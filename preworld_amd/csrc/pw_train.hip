@@ -11,12 +11,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------
-// wgrad.  One wave accumulates ONE 32 x 32 block (co0.., ci0..) of ONE tap over a slice of output rows (b, od, oh):
+// wgrad.  One wave accumulates the 32 x 32 blocks (co0.., ci0..) of the KS taps of one (kd, kh) over a slice of output rows (b, od, oh):
 // v_mfma_f32_32x32x2_f32 with K = two consecutive output voxels of the row.  Lane (i = l & 31, k = l >> 5) feeds
 //   A[i][k] = dY[row, ow + k][co0 + i]          B[k][j] = X[input row of the tap, (ow + k) s + kw - pad][ci0 + j]
 // straight from global memory: consecutive lanes read consecutive channels of a voxel row (128-byte segments), the validity of
-// the tap's input row is wave-uniform and the w range is clipped once per row, so the inner loop is 2 loads + 1 MFMA with no
-// predicate.  The four waves of a block take interleaved rows of the block's chunk and add their tiles through LDS; a second
+// the tap's input row is wave-uniform; columns outside the input along w load as zero.  The four waves of a block take interleaved rows of the block's chunk and add their tiles through LDS; a second
 // kernel sums the per-chunk partial tiles in a fixed order (deterministic, no atomics) into torch's [Cout][Cin][kd][kh][kw].
 // ------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -28,65 +27,87 @@ struct WgradArgs {
   int co_blocks, ci_blocks, n_chunks, rows_per_chunk, n_rows;
 };
 
+// KS = kernel extent along w handled by ONE block (all kw taps of a (kd, kh) pair): the dY operand is loaded once for the KS taps,
+// and at stride 1 the shifted X operands of a lane overlap (index 2 u + kw): 4 + 9 loads per 12 MFMAs instead of 24.
+template <int KS, int STRIDE>
 __global__ void __launch_bounds__(256) k_conv3d_wgrad(WgradArgs a) {
-  __shared__ float red[3][64 * 16];
+  __shared__ float red[3][KS][64 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, k = lane >> 5;
   int bid = blockIdx.x;
   const int cib = bid % a.ci_blocks; bid /= a.ci_blocks;
   const int cob = bid % a.co_blocks; bid /= a.co_blocks;
-  const int tap = bid;
+  const int kh = bid % KS, kd = bid / KS;
   const int chunk = blockIdx.y;
-  const int kw = tap % a.ks, kh = (tap / a.ks) % a.ks, kd = tap / (a.ks * a.ks);
   const int co = cob * 32 + i, ci = cib * 32 + i;
   const bool co_ok = co < a.Cout, ci_ok = ci < a.Cin;
-  // clipped w range: 0 <= ow * s + kw - pad < W
-  const int ow_lo = max(0, (a.pad - kw + a.stride - 1) / a.stride);
-  const int ow_hi = min(a.Wo, (a.W - 1 + a.pad - kw) / a.stride + 1);
-  f32x16 acc;
+  f32x16 acc[KS];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int r0 = chunk * a.rows_per_chunk, r1 = min(a.n_rows, r0 + a.rows_per_chunk);
   for (int row = r0 + wave; row < r1; row += 4) {
     const int oh = row % a.Ho, t = row / a.Ho;
     const int od = t % a.Do, b = t / a.Do;
-    const int id = od * a.stride + kd - a.pad, ih = oh * a.stride + kh - a.pad;
+    const int id = od * STRIDE + kd - a.pad, ih = oh * STRIDE + kh - a.pad;
     if ((unsigned)id >= (unsigned)a.D || (unsigned)ih >= (unsigned)a.H) continue;     // wave-uniform
     const float* dyr = a.dy + ((size_t)row * a.Wo) * a.Cout + co;
-    const float* xr = a.x + ((((size_t)b * a.D + id) * a.H + ih) * a.W + (kw - a.pad)) * a.Cin + ci;
-    int ow = ow_lo;
-    for (; ow + 8 <= ow_hi; ow += 8) {                   // 4 MFMAs, 8 loads in flight
-      float av[4], bv[4];
+    const float* xr = a.x + ((((size_t)b * a.D + id) * a.H + ih) * a.W) * a.Cin + ci;
+    for (int ow = 0; ow < a.Wo; ow += 8) {               // 4 k-pairs of output voxels per trip: 4 KS MFMAs
+      float av[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int o = ow + 2 * u + k;
-        av[u] = co_ok ? dyr[(size_t)o * a.Cout] : 0.f;
-        bv[u] = ci_ok ? xr[(size_t)o * a.stride * a.Cin] : 0.f;
+        av[u] = (co_ok && o < a.Wo) ? dyr[(size_t)o * a.Cout] : 0.f;
       }
+      if constexpr (STRIDE == 1) {
+        // X index of (u, kw) for this lane: ow + 2 u + k + kw - pad = base + (2 u + kw): 2 * 3 + KS distinct values
+        float xv[6 + KS];
+        const int base = ow + k - a.pad;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-    }
-    for (; ow < ow_hi; ow += 2) {
-      const int o = ow + k;
-      const bool ok = o < ow_hi;
-      const float av = (ok && co_ok) ? dyr[(size_t)o * a.Cout] : 0.f;
-      const float bv = (ok && ci_ok) ? xr[(size_t)o * a.stride * a.Cin] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int q = 0; q < 6 + KS; ++q) {
+          const int iw = base + q;
+          xv[q] = (ci_ok && (unsigned)iw < (unsigned)a.W) ? xr[(size_t)iw * a.Cin] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], xv[2 * u + kw], acc[kw], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float xv[KS];
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const int iw = (ow + 2 * u + k) * STRIDE + kw - a.pad;
+            xv[kw] = (ci_ok && (unsigned)iw < (unsigned)a.W) ? xr[(size_t)iw * a.Cin] : 0.f;
+          }
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], xv[kw], acc[kw], 0, 0, 0);
+        }
+      }
     }
   }
   // block reduction of the four waves' tiles (fixed order: wave 0 + 1 + 2 + 3)
   if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave - 1][r * 64 + lane] = acc[r];
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 1][t][r * 64 + lane] = acc[t][r];
   }
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r * 64 + lane]) + red[1][r * 64 + lane]) + red[2][r * 64 + lane];
-    float* dst = a.partial + ((((size_t)chunk * a.taps + tap) * a.co_blocks + cob) * a.ci_blocks + cib) * 1024;
-    // D row (co) = (r & 3) + 8 (r >> 2) + 4 k, column (ci) = i
+    for (int t = 0; t < KS; ++t) {
+      const int tap = (kd * KS + kh) * KS + t;
+      float* dst = a.partial + ((((size_t)chunk * a.taps + tap) * a.co_blocks + cob) * a.ci_blocks + cib) * 1024;
+      // D row (co) = (r & 3) + 8 (r >> 2) + 4 k, column (ci) = i
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * k) * 32 + i] = acc[r];
+      for (int r = 0; r < 16; ++r)
+        dst[((r & 3) + 8 * (r >> 2) + 4 * k) * 32 + i] =
+            ((acc[t][r] + red[0][t][r * 64 + lane]) + red[1][t][r * 64 + lane]) + red[2][t][r * 64 + lane];
+    }
   }
 }
 
@@ -108,14 +129,20 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 
 static inline int wgrad_pad(int ksize) { return ksize == 2 ? 0 : ksize / 2; }   // 2x2x2 stride-2 convs (trajectory branch) are unpadded
 
+// output rows are split into chunks so that (kd, kh) pairs x channel blocks x chunks gives ~3 000 blocks (enough waves to hide the
+// operand loads' latency), with at least 8 rows per chunk
+static int wgrad_chunks(int n_rows, int ksize, int Cin, int Cout) {
+  const int groups = ksize * ksize * ((Cout + 31) / 32) * ((Cin + 31) / 32);
+  int n = 3072 / groups;
+  if (n > n_rows / 8) n = n_rows / 8;
+  return n < 1 ? 1 : (n > 1024 ? 1024 : n);
+}
+
 PW_API size_t pw_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int ksize, int stride) {
   const int pad = wgrad_pad(ksize);
   const int Do = (D + 2 * pad - ksize) / stride + 1, Ho = (H + 2 * pad - ksize) / stride + 1;
-  const int n_rows = B * Do * Ho;
-  int n_chunks = n_rows / 32;
-  n_chunks = n_chunks < 1 ? 1 : (n_chunks > 64 ? 64 : n_chunks);
   const size_t tiles = (size_t)ksize * ksize * ksize * ((Cout + 31) / 32) * ((Cin + 31) / 32);
-  return (size_t)n_chunks * tiles * 1024 * 4;
+  return (size_t)wgrad_chunks(B * Do * Ho, ksize, Cin, Cout) * tiles * 1024 * 4;
 }
 
 PW_API int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int B, int D,
@@ -133,11 +160,15 @@ PW_API int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* wor
   a.Do = (D + 2 * a.pad - ksize) / stride + 1; a.Ho = (H + 2 * a.pad - ksize) / stride + 1; a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
   a.co_blocks = (Cout + 31) / 32; a.ci_blocks = (Cin + 31) / 32;
   a.n_rows = B * a.Do * a.Ho;
-  int n_chunks = a.n_rows / 32;
-  a.n_chunks = n_chunks < 1 ? 1 : (n_chunks > 64 ? 64 : n_chunks);
+  a.n_chunks = wgrad_chunks(a.n_rows, ksize, Cin, Cout);
   a.rows_per_chunk = (a.n_rows + a.n_chunks - 1) / a.n_chunks;
   hipStream_t st = pw_stream(stream);
-  hipLaunchKernelGGL(k_conv3d_wgrad, dim3((unsigned)(a.taps * a.co_blocks * a.ci_blocks), (unsigned)a.n_chunks), dim3(256), 0, st, a);
+  const dim3 grid((unsigned)(ksize * ksize * a.co_blocks * a.ci_blocks), (unsigned)a.n_chunks);
+  if (ksize == 3 && stride == 1) hipLaunchKernelGGL((k_conv3d_wgrad<3, 1>), grid, dim3(256), 0, st, a);
+  else if (ksize == 3) hipLaunchKernelGGL((k_conv3d_wgrad<3, 2>), grid, dim3(256), 0, st, a);
+  else if (ksize == 2) hipLaunchKernelGGL((k_conv3d_wgrad<2, 2>), grid, dim3(256), 0, st, a);
+  else if (stride == 1) hipLaunchKernelGGL((k_conv3d_wgrad<1, 1>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_conv3d_wgrad<1, 2>), grid, dim3(256), 0, st, a);
   const size_t per_chunk = (size_t)a.taps * a.co_blocks * a.ci_blocks * 1024;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)pw_cdiv((int64_t)per_chunk, 256)), dim3(256), 0, st, a.partial, dw, a.n_chunks,
                      a.taps, a.co_blocks, a.ci_blocks, Cout, Cin);
