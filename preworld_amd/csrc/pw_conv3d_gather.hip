@@ -217,7 +217,14 @@ int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, i
     // M-tiles per wave: 2 halves the weight loads per MFMA but measured slower (32->128 stride 2:
     // 199 us vs 180 us -- fewer waves to hide the L2 gather latency); PW_GATHER_MT=2 selects it
     const char* mte = getenv("PW_GATHER_MT");
-    const int MT = (!f16 && mte && atoi(mte) == 2) ? 2 : 1;
+    int MT = (!f16 && mte && atoi(mte) == 2) ? 2 : 1;
+    if (f16 && ksize == 3 && stride == 2) {
+      // split-fp16 stride-2 layers: the 32-cycle MFMA makes the weight loads weigh 4x more; two voxel tiles per wave win once the
+      // launch has few blocks anyway (8x100x100 64->2x128: 107 -> 88 us) and lose while there are enough (16x200x200 32->2x64:
+      // 135 -> 152 us)
+      MT = (pw_cdiv(n_out, 128) * ngroups < 512) ? 2 : 1;
+      if (mte) MT = atoi(mte) == 2 ? 2 : 1;
+    }
     const int nchunk = Cin / KC;
     int ksplit = 1;
     if (algo == 3) ksplit = (nchunk % 4 == 0) ? 4 : (nchunk % 2 == 0 ? 2 : 1);
@@ -250,6 +257,14 @@ int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, i
       if (NT == 2) PW_GATHER_FK(2, 1, 1); else PW_GATHER_FK(1, 1, 1);
     } else if (ksize == 3 && stride == 1) {
       if (NT == 2) PW_GATHER_FK(2, 3, 1); else PW_GATHER_FK(1, 3, 1);
+    } else if (ksize == 3 && stride == 2 && MT == 2) {   // two voxel tiles per wave share the weight fragments (A/B switch)
+      if (NT == 2) {
+        hipLaunchKernelGGL((k_conv3d_gather<2, 3, 2, 2, 1, true>), grid, dim3(256), red_bytes, st, a, n_out);
+        pw_note_kernel("k_conv3d_gather<2, 3, 2, 2, 1, true>");
+      } else {
+        hipLaunchKernelGGL((k_conv3d_gather<1, 3, 2, 2, 1, true>), grid, dim3(256), red_bytes, st, a, n_out);
+        pw_note_kernel("k_conv3d_gather<1, 3, 2, 2, 1, true>");
+      }
     } else if (ksize == 3 && stride == 2) {
       if (NT == 2) PW_GATHER_FK(2, 3, 2); else PW_GATHER_FK(1, 3, 2);
     } else {
