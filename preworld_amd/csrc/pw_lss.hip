@@ -581,7 +581,7 @@ PW_API int pw_lss_ranks(int64_t n_voxels, const int32_t* seg_start, const int32_
 // ------------------------------------------------------------------------------------
 // pooling kernels.  LPV = lanes per voxel = C/4 (float4 per lane); a wave owns 64/LPV voxels.
 // Sequential fp32 accumulation in point order, mul and add NOT contracted: the summation ORDER is that of
-// bev_pool_cuda.cu:37-41 and the result is bit-identical to the ORACLE (oracle/pw_oracle.c, built without FMA contraction).
+// bev_pool_cuda.cu:37-41 and the result is bit-identical to the CPU checker of the test suite (also built without FMA contraction).
 // Whether it is bit-identical to the reference's CUDA build depends on nvcc's own contraction choice there, which nothing here pins.
 // ------------------------------------------------------------------------------------
 constexpr int POOL_UNROLL = 8;
