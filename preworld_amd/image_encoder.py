@@ -229,8 +229,11 @@ class SwinTransformer(nn.Module):
         for i in self.out_indices:
             self.add_module('norm%d' % i, nn.LayerNorm(self.num_features[i]))
 
-    def _to_map(self, out, hw, i):
-        return out.view(-1, *hw, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
+    def _to_map(self, out, hw, i, channels_last=False):
+        m = out.view(-1, *hw, self.num_features[i]).permute(0, 3, 1, 2)
+        # the stereo feature only feeds the cost volume kernel, whose fast path reads channels-last storage: the
+        # token layout (B, H*W, C) already is that, so the NCHW-shaped view is handed out without the 138 MB copy
+        return m if channels_last else m.contiguous()
 
     def forward(self, x):
         x = self.drop_after_pos(self.patch_embed(x))
@@ -239,7 +242,7 @@ class SwinTransformer(nn.Module):
         for i, stage in enumerate(self.stages):
             x, hw_shape, out, out_hw = stage(x, hw_shape)
             if i == 0 and self.return_stereo_feat:
-                outs.append(self._to_map(out, out_hw, i))
+                outs.append(self._to_map(out, out_hw, i, channels_last=True))
             if i in self.out_indices:
                 outs.append(self._to_map(getattr(self, 'norm%d' % i)(out), out_hw, i))
             elif self.output_missing_index_as_none:
@@ -251,7 +254,7 @@ class SwinTransformer(nn.Module):
         x = self.drop_after_pos(self.patch_embed(x))
         hw_shape = (self.patch_embed.DH, self.patch_embed.DW)
         _, _, out, out_hw = self.stages[0](x, hw_shape)
-        return self._to_map(out, out_hw, 0)
+        return self._to_map(out, out_hw, 0, channels_last=True)
 
 
 # ----------------------------------------------------------------------------------------------- FPN_LSS

@@ -783,6 +783,7 @@ def stereo_cost_volume(prev, curr, frustum, k2s_sensor, intrins, post_rots, post
     Returns the softmaxed cost volume (B*N, D, H, W)."""
     BN, C, H, W = curr.shape
     D = frustum.shape[0]
+    prev, curr = prev.float(), curr.float()          # no-op on fp32; keeps the strides of a dense tensor
     if tuple(frustum.shape[1:3]) != (H, W) or tuple(prev.shape) != tuple(curr.shape) or prev.stride() != curr.stride():
         raise _lib.PreworldHipError('stereo_cost_volume: prev/curr/frustum shapes or strides disagree')
     dev = curr.device
