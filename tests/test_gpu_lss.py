@@ -239,6 +239,31 @@ def test_stereo_cost_volume(golden, channels_last):
     np.testing.assert_allclose(cv.sum(1).cpu().numpy(), 1.0, rtol=1e-5)
 
 
+@pytest.mark.parametrize('shape', [dict(C=128, H=19, W=45, D=88, n_cams=2), dict(C=16, H=9, W=21, D=33, n_cams=1)])
+def test_stereo_cost_volume_tile_kernel(monkeypatch, shape):
+    """The LDS-tiled channels-last kernel (default) against the point-per-lane kernel (itself pinned on the reference fixture):
+    same taps, the group costs summed by a lane tree instead of serially -> 1e-5-level agreement; ragged tile edges, bins
+    beyond the last chunk, bias rule; plus a strong-parallax pose that pushes near bins onto the direct-gather branch."""
+    from preworld_amd import _lib
+    prev, curr, k2s, K, pr, pt, fr = S.stereo_inputs(9, **shape)
+    cl = lambda t: T(t).contiguous(memory_format=torch.channels_last)
+    tp, tc = cl(prev), cl(curr)
+    for variant in range(2):
+        k2 = k2s.copy()
+        if variant == 1:
+            k2[0, :, :3, 3] = (1.9, 0.4, -2.5)            # large footprints for the near bins
+        args = (T(fr), T(k2), T(K), T(pr), T(pt))
+        monkeypatch.setenv('PW_STEREO_TILE', '0')
+        want = ops.stereo_cost_volume(tp, tc, *args, bias=5.0)
+        assert _lib.lib().pw_last_kernel().decode() == 'k_stereo_cost_volume<true>'
+        monkeypatch.delenv('PW_STEREO_TILE')
+        got = ops.stereo_cost_volume(tp, tc, *args, bias=5.0)
+        assert _lib.lib().pw_last_kernel().decode() == 'k_stereo_cost_volume_tile'
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=1e-7)
+        assert float(got.sum(1).sub(1).abs().max()) < 1e-5
+        assert torch.equal(got, ops.stereo_cost_volume(tp, tc, *args, bias=5.0))          # deterministic
+
+
 def test_edge_cases():
     lower, interval, size = O.grid_infos(S.GRID_CONFIG_FULL)
     # nothing inside the grid -> five Nones like view_transformer.py:237-238

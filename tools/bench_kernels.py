@@ -184,6 +184,29 @@ def bench_stereo():
     res['stereo_cv_hbm_alg_GBps'] = (2 * prev.numel() * 4 + npts * 4) / t / 1e3
     t2 = timeit(lambda: ops.stereo_cost_volume(prev.contiguous(), curr.contiguous(), *args, bias=5.0), iters=2)
     res['stereo_cv_nchw_us'] = t2
+    # the point-per-lane kernel on the same channels-last features (PW_STEREO_TILE=0)
+    import os
+    ref = fn()
+    os.environ['PW_STEREO_TILE'] = '0'
+    old = fn()
+    res['stereo_cv_point_kernel_us'] = timeit(fn, iters=5)
+    res['stereo_cv_max_abs_diff_to_point_kernel'] = float((ref - old).abs().max())
+    res['stereo_cv_max_rel_diff_to_point_kernel'] = float(((ref - old).abs() / old.clamp_min(1e-30)).max())
+    del os.environ['PW_STEREO_TILE']
+    probe = torch.zeros(48, dtype=torch.int64, device=dev)
+    os.environ['PW_STEREO_PROBE'] = str(probe.data_ptr())
+    fn()
+    torch.cuda.synchronize()
+    del os.environ['PW_STEREO_PROBE']
+    res['stereo_cv_tile_phase_cycles'] = dict(zip(['geometry', 'plan', 'stage', 'compute', 'barrier', 'softmax'],
+                                                  probe.view(8, 6).float().mean(0).tolist()))
+    # ego motion along the optical axis of every camera (the case above) vs a sideways one
+    k2s2 = torch.eye(4, device=dev).repeat(1, 6, 1, 1)
+    k2s2[0, :, 0, 3] = -2.5
+    args2 = (fr, k2s2) + args[2:]
+    fn2 = lambda: ops.stereo_cost_volume(prev, curr, *args2, bias=5.0)
+    fn2()
+    res['stereo_cv_sideways_us'] = timeit(fn2, iters=5)
     return res
 
 
