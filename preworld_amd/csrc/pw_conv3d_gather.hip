@@ -1,6 +1,6 @@
 // Gather (no LDS tile) convolution kernel: stride-2, 1x1x1, 2x2x2 and tiny grids -- see pw_conv3d.hip for
 // the GEMM view and include/preworld_hip.h (pw_conv3d_ndhwc) for the entry point.
-#include "pw_conv3d_common.h"
+#include "pw_h2.h"
 
 // ------------------------------------------------------------------------------------
 // generic gather kernel: KS in {1,2,3}, STRIDE in {1,2}; A fragments straight from global/L2.
@@ -60,8 +60,10 @@ __device__ __forceinline__ void gather_mfma(const float4 (&aq)[MT][4], const flo
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gh8, aq[mt][2 * ks + px]),
-                                                                 __builtin_bit_cast(gh8, bq[nt][2 * ks + pw]), acc[mt][nt], 0, 0, 0);
+            // TRANSPOSED product D[cout][voxel] (weights as the A operand): a lane ends up with 4 consecutive output channels
+            // of ONE voxel per register group, which the h2 epilogue stores as 8-byte pieces
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gh8, bq[nt][2 * ks + pw]),
+                                                                 __builtin_bit_cast(gh8, aq[mt][2 * ks + px]), acc[mt][nt], 0, 0, 0);
       }
     return;
   }
@@ -105,7 +107,8 @@ __device__ __forceinline__ void gather_step(const GatherCtx<KS, MT>& c, int ch, 
 // meet in LDS and partition 0 adds them in a fixed order (deterministic) before the epilogue.  Small
 // grids need this: with one (M-tile, N-group) per wave the 4x50x50 stage has ~1.2 waves of 1728-3456
 // MFMAs per SIMD, i.e. the slowest SIMD does 2 of them; split by 4 it is ~5 waves of 432.
-template <int NT, int KS, int STRIDE, int MT, int KSPL, bool F16 = false>
+// H2EPI (F16 only): every destination in h2 storage and no residual -> the vector epilogue (chosen by the launcher)
+template <int NT, int KS, int STRIDE, int MT, int KSPL, bool F16 = false, bool H2EPI = false>
 __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_out_vox) {
   constexpr int ksplit = KSPL;          // compile-time: the unsplit kernel keeps its straight-line code
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -196,6 +199,50 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
     }
   }
   if (!active) return;
+  if constexpr (F16) {
+    // transposed accumulators: column = voxel i of the M-tile, register r = output channel (r & 3) + 8 (r >> 2) + 4 half of
+    // the N-tile.  All-h2 destinations without a residual (every stride-2 / 1x1x1 layer of the encoder and the neck) get the
+    // vector epilogue: float4 scale / bias, 8-byte hi + 8-byte lo stores per 4 channels.  (The first version kept the
+    // voxel-major product and stored element by element: 2 x 2-byte stores and ~10 address instructions per output, about as
+    // many instructions as the whole tap loop.)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const long long vox = m0 + mt * 32 + i;
+      if (vox >= n_out_vox) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = (ng * NT + nt) * 32;                 // a 32-column tile lies in one destination (cout0 % 32 == 0)
+        const bool first = n0 < a.cout0;
+        const int nn0 = first ? n0 : n0 - a.n1_start;
+        if (!first && !(a.y1 && nn0 >= 0 && nn0 < a.cout1)) continue;
+        float* row = first ? a.y0 + vox * a.ld0 : a.y1 + vox * a.ld1;
+        const bool relu = first ? a.relu0 != 0 : a.relu1 != 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 8 * q + 4 * half;                   // first of this lane's 4 channels inside the tile
+          float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+          if (a.scale) { const float4 t = *reinterpret_cast<const float4*>(a.scale + n0 + c); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
+          if (a.bias) { const float4 t = *reinterpret_cast<const float4*>(a.bias + n0 + c); bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w; }
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * q + e] * sc[e] + bi[e];
+          if constexpr (H2EPI) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
+            u2 hi, lo;
+            h2_split4(v, hi, lo);
+            char* chunk = reinterpret_cast<char*>(row + ((nn0 + c) & ~31));
+            *reinterpret_cast<u2*>(chunk + h2_group_off((nn0 + c) & 31, 0)) = hi;
+            *reinterpret_cast<u2*>(chunk + h2_group_off((nn0 + c) & 31, 1)) = lo;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_out(a, n0 + c + e, (size_t)vox, v[e]);
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (ng * NT + nt) * 32 + i;
@@ -242,10 +289,12 @@ int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, i
     pw_note_kernel("k_conv3d_gather<%d, %d, %d, %d, %d>", NTv, KSv, STv, MTv, KSPv);                             \
   } while (0)
   if (f16) {          // split-fp16 operands (pw_conv3d_h2): k3 s2, k1 s1 and k3 s1 (tiny grids), one M-tile per wave
-#define PW_GATHER_F(NTv, KSv, STv, KSPv)                                                                              \
-  do {                                                                                                                \
-    hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1, KSPv, true>), grid, dim3(256), red_bytes, st, a, n_out);    \
-    pw_note_kernel("k_conv3d_gather<%d, %d, %d, 1, %d, true>", NTv, KSv, STv, KSPv);                                  \
+    const bool h2epi = a.fmt_y0 == 1 && (a.cout1 == 0 || a.fmt_y1 == 1) && !a.residual;
+#define PW_GATHER_F(NTv, KSv, STv, KSPv)                                                                                        \
+  do {                                                                                                                          \
+    if (h2epi) hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1, KSPv, true, true>), grid, dim3(256), red_bytes, st, a, n_out); \
+    else hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1, KSPv, true, false>), grid, dim3(256), red_bytes, st, a, n_out);  \
+    pw_note_kernel("k_conv3d_gather<%d, %d, %d, 1, %d, true>", NTv, KSv, STv, KSPv);                                            \
   } while (0)
 #define PW_GATHER_FK(NTv, KSv, STv)                      \
   do {                                                   \
@@ -259,10 +308,12 @@ int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, i
       if (NT == 2) PW_GATHER_FK(2, 3, 1); else PW_GATHER_FK(1, 3, 1);
     } else if (ksize == 3 && stride == 2 && MT == 2) {   // two voxel tiles per wave share the weight fragments (A/B switch)
       if (NT == 2) {
-        hipLaunchKernelGGL((k_conv3d_gather<2, 3, 2, 2, 1, true>), grid, dim3(256), red_bytes, st, a, n_out);
+        if (h2epi) hipLaunchKernelGGL((k_conv3d_gather<2, 3, 2, 2, 1, true, true>), grid, dim3(256), red_bytes, st, a, n_out);
+        else hipLaunchKernelGGL((k_conv3d_gather<2, 3, 2, 2, 1, true, false>), grid, dim3(256), red_bytes, st, a, n_out);
         pw_note_kernel("k_conv3d_gather<2, 3, 2, 2, 1, true>");
       } else {
-        hipLaunchKernelGGL((k_conv3d_gather<1, 3, 2, 2, 1, true>), grid, dim3(256), red_bytes, st, a, n_out);
+        if (h2epi) hipLaunchKernelGGL((k_conv3d_gather<1, 3, 2, 2, 1, true, true>), grid, dim3(256), red_bytes, st, a, n_out);
+        else hipLaunchKernelGGL((k_conv3d_gather<1, 3, 2, 2, 1, true, false>), grid, dim3(256), red_bytes, st, a, n_out);
         pw_note_kernel("k_conv3d_gather<1, 3, 2, 2, 1, true>");
       }
     } else if (ksize == 3 && stride == 2) {
