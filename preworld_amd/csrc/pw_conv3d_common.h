@@ -454,5 +454,7 @@ static inline int choose_wd(int B, int Do, int Ho, int Wo, int ngroups) {
 // gather kernel launcher (pw_conv3d_gather.hip)
 int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, int stride, int algo, int Cin,
                              long long n_out, hipStream_t st, bool f16 = false);
+// LDS-tiled split-fp16 stride-2 kernel (pw_conv3d_h2_s2.hip); PW_EUNSUP when the shape / formats are not built
+int pw_launch_conv3d_h2_s2(const ConvArgs& a, hipStream_t st);
 
 #endif  // PW_CONV3D_COMMON_H_

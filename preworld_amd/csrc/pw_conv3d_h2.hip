@@ -675,6 +675,15 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
   const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
   if (!(ksize == 3 && stride == 1) || algo == 2 || algo == 3) {
     // stride-2 / 1x1x1 (and, on request, tiny 3x3x3 grids): the gather kernel with split-fp16 operands
+    if (ksize == 3 && stride == 2 && algo == 0) {
+      // LDS-tiled stride-2 kernel (pw_conv3d_h2_s2.hip) for the shapes it is built for; PW_H2_S2=0 keeps the gather kernel
+      const char* e = getenv("PW_H2_S2");
+      if (!(e && atoi(e) == 0)) {
+        const int rc = pw_launch_conv3d_h2_s2(a, pw_stream(stream));
+        if (rc == PW_OK) { PW_CHECK_LAUNCH(); return PW_OK; }
+        if (rc != PW_EUNSUP) return rc;
+      }
+    }
     const int NTg = (ntiles % 2 == 0) ? 2 : 1;
     const long long n_out = (long long)B * a.Do * a.Ho * a.Wo;
     if (int rc = pw_launch_conv3d_gather(a, NTg, ntiles / NTg, ksize, stride, algo, Cin, n_out, pw_stream(stream), true)) return rc;

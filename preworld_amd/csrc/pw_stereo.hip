@@ -459,8 +459,8 @@ PW_API int pw_stereo_cost_volume(const float* prev, const float* curr, int BN, i
                       ((long long)(H - 1) * s_y + (long long)(W - 1) * s_x + C) * 4 < (1ll << 32);
   if (cl && fits32 && C <= 128 && stereo_env("PW_STEREO_TILE", 1) != 0) {
     const size_t lds = (size_t)(ST_CAP + 1) * C * 4 + 8 * 64 * sizeof(StereoGeo) + 64 * sizeof(StereoBox) + 64 * 4;
-    const int lds_max = (ST_CAP + 1) * 128 * 4 + 8 * 64 * 32 + 64 * 16 + 64 * 4;
-    static int once = [lds_max] {
+    constexpr int lds_max = (ST_CAP + 1) * 128 * 4 + 8 * 64 * 32 + 64 * 16 + 64 * 4;
+    static int once = [] {
       int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_cost_volume_tile<128>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
       if (e == 0)

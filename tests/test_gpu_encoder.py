@@ -655,6 +655,42 @@ def test_conv3d_h2_stride2_and_1x1(shape, cout):
     check_close('conv3d_h2 k1 %s' % (shape,), ncdhw(got), O.conv3d(x, w1, b1, 1, 0), 3e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('shape,cout', [((1, 32, 7, 11, 13), 64), ((2, 64, 5, 9, 18), 64), ((1, 64, 8, 20, 20), 128), ((1, 32, 16, 40, 40), 64)])
+def test_conv3d_h2_stride2_tiled(shape, cout, monkeypatch):
+    """LDS-tiled split-fp16 stride-2 kernel (pw_conv3d_h2_s2.hip) in the form the encoder uses it -- conv1 (BN + ReLU) and the
+    downsample conv (BN) of a stage's first block as one pass over 2 x Cout columns, two h2 destinations -- against the oracle
+    and against the gather kernel (PW_H2_S2=0); ragged grids (tiles cut in every axis), batch 2, a strided destination."""
+    from _parity import check_close
+    from preworld_amd import _lib
+    rs = np.random.RandomState(11)
+    x = rs.standard_normal(shape).astype(np.float32)
+    xh = ops.f32_to_h2(cl(x))
+    w1, w2 = _rand_conv(rs, cout, shape[1], 3), _rand_conv(rs, cout, shape[1], 3)
+    wpk, inv = ops.pack_conv_weights_h2_concat([T(w1), T(w2)])
+    sc = T(rs.uniform(0.5, 1.5, 2 * cout).astype(np.float32))
+    bi = T(rs.standard_normal(2 * cout).astype(np.float32))
+    y0, y1 = ops.conv3d_h2(xh, wpk, sc * inv, bi, cout0=cout, cout1=cout, relu0=True, ksize=3, stride=2)
+    assert _lib.lib().pw_last_kernel().decode().startswith('k_conv3d_h2_s2')
+    scn, bin_ = sc.cpu().numpy(), bi.cpu().numpy()
+    want0 = np.maximum(O.conv3d(x, w1, None, 2, 1) * scn[:cout, None, None, None] + bin_[:cout, None, None, None], 0)
+    want1 = O.conv3d(x, w2, None, 2, 1) * scn[cout:, None, None, None] + bin_[cout:, None, None, None]
+    check_close('s2 tiled conv1 %s' % (shape,), ncdhw(ops.h2_to_f32(y0)), want0, 3e-6, atol=2e-6)
+    check_close('s2 tiled downsample %s' % (shape,), ncdhw(ops.h2_to_f32(y1)), want1, 3e-6, atol=2e-6)
+    monkeypatch.setenv('PW_H2_S2', '0')
+    g0, g1 = ops.conv3d_h2(xh, wpk, sc * inv, bi, cout0=cout, cout1=cout, relu0=True, ksize=3, stride=2)
+    assert _lib.lib().pw_last_kernel().decode().startswith('k_conv3d_gather')
+    monkeypatch.delenv('PW_H2_S2')
+    # (the two kernels add the 27 x Cin products in different orders: same bound as against the oracle)
+    check_close('s2 tiled vs gather conv1 %s' % (shape,), ops.h2_to_f32(y0).cpu().numpy(), ops.h2_to_f32(g0).cpu().numpy(), 3e-6, atol=2e-6)
+    check_close('s2 tiled vs gather downsample %s' % (shape,), ops.h2_to_f32(y1).cpu().numpy(), ops.h2_to_f32(g1).cpu().numpy(), 3e-6, atol=2e-6)
+    # strided destination (channel slice of a wider buffer), untouched neighbours
+    B, Do, Ho, Wo = y0.shape[:4]
+    buf = torch.full((B, Do, Ho, Wo, 3 * cout), 7.0, device=DEV)
+    s0, s1 = ops.conv3d_h2(xh, wpk, sc * inv, bi, cout0=cout, cout1=cout, relu0=True, ksize=3, stride=2,
+                           out0=buf[..., 0:cout], out1=buf[..., 2 * cout:3 * cout])
+    assert torch.equal(s0.buf, y0.buf) and torch.equal(s1.buf, y1.buf) and bool((buf[..., cout:2 * cout] == 7.0).all())
+
+
 def test_pool_h2_and_fpn_h2():
     """voxel pooling with h2 output = the fp32 pooled sums split (bit-identical to converting the fp32 result); the fused
     neck with h2 input / output against its exact-fp32 self."""

@@ -13,3 +13,11 @@ for (D, H, W), cin, cout in (((16, 200, 200), 32, 64), ((8, 100, 100), 64, 128))
     t = timeit(lambda: ops.conv3d_h2(x, wpk, inv, cout0=cout, cout1=cout, relu0=True, ksize=3, stride=2))
     gf = 2.0 * (D // 2) * (H // 2) * (W // 2) * 27 * cin * 2 * cout / 1e9
     print('%dx%dx%d %d->2x%d s2  %.1f GF  %s  %.1f us (%.0f TF direct)' % (D, H, W, cin, cout, gf, _lib.lib().pw_last_kernel().decode(), t, gf / t * 1e3), flush=True)
+    probe = torch.zeros(64, dtype=torch.int64, device=DEV)
+    os.environ['PW_CONV_PROBE'] = str(probe.data_ptr())
+    ops.conv3d_h2(x, wpk, inv, cout0=cout, cout1=cout, relu0=True, ksize=3, stride=2)
+    torch.cuda.synchronize()
+    del os.environ['PW_CONV_PROBE']
+    pr = probe.view(8, 8)[:4, :5]
+    d = (pr[:, 1:] - pr[:, :-1]).float().mean(0).tolist()
+    print('   block 300 ticks: stage0 %.0f  taps0 %.0f  rest of passes %.0f  epilogue %.0f' % tuple(d), flush=True)
