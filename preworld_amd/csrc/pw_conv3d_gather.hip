@@ -112,7 +112,10 @@ template <int NT, int KS, int STRIDE, int MT, int KSPL, bool F16 = false, bool H
 __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_out_vox) {
   constexpr int ksplit = KSPL;          // compile-time: the unsplit kernel keeps its straight-line code
   extern __shared__ __attribute__((aligned(16))) float red[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // scalar wave index: the chunk partition, hence the scalar offsets / descriptors of every A and weight load, derive from it;
+  // left in a VGPR, hipcc wraps each of those loads in a waterfall loop (readfirstlane + branch)
+  const int wave = uni(tid >> 6);
   const int half = lane >> 5, i = lane & 31;
   const int mslot = wave / ksplit, kpart = wave - mslot * ksplit;
   const long long m0 = ((long long)blockIdx.x * (4 / ksplit) + mslot) * (32 * MT);
