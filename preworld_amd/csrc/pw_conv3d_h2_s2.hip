@@ -32,6 +32,12 @@ constexpr int S2_EVEN = 9;                                     // even columns o
 constexpr int S2_VOX = S2_HD * S2_HH * S2_HW;                  // 765
 constexpr int S2_LDS = S2_VOX * 64;                            // 48 960
 constexpr unsigned S2_OOB = 0xfffffff0u;
+// Compile-time A/B switches of two measured-and-rejected variants, kept because the code paths are tested by
+// building with them: -DS2_NG_V=3 puts 3 (NTW = 1) / 2 (NTW = 2) tile groups of 4 waves in one block, in lockstep through the
+// block barriers, so that their identical weight requests meet in L1 (taps 3x faster, but nothing covers the staging round
+// trip: 99 / 74 us); -DS2_PREFETCH=1 additionally issues the next pass's halo loads before the taps (95 / 71 us; vector
+// loads return in order, so the first weight wait of the pass then waits for the halo as well).  Default: one tile per block,
+// three (two) blocks per CU, 77 / 45 us.
 #ifndef S2_NG_V
 #define S2_NG_V 1
 #endif
@@ -105,9 +111,7 @@ __device__ __forceinline__ void s2_step(const S2Ctx& c, unsigned wsoff, v4f (&ax
 template <int NTW>      // cout tiles per wave: cout_total = 128 NTW
 __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3 : 2) : 1) k_conv3d_h2_s2(ConvArgs a, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char s2_lds[];
-  // S2_NG<NTW> tile groups of 4 waves per block, in lockstep through the block barriers: the groups' waves with the same cout tiles
-  // request the same weight fragments at about the same time, so two of three come from the CU's L1 instead of L2 (every
-  // block streams the whole weight set: L2 bandwidth, not latency, bounded the one-tile-per-block version)
+  // S2_NG<NTW> tile groups of 4 waves per block (1 by default; see the switches at the top of the file)
   const int group = uni((int)threadIdx.x >> 8);
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = uni(tid >> 6);                  // scalar: it feeds the weight loads' scalar offset (no waterfall loop)
@@ -148,9 +152,8 @@ __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3
 
   long long ts[6] = {0, 0, 0, 0, 0, 0};
   if (a.probe) ts[0] = __builtin_readcyclecounter();
-  // halo of a pass: 4 pieces of 16 bytes per voxel (t = 2 k-half + plane).  The loads of pass p + 1 are issued before the taps
-  // of pass p and sit in registers until the block is done with the LDS tile: the groups of a block run in lockstep, so
-  // nothing else would cover the staging round trip.
+  // halo of a pass: 4 pieces of 16 bytes per voxel (t = 2 k-half + plane); all loads of a thread go out before its first LDS
+  // write (one round trip per pass); the co-resident blocks cover each other's staging
   constexpr int NIT = (S2_VOX * 4 + 255) / 256;
   v4f val[NIT];
   auto issue_halo = [&](int pass) {
