@@ -10,6 +10,8 @@ image backbone / neck / DepthNet are plain PyTorch-ROCm modules (image_encoder.p
 (`simple_test_from_lift`) and need no 88 M-parameter Swin-B.  `PreWorld.forward_train` and `PreWorld4DTraj.forward_train` run the
 voxel side of the training step on the HIP training kernels (preworld_amd/train.py), and so does `BEVStereo4DOCC.forward_train`
 (depth loss + softmax cross entropy on the predicter's logits)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -276,13 +278,30 @@ class BEVStereo4DOCC(nn.Module):
 
         def sl(lo, hi):
             return ops.H2(x[..., lo:hi]) if h2 else x[..., lo:hi]
-        self.lift_frame_cl(out=sl((n - 1) * C, n * C), out_h2=h2, **f0)
+        # The frames' lift chains (voxel index, sort, pooling, pre_process_net) are independent until the encoder reads the
+        # buffer: the adjacent frames run on a side stream (fork / join; captured into the hipGraph as two branches), so that
+        # one frame's small latency-bound LSS kernels hide under the other's convolutions.  PW_LIFT_STREAMS=0: one stream.
+        fork = (x.is_cuda and not torch.is_grad_enabled() and self.with_prev and len(frames) > 1
+                and os.environ.get('PW_LIFT_STREAMS', '1') != '0')
+        if fork:
+            main = torch.cuda.current_stream(x.device)
+            side = self.__dict__.get('_lift_stream')
+            if side is None or side.device != x.device:
+                side = self.__dict__['_lift_stream'] = torch.cuda.Stream(x.device)
+            side.wait_stream(main)                        # x is allocated, the inputs are ready
         for j in range(self.num_adj):                      # adjacent frame j+1 sits left of frame j
             lo, hi = (n - 2 - j) * C, (n - 1 - j) * C
             if self.with_prev and len(frames) > 1 + j:
-                self.lift_frame_cl(out=sl(lo, hi), out_h2=h2, **frames[1 + j])
+                if fork:
+                    with torch.cuda.stream(side):
+                        self.lift_frame_cl(out=sl(lo, hi), out_h2=h2, **frames[1 + j])
+                else:
+                    self.lift_frame_cl(out=sl(lo, hi), out_h2=h2, **frames[1 + j])
             else:
                 x[..., lo:hi].zero_()
+        self.lift_frame_cl(out=sl((n - 1) * C, n * C), out_h2=h2, **f0)
+        if fork:
+            main.wait_stream(side)
         return self.bev_encoder_cl(ops.H2(x) if h2 else x, out_h2=out_h2)
 
     def extract_voxel_feat_cl(self, frames, out_h2=False):
