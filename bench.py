@@ -434,9 +434,19 @@ def main():
     roofline = None
     if rank == 0:
         n_probe = 3
-        with KernelProbe() as probe:
-            for _ in range(n_probe):
-                step()
+        # one stream for this pass: with the adjacent frame's lift forked onto a side stream the events around a launch
+        # would also span whatever the other branch is running
+        lift_streams = os.environ.get('PW_LIFT_STREAMS')
+        os.environ['PW_LIFT_STREAMS'] = '0'
+        try:
+            with KernelProbe() as probe:
+                for _ in range(n_probe):
+                    step()
+        finally:
+            if lift_streams is None:
+                os.environ.pop('PW_LIFT_STREAMS')
+            else:
+                os.environ['PW_LIFT_STREAMS'] = lift_streams
         roofline = roofline_object(probe.summary(), n_probe)
 
     graph = None

@@ -18,8 +18,8 @@ python tools/bench_h2.py > $O/layers_h2.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o r1 -- python $R/bench.py --steps 6 --warmup 2 --settle-s 0.2 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err
-rocprofv3 --kernel-trace --stats -d $O/prof_serial -o r1 -- python $R/bench.py --in-flight 1 --steps 20 --warmup 2 --settle-s 0.5 --no-cpu-baseline > $O/prof_bench_serial.json 2>> $O/prof.err
-EAGER="python $R/bench.py --no-graph --in-flight 1 --steps 4 --warmup 1 --settle-s 0.0 --no-cpu-baseline"
+PW_LIFT_STREAMS=0 rocprofv3 --kernel-trace --stats -d $O/prof_serial -o r1 -- python $R/bench.py --in-flight 1 --steps 20 --warmup 2 --settle-s 0.5 --no-cpu-baseline > $O/prof_bench_serial.json 2>> $O/prof.err
+EAGER="env PW_LIFT_STREAMS=0 python $R/bench.py --no-graph --in-flight 1 --steps 4 --warmup 1 --settle-s 0.0 --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_FETCH_SIZE -o p -- $EAGER > /dev/null 2>> $O/prof.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_WRITE_SIZE -o p -- $EAGER > /dev/null 2>> $O/prof.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_MFMA -o p -- $EAGER > /dev/null 2>> $O/prof.err
