@@ -297,7 +297,7 @@ int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, i
   do {                                                                                                                          \
     if (h2epi) hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1, KSPv, true, true>), grid, dim3(256), red_bytes, st, a, n_out); \
     else hipLaunchKernelGGL((k_conv3d_gather<NTv, KSv, STv, 1, KSPv, true, false>), grid, dim3(256), red_bytes, st, a, n_out);  \
-    pw_note_kernel("k_conv3d_gather<%d, %d, %d, 1, %d, true>", NTv, KSv, STv, KSPv);                                            \
+    pw_note_kernel("k_conv3d_gather<%d, %d, %d, 1, %d, true, %s>", NTv, KSv, STv, KSPv, h2epi ? "true" : "false");                                            \
   } while (0)
 #define PW_GATHER_FK(NTv, KSv, STv)                      \
   do {                                                   \
@@ -313,11 +313,11 @@ int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, i
       if (NT == 2) {
         if (h2epi) hipLaunchKernelGGL((k_conv3d_gather<2, 3, 2, 2, 1, true, true>), grid, dim3(256), red_bytes, st, a, n_out);
         else hipLaunchKernelGGL((k_conv3d_gather<2, 3, 2, 2, 1, true, false>), grid, dim3(256), red_bytes, st, a, n_out);
-        pw_note_kernel("k_conv3d_gather<2, 3, 2, 2, 1, true>");
+        pw_note_kernel("k_conv3d_gather<2, 3, 2, 2, 1, true, %s>", h2epi ? "true" : "false");
       } else {
         if (h2epi) hipLaunchKernelGGL((k_conv3d_gather<1, 3, 2, 2, 1, true, true>), grid, dim3(256), red_bytes, st, a, n_out);
         else hipLaunchKernelGGL((k_conv3d_gather<1, 3, 2, 2, 1, true, false>), grid, dim3(256), red_bytes, st, a, n_out);
-        pw_note_kernel("k_conv3d_gather<1, 3, 2, 2, 1, true>");
+        pw_note_kernel("k_conv3d_gather<1, 3, 2, 2, 1, true, %s>", h2epi ? "true" : "false");
       }
     } else if (ksize == 3 && stride == 2) {
       if (NT == 2) PW_GATHER_FK(2, 3, 2); else PW_GATHER_FK(1, 3, 2);

@@ -182,12 +182,13 @@ __device__ __forceinline__ void h2_read_a_tap(lds3_t lds3, const unsigned (&aadd
   }
 }
 
-template <int NT>
+// WR (resident hi planes, see k_conv3d_h2): only the lo pieces q = 1, 3 are fetched per tap
+template <int NT, bool WR = false>
 __device__ __forceinline__ void h2_load_b(rsrc_t wr, unsigned wsoff, unsigned lane_off, v4f (&b)[NT][4]) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = WR ? 1 : 0; q < 4; q += WR ? 2 : 1) {
       const auto v = __builtin_amdgcn_raw_buffer_load_b128(wr, lane_off + (unsigned)(q * 16), wsoff + (unsigned)(nt * 4096), 0);
       v4f o;
       o[0] = __uint_as_float(v[0]); o[1] = __uint_as_float(v[1]); o[2] = __uint_as_float(v[2]); o[3] = __uint_as_float(v[3]);
@@ -196,8 +197,8 @@ __device__ __forceinline__ void h2_load_b(rsrc_t wr, unsigned wsoff, unsigned la
 }
 
 // slots of a lane: q = 2*ks + p (p = 0 hi, 1 lo) for activations (aq) and weights (b) alike
-template <int NT>
-__device__ __forceinline__ void h2_mfma(const v4f (&aq)[2][4], const v4f (&b)[NT][4], f32x16 (&acc)[2][NT]) {
+template <int NT, bool WR = false, int TAP = 0, int NW = 1>
+__device__ __forceinline__ void h2_mfma(const v4f (&aq)[2][4], const v4f (&b)[NT][4], f32x16 (&acc)[2][NT], const v4f (&wres)[NW][2]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -206,31 +207,39 @@ __device__ __forceinline__ void h2_mfma(const v4f (&aq)[2][4], const v4f (&b)[NT
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, b[nt][2 * ks + pw]),
-                                                               __builtin_bit_cast(h8, aq[mt][2 * ks + px]), acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          v4f w = b[nt][2 * ks + pw];
+          if constexpr (WR) { if (pw == 0) w = wres[TAP][ks]; }
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, w), __builtin_bit_cast(h8, aq[mt][2 * ks + px]),
+                                                               acc[mt][nt], 0, 0, 0);
+        }
     }
   }
 }
+template <int NT>
+__device__ __forceinline__ void h2_mfma(const v4f (&aq)[2][4], const v4f (&b)[NT][4], f32x16 (&acc)[2][NT]) {
+  const v4f none[1][2] = {};
+  h2_mfma<NT, false, 0, 1>(aq, b, acc, none);
+}
 
-template <int NT, int EPI, int TAP>
+template <int NT, int EPI, int TAP, bool WR = false, int NW = 1>
 __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, const unsigned (&aaddr)[2][3][4],
                                         v4f (&ac)[2][4], v4f (&an)[2][4], v4f (&b0)[NT][4], v4f (&b1)[NT][4],
-                                        v4f (&b2)[NT][4], f32x16 (&acc)[2][NT], EpiRegs& er) {
+                                        v4f (&b2)[NT][4], f32x16 (&acc)[2][NT], EpiRegs& er, const v4f (&wres)[NW][2]) {
   if (c.tap_probe) {                       // development aid: cycle counter at every tap of one stage
     if (c.lane == 0) c.tap_probe[c.wave * 27 + TAP] = __builtin_readcyclecounter();
   }
   if constexpr (TAP + 2 < 27) {
-    h2_load_b<NT>(c.wr, c.wsoff + (unsigned)(TAP + 2) * c.wstride, c.lane_off, b2);
+    h2_load_b<NT, WR>(c.wr, c.wsoff + (unsigned)(TAP + 2) * c.wstride, c.lane_off, b2);
   } else {
-    h2_load_b<NT>(c.wr, c.wsoff_next + (unsigned)(TAP + 2 - 27) * c.wstride, c.lane_off, b2);
+    h2_load_b<NT, WR>(c.wr, c.wsoff_next + (unsigned)(TAP + 2 - 27) * c.wstride, c.lane_off, b2);
   }
   if constexpr (h2_dma_row_of_tap<NT, TAP>() >= 0) pipe_dma_row<h2_dma_row_of_tap<NT, TAP>()>(a, c.xr, c.lds3, c.dm, c.wave);
   if constexpr (TAP < 26) h2_read_a_tap<TAP + 1>(c.lds3, aaddr, an);
   __builtin_amdgcn_sched_barrier(0);
   constexpr bool epi_tap = EPI > 0 && TAP >= 2 && TAP <= 4 * NT + 1;
   if constexpr (epi_tap) h2_epi_compute<NT, EPI, TAP - 2>(a, c.epi, er);      // pass TAP-2 of the previous tile (loaded last tap)
-  h2_mfma<NT>(ac, b0, acc);
+  h2_mfma<NT, WR, TAP, NW>(ac, b0, acc, wres);
   if constexpr (epi_tap) {
     // interleave: one MFMA, then a handful of the pass's VALU instructions in its shadow; the two stores last
 #pragma unroll
@@ -244,7 +253,7 @@ __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, c
   if constexpr (EPI > 0 && TAP >= 1 && TAP <= 4 * NT)
     h2_epi_load<NT, EPI, TAP - 1>(a, c.epi, c.ldsg + c.epi.bufoff + (unsigned)c.wave * (TW * 128),
                                   reinterpret_cast<const float*>(c.ldsg + H2_SB_OFF), c.wave, c.lane, er);
-  if constexpr (TAP < 26) h2_step<NT, EPI, TAP + 1>(a, c, aaddr, an, ac, b1, b2, b0, acc, er);
+  if constexpr (TAP < 26) h2_step<NT, EPI, TAP + 1, WR, NW>(a, c, aaddr, an, ac, b1, b2, b0, acc, er, wres);
 }
 
 // ---- epilogue shared by the kernels below: y = acc*scale + bias (+residual) (ReLU) through an LDS staging area.
@@ -340,7 +349,10 @@ __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&ac
   }
 }
 
-template <int NT, int EPI>
+// WR (NT = 1, one input chunk, one cout tile: the 32 -> 32 layers of pre_process_net / final_conv): every stage uses the same
+// 27 x 4 weight pieces, so the hi planes (27 taps x 2 k-steps = 216 VGPRs; one wave per SIMD has 512) stay in registers and a
+// tap fetches only its two lo pieces -- 8 LDS + 2 global operand loads per 12 MFMAs instead of 8 + 4 (profiles/r02_hw_probes.md).
+template <int NT, int EPI, bool WR = false>
 __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -387,6 +399,19 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   c.ldsg = reinterpret_cast<const char*>(lds);
   c.epi.pending = false; c.epi.b = c.epi.d0 = c.epi.h0 = c.epi.w0 = c.epi.ng = 0; c.epi.bufoff = 0;
 
+  constexpr int NW = WR ? 27 : 1;
+  v4f wres[NW][2] = {};
+  if constexpr (WR) {
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(c.wr, c.lane_off + (unsigned)(ks * 32), (unsigned)tp * c.wstride, 0);
+        v4f o;
+        o[0] = __uint_as_float(v[0]); o[1] = __uint_as_float(v[1]); o[2] = __uint_as_float(v[2]); o[3] = __uint_as_float(v[3]);
+        wres[tp][ks] = o;
+      }
+  }
   PipeTile t = pipe_decode(a, p, item);
   int ch = 0;
   v4f a0[2][4], a1[2][4], b0[NT][4], b1[NT][4], b2[NT][4];
@@ -404,8 +429,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     pipe_lane_offsets(a, t.w0, lane, dm.voff);
     dm.b = t.b; dm.d0 = t.d0; dm.h0 = t.h0; dm.wbase = t.w0 > 0 ? t.w0 - 1 : 0; dm.ch = 0; dm.ldsbuf = 0;
     dm.live = true;
-    h2_load_b<NT>(c.wr, (unsigned)((t.ng * NT) * 4096), c.lane_off, b0);
-    h2_load_b<NT>(c.wr, (unsigned)((t.ng * NT) * 4096) + c.wstride, c.lane_off, b1);
+    h2_load_b<NT, WR>(c.wr, (unsigned)((t.ng * NT) * 4096), c.lane_off, b0);
+    h2_load_b<NT, WR>(c.wr, (unsigned)((t.ng * NT) * 4096) + c.wstride, c.lane_off, b1);
     pipe_dma_row<0>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<1>(a, c.xr, c.lds3, dm, wave);
     pipe_dma_row<2>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<3>(a, c.xr, c.lds3, dm, wave);
     pipe_dma_row<4>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<5>(a, c.xr, c.lds3, dm, wave);
@@ -448,7 +473,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     c.dm.ch = chn; c.dm.ldsbuf = (unsigned)PIPE_BUF_BYTES - bufoff; c.dm.live = c.has_next;
 
     c.tap_probe = (a.probe && blockIdx.x == 17 && stage == 3) ? a.probe + 256 * 8 * 16 * 4 : nullptr;
-    h2_step<NT, EPI, 0>(a, c, aaddr, a0, a1, b0, b1, b2, acc, er);
+    h2_step<NT, EPI, 0, WR, NW>(a, c, aaddr, a0, a1, b0, b1, b2, acc, er, wres);
     if (a.probe) ts1 = __builtin_readcyclecounter();
 
     __builtin_amdgcn_s_waitcnt(0);     // my DMA rows of the next stage have landed
@@ -734,14 +759,27 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
     static int once = set_lds_limit(k_conv3d_h2<NTv, EPIv>, H2_LDS);                      \
     if (once) return once;                                                               \
     hipLaunchKernelGGL((k_conv3d_h2<NTv, EPIv>), dim3(nb), dim3(256), H2_LDS, st, a, p);  \
-    pw_note_kernel("k_conv3d_h2<%d, %d>", NTv, EPIv);                                     \
+    pw_note_kernel("k_conv3d_h2<%d, %d, false>", NTv, EPIv);                                     \
   } while (0)
-  if (NT == 2) {
+  // resident hi planes: one chunk, one cout tile (PW_H2_WR=0 keeps the streaming variant)
+  bool wres = NT == 1 && ntiles == 1 && Cin == KC && epi > 0;
+  if (const char* e = getenv("PW_H2_WR")) { if (atoi(e) == 0) wres = false; }
+#define PW_H2_LAUNCH_WR(EPIv)                                                                  \
+  do {                                                                                         \
+    static int once = set_lds_limit(k_conv3d_h2<1, EPIv, true>, H2_LDS);                        \
+    if (once) return once;                                                                     \
+    hipLaunchKernelGGL((k_conv3d_h2<1, EPIv, true>), dim3(nb), dim3(256), H2_LDS, st, a, p);    \
+    pw_note_kernel("k_conv3d_h2<1, %d, true>", EPIv);                                             \
+  } while (0)
+  if (wres) {
+    if (epi == 1) PW_H2_LAUNCH_WR(1); else if (epi == 2) PW_H2_LAUNCH_WR(2); else PW_H2_LAUNCH_WR(3);
+  } else if (NT == 2) {
     if (epi == 1) PW_H2_LAUNCH(2, 1); else if (epi == 2) PW_H2_LAUNCH(2, 2); else if (epi == 3) PW_H2_LAUNCH(2, 3); else PW_H2_LAUNCH(2, 0);
   } else {
     if (epi == 1) PW_H2_LAUNCH(1, 1); else if (epi == 2) PW_H2_LAUNCH(1, 2); else if (epi == 3) PW_H2_LAUNCH(1, 3); else PW_H2_LAUNCH(1, 0);
   }
 #undef PW_H2_LAUNCH
+#undef PW_H2_LAUNCH_WR
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
