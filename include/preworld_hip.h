@@ -114,11 +114,12 @@ int pw_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* fea
  * channels-last = (B,Z,Y,X,C), is written exactly once (sum or zero) -- no memset, no permute.
  * seg_start/order/order_feat(=order_aux)/long_list/n_long come from pw_segment_sort over the
  * voxel ids (long_list/n_long may be NULL).  Sums run in ascending point order per voxel.
- * out_h2 != 0 (C % 32 == 0): the same fp32 sums are written in split-fp16 "h2" storage (see pw_conv3d_h2). */
+ * out_h2 != 0 (C % 32 == 0, 16-byte aligned feat / out): the same fp32 sums are written in split-fp16 "h2" storage under the
+ * range slot out_rng (see pw_f32_to_h2; NULL = exponent 0, nothing recorded). */
 int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_start,
                       const int32_t* order, const int32_t* order_feat, int64_t n_voxels, int c,
                       int long_threshold, const int32_t* long_list, const int32_t* n_long,
-                      float* out, int out_h2, void* stream);
+                      float* out, int out_h2, int32_t* out_rng, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A6-A9, A11  3-D convolution on channels-last activations, exact-fp32 MFMA implicit GEMM.
@@ -149,11 +150,12 @@ int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const 
  * resolution (32 channels each; interpolation and 1x1x1 conv commute).  trilinear,
  * align_corners=True.  x8 (B,D,H,W,Cin8), wpk8 packed [Cin8/32][1][1][64][16], out (B,D,H,W,32).
  * x_h2 != 0: x8 is in split-fp16 "h2" storage and wpk8 comes from pack_conv_weight_h2 (its inv_scale folded into `scale`);
- * out_h2 != 0: out is written in h2 storage (see pw_conv3d_h2).  y16 / y32 are always fp32. */
+ * out_h2 != 0: out is written in h2 storage (see pw_conv3d_h2).  y16 / y32 are always fp32.  x_rng / out_rng: range slots
+ * of x8 / out when they are h2 (see pw_f32_to_h2; NULL = exponent 0). */
 int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const float* y32,
                   const float* scale, const float* bias, float* out, int B, int D, int H, int W,
                   int Cin8, int D2, int H2, int W2, int D4, int H4, int W4, int relu, int x_h2, int out_h2,
-                  void* stream);
+                  const int32_t* x_rng, int32_t* out_rng, void* stream);
 
 /* 3x3x3 stride-1 pad-1 convolution by Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores: same contract
  * as pw_conv3d_ndhwc (scale/bias, residual, ReLU, two destinations, row strides) with weights in the
@@ -174,9 +176,29 @@ int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale, const 
  * (hi.hi + lo.hi + hi.lo) with fp32 accumulation (preworld_amd/csrc/pw_h2.h; measured error = that of an fp32 FMA chain).
  * An h2 tensor has the shape and byte size of its fp32 counterpart ((.., C) channels-last, C % 32 == 0); each 32-channel
  * chunk of a voxel is 8 slots of 16 bytes, slot 4*half + 2*ks + p = plane p (0 hi, 1 lo) of channels 16*ks + 8*half + 0..7.
- * pw_f32_to_h2 / pw_h2_to_f32 convert (n_vox, C) rows with row strides ld_x / ld_y floats (0 = dense). */
-int pw_f32_to_h2(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, void* stream);
-int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, void* stream);
+ * pw_f32_to_h2 / pw_h2_to_f32 convert (n_vox, C) rows with row strides ld_x / ld_y floats (0 = dense).
+ *
+ * RANGE SLOTS.  fp16 has 5 exponent bits, the reference's fp32 (backbones/resnet.py:88-123: plain Conv3d) has 8.  Every h2 tensor
+ * therefore carries a per-tensor power-of-two exponent in a range slot `rng` = int32[2] in device memory:
+ *     value = (hi + lo) * 2^rng[0];   rng[1] = bit pattern of the largest |value| (true units, a float >= 0; a NaN pattern if a
+ *     NaN was written) recorded by the kernels that wrote the tensor since the host last zeroed it.
+ * Producers store value / 2^rng[0] (unsaturated: beyond +-65504 stored units the element becomes Inf and the slot records it) and
+ * atomically raise rng[1]; consumers fold 2^rng[0] into their epilogue scale like the weights' pre-scale (powers of two, exact).
+ * The host (preworld_amd.ops.RangeCtx) picks rng[0] so that the largest magnitude lands in [2^12, 2^13) stored units -- 22-bit
+ * significands down to 2^-15 of the maximum, an absolute floor of 2^-38 of it below -- and re-runs a sample whose recorded
+ * maxima left [2^6, 65504] stored units.  A NULL slot means exponent 0 and nothing recorded.
+ * Layout: a slot is PW_RNG_ROW int32; behind rng[0..1] sit PW_RNG_WORDS partial maxima (from rng[PW_RNG_SCRATCH]) that the waves of
+ * the producing kernels raise with return-less atomics -- thousands of atomics on one address would serialise at ~100 ns each.
+ * pw_rng_fold(tab, n_slots, compact): rng[1] = max(rng[1], partials), partials cleared, for n_slots consecutive slots, and (if
+ * compact != NULL) the (n_slots, 2) pairs [exponent, maximum] copied there contiguously -- one small launch at the end of a pass.
+ * pw_f32_to_h2: auto_exp != 0 first derives rng[0] from the largest finite |x| (three extra small launches) instead of
+ * taking it as it is. */
+#define PW_RNG_ROW 1056
+#define PW_RNG_SCRATCH 32
+#define PW_RNG_WORDS 1024
+int pw_rng_fold(int32_t* tab, int n_slots, int32_t* compact, void* stream);
+int pw_f32_to_h2(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, int32_t* rng, int auto_exp, void* stream);
+int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, const int32_t* rng, void* stream);
 
 /* Convolution with split-fp16 operands, same contract as pw_conv3d_ndhwc -- scale/bias, residual, ReLU, two destinations,
  * row strides -- for ksize 3 (stride 1: persistent LDS-tiled kernel; stride 2: gather kernel) and ksize 1 (stride 1); algo 2 / 3
@@ -187,11 +209,12 @@ int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int l
  *            power of two that the caller folds back into scale[n] (preworld_amd.ops.pack_conv_weight_h2);
  *   cout0 / cout1 / ld_y0 / ld_y1 multiples of 32;
  *   fmt_y0 / fmt_y1 / fmt_res: 0 = fp32, 1 = h2 storage of y0 / y1 / residual (the residual shares y0's row stride and
- *   may be y0 itself).  Results saturate at +-65504 when written as h2. */
+ *   may be y0 itself);
+ *   x_rng / res_rng / y0_rng / y1_rng: range slots (see pw_f32_to_h2) of the operands that are in h2 storage, NULL otherwise. */
 int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* residual,
                  float* y0, float* y1, int B, int D, int H, int W, int Cin, int cout_total, int cout0, int cout1,
                  int ld_y0, int ld_y1, int ksize, int stride, int relu0, int relu1, int algo, int fmt_y0, int fmt_y1,
-                 int fmt_res, void* stream);
+                 int fmt_res, const int32_t* x_rng, const int32_t* res_rng, int32_t* y0_rng, int32_t* y1_rng, void* stream);
 
 /* A11  OccHead fused (mmdet3d/models/heads/occupancy_head.py:124-177, num_level=1,
  * use_deblock=False): conv3x3x3 Cin->16 + BN + ReLU, 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18,
@@ -216,11 +239,14 @@ int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, cons
  *   hidden channels padded to 16, lane (row = l & 15, k = 4 (l >> 4) + e)), {hi, lo} of S2 * W2 rows 0..15 and rows 16..17
  *   (k = hidden channel, padded to 16), then s1 / S1 and b1 padded to 16 floats each (folded BN of occ_pred_conv.1);
  *   inv2 = 1 / S2 rescales the logits output.  Outputs as pw_occ_head_fused.
+ * x_rng: range slot of x (see pw_f32_to_h2).  The two hidden layers are split in registers, in units chosen from a-priori bounds:
+ *   |mid| <= mid_a * 2^(16 + x_rng[0]) + mid_b with mid_a = max_c |BN scale_c| * ||w[c]||_1, mid_b = max_c |bias_c|, and
+ *   |hid| <= hid_a * max|mid| + hid_b with hid_a = max_r |s1_r| * ||W1[r]||_1, hid_b = max_r |b1_r| (preworld_amd.ops computes them).
  * Kernel k_occ_head_h2<LOGITS>: v_mfma_f32_16x16x32_f16 with all conv weights register-resident; the tail runs on
  * v_mfma_f32_16x16x16_f16 inside the next tile's tap loop. */
 int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* tailpk, float inv2,
                    uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H, int W, int Cin, int n_mid,
-                   int n_hid, int n_cls, void* stream);
+                   int n_hid, int n_cls, const int32_t* x_rng, float mid_a, float mid_b, float hid_a, float hid_b, void* stream);
 
 /* A10  state-conditioned forecast (mmdet3d/models/detectors/preworld_temporal_traj.py:329-368).
  * pw_forecast_pack: fusion_head.{0,2}.weight ([128][64], [32][128]) -> per-lane MFMA operand
@@ -245,10 +271,13 @@ int pw_forecast_steps(const float* v0, int64_t n_vox_per_sample, int n_samples, 
  * float[4 tiles][2 k-blocks][2 planes][64 lanes][4] built by preworld_amd.ops.forecast_pack_h2 with power-of-two pre-scales
  * whose inverses are inv1 / inv2; everything else as pw_forecast_steps.  v0_h2 / out_h2 != 0: v0 is read / the states are
  * written in h2 storage (same 4 bytes per element, see pw_f32_to_h2) instead of fp32 -- what pw_conv3d_h2 writes and
- * pw_occ_head_h2 reads. */
+ * pw_occ_head_h2 reads.  v0_rng: range slot of an h2 v0.  states_rng: range slot the recursion runs under -- the units of the
+ * split operands of every step and of h2 states (fp32 states are written in true units; the largest state magnitude is recorded
+ * either way).  w1_l1max = max row L1 norm of fusion_head.0.weight[:, :32] bounds the hidden activations a priori. */
 int pw_forecast_steps_h2(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
                          const float* w2p, float inv1, float inv2, const float* c1p, const float* fusion_b2,
-                         int n_steps, float* states, int v0_h2, int out_h2, void* stream);
+                         int n_steps, float* states, int v0_h2, int out_h2, const int32_t* v0_rng, int32_t* states_rng,
+                         float w1_l1max, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * A14/A16/A17  render ops with the reference's semantics on compacted point arrays

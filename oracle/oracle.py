@@ -423,6 +423,82 @@ def preworld4d_decode(voxel_feats, ego, sd, n_steps=6, post_finetune=True):
     return states, feats
 
 
+# --------------------------------------------------------------------------- detector-level composition
+def prepare_inputs(inputs, num_frame=3, temporal_frame=2):
+    """BEVStereo4DOCC.prepare_inputs (bevdet_occ.py:88-139) in numpy: poses of every sweep expressed in the KEY frame's ego
+    system, fp64 algebra rounded to fp32 at the end (:103-106), and curr2adjsensor of the stereo pairs (:108-124).
+    inputs = (imgs (B, N*T, C, H, W), sensor2egos (B, T*N, 4, 4), ego2globals, intrins (B, T*N, 3, 3), post_rots, post_trans
+    (B, T*N, 3), bda).  Returns per-frame lists (sensor2keyegos, ego2globals, intrins, post_rots, post_trans), bda, curr2adjsensor."""
+    B = inputs[0].shape[0]
+    N = inputs[0].shape[1] // num_frame
+    s2e = np.asarray(inputs[1], np.float32).reshape(B, num_frame, N, 4, 4)
+    e2g = np.asarray(inputs[2], np.float32).reshape(B, num_frame, N, 4, 4)
+    keyego2global = e2g[:, 0, 0][:, None, None].astype(np.float64)
+    s2k = (np.linalg.inv(keyego2global) @ e2g.astype(np.float64) @ s2e.astype(np.float64)).astype(np.float32)
+    cur = e2g[:, :temporal_frame].astype(np.float64) @ s2e[:, :temporal_frame].astype(np.float64)
+    adj = e2g[:, 1:temporal_frame + 1].astype(np.float64) @ s2e[:, 1:temporal_frame + 1].astype(np.float64)
+    c2a = (np.linalg.inv(adj) @ cur).astype(np.float32)
+    per = lambda a, tail: [np.asarray(a, np.float32).reshape((B, num_frame, N) + tail)[:, t] for t in range(num_frame)]   # noqa: E731
+    return ([s2k[:, t] for t in range(num_frame)], [e2g[:, t] for t in range(num_frame)], per(inputs[3], (3, 3)),
+            per(inputs[4], (3, 3)), per(inputs[5], (3,)), np.asarray(inputs[6], np.float32),
+            [c2a[:, t] for t in range(temporal_frame)] + [None] * (num_frame - temporal_frame))
+
+
+def get_mlp_input(sensor2ego, intrin, post_rot, post_tran, bda):
+    """LSSViewTransformerBEVDepth.get_mlp_input (view_transformer.py:713-734): 15 camera scalars + sensor2ego[:3, :] = 27"""
+    B, N = sensor2ego.shape[:2]
+    b = np.broadcast_to(bda.reshape(B, 1, 3, 3), (B, N, 3, 3))
+    v = np.stack([intrin[:, :, 0, 0], intrin[:, :, 1, 1], intrin[:, :, 0, 2], intrin[:, :, 1, 2], post_rot[:, :, 0, 0],
+                  post_rot[:, :, 0, 1], post_tran[:, :, 0], post_rot[:, :, 1, 0], post_rot[:, :, 1, 1], post_tran[:, :, 1],
+                  b[:, :, 0, 0], b[:, :, 0, 1], b[:, :, 1, 0], b[:, :, 1, 1], b[:, :, 2, 2]], axis=-1)
+    return np.concatenate([v, sensor2ego[:, :, :3, :].reshape(B, N, -1)], axis=-1).astype(np.float32)
+
+
+def detector_simple_test(inputs, depthnet, ego, sd, grid_config, input_size, downsample, detector='PreWorld4DTraj',
+                         post_finetune=True, with_prev=True, test_threshold=8.5, D=88, C=32):
+    """PreWorld4DTraj.simple_test (preworld_temporal_traj.py:212-370) / PreWorld.simple_test (preworld.py:159-226) on top of
+    BEVStereo4DOCC.extract_img_feat's frame loop (bevdet_occ.py:167-269), downstream of the DepthNet:
+    depthnet(k, mlp_input) -> the (B*N, D+C, H, W) DepthNet output of the k-th processed frame (frames are visited
+    extra-reference, adjacent, key: :191; only adjacent and key reach the DepthNet; with_prev=False visits the key frame only
+    and feeds zeros as the adjacent BEV feature, :243-258).  Returns (result dict like the reference's, bev_feat, voxel_feats)."""
+    s2k, e2g, K, pr, pt, bda, _ = prepare_inputs(inputs)
+    bevs, k = [], 0
+    for fid in (1, 0):
+        if fid != 0 and not with_prev:
+            continue
+        mlp = get_mlp_input(s2k[0], K[fid], pr[fid], pt[fid], bda)          # always the KEY frame's sensor2keyego (:197-199)
+        x = depthnet(k, mlp)
+        k += 1
+        B, N = s2k[fid].shape[:2]
+        depth, feat_cl = depthnet_tail(x, D, C)
+        H, W = depth.shape[-2:]
+        tran = np.ascontiguousarray(feat_cl.transpose(0, 3, 1, 2)).reshape(B, N, C, H, W)
+        bev = lss_view_transform(depth.reshape(B, N, D, H, W), tran, s2k[fid], K[fid], pr[fid], pt[fid], bda, grid_config,
+                                 input_size, downsample)
+        bevs.append(pre_process(bev, sd))
+    if not with_prev:
+        bevs = [np.zeros_like(bevs[0])] + bevs                                  # [zeros, key]
+    bev_feat = encoder_forward(bevs[0], bevs[1], sd)                            # cat([adjacent, key]) (:266)
+    vf = final_conv(bev_feat, sd)                                               # (B,X,Y,Z,C) like :222
+    res = {}
+    if detector == 'PreWorld':
+        occ = occ_decode(vf, sd)[0] if post_finetune else attribute_decode(vf, sd, test_threshold)[0][0]
+        res['semantic_occ'] = [occ]
+        res['geo_occ'] = [np.where(occ != 17, 0, 17).astype(np.uint8)]
+        return res, bev_feat, vf
+    e = plan_head(_f32(ego).reshape(1, -1), sd)[0]
+    v = vf
+    dec = (lambda f: occ_decode(f, sd)[0]) if post_finetune else (lambda f: attribute_decode(f, sd, test_threshold)[0][0])
+    for step in range(7):
+        if step:
+            v = forecast_step(v, e, sd)
+        occ = dec(v)
+        name = step if (post_finetune or step == 0) else step + 1               # :361 names k+1, :294 names k+2
+        res['semantic_occ_%ds' % name] = [occ]
+        res['geo_occ_%ds' % name] = [np.where(occ != 17, 0, 17).astype(np.uint8)]
+    return res, bev_feat, vf
+
+
 # --------------------------------------------------------------------------- render head
 class NerfConsts:
     """nerf_head.py:105-162 buffers/constants for a given config."""

@@ -36,6 +36,18 @@ struct ConvArgs {
   long long* probe;       // development aid: per-wave phase timestamps (PW_CONV_PROBE) or null
   int dma_stage;          // tile-per-block kernels: stage the halo with buffer_load ... lds
   int fmt_y0, fmt_y1, fmt_res;  // split-fp16 kernels (pw_h2.h): 0 = fp32, 1 = h2 storage of y0 / y1 / residual
+  // range slots of the h2 operands (pw_h2.h "Range"; null = exponent 0, nothing recorded): x / residual are read under
+  // x_rng[0] / res_rng[0], y0 / y1 are written under y*_rng[0] and their largest magnitude is recorded in y*_rng[1]
+  const int* x_rng;
+  const int* res_rng;
+  int* y0_rng;
+  int* y1_rng;
+};
+
+// per-lane epilogue state of the split-fp16 kernels that write through store_out
+struct RngEpi {
+  float res_mul;          // residual as stored -> units y0 is stored in
+  float amax0, amax1;     // largest |stored value| this lane wrote to y0 / y1
 };
 
 // MFMA row (0..31) -> voxel of the 4x8 patch, chosen for conflict-free ds_read_b128 groups
@@ -52,27 +64,32 @@ __device__ __forceinline__ size_t h2_elem_off(int n) {
 }
 __device__ __forceinline__ void h2_store_elem(float* row, int n, float v) {
   char* p = reinterpret_cast<char*>(row) + h2_elem_off(n);
-  v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-  const _Float16 hi = (_Float16)v;
+  const _Float16 hi = (_Float16)v;                       // unsaturated: see h2_split1 (pw_h2.h)
   *reinterpret_cast<_Float16*>(p) = hi;
-  *reinterpret_cast<_Float16*>(p + 16) = (_Float16)(v - (float)hi);
+  *reinterpret_cast<_Float16*>(p + 16) = (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.f, 65504.f);
 }
 __device__ __forceinline__ float h2_load_elem(const float* row, int n) {
   const char* p = reinterpret_cast<const char*>(row) + h2_elem_off(n);
   return (float)*reinterpret_cast<const _Float16*>(p) + (float)*reinterpret_cast<const _Float16*>(p + 16);
 }
 
-__device__ __forceinline__ void store_out(const ConvArgs& a, int n, size_t vox, float v) {
-  // n = packed output column; fmt_* = 0 (fp32) in the fp32 kernels (ConvArgs zero-initialised there)
+__device__ __forceinline__ void store_out(const ConvArgs& a, int n, size_t vox, float v, RngEpi* re = nullptr) {
+  // n = packed output column; fmt_* = 0 (fp32) in the fp32 kernels (ConvArgs zero-initialised there).  re (split-fp16 kernels):
+  // v arrives in the units its destination is stored in; the residual is rescaled into them and the magnitude recorded.
   if (n < a.cout0) {
-    if (a.residual) v += a.fmt_res ? h2_load_elem(a.residual + vox * a.ld0, n) : a.residual[vox * a.ld0 + n];
+    if (a.residual) {
+      const float r = a.fmt_res ? h2_load_elem(a.residual + vox * a.ld0, n) : a.residual[vox * a.ld0 + n];
+      v += re ? r * re->res_mul : r;
+    }
     if (a.relu0) v = fmaxf(v, 0.f);
+    if (re) re->amax0 = fmaxf(re->amax0, fabsf(v));
     if (a.fmt_y0) h2_store_elem(a.y0 + vox * a.ld0, n, v);
     else a.y0[vox * a.ld0 + n] = v;
   } else {
     int n1 = n - a.n1_start;
     if (a.y1 && n1 >= 0 && n1 < a.cout1) {
       if (a.relu1) v = fmaxf(v, 0.f);
+      if (re) re->amax1 = fmaxf(re->amax1, fabsf(v));
       if (a.fmt_y1) h2_store_elem(a.y1 + vox * a.ld1, n1, v);
       else a.y1[vox * a.ld1 + n1] = v;
     }

@@ -208,6 +208,9 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
     // vector epilogue: float4 scale / bias, 8-byte hi + 8-byte lo stores per 4 channels.  (The first version kept the
     // voxel-major product and stored element by element: 2 x 2-byte stores and ~10 address instructions per output, about as
     // many instructions as the whole tap loop.)
+    // Range exponents of the operands (pw_h2.h "Range") are folded into scale / bias; the magnitudes written are recorded.
+    const RngScale rs = rng_scales(a);
+    RngEpi re = {rs.res, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const long long vox = m0 + mt * 32 + i;
@@ -227,11 +230,14 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
           if (a.scale) { const float4 t = *reinterpret_cast<const float4*>(a.scale + n0 + c); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
           if (a.bias) { const float4 t = *reinterpret_cast<const float4*>(a.bias + n0 + c); bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w; }
           float v[4];
+          const float sm = first ? rs.s0 : rs.s1, bm = first ? rs.b0 : rs.b1;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * q + e] * sc[e] + bi[e];
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * q + e] * (sc[e] * sm) + bi[e] * bm;
           if constexpr (H2EPI) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
+            const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            if (first) re.amax0 = fmaxf(re.amax0, m4); else re.amax1 = fmaxf(re.amax1, m4);
             u2 hi, lo;
             h2_split4(v, hi, lo);
             char* chunk = reinterpret_cast<char*>(row + ((nn0 + c) & ~31));
@@ -239,11 +245,13 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
             *reinterpret_cast<u2*>(chunk + h2_group_off((nn0 + c) & 31, 1)) = lo;
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) store_out(a, n0 + c + e, (size_t)vox, v[e]);
+            for (int e = 0; e < 4; ++e) store_out(a, n0 + c + e, (size_t)vox, v[e], &re);
           }
         }
       }
     }
+    if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(re.amax0), rs.e0);
+    if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(re.amax1), rs.e1);
     return;
   }
 #pragma unroll

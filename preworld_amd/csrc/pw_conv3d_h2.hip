@@ -37,7 +37,7 @@ constexpr int H2_LDS = H2_SB_OFF + 2 * H2_MAX_COUT * 4;
 // Parking area = this wave's own halo rows (wave + 4 K, K < 7 / 13 for NT 1 / 2) of the buffer the stage just consumed: those
 // rows are refilled only by this wave's own DMA instructions, which are issued after the passes (other rows first).
 struct EpiTile { int b, d0, h0, w0, ng; unsigned bufoff; bool pending; };
-struct EpiRegs { v4f x0, x1, s0, s1, b0, b1; float4 r0, r1; unsigned vbase, soff; };
+struct EpiRegs { v4f x0, x1, s0, s1, b0, b1; float4 r0, r1; unsigned vbase, soff; float amax0, amax1; };   // amax*: largest |stored value| written to y0 / y1
 
 __device__ __forceinline__ unsigned epi_slot_off(int u) {          // parked voxel row u (128 B): 10 per halo row
   const int row = (int)(((unsigned)u * 205u) >> 11);               // u / 10 for u < 1024
@@ -98,7 +98,7 @@ __device__ __forceinline__ void h2_epi_load(const ConvArgs& a, const EpiTile& t,
 }
 
 template <int NT, int EPI, int P>
-__device__ __forceinline__ void h2_epi_compute(const ConvArgs& a, const EpiTile& t, const EpiRegs& r) {
+__device__ __forceinline__ void h2_epi_compute(const ConvArgs& a, const EpiTile& t, EpiRegs& r, float res_mul) {
   constexpr int nt = P >> 2;
   const int n0 = (t.ng * NT + nt) * 32;
   const bool to_y0 = n0 < a.cout0;
@@ -113,10 +113,18 @@ __device__ __forceinline__ void h2_epi_compute(const ConvArgs& a, const EpiTile&
   if constexpr (EPI == 2) {                         // r0 = 8 hi halves, r1 = 8 lo halves of channels 8o .. 8o+7
     const h8 rh = __builtin_bit_cast(h8, r.r0), rl = __builtin_bit_cast(h8, r.r1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += (float)rh[e] + (float)rl[e];
+    for (int e = 0; e < 8; ++e) v[e] = fmaf((float)rh[e] + (float)rl[e], res_mul, v[e]);
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], lo_clamp);
+  {                                                 // range bookkeeping: rows that are not stored (nothing parked, outside the volume) do not count
+    float m = fabsf(v[0]);
+#pragma unroll
+    for (int e = 1; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+    m = r.vbase == PIPE_OOB ? 0.f : m;
+    r.amax0 = fmaxf(r.amax0, to_y0 ? m : 0.f);        // selects, not a branch: this runs inside the MFMA scheduling region
+    r.amax1 = fmaxf(r.amax1, to_y0 ? 0.f : m);
+  }
   const unsigned second = r.vbase == PIPE_OOB ? PIPE_OOB : r.vbase + 16u;
   if constexpr (EPI == 3) {
     const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
@@ -126,9 +134,9 @@ __device__ __forceinline__ void h2_epi_compute(const ConvArgs& a, const EpiTile&
     h8 oh, ol;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float x = __builtin_amdgcn_fmed3f(v[e], -H2_MAX, H2_MAX);
-      oh[e] = (_Float16)x;
-      ol[e] = (_Float16)(x - (float)oh[e]);
+      _Float16 th, tl;
+      h2_split1(v[e], th, tl);
+      oh[e] = th; ol[e] = tl;
     }
     const v4f wh = __builtin_bit_cast(v4f, oh), wl = __builtin_bit_cast(v4f, ol);
     const float va[4] = {wh[0], wh[1], wh[2], wh[3]}, vb[4] = {wl[0], wl[1], wl[2], wl[3]};
@@ -139,12 +147,11 @@ __device__ __forceinline__ void h2_epi_compute(const ConvArgs& a, const EpiTile&
 
 template <int NT, int EPI, int P>
 __device__ __forceinline__ void h2_epi_rest(const ConvArgs& a, const EpiTile& t, const char* stg, const float* sb, int wave,
-                                            int lane) {
+                                            int lane, EpiRegs& r, float res_mul) {
   if constexpr (P < 4 * NT) {
-    EpiRegs r;
     h2_epi_load<NT, EPI, P>(a, t, stg, sb, wave, lane, r);
-    h2_epi_compute<NT, EPI, P>(a, t, r);
-    h2_epi_rest<NT, EPI, P + 1>(a, t, stg, sb, wave, lane);
+    h2_epi_compute<NT, EPI, P>(a, t, r, res_mul);
+    h2_epi_rest<NT, EPI, P + 1>(a, t, stg, sb, wave, lane, r, res_mul);
   }
 }
 
@@ -167,6 +174,7 @@ struct H2Ctx {
   long long* tap_probe;
   EpiTile epi;                 // tile parked by the previous stage, written out during this one
   const char* ldsg;            // generic pointer to the LDS base (the parked rows are read through it)
+  float res_mul;               // residual as stored -> units of y0 as stored (RngScale::res)
 };
 
 template <int TAP>
@@ -238,7 +246,7 @@ __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, c
   if constexpr (TAP < 26) h2_read_a_tap<TAP + 1>(c.lds3, aaddr, an);
   __builtin_amdgcn_sched_barrier(0);
   constexpr bool epi_tap = EPI > 0 && TAP >= 2 && TAP <= 4 * NT + 1;
-  if constexpr (epi_tap) h2_epi_compute<NT, EPI, TAP - 2>(a, c.epi, er);      // pass TAP-2 of the previous tile (loaded last tap)
+  if constexpr (epi_tap) h2_epi_compute<NT, EPI, TAP - 2>(a, c.epi, er, c.res_mul);      // pass TAP-2 of the previous tile (loaded last tap)
   h2_mfma<NT, WR, TAP, NW>(ac, b0, acc, wres);
   if constexpr (epi_tap) {
     // interleave: one MFMA, then a handful of the pass's VALU instructions in its shadow; the two stores last
@@ -264,7 +272,8 @@ __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, c
 // from the accumulator layout cost 6.3 k cycles per stage, store-issue bound).
 template <int NT>
 __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][NT], const float* sb, char* stg,
-                                            int b, int d0, int h0, int w0, int ng, int wave, int lane) {
+                                            int b, int d0, int h0, int w0, int ng, int wave, int lane, float res_mul,
+                                            float& amax0, float& amax1) {
   const int od = d0 + wave;
   const int half = lane >> 5, pj = patch_of_row(lane & 31);
   const unsigned out_vox = (unsigned)((size_t)a.B * a.Do * a.Ho * a.Wo);
@@ -318,15 +327,23 @@ __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&ac
         const unsigned base = ok ? vox + rpos : PIPE_OOB;
         const float4 r0 = buf_load4(rr, base, soff), r1 = buf_load4(rr, ok ? base + 16u : PIPE_OOB, soff);
         if (a.fmt_res == 0) {
-          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+          const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(rv[e], res_mul, v[e]);
         } else {                                    // r0 = 8 hi halves, r1 = 8 lo halves of channels 8o .. 8o+7
           const h8 rh = __builtin_bit_cast(h8, r0), rl = __builtin_bit_cast(h8, r1);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rh[e] + (float)rl[e];
+          for (int e = 0; e < 8; ++e) v[e] = fmaf((float)rh[e] + (float)rl[e], res_mul, v[e]);
         }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], lo_clamp);
+      if (ok) {
+        float m = fabsf(v[0]);
+#pragma unroll
+        for (int e = 1; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+        if (to_y0) amax0 = fmaxf(amax0, m); else amax1 = fmaxf(amax1, m);
+      }
       const unsigned obase = ok ? vox + pos : PIPE_OOB;
       if (fmt == 0) {
         const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
@@ -336,9 +353,9 @@ __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&ac
         h8 oh, ol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float x = __builtin_amdgcn_fmed3f(v[e], -H2_MAX, H2_MAX);
-          oh[e] = (_Float16)x;
-          ol[e] = (_Float16)(x - (float)oh[e]);
+          _Float16 th, tl;
+          h2_split1(v[e], th, tl);
+          oh[e] = th; ol[e] = tl;
         }
         const v4f wh = __builtin_bit_cast(v4f, oh), wl = __builtin_bit_cast(v4f, ol);
         const float va[4] = {wh[0], wh[1], wh[2], wh[3]}, vb[4] = {wl[0], wl[1], wl[2], wl[3]};
@@ -362,12 +379,15 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   const int ntiles_total = a.cout_total >> 5;
   const int nchunk = a.Cin / KC;
 
-  // folded-BN scale / bias of every packed column -> LDS (read back as float4 per channel group in the epilogue)
+  // folded-BN scale / bias of every packed column -> LDS (read back as float4 per channel group in the epilogue), with the
+  // operands' range exponents folded in (pw_h2.h "Range": powers of two, exact)
+  const RngScale rs = rng_scales(a);
   {
     float* sb = lds + H2_SB_OFF / 4;
     for (int n = tid; n < a.cout_total; n += 256) {
-      sb[n] = a.scale ? a.scale[n] : 1.f;
-      sb[H2_MAX_COUT + n] = a.bias ? a.bias[n] : 0.f;
+      const bool to_y0 = n < a.cout0;
+      sb[n] = (a.scale ? a.scale[n] : 1.f) * (to_y0 ? rs.s0 : rs.s1);
+      sb[H2_MAX_COUT + n] = (a.bias ? a.bias[n] : 0.f) * (to_y0 ? rs.b0 : rs.b1);
     }
   }
 
@@ -398,6 +418,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   c.wave = wave; c.lane = lane;
   c.ldsg = reinterpret_cast<const char*>(lds);
   c.epi.pending = false; c.epi.b = c.epi.d0 = c.epi.h0 = c.epi.w0 = c.epi.ng = 0; c.epi.bufoff = 0;
+  c.res_mul = rs.res;
 
   constexpr int NW = WR ? 27 : 1;
   v4f wres[NW][2] = {};
@@ -485,7 +506,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
       char* stg = reinterpret_cast<char*>(lds) + bufoff + (unsigned)wave * (TW * 128);
       if constexpr (EPI == 0) {
         // generic epilogue phase (any mix of formats / residual): parks, reads back and stores before the next stage
-        h2_epilogue<NT>(a, acc, lds + H2_SB_OFF / 4, stg, t.b, t.d0, t.h0, t.w0, t.ng, wave, lane);
+        h2_epilogue<NT>(a, acc, lds + H2_SB_OFF / 4, stg, t.b, t.d0, t.h0, t.w0, t.ng, wave, lane, rs.res, er.amax0, er.amax1);
       } else {
         // first half of the pipelined epilogue: park the raw accumulators in this wave's rows of the consumed buffer
         h2_epi_park<NT>(acc, stg, lane);
@@ -510,8 +531,10 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   if constexpr (EPI > 0) {
     if (c.epi.pending)
       h2_epi_rest<NT, EPI, 0>(a, c.epi, reinterpret_cast<const char*>(lds) + c.epi.bufoff + (unsigned)wave * (TW * 128),
-                              lds + H2_SB_OFF / 4, wave, lane);
+                              lds + H2_SB_OFF / 4, wave, lane, er, rs.res);
   }
+  if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(er.amax0), rs.e0);
+  if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(er.amax1), rs.e1);
 }
 
 // ------------------------------------------------------------------------------------
@@ -592,12 +615,18 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_h2_tile(ConvArgs a) {
   // every wave is done with the halo buffer; scale / bias go to the tail of it, the accumulators to this wave's rows
   __syncthreads();
   float* sb = lds + (PIPE_BUF_BYTES - 2 * H2_MAX_COUT * 4) / 4;      // rows 58, 59 (never staging rows: those end at 31)
+  const RngScale rs = rng_scales(a);
   for (int n = tid; n < a.cout_total; n += 256) {
-    sb[n] = a.scale ? a.scale[n] : 1.f;
-    sb[H2_MAX_COUT + n] = a.bias ? a.bias[n] : 0.f;
+    const bool to_y0 = n < a.cout0;
+    sb[n] = (a.scale ? a.scale[n] : 1.f) * (to_y0 ? rs.s0 : rs.s1);
+    sb[H2_MAX_COUT + n] = (a.bias ? a.bias[n] : 0.f) * (to_y0 ? rs.b0 : rs.b1);
   }
   __syncthreads();
-  h2_epilogue<NT>(a, acc, sb, reinterpret_cast<char*>(lds) + (unsigned)wave * (TW * 128), b, d0, h0, w0, ng, wave, lane);
+  float amax0 = 0.f, amax1 = 0.f;
+  h2_epilogue<NT>(a, acc, sb, reinterpret_cast<char*>(lds) + (unsigned)wave * (TW * 128), b, d0, h0, w0, ng, wave, lane, rs.res,
+                  amax0, amax1);
+  if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(amax0), rs.e0);
+  if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(amax1), rs.e1);
   if (a.probe && lane == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
     long long* pp = a.probe + ((size_t)blockIdx.x * 4 + wave) * 4;
     pp[0] = ts0; pp[1] = ts1; pp[2] = ts2; pp[3] = __builtin_readcyclecounter();
@@ -605,26 +634,84 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_h2_tile(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ fp32 <-> h2
-// one thread per (voxel, 4-channel group); ld_* = floats between consecutive voxels (channel slices of wider buffers)
-__global__ void k_f32_to_h2(const float* __restrict__ x, float* __restrict__ y, long long n_vox, int C, int ld_x, int ld_y) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int groups = C >> 2;
-  if (idx >= n_vox * groups) return;
-  const long long v = idx / groups;
-  const int c = (int)(idx - v * groups) * 4;
-  const float4 f = *reinterpret_cast<const float4*>(x + v * ld_x + c);
-  const float in[4] = {f.x, f.y, f.z, f.w};
-  u2 hi, lo;
-  h2_split4(in, hi, lo);
-  char* dst = reinterpret_cast<char*>(y + v * ld_y + (c & ~31));
-  *reinterpret_cast<u2*>(dst + h2_group_off(c & 31, 0)) = hi;
-  *reinterpret_cast<u2*>(dst + h2_group_off(c & 31, 1)) = lo;
+// one thread per (voxel, 4-channel group); ld_* = floats between consecutive voxels (channel slices of wider buffers).
+// rng: the destination's / source's range slot (pw_h2.h "Range") or null.  auto_exp (host side): the slot's exponent is first
+// derived from the largest FINITE |x| (k_rng_clear, k_absmax, k_rng_pick) instead of being taken as it is.
+// one block per slot: rng[1] = max(rng[1], partial maxima), partials cleared; optional compact (n, 2) copy
+__global__ void __launch_bounds__(256) k_rng_fold(int* tab, int* compact) {
+  int* r = tab + (size_t)blockIdx.x * PW_RNG_ROW;
+  __shared__ unsigned sm[4];
+  unsigned m = 0u;
+  for (int k = threadIdx.x; k < PW_RNG_WORDS; k += 256) {
+    m = max(m, (unsigned)r[PW_RNG_SCRATCH + k]);
+    r[PW_RNG_SCRATCH + k] = 0;
+  }
+#pragma unroll
+  for (int off = 32; off; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    m = max(m, (unsigned)r[1]);
+    r[1] = (int)m;
+    if (compact) { compact[2 * blockIdx.x] = r[0]; compact[2 * blockIdx.x + 1] = (int)m; }
+  }
+}
+// auto_exp of pw_f32_to_h2: fold k_absmax's partials, then pick the exponent (and start recording afresh)
+__global__ void k_rng_clear(int* rng) { rng[1] = 0; }
+__global__ void k_rng_pick(int* rng) { rng[0] = rng_ideal_exp((unsigned)rng[1]); rng[1] = 0; }
+
+PW_API int pw_rng_fold(int32_t* tab, int n_slots, int32_t* compact, void* stream) {
+  PW_CHECK_ARG(tab && n_slots > 0, "pw_rng_fold: bad arguments");
+  hipLaunchKernelGGL(k_rng_fold, dim3((unsigned)n_slots), dim3(256), 0, pw_stream(stream), tab, compact);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
 }
 
-__global__ void k_h2_to_f32(const float* __restrict__ x, float* __restrict__ y, long long n_vox, int C, int ld_x, int ld_y) {
+__global__ void k_absmax(const float* __restrict__ x, long long n_vox, int C, int ld_x, int* rng) {
+  const int groups = C >> 2;
+  const long long n = n_vox * groups;
+  unsigned m = 0u;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    const long long v = idx / groups;
+    const int c = (int)(idx - v * groups) * 4;
+    const float4 f = *reinterpret_cast<const float4*>(x + v * ld_x + c);
+    const unsigned b[4] = {rng_absbits(f.x), rng_absbits(f.y), rng_absbits(f.z), rng_absbits(f.w)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = max(m, b[k] < 0x7f800000u ? b[k] : 0u);       // Inf / NaN do not choose the exponent
+  }
+  rng_note(rng, m, 0);
+}
+
+__global__ void k_f32_to_h2(const float* __restrict__ x, float* __restrict__ y, long long n_vox, int C, int ld_x, int ld_y,
+                            int* rng) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int groups = C >> 2;
+  const int e = rng ? rng[0] : 0;
+  unsigned m = 0u;
+  if (idx < n_vox * groups) {
+    const float mul = rng_pow2(-e);
+    const long long v = idx / groups;
+    const int c = (int)(idx - v * groups) * 4;
+    const float4 f = *reinterpret_cast<const float4*>(x + v * ld_x + c);
+    const float in[4] = {f.x * mul, f.y * mul, f.z * mul, f.w * mul};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = max(m, rng_absbits(in[k]));
+    u2 hi, lo;
+    h2_split4(in, hi, lo);
+    char* dst = reinterpret_cast<char*>(y + v * ld_y + (c & ~31));
+    *reinterpret_cast<u2*>(dst + h2_group_off(c & 31, 0)) = hi;
+    *reinterpret_cast<u2*>(dst + h2_group_off(c & 31, 1)) = lo;
+  }
+  rng_note(rng, m, e);
+}
+
+__global__ void k_h2_to_f32(const float* __restrict__ x, float* __restrict__ y, long long n_vox, int C, int ld_x, int ld_y,
+                            const int* rng) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int groups = C >> 2;
   if (idx >= n_vox * groups) return;
+  const float mul = rng_pow2(rng ? rng[0] : 0);
   const long long v = idx / groups;
   const int c = (int)(idx - v * groups) * 4;
   const char* src = reinterpret_cast<const char*>(x + v * ld_x + (c & ~31));
@@ -632,30 +719,41 @@ __global__ void k_h2_to_f32(const float* __restrict__ x, float* __restrict__ y, 
   const u2 lo = *reinterpret_cast<const u2*>(src + h2_group_off(c & 31, 1));
   float out[4];
   h2_join4(hi, lo, out);
-  *reinterpret_cast<float4*>(y + v * ld_y + c) = make_float4(out[0], out[1], out[2], out[3]);
+  *reinterpret_cast<float4*>(y + v * ld_y + c) = make_float4(out[0] * mul, out[1] * mul, out[2] * mul, out[3] * mul);
 }
 
-PW_API int pw_f32_to_h2(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, void* stream) {
+PW_API int pw_f32_to_h2(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, int32_t* rng, int auto_exp,
+                        void* stream) {
   PW_CHECK_ARG(x && y && n_vox > 0 && C > 0 && C % 32 == 0, "pw_f32_to_h2: C must be a positive multiple of 32");
   if (ld_x <= 0) ld_x = C;
   if (ld_y <= 0) ld_y = C;
   PW_CHECK_ARG(ld_x >= C && ld_y >= C && ld_x % 4 == 0 && ld_y % 32 == 0, "pw_f32_to_h2: bad row strides");
   PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "pw_f32_to_h2: pointers must be 16-B aligned");
+  PW_CHECK_ARG(!(auto_exp && !rng), "pw_f32_to_h2: auto_exp needs a range slot");
   const long long n = n_vox * (C / 4);
-  hipLaunchKernelGGL(k_f32_to_h2, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0, pw_stream(stream), x, y, (long long)n_vox, C, ld_x, ld_y);
+  hipStream_t st = pw_stream(stream);
+  if (auto_exp) {
+    hipLaunchKernelGGL(k_rng_clear, dim3(1), dim3(1), 0, st, rng);
+    const long long want = pw_cdiv(n, 256);
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, st, x, (long long)n_vox, C, ld_x, rng);
+    hipLaunchKernelGGL(k_rng_fold, dim3(1), dim3(256), 0, st, rng, (int*)nullptr);
+    hipLaunchKernelGGL(k_rng_pick, dim3(1), dim3(1), 0, st, rng);
+  }
+  hipLaunchKernelGGL(k_f32_to_h2, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0, st, x, y, (long long)n_vox, C, ld_x, ld_y, rng);
   pw_note_kernel("k_f32_to_h2");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
 
-PW_API int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, void* stream) {
+PW_API int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, const int32_t* rng, void* stream) {
   PW_CHECK_ARG(x && y && n_vox > 0 && C > 0 && C % 32 == 0, "pw_h2_to_f32: C must be a positive multiple of 32");
   if (ld_x <= 0) ld_x = C;
   if (ld_y <= 0) ld_y = C;
   PW_CHECK_ARG(ld_x >= C && ld_y >= C && ld_x % 32 == 0 && ld_y % 4 == 0, "pw_h2_to_f32: bad row strides");
   PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "pw_h2_to_f32: pointers must be 16-B aligned");
   const long long n = n_vox * (C / 4);
-  hipLaunchKernelGGL(k_h2_to_f32, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0, pw_stream(stream), x, y, (long long)n_vox, C, ld_x, ld_y);
+  hipLaunchKernelGGL(k_h2_to_f32, dim3((unsigned)pw_cdiv(n, 256)), dim3(256), 0, pw_stream(stream), x, y, (long long)n_vox, C, ld_x,
+                     ld_y, rng);
   pw_note_kernel("k_h2_to_f32");
   PW_CHECK_LAUNCH();
   return PW_OK;
@@ -665,7 +763,7 @@ PW_API int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x
 PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* residual,
                         float* y0, float* y1, int B, int D, int H, int W, int Cin, int cout_total, int cout0, int cout1,
                         int ld_y0, int ld_y1, int ksize, int stride, int relu0, int relu1, int algo, int fmt_y0, int fmt_y1,
-                        int fmt_res, void* stream) {
+                        int fmt_res, const int32_t* x_rng, const int32_t* res_rng, int32_t* y0_rng, int32_t* y1_rng, void* stream) {
   PW_CHECK_ARG(x && wpk && y0, "pw_conv3d_h2: null pointer");
   PW_CHECK_ARG((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1),
                "pw_conv3d_h2: 3x3x3 stride 1 / 2 and 1x1x1 stride 1 are built");
@@ -691,6 +789,7 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
   a.n1_start = cout0;
   a.relu0 = relu0; a.relu1 = relu1;
   a.fmt_y0 = fmt_y0; a.fmt_y1 = fmt_y1; a.fmt_res = fmt_res;
+  a.x_rng = x_rng; a.res_rng = res_rng; a.y0_rng = y0_rng; a.y1_rng = y1_rng;
   if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
   a.tiles_d = (a.Do + BD - 1) / BD; a.tiles_h = (a.Ho + BH - 1) / BH; a.tiles_w = (a.Wo + BW - 1) / BW;
   PW_CHECK_ARG((size_t)B * D * H * W * Cin * 4 < (1ull << 32) &&

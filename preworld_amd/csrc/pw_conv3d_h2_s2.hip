@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3
   // 16 bytes per lane with 8 consecutive lanes covering one voxel's 128-byte chunk: whole lines per store.
   __syncthreads();                                   // every wave is done with the halo
   char* const stg = my_lds + wave * 4096;
+  const RngScale rs = rng_scales(a);                 // range exponents of x / y0 / y1 (pw_h2.h "Range") folded into scale / bias
+  float amax0 = 0.f, amax1 = 0.f;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int n0 = (wave + 4 * nt) * 32;                      // a 32-column tile lies in one destination (cout0 % 32 == 0)
@@ -222,11 +224,14 @@ __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3
       const int cc = 8 * q + 4 * half;
       const float4 s4 = a.scale ? *reinterpret_cast<const float4*>(a.scale + n0 + cc) : make_float4(1.f, 1.f, 1.f, 1.f);
       const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + n0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
-      sc[q][0] = s4.x; sc[q][1] = s4.y; sc[q][2] = s4.z; sc[q][3] = s4.w;
-      bi[q][0] = b4.x; bi[q][1] = b4.y; bi[q][2] = b4.z; bi[q][3] = b4.w;
+      const float sm = first ? rs.s0 : rs.s1, bm = first ? rs.b0 : rs.b1;
+      sc[q][0] = s4.x * sm; sc[q][1] = s4.y * sm; sc[q][2] = s4.z * sm; sc[q][3] = s4.w * sm;
+      bi[q][0] = b4.x * bm; bi[q][1] = b4.y * bm; bi[q][2] = b4.z * bm; bi[q][3] = b4.w * bm;
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
+      // this lane's accumulators belong to output voxel (od, oh, 4 nb + ow) of the tile: inside the volume?
+      const bool mine = live && d0 + od < a.Do && h0 + oh < a.Ho && w0 + 4 * nb + ow < a.Wo;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int cc = 8 * q + 4 * half;
@@ -236,6 +241,8 @@ __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3
           v[e] = acc[nb][nt][4 * q + e] * sc[q][e] + bi[q][e];
           v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
         }
+        const float m4 = mine ? fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) : 0.f;
+        if (first) amax0 = fmaxf(amax0, m4); else amax1 = fmaxf(amax1, m4);
         u2 hi, lo;
         h2_split4(v, hi, lo);
         const int o0 = h2_group_off(cc, 0), o1 = h2_group_off(cc, 1);      // 16-byte slot = off >> 4, position inside = off & 15
@@ -255,6 +262,8 @@ __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3
       }
     }
   }
+  rng_note(a.y0_rng, __float_as_uint(amax0), rs.e0);
+  if (a.y1) rng_note(a.y1_rng, __float_as_uint(amax1), rs.e1);
   if (a.probe && lane == 0 && blockIdx.x == 100 && group == 0) {     // {start, pass 0 staged, pass 0 taps done, all passes done, epilogue done}
     ts[4] = __builtin_readcyclecounter();
     long long* pp = a.probe + wave * 8;

@@ -16,7 +16,7 @@
 //     v regs --W1a--> 4 x f32x16 hidden (softplus in place) --W2--> f32x16 + v  ->  v regs ...
 // Weights are pre-packed per lane (pw_forecast_pack) and live in LDS (32 KB); c1/b2 enter as
 // the MFMA C operand.  Each step's state is streamed out with 16-byte stores.
-#include "pw_common.h"
+#include "pw_h2.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -252,35 +252,75 @@ typedef _Float16 fh4 __attribute__((ext_vector_type(4)));
 typedef float fv4 __attribute__((ext_vector_type(4)));
 constexpr int WH2 = 4 * 2 * 2 * 64 * 4;     // floats per packed split matrix (16 KB)
 
-// registers r0 .. r0+7 of an accumulator -> (8 hi halves, 8 lo halves)
+// registers r0 .. r0+7 of an accumulator -> (8 hi halves, 8 lo halves); unsaturated like h2_split1 (pw_h2.h)
 __device__ __forceinline__ void split8(const float* x, fh8& hi, fh8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float c = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f);
-    hi[e] = (_Float16)c;
-    lo[e] = (_Float16)(c - (float)hi[e]);
+    hi[e] = (_Float16)x[e];
+    lo[e] = (_Float16)__builtin_amdgcn_fmed3f(x[e] - (float)hi[e], -65504.f, 65504.f);
   }
+}
+
+// softplus_t20(z) / 2^eh from zs = z / 2^eh:  max(zs, 0) + (ln2 / 2^eh) log2(1 + exp2(-|zs| 2^eh log2e)) -- the same six
+// instructions, the hidden activations come out in the units they are split in (kexp = 2^eh log2e, kln = ln2 / 2^eh)
+__device__ __forceinline__ float softplus_scaled(float zs, float kexp, float kln) {
+  const float t = __builtin_amdgcn_exp2f(-fabsf(zs) * kexp);
+  return fmaf(__builtin_amdgcn_logf(1.f + t), kln, fmaxf(zs, 0.f));
 }
 
 __global__ void __launch_bounds__(256, 2)
 k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_samples, const float* __restrict__ w1p,
               const float* __restrict__ w2p, float inv1, float inv2, const float* __restrict__ c1p,
-              const float* __restrict__ fb2, int n_steps, float* __restrict__ states, int v0_h2, int out_h2) {
+              const float* __restrict__ fb2, int n_steps, float* __restrict__ states, int v0_h2, int out_h2,
+              const int* __restrict__ v0_rng, int* __restrict__ st_rng, float w1_l1max) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* l_w1 = lds;
   float* l_w2 = lds + WH2;
+  float* l_c1 = lds + 2 * WH2;               // the hoisted ego terms of all samples, in the hidden layer's units
+  __shared__ float s_cmax[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
   for (int k = tid; k < WH2 / 4; k += 256) {
     reinterpret_cast<float4*>(l_w1)[k] = reinterpret_cast<const float4*>(w1p)[k];
     reinterpret_cast<float4*>(l_w2)[k] = reinterpret_cast<const float4*>(w2p)[k];
   }
+  // Range (pw_h2.h "Range").  The recursion runs in the units of the states' slot: u = v / 2^eu (eu = st_rng[0], calibrated by
+  // the host from the largest state magnitude), so the split operand of every step sits in fp16's comfortable range whatever
+  // the scale of the features.  The hidden activations softplus(z) are bounded A PRIORI, z <= ||W1a||_1 max|v| + max|c1|
+  // with max|v| < 2^(16 + eu) (anything larger is Inf in h2 storage and flagged through the slot), and are computed directly in
+  // units 2^eh that put this bound at 2^15.  All factors are powers of two folded into constants the loop already multiplies by.
+  const int e0 = v0_h2 ? rng_exp(v0_rng) : 0;
+  const int eu = rng_exp(st_rng);
+  {
+    float cm = 0.f;
+    for (int k = tid; k < n_samples * HID; k += 256) cm = fmaxf(cm, fabsf(c1p[k]));
+#pragma unroll
+    for (int off = 32; off; off >>= 1) cm = fmaxf(cm, __shfl_xor(cm, off));
+    if (lane == 0) s_cmax[wave] = cm;
+  }
   __syncthreads();
+  int eh;
+  {
+    const float cmax = fmaxf(fmaxf(s_cmax[0], s_cmax[1]), fmaxf(s_cmax[2], s_cmax[3]));
+    const float zb = fmaf(w1_l1max, rng_pow2(16 + eu), cmax + 1.f);
+    int ex;
+    (void)frexpf(zb, &ex);
+    eh = __builtin_amdgcn_readfirstlane(ex) - 15;
+    eh = eh < -100 ? -100 : (eh > 100 ? 100 : eh);
+  }
+  for (int k = tid; k < n_samples * HID; k += 256) l_c1[k] = c1p[k] * rng_pow2(-eh);
+  __syncthreads();
+  const float k_in = rng_pow2(e0 - eu);                       // v0 as stored -> u
+  const float k1 = inv1 * rng_pow2(eu - eh);                  // (S1 W1a) u -> z / 2^eh
+  const float k2 = inv2 * rng_pow2(eh - eu);                  // (S2 W2) hs / 2^eh -> u
+  const float kexp = 1.44269504088896341f * rng_pow2(eh), kln = 0.693147180559945309f * rng_pow2(-eh);
+  const float k_out = rng_pow2(eu);                           // u -> true value (fp32 output)
   const long long n_total = n_vox_per_sample * n_samples;
   const long long n_tiles = (n_total + 31) / 32;
   float b2r[16];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) b2r[s] = fb2[row_of(s, h)];
+  for (int s = 0; s < 16; ++s) b2r[s] = fb2[row_of(s, h)] * rng_pow2(-eu);
+  float amax = 0.f;
   // A fragment (t, k-block, plane) of this lane: 16 bytes at ((t*2 + kb)*2 + p)*1024 + lane*16
   const char* a1 = reinterpret_cast<const char*>(l_w1) + lane * 16;
   const char* a2 = reinterpret_cast<const char*>(l_w2) + lane * 16;
@@ -291,7 +331,7 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
     const bool valid = m < n_total;
     if (!valid) m = n_total - 1;
     const int sample = (int)(m / n_vox_per_sample);
-    const float* c1s = c1p + (size_t)sample * HID + h * 64;
+    const float* c1s = l_c1 + (size_t)sample * HID + h * 64;
     float v[16];
     if (v0_h2) {
       // h2 storage (pw_h2.h): channels 8 q + 4 h + 0..3 = the 8-byte group at slot 4 (q & 1) + 2 (q >> 1) + plane, byte 8 h
@@ -301,14 +341,14 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
         const int off = (4 * (q & 1) + 2 * (q >> 1)) * 16;
         const fh4 hi4 = *reinterpret_cast<const fh4*>(src + off), lo4 = *reinterpret_cast<const fh4*>(src + off + 16);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] = (float)hi4[e] + (float)lo4[e];
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = ((float)hi4[e] + (float)lo4[e]) * k_in;
       }
     } else {
       const float* src = v0 + (size_t)m * C + 4 * h;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 t4 = *reinterpret_cast<const float4*>(src + 8 * q);
-        v[4 * q + 0] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+        v[4 * q + 0] = t4.x * k_in; v[4 * q + 1] = t4.y * k_in; v[4 * q + 2] = t4.z * k_in; v[4 * q + 3] = t4.w * k_in;
       }
     }
     fh8 vh[2], vl[2];                        // split of the current state: GEMM operand of this step AND the h2 output of the last
@@ -335,10 +375,10 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 c4 = *reinterpret_cast<const float4*>(c1s + t * 16 + q * 4);
-          hs[4 * q + 0] = softplus_t20(fmaf(hid[4 * q + 0], inv1, c4.x));
-          hs[4 * q + 1] = softplus_t20(fmaf(hid[4 * q + 1], inv1, c4.y));
-          hs[4 * q + 2] = softplus_t20(fmaf(hid[4 * q + 2], inv1, c4.z));
-          hs[4 * q + 3] = softplus_t20(fmaf(hid[4 * q + 3], inv1, c4.w));
+          hs[4 * q + 0] = softplus_scaled(fmaf(hid[4 * q + 0], k1, c4.x), kexp, kln);
+          hs[4 * q + 1] = softplus_scaled(fmaf(hid[4 * q + 1], k1, c4.y), kexp, kln);
+          hs[4 * q + 2] = softplus_scaled(fmaf(hid[4 * q + 2], k1, c4.z), kexp, kln);
+          hs[4 * q + 3] = softplus_scaled(fmaf(hid[4 * q + 3], k1, c4.w), kexp, kln);
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -352,10 +392,12 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
         }
       }
 #pragma unroll
-      for (int s = 0; s < 16; ++s) v[s] = fmaf(o[s], inv2, b2r[s]) + v[s];   // + b2, residual connection (:342)
+      for (int s = 0; s < 16; ++s) v[s] = fmaf(o[s], k2, b2r[s]) + v[s];   // + b2, residual connection (:342)
       split8(v, vh[0], vl[0]);
       split8(v + 8, vh[1], vl[1]);
       if (valid) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) amax = fmaxf(amax, fabsf(v[s]));
         if (out_h2) {
           // h2 storage: a 16-byte slot holds 8 channels of one plane, but this lane has only 4 of them (8 q + 4 h + e) and its
           // partner lane (l ^ 32, same voxel) the other 4.  One v_permlane32_swap per dword trades the pieces so that lane half
@@ -386,26 +428,30 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
           float* dst = states + ((size_t)step * n_total + m) * C + 4 * h;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(v[4 * q + 0] * k_out, v[4 * q + 1] * k_out, v[4 * q + 2] * k_out,
+                                                                  v[4 * q + 3] * k_out);
         }
       }
     }
   }
+  rng_note(st_rng, __float_as_uint(amax), eu);
 }
 
 PW_API int pw_forecast_steps_h2(const float* v0, int64_t n_vox_per_sample, int n_samples, const float* w1p,
                                 const float* w2p, float inv1, float inv2, const float* c1p, const float* fusion_b2,
-                                int n_steps, float* states, int v0_h2, int out_h2, void* stream) {
+                                int n_steps, float* states, int v0_h2, int out_h2, const int32_t* v0_rng, int32_t* states_rng,
+                                float w1_l1max, void* stream) {
   PW_CHECK_ARG(v0 && w1p && w2p && c1p && fusion_b2 && states, "pw_forecast_steps_h2: null pointer");
-  PW_CHECK_ARG(n_vox_per_sample > 0 && n_samples > 0 && n_steps > 0, "pw_forecast_steps_h2: bad sizes");
+  PW_CHECK_ARG(n_vox_per_sample > 0 && n_samples > 0 && n_samples <= 64 && n_steps > 0, "pw_forecast_steps_h2: bad sizes (<= 64 samples)");
+  PW_CHECK_ARG(w1_l1max >= 0.f, "pw_forecast_steps_h2: w1_l1max = max row L1 norm of fusion_head.0.weight[:, :32]");
   PW_CHECK_ARG((((uintptr_t)v0 | (uintptr_t)states | (uintptr_t)w1p | (uintptr_t)w2p) & 15) == 0,
                "pw_forecast_steps_h2: pointers must be 16-B aligned");
-  const size_t lds_bytes = (size_t)2 * WH2 * 4;   // 32 KB
+  const size_t lds_bytes = (size_t)2 * WH2 * 4 + (size_t)n_samples * HID * 4;   // 32 KB + the scaled ego terms
   long long n_tiles = (n_vox_per_sample * n_samples + 31) / 32;
   long long want = (n_tiles + 3) / 4;
   unsigned nb = (unsigned)(want < 1024 ? want : 1024);   // 4 blocks x 256 CUs, grid-stride
   hipLaunchKernelGGL(k_forecast_h2, dim3(nb), dim3(256), lds_bytes, pw_stream(stream), v0, (long long)n_vox_per_sample,
-                     n_samples, w1p, w2p, inv1, inv2, c1p, fusion_b2, n_steps, states, v0_h2, out_h2);
+                     n_samples, w1p, w2p, inv1, inv2, c1p, fusion_b2, n_steps, states, v0_h2, out_h2, v0_rng, states_rng, w1_l1max);
   pw_note_kernel("k_forecast_h2");
   PW_CHECK_LAUNCH();
   return PW_OK;

@@ -1,5 +1,5 @@
 // LSSFPN3D fused tail (A8) -- entry point pw_fpn3d_fuse in include/preworld_hip.h.
-#include "pw_conv3d_common.h"
+#include "pw_h2.h"
 
 // ------------------------------------------------------------------------------------
 // LSSFPN3D fused (mmdet3d/models/necks/lss_fpn.py:132-148): the reference upsamples the 1/2
@@ -75,8 +75,12 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
     }
     }
   }
-  const float sc = a.scale ? a.scale[i] : 1.f;
-  const float bi = a.bias ? a.bias[i] : 0.f;
+  // range exponents (pw_h2.h "Range"): x8 is read under x_rng (y16 / y32 are fp32, true units), out is written under y0_rng
+  const int e_out = a.fmt_y0 ? rng_exp(a.y0_rng) : 0;
+  const float xmul = rng_pow2(a.dma_stage ? rng_exp(a.x_rng) : 0), omul = rng_pow2(-e_out);
+  const float sc = (a.scale ? a.scale[i] : 1.f) * omul;
+  const float bi = (a.bias ? a.bias[i] : 0.f) * omul;
+  float amax = 0.f;
   const float sd2 = a.D > 1 ? (float)(f.D2 - 1) / (float)(a.D - 1) : 0.f;
   const float sh2 = a.H > 1 ? (float)(f.H2 - 1) / (float)(a.H - 1) : 0.f;
   const float sw2 = a.W > 1 ? (float)(f.W2 - 1) / (float)(a.W - 1) : 0.f;
@@ -131,14 +135,16 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      float v = acc[r];
+      float v = acc[r] * xmul;
       v += lerp_w(c2, f.W2, sw2, wb2, ow0 + row);
       v += lerp_w(c4, f.W4, sw4, wb4, ow0 + row);
       v = v * sc + bi;
       if (a.relu0) v = fmaxf(v, 0.f);
+      amax = fmaxf(amax, fabsf(v));
       if (a.fmt_y0) h2_store_elem(a.y0 + (size_t)(m0 + row) * 32, i, v);
       else out[(unsigned)row * 32u] = v;
     }
+    if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(amax), e_out);
     return;
   }
 #pragma unroll
@@ -154,21 +160,23 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
       const int oh = (int)(t1 - t2 * (unsigned)a.H);
       const int b = (int)(t2 / (unsigned)a.D);
       const int od = (int)(t2 - (unsigned)b * (unsigned)a.D);
-      float v = acc[r];
+      float v = acc[r] * xmul;
       v += trilerp_ac(f.y16, b, f.D2, f.H2, f.W2, sd2, sh2, sw2, od, oh, ow, i);
       v += trilerp_ac(f.y32, b, f.D4, f.H4, f.W4, sd4, sh4, sw4, od, oh, ow, i);
       v = v * sc + bi;
       if (a.relu0) v = fmaxf(v, 0.f);
+      amax = fmaxf(amax, fabsf(v));
       if (a.fmt_y0) h2_store_elem(a.y0 + (size_t)vox * 32, i, v);
       else a.y0[(size_t)vox * 32 + i] = v;
     }
   }
+  if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(amax), e_out);
 }
 
 PW_API int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, const float* y32,
                          const float* scale, const float* bias, float* out, int B, int D, int H,
                          int W, int Cin8, int D2, int H2, int W2, int D4, int H4, int W4, int relu,
-                         int x_h2, int out_h2, void* stream) {
+                         int x_h2, int out_h2, const int32_t* x_rng, int32_t* out_rng, void* stream) {
   PW_CHECK_ARG(x8 && wpk8 && y16 && y32 && out, "pw_fpn3d_fuse: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin8 > 0 && Cin8 % 32 == 0, "pw_fpn3d_fuse: bad shape");
   PW_CHECK_ARG(D2 > 0 && H2 > 0 && W2 > 0 && D4 > 0 && H4 > 0 && W4 > 0, "pw_fpn3d_fuse: bad level shape");
@@ -177,6 +185,7 @@ PW_API int pw_fpn3d_fuse(const float* x8, const float* wpk8, const float* y16, c
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin8; a.relu0 = relu; a.cout_total = 32; a.cout0 = 32; a.ld0 = 32;
   a.dma_stage = x_h2 ? 1 : 0;          // reused as the input-format flag: x8 and wpk8 are split-fp16
   a.fmt_y0 = out_h2 ? 1 : 0;
+  a.x_rng = x_rng; a.y0_rng = out_rng;
   FpnArgs f = {y16, y32, D2, H2, W2, D4, H4, W4};
   const long long n = (long long)B * D * H * W;
   PW_CHECK_ARG(n < (1ll << 31), "pw_fpn3d_fuse: more than 2^31 voxels");

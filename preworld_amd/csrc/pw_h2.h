@@ -16,7 +16,18 @@
 // so that an MFMA lane of lane-half `half` finds its 8-channel fragments of both k-steps and both planes in the four
 // consecutive slots 4*half .. 4*half+3: exactly the 64 contiguous bytes the fp32 kernels read per lane, so the halo
 // tile layout, its XOR swizzle (conflict-free ds_read_b128) and the `buffer_load ... lds` staging of
-// pw_conv3d_common.h apply unchanged.  Values saturate at +-65504 (fp16 range).
+// pw_conv3d_common.h apply unchanged.
+//
+// Range.  fp16 has 5 exponent bits: hi overflows above 65504 and lo goes subnormal (absolute resolution 2^-25) once |x| < 2^-3.
+// The reference is fp32 with no such domain (backbones/resnet.py:88-123 is plain Conv3d), so every h2 tensor carries a
+// per-tensor power-of-two exponent e in a RANGE SLOT (two int32 in device memory, see RngSlot below):
+//     value = (hi + lo) * 2^e
+// Producers divide by 2^e before the split (folded into their epilogue scale / bias: powers of two, exact) and record the
+// largest |value| they wrote; consumers fold 2^e into THEIR epilogue scale exactly like the weights' pre-scale.  The host
+// (preworld_amd.ops.RangeCtx) chooses e so that the tensor's largest magnitude lands in [2^12, 2^13) of the stored units --
+// 22-bit significands for everything within 2^-15 of the maximum, an absolute floor of 2^-38 of it below -- and re-runs a
+// sample whose recorded maximum left [2^6, 65504] under the exponents it was run with.  Nothing is clamped: a value beyond
+// +-65504 stored units becomes Inf (NaN stays NaN), is recorded as such in the slot, and propagates like it would in fp32.
 #ifndef PW_H2_H_
 #define PW_H2_H_
 #include "pw_conv3d_common.h"
@@ -33,16 +44,71 @@ __host__ __device__ __forceinline__ constexpr int h2_group_off(int c, int p) {
   return (4 * ((c >> 3) & 1) + 2 * (c >> 4) + p) * 16 + 2 * (c & 7);
 }
 
+// x -> (hi, lo).  No saturation: |x| >= 65520 gives hi = +-Inf (lo is then clamped to a finite value so that hi + lo stays Inf
+// instead of Inf - Inf), NaN gives NaN.
+__device__ __forceinline__ void h2_split1(float x, _Float16& h, _Float16& l) {
+  h = (_Float16)x;
+  l = (_Float16)__builtin_amdgcn_fmed3f(x - (float)h, -H2_MAX, H2_MAX);
+}
+
 __device__ __forceinline__ void h2_split4(const float (&v)[4], u2& hi, u2& lo) {
   h4 h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float x = __builtin_amdgcn_fmed3f(v[e], -H2_MAX, H2_MAX);
-    h[e] = (_Float16)x;
-    l[e] = (_Float16)(x - (float)h[e]);
+    _Float16 a, b;
+    h2_split1(v[e], a, b);
+    h[e] = a; l[e] = b;
   }
   hi = __builtin_bit_cast(u2, h);
   lo = __builtin_bit_cast(u2, l);
+}
+
+// ---- range slots (see "Range" above).  A slot is PW_RNG_ROW int32: rng[0] = exponent e; rng[1] = bit pattern of the largest
+// |value| in TRUE units (non-negative floats order like unsigned integers; a NaN pattern is above every number), valid after
+// pw_rng_fold; rng[PW_RNG_SCRATCH ..] = PW_RNG_WORDS partial maxima the waves of the producing kernels raise.  Why partials:
+// device-scope atomics on ONE address serialise at ~100 ns each -- 8 192 waves raising one word cost the pooling
+// kernel 150 us; spread over 1 024 words, without a returned value, they cost nothing measurable.  pw_rng_fold (one small
+// launch per pass) folds them into rng[1] and clears them.  A null slot = exponent 0, nothing recorded.
+__device__ __forceinline__ int rng_exp(const int* r) { return r ? __builtin_amdgcn_readfirstlane(r[0]) : 0; }
+__device__ __forceinline__ float rng_pow2(int e) { return __builtin_ldexpf(1.0f, e); }
+__device__ __forceinline__ unsigned rng_absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+// every lane of a wave calls this once, at the end of the kernel: bits = |largest STORED value| of the lane, e = the exponent
+// it was stored under
+__device__ __forceinline__ void rng_note(int* r, unsigned bits, int e) {
+  if (!r) return;
+#pragma unroll
+  for (int off = 32; off; off >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
+  if ((threadIdx.x & 63) == 0 && bits) {
+    const unsigned m = rng_absbits(__builtin_ldexpf(__uint_as_float(bits), e));
+    const unsigned w = ((unsigned)blockIdx.x * 16u + (threadIdx.x >> 6)) & (unsigned)(PW_RNG_WORDS - 1);
+    (void)__hip_atomic_fetch_max(reinterpret_cast<unsigned*>(r) + PW_RNG_SCRATCH + w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// the exponent the host's calibration picks for a tensor whose largest magnitude has this bit pattern: it puts that magnitude
+// in [2^12, 2^13) of the stored units (preworld_amd.ops.RangeCtx.ideal_exp computes the same number); 0 for an all-zero or
+// non-finite tensor
+__host__ __device__ __forceinline__ int rng_ideal_exp(unsigned bits) {
+  if (bits == 0u || bits >= 0x7f800000u) return 0;
+  const int k = (int)(bits >> 23) - 127 - 12;
+  return k < -100 ? -100 : (k > 100 ? 100 : k);
+}
+// how a conv-shaped kernel folds the exponents of its operands into its epilogue constants
+struct RngScale {
+  int e0, e1;              // exponents y0 / y1 are stored under (0 for fp32 destinations)
+  float s0, s1;            // multiply scale[n] of y0 / y1 columns:  2^(e_x - e_y)
+  float b0, b1;            // multiply bias[n]:                      2^(-e_y)
+  float res;               // residual as stored -> y0 as stored:    2^(e_res - e_y0)
+};
+__device__ __forceinline__ RngScale rng_scales(const ConvArgs& a) {
+  RngScale s;
+  const int ex = rng_exp(a.x_rng);
+  const int er = a.fmt_res ? rng_exp(a.res_rng) : 0;
+  s.e0 = a.fmt_y0 ? rng_exp(a.y0_rng) : 0;
+  s.e1 = a.fmt_y1 ? rng_exp(a.y1_rng) : 0;
+  s.s0 = rng_pow2(ex - s.e0); s.s1 = rng_pow2(ex - s.e1);
+  s.b0 = rng_pow2(-s.e0); s.b1 = rng_pow2(-s.e1);
+  s.res = rng_pow2(er - s.e0);
+  return s;
 }
 
 __device__ __forceinline__ void h2_join4(u2 hi, u2 lo, float (&v)[4]) {

@@ -605,11 +605,15 @@ constexpr int LONG_BLOCKS = 128;    // x 4 waves
 
 // one lane's 4 channels (quad `sub`) of voxel row v: fp32, or split-fp16 (h2, pw_h2.h) for the fp16-matrix-core encoder
 template <int LPV>
-__device__ __forceinline__ void pool_store(float4* __restrict__ out, int64_t v, int sub, const float4& acc, int out_h2) {
+__device__ __forceinline__ void pool_store(float4* __restrict__ out, int64_t v, int sub, const float4& acc, int out_h2,
+                                           float mul, unsigned& amax) {
   if (!out_h2) {
     out[v * LPV + sub] = acc;
   } else {
-    const float f[4] = {acc.x, acc.y, acc.z, acc.w};
+    // h2: the sums are stored divided by 2^e of the destination's range slot (mul = 2^-e, exact) and their largest magnitude
+    // is recorded (pw_h2.h "Range"); bit-pattern maximum, so a NaN among the inputs shows up in the slot
+    const float f[4] = {acc.x * mul, acc.y * mul, acc.z * mul, acc.w * mul};
+    amax = max(max(amax, rng_absbits(f[0])), max(rng_absbits(f[1]), max(rng_absbits(f[2]), rng_absbits(f[3]))));
     u2 hi, lo;
     h2_split4(f, hi, lo);
     char* row = reinterpret_cast<char*>(out + v * LPV) + (sub >> 3) * 128;
@@ -625,9 +629,12 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
              const int32_t* __restrict__ seg_start, const int32_t* __restrict__ order,
              const int32_t* __restrict__ order_feat, int64_t n_voxels, int long_threshold,
              const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
-             float4* __restrict__ out, int out_h2) {
+             float4* __restrict__ out, int out_h2, int* __restrict__ out_rng) {
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPV;
+  const int e_out = out_h2 ? rng_exp(out_rng) : 0;
+  const float omul = rng_pow2(-e_out);
+  unsigned amax = 0u;
   const int long_blocks = long_list ? LONG_BLOCKS : 0;
   if ((int)blockIdx.x < long_blocks) {
     // Long segments: one wave per segment, 64 points per batch.  Lane L owns point base+L (its
@@ -682,8 +689,9 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
           }
         }
       }
-      if (lane < LPV) pool_store<LPV>(out, v, sub, acc, out_h2);     // every lane group holds the same sums
+      if (lane < LPV) pool_store<LPV>(out, v, sub, acc, out_h2, omul, amax);     // every lane group holds the same sums
     }
+    if (out_h2) rng_note(out_rng, amax, e_out);
     return;
   }
   // Dense sweep, software-pipelined over the voxels of one lane group.  A voxel costs a chain of
@@ -756,10 +764,11 @@ k_pool_dense(const float* __restrict__ depth, const float4* __restrict__ feat,
           if (u < rc) fma4_nc(acc, feat[(int64_t)pf * LPV + sub], d);
         }
       }
-      pool_store<LPV>(out, v, sub, acc, out_h2);
+      pool_store<LPV>(out, v, sub, acc, out_h2, omul, amax);
     }
     v = vn; s = sn; e = en; my_pf = n_pf; my_o = n_o; sn = s2; en = e2;
   }
+  if (out_h2) rng_note(out_rng, amax, e_out);
 }
 
 // interval-driven (reference ABI): out pre-zeroed by the caller, assign per interval
@@ -845,7 +854,7 @@ static bool lpv_supported(int c) {
 PW_API int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_start,
                              const int32_t* order, const int32_t* order_feat, int64_t n_voxels,
                              int c, int long_threshold, const int32_t* long_list,
-                             const int32_t* n_long, float* out, int out_h2, void* stream) {
+                             const int32_t* n_long, float* out, int out_h2, int32_t* out_rng, void* stream) {
   PW_CHECK_ARG(depth && feat && seg_start && order && order_feat && out && n_voxels > 0 && c > 0,
                "pw_bev_pool_dense: bad arguments");
   PW_CHECK_ARG(!out_h2 || (c % 32 == 0 && lpv_supported(c)), "pw_bev_pool_dense: h2 output needs C %% 32 == 0");
@@ -860,9 +869,10 @@ PW_API int pw_bev_pool_dense(const float* depth, const float* feat, const int32_
     PW_DISPATCH_LPV(lpv, hipLaunchKernelGGL((k_pool_dense<L>), dim3(nb), dim3(256), 0, st, depth,
                                             (const float4*)feat, seg_start, order, order_feat,
                                             n_voxels, long_threshold, long_list, n_long,
-                                            (float4*)out, out_h2));
+                                            (float4*)out, out_h2, out_rng));
     pw_note_kernel("k_pool_dense<%d>", lpv);
   } else {
+    PW_CHECK_ARG(!out_h2, "pw_bev_pool_dense: h2 output needs 16-byte aligned feat / out (the generic kernel writes fp32)");
     hipLaunchKernelGGL(k_pool_dense_generic, dim3((unsigned)pw_cdiv(n_voxels * c, 256)), dim3(256),
                        0, st, c, depth, feat, seg_start, order, order_feat, n_voxels, out);
     pw_note_kernel("k_pool_dense_generic");

@@ -215,8 +215,12 @@ __device__ __forceinline__ void oh_step(const ConvArgs& a, const OhCtx& c, const
   if constexpr (G + 1 < 9) oh_step<G + 1>(a, c, ad, wh, wl, Rn, Rc, acc);
 }
 
+// a-priori magnitude bounds of the two hidden layers (host: preworld_amd.ops.pack_occ_*_h2), see the range note in the kernel
+struct OhBounds { float mid_a, mid_b, hid_a, hid_b; };
+
 template <bool LOGITS>
-__global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, OccTail tail, const float* tailpk, float inv2) {
+__global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, OccTail tail, const float* tailpk, float inv2,
+                                                        OhBounds bd) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
@@ -239,7 +243,25 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
   c.occr = make_rsrc(tail.occ, nvox);
   c.geor = make_rsrc(tail.geo, tail.geo ? nvox : 0u);
   c.lgr = make_rsrc(tail.logits, tail.logits ? nvox * 72u : 0u);
-  c.wave = wave; c.g = g; c.inv2 = inv2;
+  c.wave = wave; c.g = g;
+  // Range (pw_h2.h "Range").  x is read under its slot's exponent e_in.  The two hidden layers are split in registers, so their
+  // units are chosen from A-PRIORI bounds: |mid| <= mid_a 2^(16 + e_in) + mid_b (mid_a = max_c |scale_c| ||S w_c||_1: every
+  // stored input is below 2^16) and |hid| <= hid_a |mid|_max + hid_b; each layer is computed directly in units that put its
+  // bound at 2^15.  Powers of two, folded into the BN constants below; the logits come back in true units through inv2.
+  const int e_in = rng_exp(a.x_rng);
+  int e_mid, e_hid;
+  {
+    const float midb = fmaf(bd.mid_a, rng_pow2(16 + e_in), bd.mid_b);
+    const float hidb = fmaf(bd.hid_a, midb, bd.hid_b);
+    int ex;
+    (void)frexpf(midb, &ex);
+    e_mid = midb > 0.f ? __builtin_amdgcn_readfirstlane(ex) - 15 : 0;
+    (void)frexpf(hidb, &ex);
+    e_hid = hidb > 0.f ? __builtin_amdgcn_readfirstlane(ex) - 15 : 0;
+    e_mid = e_mid < -100 ? -100 : (e_mid > 100 ? 100 : e_mid);
+    e_hid = e_hid < -100 ? -100 : (e_hid > 100 ? 100 : e_hid);
+  }
+  c.inv2 = inv2 * rng_pow2(e_hid);
 
   // fragment addresses: [kw][j >= 4][plane] for halo rows {j, j + 4} (row-pair base at j = 0 / immediates add (kd, j))
   unsigned ad0[3][2][2];
@@ -285,16 +307,16 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
     tw.w2h[1] = __builtin_bit_cast(h4, f4); tw.w2l[1] = __builtin_bit_cast(h4, f5);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      tw.s1[r] = tailpk[768 + 4 * g + r];
-      tw.b1[r] = tailpk[784 + 4 * g + r];
+      tw.s1[r] = tailpk[768 + 4 * g + r] * rng_pow2(e_mid - e_hid);
+      tw.b1[r] = tailpk[784 + 4 * g + r] * rng_pow2(-e_hid);
     }
   }
   // folded BN of the conv for this lane's 4 channels (4 g + r); the weights' power-of-two pre-scale is folded into scale
   float sc[4], bi[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    sc[r] = a.scale[4 * g + r];
-    bi[r] = a.bias[4 * g + r];
+    sc[r] = a.scale[4 * g + r] * rng_pow2(e_in - e_mid);
+    bi[r] = a.bias[4 * g + r] * rng_pow2(-e_mid);
   }
 
   PipeTile t = pipe_decode(a, p, item);
@@ -383,7 +405,8 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
 // the pre-scale of the last layer (applied to the logits output only; argmax does not need it).  Outputs as pw_occ_head_fused.
 PW_API int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* tailpk,
                           float inv2, uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H, int W,
-                          int Cin, int n_mid, int n_hid, int n_cls, void* stream) {
+                          int Cin, int n_mid, int n_hid, int n_cls, const int32_t* x_rng, float mid_a, float mid_b, float hid_a,
+                          float hid_b, void* stream) {
   PW_CHECK_ARG(x && wpk && scale && bias && tailpk && occ, "pw_occ_head_h2: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "pw_occ_head_h2: bad shape");
   if (Cin != KC || n_mid != 16 || n_hid != 8 || n_cls != 18) {
@@ -398,6 +421,9 @@ PW_API int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, 
   a.x = x; a.wpk = wpk; a.scale = scale; a.bias = bias;
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Do = D; a.Ho = H; a.Wo = W;
   a.cout_total = 16; a.cout0 = n_mid; a.relu0 = 1;
+  a.x_rng = x_rng;
+  PW_CHECK_ARG(mid_a >= 0.f && mid_b >= 0.f && hid_a >= 0.f && hid_b >= 0.f, "pw_occ_head_h2: magnitude bounds must be >= 0");
+  const OhBounds bd = {mid_a, mid_b, hid_a, hid_b};
   a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
   if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
   const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
@@ -411,12 +437,12 @@ PW_API int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, 
     PW_CHECK_ARG((size_t)B * D * H * W * 72 < (1ull << 32), "pw_occ_head_h2: logits must stay below 4 GiB");
     static int once = set_lds_limit(k_occ_head_h2<true>, OH_LDS);
     if (once) return once;
-    hipLaunchKernelGGL(k_occ_head_h2<true>, dim3(nb), dim3(256), OH_LDS, pw_stream(stream), a, p, t, tailpk, inv2);
+    hipLaunchKernelGGL(k_occ_head_h2<true>, dim3(nb), dim3(256), OH_LDS, pw_stream(stream), a, p, t, tailpk, inv2, bd);
     pw_note_kernel("k_occ_head_h2<true>");
   } else {
     static int once = set_lds_limit(k_occ_head_h2<false>, OH_LDS);
     if (once) return once;
-    hipLaunchKernelGGL(k_occ_head_h2<false>, dim3(nb), dim3(256), OH_LDS, pw_stream(stream), a, p, t, tailpk, inv2);
+    hipLaunchKernelGGL(k_occ_head_h2<false>, dim3(nb), dim3(256), OH_LDS, pw_stream(stream), a, p, t, tailpk, inv2, bd);
     pw_note_kernel("k_occ_head_h2<false>");
   }
   PW_CHECK_LAUNCH();

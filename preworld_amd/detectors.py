@@ -156,7 +156,7 @@ class BEVStereo4DOCC(nn.Module):
     @torch.no_grad()
     def extract_img_feat(self, img_inputs, img_metas=None, **kwargs):
         frames = self.lift_inputs_from_images(img_inputs)
-        x_cl = as_f32(self.extract_bev_feat_cl(frames))
+        x_cl = self._ranged(lambda: as_f32(self.extract_bev_feat_cl(frames)))
         return [x_cl.permute(0, 4, 1, 2, 3)], frames[0]['depth']
 
     # ---- bevdet.py:139-175: the test-time entry the runner calls (`model(return_loss=False, **data)`)
@@ -236,6 +236,20 @@ class BEVStereo4DOCC(nn.Module):
         return as_f32(self.bev_encoder_cl(x)), depth_key
 
 
+    # ---- activation ranges of the split-fp16 path (ops.RangeCtx; include/preworld_hip.h "RANGE SLOTS")
+    def _ranged(self, fn):
+        """Run one inference pass fn() with its h2 tensors' exponents calibrated to the data: under this detector's own
+        RangeCtx, repeated until the recorded maxima sit inside the window (one pass once the exponents fit; the check is
+        one 2 KB D2H copy).  Inside an outer ops.use_range scope (pipeline.CapturedSample, the sharded harness) the owner of
+        that scope calibrates and fn() simply runs."""
+        if precision() != 'h2' or ops.current_range() is not None:
+            return fn()
+        dev = next(self.parameters()).device
+        ctx = self.__dict__.get('_range_ctx')
+        if ctx is None or ctx.device != dev:
+            ctx = self.__dict__['_range_ctx'] = ops.RangeCtx(dev)
+        return ops.ranged(fn, ctx)
+
     # ---- bevdet.py:52-58
     def bev_encoder_cl(self, x_cl, out_h2=False):
         h2 = precision() == 'h2'
@@ -255,10 +269,11 @@ class BEVStereo4DOCC(nn.Module):
         if self.pre_process:
             return self.pre_process_net.forward_cl(x, out_last=out, keep_h2=out_h2)[0]
         if out is not None:
+            if out_h2:                                      # into the destination's storage, under ITS range slot
+                return ops.f32_to_h2(as_f32(x), out=out)
             dst = out.buf if isinstance(out, ops.H2) else out
-            src = x if isinstance(x, ops.H2) == out_h2 else (ops.f32_to_h2(x) if out_h2 else as_f32(x))
-            dst.copy_(src.buf if isinstance(src, ops.H2) else src)
-            return ops.H2(dst) if out_h2 else dst
+            dst.copy_(as_f32(x))
+            return dst
         return x if isinstance(x, ops.H2) == out_h2 else (ops.f32_to_h2(x) if out_h2 else as_f32(x))
 
     # ---- bevdet_occ.py:167-269 (frame loop, [adj, key] concat, with_prev=False -> zeros)
@@ -275,9 +290,10 @@ class BEVStereo4DOCC(nn.Module):
         n = self.num_adj + 1
         h2 = precision() == 'h2' and C % 32 == 0
         x = torch.empty(B, size[2], size[1], size[0], n * C, device=f0['depth'].device, dtype=torch.float32)
+        xslot = ops.new_slot(x.device) if h2 else None      # ONE range slot for the whole buffer: every frame is written under it
 
         def sl(lo, hi):
-            return ops.H2(x[..., lo:hi]) if h2 else x[..., lo:hi]
+            return ops.H2(x[..., lo:hi], xslot) if h2 else x[..., lo:hi]
         # The frames' lift chains (voxel index, sort, pooling, pre_process_net) are independent until the encoder reads the
         # buffer: the adjacent frames run on a side stream (fork / join; captured into the hipGraph as two branches), so that
         # one frame's small latency-bound LSS kernels hide under the other's convolutions.  PW_LIFT_STREAMS=0: one stream.
@@ -302,7 +318,7 @@ class BEVStereo4DOCC(nn.Module):
         self.lift_frame_cl(out=sl((n - 1) * C, n * C), out_h2=h2, **f0)
         if fork:
             main.wait_stream(side)
-        return self.bev_encoder_cl(ops.H2(x) if h2 else x, out_h2=out_h2)
+        return self.bev_encoder_cl(ops.H2(x, xslot) if h2 else x, out_h2=out_h2)
 
     def extract_voxel_feat_cl(self, frames, out_h2=False):
         """... followed by final_conv: conv + bias + ReLU (preworld.py:72-79), channels-last (B,Z,Y,X,out_dim); out_h2: keep
@@ -313,6 +329,9 @@ class BEVStereo4DOCC(nn.Module):
     # ---- bevdet_occ.py:281-301: final_conv -> predicter MLP -> argmax(softmax) (softmax is monotone: argmax of logits)
     @torch.no_grad()
     def simple_test_from_lift(self, frames, **kwargs):
+        return self._ranged(lambda: self._simple_test_from_lift(frames, **kwargs))
+
+    def _simple_test_from_lift(self, frames, **kwargs):
         v = self.extract_voxel_feat_cl(frames)
         if self.use_predicter:
             p = self.predicter
@@ -439,6 +458,9 @@ class PreWorld(_PreWorldCommon):
 
     @torch.no_grad()
     def simple_test_from_lift(self, frames, want_logits=False, **kwargs):
+        return self._ranged(lambda: self._simple_test_from_lift(frames, want_logits=want_logits, **kwargs))
+
+    def _simple_test_from_lift(self, frames, want_logits=False, **kwargs):
         v0 = self.extract_voxel_feat_cl(frames, out_h2=self.if_post_finetune)   # (B,Z,Y,X,C); ops.H2 on the split-fp16 path
         res = {'voxel_feats': [v0]}
         if not self.if_post_finetune:
@@ -548,6 +570,9 @@ class PreWorld4DTraj(_PreWorldCommon):
     # ---- preworld_temporal_traj.py:212-370 (post-finetune branch) from lifted inputs
     @torch.no_grad()
     def simple_test_from_lift(self, frames, temporal_ego_states, n_steps=6, want_logits=False):
+        return self._ranged(lambda: self._simple_test_from_lift(frames, temporal_ego_states, n_steps, want_logits))
+
+    def _simple_test_from_lift(self, frames, temporal_ego_states, n_steps=6, want_logits=False):
         # post-finetune decode: final_conv -> forecast -> OccHead stay in h2 storage end to end on the split-fp16 path
         v0 = self.extract_voxel_feat_cl(frames, out_h2=self.if_post_finetune)      # (B,Z,Y,X,C)
         if not self.if_post_finetune:

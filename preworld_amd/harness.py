@@ -106,26 +106,39 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
     B, C = f0['sensor2keyego'].shape[0], vt.out_channels
     n = net.num_adj + 1
     use = frames[:n] if net.with_prev else frames[:1]
-    # same storage as the single-process path: in the 'h2' precision the exchanged features are the split-fp16 buffers
-    # themselves (same shape and byte count as fp32), so every rank continues with exactly the single-process bits
+    # The exchanged features are fp32 values: an h2 buffer is only meaningful together with the exponent of its range slot,
+    # which every rank calibrates for itself (ops.RangeCtx).  On the split-fp16 path a frame is lifted in h2, expanded
+    # (hi + lo) * 2^e -- exact -- for the all_gather, and the concatenated buffer is split again under ONE exponent derived
+    # from its own maximum, which is the same number on every rank.
     h2 = precision() == 'h2' and C % 32 == 0
+    from .modules import as_f32
 
     def lift(fr):
-        y = net.lift_frame_cl(out_h2=h2, **fr)
-        return y.buf if h2 else y
-    lifted = parallel.lift_frames_sharded(use, lift, (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device,
-                                          group, via_host=gather_on_host)
-    x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                       # [adjacent ..., key] (bevdet_occ.py:266)
-    if len(lifted) < n:
-        x = torch.cat([x.new_zeros(x.shape[:-1] + ((n - len(lifted)) * C,)), x], dim=-1)
-    # final_conv -> forecast -> OccHead keep h2 storage like simple_test_from_lift (post-finetune decode)
-    v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.H2(x) if h2 else x, out_h2=h2), out_h2=h2)
+        return as_f32(net.lift_frame_cl(out_h2=h2, **fr))
 
     def decode(f):
         occ = net.occupancy_head.decode_cl(f, transposed=True)
         occ = occ.permute(0, 3, 2, 1)[0].contiguous()                          # batch element 0, (X,Y,Z) (:306)
         return occ.cpu() if gather_on_host else occ
 
-    grids = parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k, out_h2=h2)[0][k - 1], decode, n_steps + 1,
-                                           group)
+    def one_pass():
+        lifted = parallel.lift_frames_sharded(use, lift, (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device,
+                                              group, via_host=gather_on_host)
+        x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                   # [adjacent ..., key] (bevdet_occ.py:266)
+        if len(lifted) < n:
+            x = torch.cat([x.new_zeros(x.shape[:-1] + ((n - len(lifted)) * C,)), x], dim=-1)
+        # final_conv -> forecast -> OccHead keep h2 storage like simple_test_from_lift (post-finetune decode)
+        v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.f32_to_h2(x) if h2 else x, out_h2=h2), out_h2=h2)
+        return parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k, out_h2=h2)[0][k - 1], decode,
+                                              n_steps + 1, group)
+
+    if h2:
+        # ranks own different tensors, so they must agree on whether another calibration pass runs (the passes contain
+        # collectives): one tiny MIN all-reduce per pass
+        ctx = net.__dict__.get('_range_ctx_sharded')
+        if ctx is None or ctx.device != f0['depth'].device:
+            ctx = net.__dict__['_range_ctx_sharded'] = ops.RangeCtx(f0['depth'].device)
+        grids = ops.ranged(one_pass, ctx, agree=lambda ok: parallel.all_agree(ok, f0['depth'].device, group, gather_on_host))
+    else:
+        grids = one_pass()
     return {'semantic_occ_%ds' % k: [g] for k, g in enumerate(grids)}

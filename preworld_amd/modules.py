@@ -147,6 +147,8 @@ class LSSViewTransformer(nn.Module):
                                       (B, size[2], size[1], size[0], self.out_channels), st, ln)
         else:
             out = ops.bev_pool_dense(dep, feat, vs, out_h2=getattr(self, '_pool_h2', False))
+            if isinstance(out, ops.H2):                   # pool_cl re-wraps the buffer under this range slot
+                self._pool_rng, out = out.rng, out.buf
             bev = out.view(B, size[2], size[1], size[0], self.out_channels).permute(0, 4, 1, 2, 3)
         if self.collapse_z:
             bev = torch.cat(bev.unbind(dim=2), 1)
@@ -169,7 +171,7 @@ class LSSViewTransformer(nn.Module):
             self.collapse_z = keep
             h2, self._pool_h2 = self._pool_h2, False
         x = to_channels_last_3d(bev)
-        return ops.H2(x) if h2 else x
+        return ops.H2(x, self.__dict__.pop('_pool_rng', None)) if h2 else x
 
     def forward(self, input):
         x = input[0]
@@ -441,11 +443,11 @@ class BasicBlock3D(nn.Module):
         return out
 
     def _forward_cl_h2(self, x, out, out_h2):
-        """split-fp16 path: conv1 + downsample as ONE pass over x (N = 2 x Cout), everything between the convs in h2"""
+        """split-fp16 path: conv1 + downsample as ONE pass over x (N = 2 x Cout), everything between the convs in h2.  An
+        ops.H2 destination keeps its range slot: the identity branch and the block output are both written under it."""
         c1, c2, ds = self.conv1, self.conv2, self.downsample
         c1._check_eval()
         x = as_h2(x)
-        dst = out.buf if isinstance(out, ops.H2) else out
         if ds is not None:
             params = [c1.conv.weight, c1.bn.weight, c1.bn.bias, c1.bn.running_mean, c1.bn.running_var,
                       ds.conv.weight, ds.bn.weight, ds.bn.bias, ds.bn.running_mean, ds.bn.running_var]
@@ -459,21 +461,19 @@ class BasicBlock3D(nn.Module):
                         torch.cat([b1, bd]).contiguous())
             wpk, sc, bi = self._h2cache.get(params, build)
             y, identity = ops.conv3d_h2(x, wpk, sc, bi, cout0=c1.out_channels, cout1=ds.out_channels, relu0=True, relu1=False,
-                                        out1=dst, ksize=3, stride=c1.stride, out_h2=(True, out_h2))
+                                        out1=out, ksize=3, stride=c1.stride, out_h2=(True, out_h2))
         else:
             w1, s1, b1 = c1.folded_h2()
             y = ops.conv3d_h2(x, w1, s1, b1, cout0=c1.out_channels, relu0=True, ksize=3, stride=c1.stride, out_h2=(True, True))
             w2, s2, b2 = c2.folded_h2()
-            if dst is None:                                   # identity = the block input itself, result in a new buffer
+            if out is None:                                   # identity = the block input itself, result in a new buffer
                 return ops.conv3d_h2(y, w2, s2, b2, residual=x, cout0=c2.out_channels, relu0=True, out_h2=(out_h2, out_h2))
-            if out_h2:
-                dst.copy_(x.buf)
+            if out_h2:                                        # re-express x under the destination's exponent
+                identity = ops.f32_to_h2(ops.h2_to_f32(x), out=out)
             else:
-                ops.h2_to_f32(x, out=dst)
-            identity = ops.H2(dst) if out_h2 else dst
+                identity = ops.h2_to_f32(x, out=out.buf if isinstance(out, ops.H2) else out)
         w2, s2, b2 = c2.folded_h2()
-        idb = identity.buf if isinstance(identity, ops.H2) else identity
-        return ops.conv3d_h2(y, w2, s2, b2, residual=identity, cout0=c2.out_channels, relu0=True, out0=idb,
+        return ops.conv3d_h2(y, w2, s2, b2, residual=identity, cout0=c2.out_channels, relu0=True, out0=identity,
                              out_h2=(out_h2, out_h2))
 
     def _forward_cl_f32(self, x, out=None):
@@ -701,12 +701,13 @@ class OccHead(nn.Module):
                 packs.append((wpk, (s0 * inv).contiguous()))
             tailpk, inv2 = ops.pack_occ_tail_h2(c1.weight.reshape(c1.weight.shape[0], -1).float(), s1, b1,
                                                 c2.weight.reshape(c2.weight.shape[0], -1).float())
-            return packs, b0.contiguous(), tailpk, inv2
+            bounds = ops.occ_head_bounds(c0.weight, s0, b0, c1.weight.reshape(c1.weight.shape[0], -1), s1, b1)
+            return packs, b0.contiguous(), tailpk, inv2, bounds
         if not hasattr(self, '_cache_h2'):
             self._cache_h2 = _PackedCache()
-        packs, b0, tailpk, inv2 = self._cache_h2.get(params, build)
+        packs, b0, tailpk, inv2, bounds = self._cache_h2.get(params, build)
         wpk, s0 = packs[1 if transposed else 0]
-        return wpk, s0, b0, tailpk, inv2
+        return wpk, s0, b0, tailpk, inv2, bounds
 
     def decode_cl(self, x_cl, want_logits=False, transposed=False, want_geo=False):
         """x_cl (B,D,H,W,C) channels-last (fp32 tensor or ops.H2) -> uint8 argmax (B,D,H,W) [, logits (B,D,H,W,18)].
@@ -721,8 +722,8 @@ class OccHead(nn.Module):
         is_h2 = isinstance(x_cl, ops.H2)
         if C == 32 and (is_h2 or precision() == 'h2') and os.environ.get('PW_OCC_H2', '1') != '0':
             # split-fp16 kernel (k_occ_head_h2); an fp32 input is converted first (30 us at 16x200x200, still ahead)
-            wpk, s0, b0, tailpk, inv2 = self._folded_h2(transposed)
-            return ops.occ_head_h2(x_cl if is_h2 else ops.f32_to_h2(x_cl.contiguous()), wpk, s0, b0, tailpk, inv2,
+            wpk, s0, b0, tailpk, inv2, bounds = self._folded_h2(transposed)
+            return ops.occ_head_h2(x_cl if is_h2 else ops.f32_to_h2(x_cl.contiguous()), wpk, s0, b0, tailpk, inv2, bounds,
                                    want_logits=want_logits, want_geo=want_geo, empty_idx=self.empty_idx)
         if is_h2:
             x_cl = ops.h2_to_f32(x_cl)

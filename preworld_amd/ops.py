@@ -12,6 +12,7 @@ from . import _lib
 
 _i32 = torch.int32
 _f32 = torch.float32
+RNG_ROW = 1056       # PW_RNG_ROW of include/preworld_hip.h: int32 per range slot
 
 
 def _stream():
@@ -137,19 +138,22 @@ def lss_ranks(seg_start, order, n_voxels, D, HW):
 
 def bev_pool_dense(depth, feat, vs, out=None, out_h2=False):
     """Write-once dense pooling.  depth (B,N,D,H,W) flat, feat (B,N,H,W,C), vs = VoxelSort built
-    with aux_div=D*H*W, aux_mod=H*W  ->  (n_voxels, C) fp32, or the same sums in split-fp16 storage (out_h2=True:
-    returns the float32-typed buffer; wrap it in ops.H2)."""
+    with aux_div=D*H*W, aux_mod=H*W  ->  (n_voxels, C) fp32, or (out_h2=True) the same sums as an ops.H2 under a new
+    range slot (or under `out`'s when an ops.H2 is passed)."""
     C = feat.shape[-1]
     if vs.order_feat is None:
         raise _lib.PreworldHipError('bev_pool_dense needs a VoxelSort built with aux_div/aux_mod')
     if out is None:
         out = torch.empty(vs.n_keys, C, device=feat.device, dtype=_f32)
+    orng = None
+    if out_h2:
+        out, orng = _out_h2(out, feat.device)
     _lib.call('pw_bev_pool_dense', _chk(depth, _f32, 'depth'), _chk(feat, _f32, 'feat'),
               _chk(vs.seg_start, _i32, 'seg_start'), _chk(vs.order, _i32, 'order'),
               _chk(vs.order_feat, _i32, 'order_feat'), vs.n_keys, C,
               LONG_SEGMENT if vs.long_list is not None else 0, _p(vs.long_list), _p(vs.n_long),
-              _chk(out, _f32, 'out'), int(bool(out_h2)), _stream())
-    return out
+              _chk(out, _f32, 'out'), int(bool(out_h2)), _p(orng), _stream())
+    return H2(out, orng) if out_h2 else out
 
 
 # ------------------------------------------------------------------------------ bev_pool_v2
@@ -382,16 +386,157 @@ def conv3d_wino(x, uwpk, scale=None, bias=None, residual=None, cout0=None, cout1
 
 
 # ------------------------------------------------------------------------------ split-fp16 ("h2") path
+class RangeCtx:
+    """Activation ranges of the split-fp16 path (include/preworld_hip.h "RANGE SLOTS").
+
+    fp16 has 5 exponent bits, the reference's fp32 activations 8 (backbones/resnet.py:88-123 is plain Conv3d): an h2 tensor
+    stores value / 2^e with a per-tensor exponent e kept in a device-resident *range slot* (int32[2] = [e, bit pattern of the
+    largest |value| written]).  A RangeCtx owns a table of slots.  Producers take the next slot in CALL ORDER
+    (`new_slot`), so the i-th h2 tensor of a deterministic forward pass always maps to slot i and its exponent persists from
+    one pass to the next; kernels read the exponents from the table itself, so a captured hipGraph follows later updates.
+
+    `ranged(fn)` is the calibration loop: run the pass, read the recorded maxima back (one small D2H copy), move every
+    exponent whose tensor left the comfortable window, and repeat until nothing moves -- typically two passes on a cold
+    table, one afterwards.  `check()` is the cheap steady-state test (hard window) a graph replay is followed by."""
+    TARGET = 12          # ideal exponent puts the largest magnitude in [2^12, 2^13) stored units
+    SETTLE_LO, SETTLE_HI = 8, 15      # calibration accepts a stored maximum in [2^8, 2^15)
+    HARD_LO, HARD_HI = 6, 65504.0     # steady state accepts [2^6, 65504]
+
+    def __init__(self, device, n_slots=128):
+        # a slot = RNG_ROW int32: [exponent, folded maximum, ..., 1 024 partial maxima] (include/preworld_hip.h "RANGE SLOTS")
+        self.tab = torch.zeros(n_slots, RNG_ROW, dtype=_i32, device=device)
+        self.compact = torch.zeros(n_slots, 2, dtype=_i32, device=device)      # [exponent, maximum] pairs, written by fold()
+        self.n = 0
+        self.device = torch.device(device)
+
+    def begin(self):
+        """start of a pass: slots are handed out from 0 again, recorded maxima are cleared (a kernel, capturable)"""
+        self.n = 0
+        self.tab[:, 1].zero_()
+
+    def fold(self):
+        """end of a pass: fold the partial maxima the kernels raised into the slots and refresh `compact` (one small launch)"""
+        _lib.call('pw_rng_fold', _p(self.tab), self.tab.shape[0], _p(self.compact), _stream())
+
+    def new_slot(self):
+        if self.n >= self.tab.shape[0]:
+            raise _lib.PreworldHipError('RangeCtx: more than %d h2 tensors in one pass' % self.tab.shape[0])
+        self.n += 1
+        return self.tab[self.n - 1]
+
+    @staticmethod
+    def ideal_exp(amax):
+        """the exponent k_f32_to_h2 / rng_ideal_exp (pw_h2.h) derive from a maximum: largest magnitude in [2^12, 2^13)"""
+        import math
+        if not (amax > 0.0) or math.isinf(amax) or math.isnan(amax):
+            return 0
+        return max(-100, min(100, math.frexp(amax)[1] - 1 - RangeCtx.TARGET))
+
+    def _read(self, host=None):
+        import numpy as np
+        t = (self.compact.cpu() if host is None else host).numpy()
+        return t[:, 0].astype(np.int64), t[:, 1].astype(np.int32).view(np.float32).astype(np.float64)
+
+    def check(self, host=None):
+        """indices of the slots whose recorded maximum left the hard window under the exponent it was written with, as of the
+        last fold() (host: an already copied `compact` table, e.g. the one a graph replay delivers)"""
+        import numpy as np
+        e, amax = self._read(host)
+        with np.errstate(over='ignore', invalid='ignore'):
+            stored = amax * np.exp2(-e.astype(np.float64))
+        bad = (amax != 0) & ~((stored >= 2.0 ** self.HARD_LO) & (stored <= self.HARD_HI))
+        return np.nonzero(bad)[0].tolist()
+
+    def settle(self):
+        """after a pass: move the exponents of tensors outside the calibration window; True when nothing had to move"""
+        import numpy as np
+        self.fold()
+        e, amax = self._read()
+        new = e.copy()
+        for i in range(len(e)):
+            a = float(amax[i])
+            if a == 0.0:
+                continue
+            if not np.isfinite(a):                    # overflowed under this exponent (or fed by a tensor that did)
+                new[i] = min(int(e[i]) + 12, 100)
+                continue
+            ideal = self.ideal_exp(a)
+            if not (ideal + self.TARGET - self.SETTLE_HI < e[i] <= ideal + self.TARGET - self.SETTLE_LO):
+                new[i] = ideal
+        if (new == e).all():
+            return True
+        self.tab[:len(e), 0] = torch.from_numpy(new.astype(np.int32)).to(self.device)
+        return False
+
+
+_range_stack = []
+
+
+class use_range:
+    """`with ops.use_range(ctx):` h2 producers called inside take their slots from ctx"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        _range_stack.append(self.ctx)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _range_stack.pop()
+
+
+def current_range():
+    return _range_stack[-1] if _range_stack else None
+
+
+def new_slot(device):
+    """range slot for a new h2 tensor: the active RangeCtx's next one, else a private slot with exponent 0 (the stored units
+    are the values themselves -- fine for O(1) data; wrap the computation in ops.ranged() for anything else)"""
+    ctx = current_range()
+    return ctx.new_slot() if ctx is not None else torch.zeros(RNG_ROW, dtype=_i32, device=device)
+
+
+def slot_state(slot):
+    """(exponent, largest recorded |value|) of one range slot as host numbers (folds its partial maxima first; syncs)"""
+    _lib.call('pw_rng_fold', _p(slot), 1, None, _stream())
+    e, bits = slot[:2].tolist()
+    import struct
+    return e, struct.unpack('f', struct.pack('i', bits))[0]
+
+
+def ranged(fn, ctx, max_iter=12, agree=None):
+    """Run fn() under ctx until its activation ranges have settled (RangeCtx.settle) and return the last result.  Under
+    stream capture fn() runs once with the exponents as they are (calibrate before capturing; `check()` after replays).
+    agree(ok) -> bool: multi-process passes (fn contains collectives) pass a function that ANDs `ok` over the ranks."""
+    with use_range(ctx):
+        for _ in range(max_iter):
+            ctx.begin()
+            out = fn()
+            if torch.cuda.is_current_stream_capturing():
+                ctx.fold()
+                return out
+            ok = ctx.settle()
+            if agree(ok) if agree is not None else ok:
+                return out
+    raise _lib.PreworldHipError('activation ranges did not settle in %d passes (non-finite inputs or weights?): slots %s'
+                                % (max_iter, ctx.check()))
+
+
 class H2:
     """A channels-last activation tensor in h2 storage (include/preworld_hip.h): `.buf` is a float32-typed torch
-    tensor of the logical shape (.., C), C % 32 == 0, whose bytes are the split-fp16 encoding.  Channel slices at
-    multiples of 32 and leading-axis slices of `.buf` are again valid h2 tensors."""
-    __slots__ = ('buf',)
+    tensor of the logical shape (.., C), C % 32 == 0, whose bytes are the split-fp16 encoding of value / 2^e; `.rng` is the
+    range slot (int32[2] device tensor: [e, recorded maximum]) the tensor was written under, or None for e = 0.  Channel
+    slices at multiples of 32 and leading-axis slices of `.buf` are again valid h2 tensors under the same slot."""
+    __slots__ = ('buf', 'rng')
 
-    def __init__(self, buf):
+    def __init__(self, buf, rng=None):
         if buf.dtype != _f32 or buf.shape[-1] % 32:
             raise _lib.PreworldHipError('h2 tensors are float32-typed with a multiple of 32 channels')
+        if rng is not None and (rng.dtype != _i32 or rng.numel() != RNG_ROW or not rng.is_contiguous() or rng.device != buf.device):
+            raise _lib.PreworldHipError('h2 range slot must be a contiguous int32[%d] tensor on the same device' % RNG_ROW)
         self.buf = buf
+        self.rng = rng
 
     @property
     def shape(self):
@@ -402,10 +547,22 @@ class H2:
         return self.buf.device
 
     def __getitem__(self, idx):
-        return H2(self.buf[idx])
+        return H2(self.buf[idx], self.rng)
 
     def view(self, *shape):
-        return H2(self.buf.view(*shape))
+        return H2(self.buf.view(*shape), self.rng)
+
+
+def _rng(h):
+    """ctypes pointer of an H2's range slot (NULL without one)"""
+    return _p(h.rng) if isinstance(h, H2) and h.rng is not None else None
+
+
+def _out_h2(o, device):
+    """(buffer, slot) of an h2 destination: an ops.H2 keeps its slot, a raw buffer / a new tensor gets a new one"""
+    if isinstance(o, H2):
+        return o.buf, (o.rng if o.rng is not None else None)
+    return o, new_slot(device)
 
 
 def _rows(t, name):
@@ -433,22 +590,29 @@ def _rows(t, name):
 
 
 def f32_to_h2(x, out=None):
-    """fp32 channels-last (.., C) -> H2 of the same shape (pw_f32_to_h2)."""
+    """fp32 channels-last (.., C) -> H2 of the same shape (pw_f32_to_h2).  out: None (new tensor under a private slot whose
+    exponent is derived from max|x| on the device: exact for any scale), an ops.H2 (written under ITS slot's exponent) or a
+    raw float32 buffer (same, new private slot)."""
     n, C, ldx = _rows(x, 'x')
-    if out is None:
-        out = torch.empty(x.shape, device=x.device, dtype=_f32)
-    _, _, ldy = _rows(out, 'out')
-    _lib.call('pw_f32_to_h2', _p(x), _p(out), n, C, ldx, ldy, _stream())
-    return H2(out)
+    if isinstance(out, H2) and out.rng is not None:
+        buf, slot, auto = out.buf, out.rng, 0
+    else:
+        buf = out.buf if isinstance(out, H2) else out
+        if buf is None:
+            buf = torch.empty(x.shape, device=x.device, dtype=_f32)
+        slot, auto = torch.zeros(RNG_ROW, dtype=_i32, device=x.device), 1
+    _, _, ldy = _rows(buf, 'out')
+    _lib.call('pw_f32_to_h2', _p(x), _p(buf), n, C, ldx, ldy, _p(slot), auto, _stream())
+    return H2(buf, slot)
 
 
 def h2_to_f32(x, out=None):
-    """H2 -> fp32 channels-last tensor of the same shape (pw_h2_to_f32): hi + lo, exact."""
+    """H2 -> fp32 channels-last tensor of the same shape (pw_h2_to_f32): (hi + lo) * 2^e, exact."""
     n, C, ldx = _rows(x.buf, 'x')
     if out is None:
         out = torch.empty(x.shape, device=x.buf.device, dtype=_f32)
     _, _, ldy = _rows(out, 'out')
-    _lib.call('pw_h2_to_f32', _p(x.buf), _p(out), n, C, ldx, ldy, _stream())
+    _lib.call('pw_h2_to_f32', _p(x.buf), _p(out), n, C, ldx, ldy, _rng(x), _stream())
     return out
 
 
@@ -491,7 +655,8 @@ def conv3d_h2(x, wpk, scale, bias=None, residual=None, cout0=None, cout1=0, relu
     """3x3x3 stride-1 pad-1 conv on the fp16 matrix cores with split-fp16 operands (pw_conv3d_h2).
     x: H2 (B,D,H,W,Cin); wpk from pack_conv_weight_h2; scale (cout_total,) MUST already contain the packer's
     inv_scale (scale = bn_scale * inv_scale).  residual: H2 or fp32 tensor with y0's layout (may be out0 itself).
-    out_h2: storage of (y0, y1): True -> H2, False -> fp32 tensor.  Returns y0 [, y1]."""
+    out_h2: storage of (y0, y1): True -> H2, False -> fp32 tensor.  out0 / out1: destinations -- an ops.H2 is written under
+    its own range slot, a raw buffer (or None) in h2 format gets a new slot (ops.new_slot).  Returns y0 [, y1]."""
     if not isinstance(x, H2):
         raise _lib.PreworldHipError('conv3d_h2 takes an ops.H2 input (ops.f32_to_h2)')
     B, D, H, W, Cin = x.shape
@@ -506,15 +671,17 @@ def conv3d_h2(x, wpk, scale, bias=None, residual=None, cout0=None, cout1=0, relu
         cout0 = cout_total
     fm0, fm1 = int(bool(out_h2[0])), int(bool(out_h2[1]))
 
-    def _dst(o, c):
+    def _dst(o, c, fm):
         if o is None:
-            return torch.empty(B, D, H, W, c, device=x.buf.device, dtype=_f32)
-        return o.buf if isinstance(o, H2) else o
-    y0 = _dst(out0, cout0)
+            o = torch.empty(B, D, H, W, c, device=x.buf.device, dtype=_f32)
+        if not fm:
+            return (o.buf if isinstance(o, H2) else o), None
+        return _out_h2(o, x.buf.device)
+    y0, rng0 = _dst(out0, cout0, fm0)
     ld0 = _row_stride(y0, (B, D, H, W, cout0), 'y0')
-    y1, ld1 = None, 0
+    y1, ld1, rng1 = None, 0, None
     if cout1:
-        y1 = _dst(out1, cout1)
+        y1, rng1 = _dst(out1, cout1, fm1)
         ld1 = _row_stride(y1, (B, D, H, W, cout1), 'y1')
     res, fmr = None, 0
     if residual is not None:
@@ -530,10 +697,11 @@ def conv3d_h2(x, wpk, scale, bias=None, residual=None, cout0=None, cout1=0, relu
     if not xb.is_contiguous():
         raise _lib.PreworldHipError('x must be dense')
     _lib.call('pw_conv3d_h2', _p(xb), _chk(wpk, _f32, 'wpk'), _p(scale), _p(bias), _p(res), _p(y0), _p(y1), B, Din, Hin, Win,
-              Cin, cout_total, cout0, cout1, ld0, ld1, ksize, stride, int(relu0), int(relu1), algo, fm0, fm1, fmr, _stream())
-    r0 = H2(y0) if fm0 else y0
+              Cin, cout_total, cout0, cout1, ld0, ld1, ksize, stride, int(relu0), int(relu1), algo, fm0, fm1, fmr,
+              _rng(x), _rng(residual), _p(rng0), _p(rng1), _stream())
+    r0 = H2(y0, rng0) if fm0 else y0
     if cout1:
-        return r0, (H2(y1) if fm1 else y1)
+        return r0, (H2(y1, rng1) if fm1 else y1)
     return r0
 
 
@@ -545,11 +713,14 @@ def fpn3d_fuse(x8, wpk8, y16, y32, scale, bias, relu=True, out=None, out_h2=Fals
     B, D, H, W, C8 = xb.shape
     if out is None:
         out = torch.empty(B, D, H, W, 32, device=xb.device, dtype=_f32)
+    orng = None
+    if out_h2:
+        out, orng = _out_h2(out, xb.device)
     _lib.call('pw_fpn3d_fuse', _chk(xb, _f32, 'x8'), _chk(wpk8, _f32, 'wpk8'), _chk(y16, _f32, 'y16'),
               _chk(y32, _f32, 'y32'), _p(scale), _p(bias), _chk(out, _f32, 'out'), B, D, H, W, C8,
               y16.shape[1], y16.shape[2], y16.shape[3], y32.shape[1], y32.shape[2], y32.shape[3],
-              int(relu), int(x_h2), int(bool(out_h2)), _stream())
-    return H2(out) if out_h2 else out
+              int(relu), int(x_h2), int(bool(out_h2)), _rng(x8), _p(orng), _stream())
+    return H2(out, orng) if out_h2 else out
 
 
 def pack_conv_weight16(w):
@@ -599,6 +770,14 @@ def pack_occ_weight_h2(w):
     return wpk, (1.0 / S).float()
 
 
+def occ_head_bounds(w0, s0, b0, w1, s1, b1):
+    """a-priori magnitude bounds of OccHead's two hidden layers for pw_occ_head_h2 (include/preworld_hip.h): w0 (16,32,3,3,3) /
+    w1 (8,16) conv weights, s* / b* folded BN.  Returns host floats (mid_a, mid_b, hid_a, hid_b)."""
+    mid_a = float((s0.double().abs()[:w0.shape[0]] * w0.double().abs().flatten(1).sum(1)).max())
+    hid_a = float((s1.double().abs() * w1.double().abs().flatten(1).sum(1)).max())
+    return mid_a, float(b0.double().abs().max()), hid_a, float(b1.double().abs().max())
+
+
 def pack_occ_tail_h2(w1, s1, b1, w2):
     """The 16 -> 8 (+BN+ReLU) -> 18 tail of OccHead as operands of pw_occ_head_h2: w1 (8,16), s1 / b1 (8,) folded BN, w2 (18,8)
     -> (tailpk float32 (800,), inv2).  One power-of-two pre-scale per matrix (argmax must see one common scale)."""
@@ -623,9 +802,9 @@ def pack_occ_tail_h2(w1, s1, b1, w2):
     return torch.cat([pk, s1p, b1p]).contiguous(), 1.0 / S2
 
 
-def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, want_logits=False, occ=None, want_geo=False, empty_idx=17):
+def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, bounds, want_logits=False, occ=None, want_geo=False, empty_idx=17):
     """OccHead (occupancy_head.py:124-177) on the fp16 matrix cores: x = ops.H2 (B,D,H,W,32); wpk from pack_occ_weight_h2;
-    scale (16,) MUST already contain the packer's inv_scale; (tailpk, inv2) from pack_occ_tail_h2.
+    scale (16,) MUST already contain the packer's inv_scale; (tailpk, inv2) from pack_occ_tail_h2; bounds from occ_head_bounds.
     Returns like occ_head_fused."""
     if not isinstance(x, H2):
         raise _lib.PreworldHipError('occ_head_h2 takes an ops.H2 input (ops.f32_to_h2)')
@@ -638,7 +817,8 @@ def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, want_logits=False, occ=None, 
         raise _lib.PreworldHipError('occ_head_h2: tailpk (800,), scale / bias (16,) expected')
     _lib.call('pw_occ_head_h2', _chk(x.buf, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
               _chk(bias, _f32, 'bias'), _chk(tailpk, _f32, 'tailpk'), float(inv2), _p(occ), _p(logits), _p(geo),
-              int(empty_idx), B, D, H, W, Cin, 16, 8, 18, _stream())
+              int(empty_idx), B, D, H, W, Cin, 16, 8, 18, _rng(x), float(bounds[0]), float(bounds[1]), float(bounds[2]),
+              float(bounds[3]), _stream())
     out = (occ,) + ((logits,) if want_logits else ()) + ((geo,) if want_geo else ())
     return out if len(out) > 1 else occ
 
@@ -686,8 +866,9 @@ def _split_planes(w):
 
 
 def forecast_pack_h2(fusion_w1, fusion_w2):
-    """fusion_head.{0,2}.weight ([128][64], [32][128]) -> (w1p, w2p, inv1, inv2): split-fp16 MFMA A operands in the order
-    pw_forecast_steps_h2 documents (include/preworld_hip.h) and the inverses of their power-of-two pre-scales."""
+    """fusion_head.{0,2}.weight ([128][64], [32][128]) -> (w1p, w2p, inv1, inv2, w1_l1max): split-fp16 MFMA A operands in the
+    order pw_forecast_steps_h2 documents (include/preworld_hip.h), the inverses of their power-of-two pre-scales and the largest
+    row L1 norm of the voxel part of W1 (the kernel's a-priori bound on the hidden activations)."""
     import numpy as np
     dev = fusion_w1.device
     lane = np.arange(64)
@@ -706,24 +887,27 @@ def forecast_pack_h2(fusion_w1, fusion_w2):
     w1p = torch.stack([h1[idx1].view(4, 2, 64, 8), l1[idx1].view(4, 2, 64, 8)], dim=2)     # (t, kb, p, lane, e)
     w2p = torch.stack([h2_[idx2].view(4, 2, 64, 8), l2[idx2].view(4, 2, 64, 8)], dim=2)
     return (w1p.contiguous().view(torch.float32).contiguous(), w2p.contiguous().view(torch.float32).contiguous(),
-            1.0 / S1, 1.0 / S2)
+            1.0 / S1, 1.0 / S2, float(fusion_w1[:, :32].double().abs().sum(1).max()))
 
 
 def forecast_steps_h2(v0, n_samples, packed, c1p, fusion_b2, n_steps, states=None, out_h2=False):
     """forecast_steps on the fp16 matrix cores with split-fp16 operands; packed = forecast_pack_h2(...).
-    v0: fp32 tensor or ops.H2; out_h2=True returns the states as ONE ops.H2 of shape (n_steps, *v0.shape)."""
-    w1p, w2p, inv1, inv2 = packed
+    v0: fp32 tensor or ops.H2; out_h2=True returns the states as ONE ops.H2 of shape (n_steps, *v0.shape).  The recursion
+    runs in the units of the states' range slot (a new one, or `states.rng`) whatever the output format; with fp32 output
+    the slot is returned as the second value only when want_slot."""
+    w1p, w2p, inv1, inv2, l1 = packed
     v0_h2 = isinstance(v0, H2)
     vbuf = v0.buf if v0_h2 else v0
     n_total = vbuf.numel() // 32
     if states is None:
         states = torch.empty((n_steps,) + tuple(vbuf.shape), device=vbuf.device, dtype=_f32)
-    elif isinstance(states, H2):
-        states = states.buf
+    states, srng = _out_h2(states, vbuf.device)
+    if srng is None:
+        srng = new_slot(vbuf.device)
     _lib.call('pw_forecast_steps_h2', _chk(vbuf, _f32, 'v0'), n_total // n_samples, n_samples, _chk(w1p, _f32, 'w1p'),
               _chk(w2p, _f32, 'w2p'), float(inv1), float(inv2), _chk(c1p, _f32, 'c1p'), _chk(fusion_b2, _f32, 'fb2'),
-              n_steps, _chk(states, _f32, 'states'), int(v0_h2), int(bool(out_h2)), _stream())
-    return H2(states) if out_h2 else states
+              n_steps, _chk(states, _f32, 'states'), int(v0_h2), int(bool(out_h2)), _rng(v0), _p(srng), float(l1), _stream())
+    return H2(states, srng) if out_h2 else states
 
 
 def softplus(x):

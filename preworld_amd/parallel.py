@@ -23,6 +23,15 @@ import torch.distributed as dist
 ALWAYS_COLLECTIVE = False
 
 
+def all_agree(ok, device, group=None, via_host=False):
+    """True iff `ok` is true on every rank (one 4-byte MIN all-reduce; trivially `ok` without a process group)"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device='cpu' if via_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
 def owned_states(n_states, rank, world):
     """round-robin ownership: cheap states (few recursion steps) and expensive ones interleave"""
     return list(range(rank, n_states, world))

@@ -9,6 +9,8 @@ once the kernels themselves run in 10-1000 us."""
 import numpy as np
 import torch
 
+from . import ops
+
 
 def to_dev(a, dev='cuda:0'):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -29,17 +31,26 @@ class CapturedSample:
         self.host = self.host_keys = None
         self.frames = [{k: v.clone() for k, v in f.items()} for f in frames]
         self.ego = ego.clone()
+        # Activation ranges of the split-fp16 path (ops.RangeCtx): this sample's own table of per-tensor exponents.  The
+        # warm-up calibrates it (repeats the pass until every h2 tensor's maximum sits in the window); the captured kernels
+        # read the exponents from the table, clear and re-record the maxima on every replay, and the table travels to pinned
+        # host memory with the results: ranges_ok() is the per-replay check, recalibrate() the (rare) repair.
+        self.rctx = ops.RangeCtx(self.ego.device)
+        self.host_rng = torch.zeros(tuple(self.rctx.compact.shape), dtype=torch.int32, pin_memory=True)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():        # warm-up off the capture stream: fills the packed-weight
-            self._step()                                       # caches and sets the kernels' LDS attributes
+            ops.ranged(self._step, self.rctx)                  # caches, sets the kernels' LDS attributes, calibrates the ranges
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: a HIP call from another thread of the process (the RCCL watchdog of a multi-GPU run polls
         # events) must not invalidate this thread's capture
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'), torch.no_grad():
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'), torch.no_grad(), ops.use_range(self.rctx):
+            self.rctx.begin()
             self.out = self._step()
+            self.rctx.fold()
+            self.host_rng.copy_(self.rctx.compact, non_blocking=True)
 
     def _step(self):
         kw = dict(n_steps=self.n_steps) if hasattr(self.net, 'forecast_cl') else {}
@@ -57,6 +68,41 @@ class CapturedSample:
     def replay(self):
         self.graph.replay()
         return self.out
+
+    def eager(self):
+        """the same pass as a replay -- same static buffers, same exponent table, same slot order -- launched eagerly on the
+        current stream: results are bit-identical to replay() (all kernels are deterministic)"""
+        with torch.no_grad(), ops.use_range(self.rctx):
+            self.rctx.begin()
+            out = self._step()
+            self.rctx.fold()
+            return out
+
+    def ranges_ok(self):
+        """after the replay has completed (stream / device synchronised): did every h2 tensor of it stay inside the
+        representable window under the exponents it ran with?  False -> recalibrate() and replay that sample again."""
+        return not self.rctx.check(self.host_rng)
+
+    def recalibrate(self):
+        """re-derive the exponents from the inputs currently in the static buffers (eager passes; the graph keeps reading
+        the same table).  Waits for everything in flight first: a replay must not see the table change under it."""
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ops.ranged(self._step, self.rctx)
+        torch.cuda.synchronize()
+
+    def run_checked(self, frames, ego):
+        """run() + wait + range check, repaired and replayed once if the sample left the calibrated window"""
+        out = self.run(frames, ego)
+        torch.cuda.current_stream().synchronize()
+        if not self.ranges_ok():
+            self.recalibrate()
+            out = self.replay()
+            torch.cuda.current_stream().synchronize()
+            if not self.ranges_ok():
+                raise ops._lib.PreworldHipError('activation ranges still outside the window after recalibration: slots %s'
+                                                % self.rctx.check(self.host_rng))
+        return out
 
     def run(self, frames, ego):
         for dst, src in zip(self.frames, frames):

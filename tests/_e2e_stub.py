@@ -1,0 +1,104 @@
+"""Shared by tools/gen_golden.py (which runs the REFERENCE's detector classes in the development container) and
+tests/test_gpu_e2e_reference.py (which runs the drop-in detectors on the GPU): seeded `img_inputs`, and stand-ins for the image
+side -- the part north_star leaves on PyTorch and SURVEY 8a excludes from the hot path.  Both sides install the same stand-ins,
+so everything downstream of the DepthNet output (the frame loop, pose algebra, lift, pre_process, concat order, encoder, neck,
+final_conv, permutes, forecast recursion, heads, argmax, result keys) is the code under test.  No reference source here."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from preworld_amd import synth as S
+
+GRID = {'x': [-40, 40, 2.0], 'y': [-40, 40, 2.0], 'z': [-1, 5.4, 0.8], 'depth': [1.0, 45.0, 0.5]}
+INPUT_SIZE = (128, 352)
+N_CAMS = 2
+IN_CH = 16           # channels of the (stand-in) image-view feature map
+D, C = 88, 32
+TEST_THRESHOLD = 0.7  # density threshold of the attribute-MLP decode (8.5 in the configs; random weights never reach that)
+RUNS = [('p4d_ft', 'PreWorld4DTraj', True, True), ('p4d_ft_noprev', 'PreWorld4DTraj', True, False),
+        ('p4d_attr', 'PreWorld4DTraj', False, True), ('pw_ft', 'PreWorld', True, True), ('pw_attr', 'PreWorld', False, True)]
+
+
+def model_cfg(detector, if_post_finetune, with_prev=True):
+    """the `model = dict(...)` of configs/preworld/**.py at the reduced grid above (cf. harness.model_cfg)"""
+    from preworld_amd import harness
+    cfg = harness.model_cfg(GRID, with_prev=with_prev, if_post_finetune=if_post_finetune, detector=detector)
+    cfg['img_view_transformer'].update(input_size=INPUT_SIZE, in_channels=IN_CH)
+    cfg['use_focal_loss'] = False        # loss objects are not part of the inference path (mmdet registry, not in the tree)
+    cfg['test_threshold'] = TEST_THRESHOLD
+    return cfg
+
+
+def _pose(yaw, t):
+    m = np.eye(4)
+    c, s = np.cos(yaw), np.sin(yaw)
+    m[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    m[:3, 3] = t
+    return m
+
+
+def img_inputs(seed=0):
+    """the 7-tuple `img_inputs` the dataset pipeline delivers (datasets/pipelines/loading.py:1091-1123): imgs (B, N*T, 3, H, W)
+    camera-major / frame-minor, sensor2egos / ego2globals (B, T*N, 4, 4) frame-major, intrins, post_rots, post_trans, bda.
+    T = 3 frames (key, adjacent, extra stereo reference) with a moving ego; per-camera image augmentation; a BEV augmentation."""
+    rs = np.random.RandomState(1000 + seed)
+    T = 3
+    rig = S.synthetic_rig(6, dtype=np.float64)
+    cams = [1, 4][:N_CAMS]
+    s2e = np.stack([rig['sensor2ego'][0, cams]] * T, 0)                      # (T, N, 4, 4): same rig every frame
+    e2g = np.stack([np.stack([_pose(0.10 - 0.03 * t, [10.0 - 2.4 * t, 5.0 - 0.3 * t, 0.2])] * N_CAMS, 0) for t in range(T)], 0)
+    K = np.stack([rig['intrin'][0, cams]] * T, 0)
+    K[..., 0, 0] *= 0.25; K[..., 1, 1] *= 0.25; K[..., 0, 2] *= 0.25; K[..., 1, 2] *= 0.25     # a 128 x 352 image
+    pr = np.stack([np.stack([np.diag([0.9 + 0.05 * n, 0.9 + 0.05 * n, 1.0]) for n in range(N_CAMS)], 0)] * T, 0)
+    pt = np.stack([np.stack([np.array([3.0 * n, -20.0 + 2.0 * n, 0.0]) for n in range(N_CAMS)], 0)] * T, 0)
+    a = 0.05
+    bda = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]) * np.array([1.02, 1.02, 1.0])[None, :]
+    f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))       # noqa: E731
+    imgs = torch.from_numpy(rs.standard_normal((1, N_CAMS * T, 3) + INPUT_SIZE).astype(np.float32))
+    return (imgs, f32(s2e.reshape(1, T * N_CAMS, 4, 4)), f32(e2g.reshape(1, T * N_CAMS, 4, 4)),
+            f32(K.reshape(1, T * N_CAMS, 3, 3)), f32(pr.reshape(1, T * N_CAMS, 3, 3)), f32(pt.reshape(1, T * N_CAMS, 3)),
+            f32(bda[None]))
+
+
+def ego_states(seed=0):
+    """kwargs['temporal_ego_states'] as the detectors index it: [0][0] is the (B, 1, 21) tensor (preworld_temporal_traj.py:228,259)"""
+    return [[torch.from_numpy(S.ego_state(40 + seed))]]
+
+
+class SeededDepthNet(nn.Module):
+    """stands in for view_transformer.DepthNet: call k returns a seeded (B*N, D + C, H, W) tensor (depth logits + context) and
+    records the `mlp_input` it was handed"""
+
+    def __init__(self, seed=0):
+        super().__init__()
+        self.seed, self.k, self.mlp_inputs = seed, 0, []
+
+    def reset(self):
+        self.k, self.mlp_inputs = 0, []
+
+    def forward(self, x, mlp_input, stereo_metas=None):
+        rs = np.random.RandomState(2000 + 10 * self.seed + self.k)
+        self.k += 1
+        self.mlp_inputs.append(mlp_input.detach().cpu().clone())
+        H, W = INPUT_SIZE[0] // 16, INPUT_SIZE[1] // 16
+        out = rs.standard_normal((x.shape[0], D + C, H, W)).astype(np.float32)
+        out[:, :D] *= 2.0
+        return torch.from_numpy(out).to(x.device)
+
+
+def install_image_side(model, seed=0):
+    """replace the image side of a detector (reference class or drop-in) by the stand-ins; returns the SeededDepthNet"""
+    H, W = INPUT_SIZE[0] // 16, INPUT_SIZE[1] // 16
+
+    def image_encoder(img, stereo=False):
+        B, N = img.shape[:2]
+        return img.new_zeros(B, N, IN_CH, H, W), img.new_zeros(B * N, 8, 4 * H, 4 * W)
+
+    def extract_stereo_ref_feat(x):
+        B, N = x.shape[:2]
+        return x.new_zeros(B * N, 8, 4 * H, 4 * W)
+    model.image_encoder = image_encoder
+    model.extract_stereo_ref_feat = extract_stereo_ref_feat
+    dn = SeededDepthNet(seed)
+    model.img_view_transformer.depth_net = dn
+    return dn

@@ -83,23 +83,33 @@ def test_geo_occ_comes_from_the_same_kernel():
 
 
 def test_captured_sample_replays_like_eager():
-    """pipeline.CapturedSample: a hipGraph replay with new inputs copied into the static buffers gives
-    exactly the eager results (all kernels are deterministic)."""
+    """pipeline.CapturedSample: a hipGraph replay with new inputs copied into the static buffers gives exactly the results of
+    the same pass launched eagerly under the runner's activation-range table (all kernels are deterministic; `cap.eager()`),
+    and the detector's own eager entry point -- which calibrates its own table, so a tensor's exponent may differ by a few
+    units -- agrees up to a handful of exact ties."""
     from preworld_amd.pipeline import CapturedSample
     sd = S.synth_state_dict(0)
     net = harness.build_model(harness.model_cfg(GC), sd, DEV)
     f1, e1 = harness.lifted_frames(1, 1, DEV), torch.from_numpy(S.ego_state(1)).to(DEV)
     f2, e2 = harness.lifted_frames(2, 1, DEV), torch.from_numpy(S.ego_state(2)).to(DEV)
     cap = CapturedSample(net, f1, e1, n_steps=6)
+
+    def grids(res):
+        return {k: v[0].clone() for k, v in res.items() if k.startswith('semantic_occ')}
     with torch.no_grad():
-        want2 = {k: v[0].clone() for k, v in net.simple_test_from_lift(f2, e2, n_steps=6).items() if k.startswith('semantic_occ')}
-        want1 = {k: v[0].clone() for k, v in net.simple_test_from_lift(f1, e1, n_steps=6).items() if k.startswith('semantic_occ')}
-    got2 = {k: v[0].clone() for k, v in cap.run(f2, e2).items() if k.startswith('semantic_occ')}
-    got1 = {k: v[0].clone() for k, v in cap.run(f1, e1).items() if k.startswith('semantic_occ')}
+        own2 = grids(net.simple_test_from_lift(f2, e2, n_steps=6))
+        own1 = grids(net.simple_test_from_lift(f1, e1, n_steps=6))
+    got2 = grids(cap.run(f2, e2))
+    want2 = grids(cap.eager())
+    got1 = grids(cap.run(f1, e1))
+    want1 = grids(cap.eager())
+    torch.cuda.synchronize()
+    assert cap.ranges_ok()
     assert len(got1) == 7
     for k in want1:
         assert torch.equal(got1[k], want1[k]), k
         assert torch.equal(got2[k], want2[k]), k
+        assert int((got1[k] != own1[k]).sum()) <= 8 and int((got2[k] != own2[k]).sum()) <= 8, k
     assert any(not torch.equal(got1[k], got2[k]) for k in got1)
 
 

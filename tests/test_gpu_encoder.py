@@ -408,7 +408,7 @@ def test_occ_head_h2_matches_direct_and_oracle(shape):
     occ_d, lg_d, geo_d = ops.occ_head_fused(x, ops.pack_conv_weight16(w0), ops._pad32(s0, 1.0), ops._pad32(b0, 0.0), w1, s1, b1,
                                             w2, want_logits=True, want_geo=True)
     wpk, inv = ops.pack_occ_weight_h2(w0)
-    hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_h2(w1, s1, b1, w2)
+    hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_h2(w1, s1, b1, w2) + (ops.occ_head_bounds(w0, s0, b0, w1, s1, b1),)
     xh = ops.f32_to_h2(x)
     occ_h, lg_h, geo_h = ops.occ_head_h2(xh, wpk, *hargs, want_logits=True, want_geo=True)
     from _parity import check_argmax, check_close
@@ -567,21 +567,33 @@ def test_softplus_accuracy():
 
 # ----------------------------------------------------------------------------- split-fp16 ("h2") path
 def test_h2_round_trip_and_slices():
-    """fp32 -> h2 -> fp32 is hi + lo: exact to 2^-22 relative (2^-25 absolute below 0.125), saturating at 65504; works on
-    channel slices of wider buffers."""
+    """fp32 -> h2 -> fp32 is (hi + lo) * 2^e with e derived from the tensor's largest magnitude (pw_f32_to_h2 auto_exp): exact
+    to 2^-22 relative for everything within 2^-15 of that maximum, 2^-38 of it absolute below -- at ANY scale (1e9 here; the
+    round-2 format saturated at 65504); works on channel slices of wider buffers and under an explicit range slot."""
     rs = np.random.RandomState(5)
     x = (rs.standard_normal((2, 3, 5, 7, 64)) * np.exp(rs.uniform(-12, 6, (2, 3, 5, 7, 64)))).astype(np.float32)
     x[0, 0, 0, 0, :4] = [70000.0, -1e9, 0.0, 65504.0]
     xt = T(x)
-    back = ops.h2_to_f32(ops.f32_to_h2(xt)).cpu().numpy()
-    want = np.clip(x, -65504, 65504)
-    err = np.abs(back - want)
-    assert (err <= np.maximum(np.abs(want) * 2.0 ** -21, 2.0 ** -24)).all(), float((err / np.maximum(np.abs(want), 1e-30)).max())
+    h0 = ops.f32_to_h2(xt)
+    back = ops.h2_to_f32(h0).cpu().numpy()
+    amax = float(np.abs(x).max())
+    assert ops.slot_state(h0.rng) == (ops.RangeCtx.ideal_exp(amax), amax)
+    err = np.abs(back.astype(np.float64) - x)
+    assert (err <= np.maximum(np.abs(x) * 2.0 ** -21, amax * 2.0 ** -37)).all(), float((err / np.maximum(np.abs(x), 1e-30)).max())
     buf = torch.zeros(2, 3, 5, 7, 96, device=DEV)
     h = ops.f32_to_h2(xt[..., 32:64], out=buf[..., 64:96])
-    np.testing.assert_array_equal(ops.h2_to_f32(h).cpu().numpy(), back[..., 32:64])
+    sub = ops.h2_to_f32(h).cpu().numpy()
+    a2 = float(np.abs(x[..., 32:64]).max())
+    assert (np.abs(sub.astype(np.float64) - x[..., 32:64]) <= np.maximum(np.abs(x[..., 32:64]) * 2.0 ** -21, a2 * 2.0 ** -37)).all()
     assert float(buf[..., :64].abs().max()) == 0.0
-    np.testing.assert_array_equal(ops.h2_to_f32(ops.f32_to_h2(xt)[..., 0:32]).cpu().numpy(), back[..., 0:32])
+    np.testing.assert_array_equal(ops.h2_to_f32(h0[..., 0:32]).cpu().numpy(), back[..., 0:32])
+    # an explicit slot fixes the exponent: same bytes as a tensor whose values are all 2^e times smaller under exponent 0
+    slot = torch.zeros(ops.RNG_ROW, dtype=torch.int32, device=DEV)
+    slot[0] = 7
+    hs = ops.f32_to_h2(xt[..., :32].contiguous(), out=ops.H2(torch.empty(2, 3, 5, 7, 32, device=DEV), slot))
+    h1 = ops.f32_to_h2((xt[..., :32] / 128.0).contiguous(), out=ops.H2(torch.empty(2, 3, 5, 7, 32, device=DEV),
+                                                                           torch.zeros(ops.RNG_ROW, dtype=torch.int32, device=DEV)))
+    assert torch.equal(hs.buf, h1.buf) and ops.slot_state(hs.rng) == (7, float(np.abs(x[..., :32]).max()))
 
 
 @pytest.mark.parametrize('shape', [(1, 32, 4, 8, 8), (2, 32, 5, 11, 13), (1, 64, 3, 9, 17), (1, 128, 4, 6, 10),
@@ -691,6 +703,12 @@ def test_conv3d_h2_stride2_tiled(shape, cout, monkeypatch):
     assert torch.equal(s0.buf, y0.buf) and torch.equal(s1.buf, y1.buf) and bool((buf[..., cout:2 * cout] == 7.0).all())
 
 
+def _slot_with_exp(e):
+    slot = torch.zeros(ops.RNG_ROW, dtype=torch.int32, device=DEV)
+    slot[0] = e
+    return slot
+
+
 def test_pool_h2_and_fpn_h2():
     """voxel pooling with h2 output = the fp32 pooled sums split (bit-identical to converting the fp32 result); the fused
     neck with h2 input / output against its exact-fp32 self."""
@@ -704,8 +722,14 @@ def test_pool_h2_and_fpn_h2():
     depth, feat = S.lift_inputs(7, B=1, N=1)
     d_t, f_t = T(depth), T(np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2)))
     ref = ops.bev_pool_dense(d_t, f_t, vs)
-    h = ops.bev_pool_dense(d_t, f_t, vs, out_h2=True)
-    assert torch.equal(h, ops.f32_to_h2(ref).buf)
+    h = ops.bev_pool_dense(d_t, f_t, vs, out_h2=True)                      # private slot, exponent 0 (sums of softmax weights x N(0,1): O(1))
+    assert torch.equal(h.buf, ops.f32_to_h2(ref, out=ops.H2(torch.empty_like(ref), torch.zeros(ops.RNG_ROW, dtype=torch.int32, device=DEV))).buf)
+    assert ops.slot_state(h.rng) == (0, float(ref.abs().max()))
+    # under a range slot with exponent -3 the sums are stored 8x larger: same values up to the storage rounding
+    h3 = ops.bev_pool_dense(d_t, f_t, vs, out_h2=True, out=ops.H2(torch.empty_like(ref), _slot_with_exp(-3)))
+    d3 = (ops.h2_to_f32(h3) - ref).abs()
+    assert bool((d3 <= torch.maximum(ref.abs() * 2.0 ** -21, torch.full_like(ref, 2.0 ** -27))).all())
+    assert ops.slot_state(h3.rng) == (-3, float(ref.abs().max()))
     # neck: x8 (32 ch), x16 (64 ch at 1/2), x32 (128 ch at 1/4)
     rs = np.random.RandomState(2)
     neck = M.LSSFPN3D(in_channels=224, out_channels=32).to(DEV).eval()

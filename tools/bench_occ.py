@@ -16,7 +16,7 @@ w1 = T((rs.standard_normal((8, 16)) * 0.4).astype(np.float32))
 s1 = T(rs.uniform(0.5, 1.5, 8).astype(np.float32)); b1 = T((rs.standard_normal(8) * 0.3).astype(np.float32))
 w2 = T((rs.standard_normal((18, 8)) * 0.5).astype(np.float32))
 wpk, inv = ops.pack_occ_weight_h2(w0)
-hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_h2(w1, s1, b1, w2)
+hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_h2(w1, s1, b1, w2) + (ops.occ_head_bounds(w0, s0, b0, w1, s1, b1),)
 wino = ops.pack_conv_weight_wino(w0, cout_total=16)
 fargs = (ops._pad32(s0, 1.0), ops._pad32(b0, 0.0), w1, s1, b1, w2)
 for B in (1, 6):

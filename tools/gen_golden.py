@@ -157,8 +157,19 @@ def _segment_coo(src, index, out, reduce='sum'):
     return out.index_add_(0, index, src)
 
 
+_REG = _Registry()
+
+
+def _build_from_cfg(cfg):
+    """what mmdet3d.models.builder.build_{backbone,neck,head} do for the reference classes the shim has loaded"""
+    if cfg is None:
+        return None
+    cfg = dict(cfg)
+    return _REG.d[cfg.pop('type')](**cfg)
+
+
 def install_shim():
-    reg = _Registry()
+    reg = _REG
     _mod('mmcv')
     _mod('mmcv.cnn', build_conv_layer=_build_conv_layer, build_norm_layer=_build_norm_layer,
          build_upsample_layer=None, ConvModule=_ConvModule, MODELS=reg)
@@ -178,8 +189,9 @@ def install_shim():
     _mod('cv2')
     _mod('termcolor', colored=lambda s, *a, **k: s)
     _mod('mmdet3d')
-    _mod('mmdet3d.models', builder=types.SimpleNamespace())
-    _mod('mmdet3d.models.builder', NECKS=reg, HEADS=reg, BACKBONES=reg)
+    bld = _mod('mmdet3d.models.builder', NECKS=reg, HEADS=reg, BACKBONES=reg, DETECTORS=reg, build_backbone=_build_from_cfg,
+               build_neck=_build_from_cfg, build_head=_build_from_cfg, build_loss=lambda cfg: None)
+    _mod('mmdet3d.models', builder=bld)
     _mod('mmdet3d.models.necks')
     _mod('mmdet3d.models.backbones')
     _mod('mmdet3d.models.heads')
@@ -906,6 +918,89 @@ def gen_neck_head_train(fpn, occ):
     save('neck_head_train_small.npz', **out)
 
 
+class _FakeCenterPoint(nn.Module):
+    """stands in for mmdet3d CenterPoint / MVXTwoStageDetector / mmdet BaseDetector (class plumbing the camera -> occupancy path
+    never executes): builds the image modules it is given, nothing else"""
+
+    def __init__(self, img_backbone=None, img_neck=None, **kwargs):
+        super().__init__()
+        self.img_backbone = _build_from_cfg(img_backbone)
+        self.img_neck = _build_from_cfg(img_neck)
+
+    @property
+    def with_img_neck(self):
+        return self.img_neck is not None
+
+
+def load_detectors(occ):
+    """import the reference's detector classes themselves (bevdet.py, bevdet_occ.py, preworld.py, preworld_temporal_traj.py) on
+    top of the sub-modules already loaded: fakes for the bases and for the debugging / plotting imports they carry"""
+    pkg = _mod('mmdet3d.models.detectors')
+    _mod('mmdet3d.models.detectors.centerpoint', CenterPoint=_FakeCenterPoint)
+    if 'mmdet3d.models.backbones.swin' not in sys.modules:
+        _mod('mmdet3d.models.backbones.swin', SwinTransformer=type('SwinTransformer', (nn.Module,), {}))
+    sys.modules['mmdet.models.backbones.resnet'].ResNet = type('ResNet', (nn.Module,), {})
+    _mod('IPython', embed=lambda *a, **k: None)
+    _mod('matplotlib', cm=None)
+    _mod('matplotlib.pyplot')
+    sys.modules['mmdet3d.models.heads'].DownScaleModule3DCustom = occ.DownScaleModule3DCustom
+    _mod('mmdet3d.core')
+    _mod('mmdet3d.core.bbox', Box3DMode=types.SimpleNamespace(LIDAR=0), Coord3DMode=None, LiDARInstance3DBoxes=None)
+    load_ref('mmdet3d.models.detectors.loss', 'mmdet3d/models/detectors/loss.py')
+    load_ref('mmdet3d.models.detectors.lovasz_softmax', 'mmdet3d/models/detectors/lovasz_softmax.py')
+    load_ref('mmdet3d.models.detectors.bevdet', 'mmdet3d/models/detectors/bevdet.py')
+    load_ref('mmdet3d.models.detectors.bevdet_occ', 'mmdet3d/models/detectors/bevdet_occ.py')
+    pw = load_ref('mmdet3d.models.detectors.preworld', 'mmdet3d/models/detectors/preworld.py')
+    pt = load_ref('mmdet3d.models.detectors.preworld_temporal_traj', 'mmdet3d/models/detectors/preworld_temporal_traj.py')
+    return pw, pt
+
+
+def gen_e2e(vtm, occ):
+    """G13 (missing 1): the reference's OWN PreWorld4DTraj.simple_test / PreWorld.simple_test
+    (preworld_temporal_traj.py:212-370, preworld.py:159-226) with BEVStereo4DOCC.prepare_inputs / extract_img_feat
+    (bevdet_occ.py:88-269) running end to end at a reduced grid, image side replaced by the seeded stand-ins of
+    tests/_e2e_stub.py, native ops bound to the oracle.  Records prepare_inputs' pose algebra, the mlp_input handed to the
+    DepthNet, sampled rows of the encoder output and of voxel_feats, and every uint8 grid."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import _e2e_stub as E
+    vtm.BasicBlock = _RefBasicBlock
+    load_detectors(occ)
+    sd = S.synth_state_dict(0)
+    inputs = E.img_inputs(0)
+    rs = np.random.RandomState(77)
+    out = {}
+    for tag, det, post_ft, with_prev in E.RUNS:
+        model = _build_from_cfg(E.model_cfg(det, post_ft, with_prev))
+        own = set(model.state_dict().keys())
+        state = {k: torch.from_numpy(v) for k, v in sd.items() if k in own}      # (PreWorld has no forecast / trajectory heads)
+        missing, unexpected = model.load_state_dict(state, strict=False)
+        hot_missing = [k for k in missing if 'depth_net' not in k and 'num_batches_tracked' not in k and not k.startswith('semantic_loss')]
+        assert not hot_missing and not unexpected, (hot_missing[:5], unexpected[:5])
+        model.eval()
+        dn = E.install_image_side(model, seed=0)
+        rec = {}
+        model.final_conv.register_forward_hook(lambda m, i, o: rec.update(bev=i[0].detach(), vf=o.detach()))
+        with torch.no_grad():
+            prep = model.prepare_inputs(inputs, stereo=True)
+            res = model.simple_test(None, None, img=inputs, temporal_ego_states=E.ego_states(0))
+        if tag == 'p4d_ft':
+            out['prep_sensor2keyego'] = torch.stack(prep[1], 0).numpy()             # (T, B, N, 4, 4)
+            out['prep_curr2adjsensor'] = torch.stack(prep[7][:2], 0).numpy()
+            out['mlp_input'] = torch.stack(dn.mlp_inputs, 0).numpy()                # calls: adjacent frame, key frame
+            out['sample_idx'] = rs.randint(0, 40 * 40 * 8, 1024).astype(np.int64)
+        idx = out['sample_idx']
+        # rows of the (B,C,Z,Y,X) tensors at flat voxel index z*Y*X + y*X + x
+        out[tag + '_bev_rows'] = rec['bev'][0].reshape(32, -1)[:, idx].T.contiguous().numpy()
+        out[tag + '_vf_rows'] = rec['vf'][0].reshape(32, -1)[:, idx].T.contiguous().numpy()
+        out[tag + '_bev_abs_sum'] = np.float64(rec['bev'].double().abs().sum())
+        out[tag + '_n_depthnet_calls'] = np.int64(dn.k)
+        for k, v in res.items():
+            assert v[0].dtype == np.uint8 and v[0].shape == (40, 40, 8), (k, v[0].dtype, v[0].shape)
+            out[tag + '_' + k] = v[0]
+        out[tag + '_keys'] = np.array(sorted(res.keys()))
+    save('e2e_small.npz', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shim()
@@ -945,6 +1040,8 @@ def main():
         gen_encoder_train(res)
     if want('neck_head_train'):
         gen_neck_head_train(fpn, occ)
+    if want('e2e'):
+        gen_e2e(vtm, occ)
     if only:
         return
     gen_kat(bp)

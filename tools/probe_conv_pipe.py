@@ -25,7 +25,7 @@ if os.environ.get('OCC', '0') == '1':         # k_occ_head_h2 (same probe layout
     wpk, inv = ops.pack_occ_weight_h2(w0)
     hargs = (inv.contiguous(), T(_np.zeros(16, _np.float32))) + ops.pack_occ_tail_h2(
         T(rs.standard_normal((8, 16)).astype(_np.float32)), T(_np.ones(8, _np.float32)), T(_np.zeros(8, _np.float32)),
-        T(rs.standard_normal((18, 8)).astype(_np.float32)))
+        T(rs.standard_normal((18, 8)).astype(_np.float32))) + ((30.0, 0.0, 30.0, 0.0),)
     xh = ops.f32_to_h2(x)
     for _ in range(3):
         buf.zero_()
