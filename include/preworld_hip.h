@@ -44,6 +44,7 @@ extern "C" {
 #define PW_EUNSUP (-4)   /* configuration not supported by the kernels */
 
 int pw_version(void);
+const char* pw_build_id(void);   /* hash of the sources the library was built from (preworld_amd.build.source_hash) */
 const char* pw_last_error(void);
 /* name, as rocprofv3 --kernel-trace prints it, of the dominant kernel the calling thread's last pw_* compute call
  * launched (which variant the library picked); measurement aid for bench.py's roofline object */

@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libpreworld_hip.so')
+LIB_PATH = os.environ.get('PW_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libpreworld_hip.so')      # PW_LIB_PATH: A/B builds (tools/build_variant.py)
 HEADER_PATH = os.path.join(_HERE, '..', 'include', 'preworld_hip.h')
 
 _CTYPES = {

@@ -31,6 +31,26 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
+def source_hash():
+    """sha256[:16] over every kernel source, kernel header and the C ABI header (names + contents, sorted): what
+    pw_build_id() of a library built from this tree returns"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    for f in files + [os.path.join('..', '..', 'include', 'preworld_hip.h')]:
+        h.update(os.path.basename(f).encode() + b'\0')
+        h.update(open(os.path.join(CSRC, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def _write_build_id():
+    path = os.path.join(CSRC, 'pw_build_id.inc')
+    text = '#define PW_BUILD_ID "%s"\n' % source_hash()
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, 'w') as f:
+            f.write(text)
+
+
 def _needs_build(out, deps):
     if not os.path.exists(out):
         return True
@@ -42,6 +62,8 @@ def _compile(src, force, verbose):
     obj = os.path.join(CSRC, src[:-4] + '.o')
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC)
                                         if h.endswith('.h')]
+    if src == 'pw_core.hip':
+        deps.append(os.path.join(CSRC, 'pw_build_id.inc'))
     deps.append(os.path.join(HERE, '..', 'include', 'preworld_hip.h'))
     if not force and not _needs_build(obj, deps):
         return obj, False
@@ -53,6 +75,7 @@ def _compile(src, force, verbose):
 
 
 def build(force=False, verbose=False, jobs=4):
+    _write_build_id()
     srcs = sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
         res = list(ex.map(lambda s: _compile(s, force, verbose), srcs))

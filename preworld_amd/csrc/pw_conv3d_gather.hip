@@ -125,6 +125,8 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
   constexpr int TAPS = KS * KS * KS;
   constexpr int PAD = (KS - 1) / 2;       // k3: 1, k2 (stride-2 patchify, A20): 0, k1: 0
 
+  RngScale rs = {};                                  // split-fp16 kernels: loaded here, first used in the epilogue
+  if constexpr (F16) rs = rng_scales(a);
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -209,7 +211,6 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
     // voxel-major product and stored element by element: 2 x 2-byte stores and ~10 address instructions per output, about as
     // many instructions as the whole tap loop.)
     // Range exponents of the operands (pw_h2.h "Range") are folded into scale / bias; the magnitudes written are recorded.
-    const RngScale rs = rng_scales(a);
     RngEpi re = {rs.res, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {

@@ -37,7 +37,24 @@ constexpr int H2_LDS = H2_SB_OFF + 2 * H2_MAX_COUT * 4;
 // Parking area = this wave's own halo rows (wave + 4 K, K < 7 / 13 for NT 1 / 2) of the buffer the stage just consumed: those
 // rows are refilled only by this wave's own DMA instructions, which are issued after the passes (other rows first).
 struct EpiTile { int b, d0, h0, w0, ng; unsigned bufoff; bool pending; };
-struct EpiRegs { v4f x0, x1, s0, s1, b0, b1; float4 r0, r1; unsigned vbase, soff; float amax0, amax1; };   // amax*: largest |stored value| written to y0 / y1
+struct EpiRegs {
+  v4f x0, x1, s0, s1, b0, b1; float4 r0, r1; unsigned vbase, soff;
+  float amax0, amax1;        // largest |stored value| written to y0 / y1 (tiles whose passes have completed)
+  float amax_nt[2];          // ... by the passes of the tile in flight, per N-tile of the wave: which destination an N-tile
+                             // feeds depends on the tile's N-group (wave-uniform), so it is resolved once per tile (epi_fold_amax)
+};
+
+// fold the in-flight tile's per-N-tile maxima into the per-destination ones; ng = that tile's N-group
+template <int NT>
+__device__ __forceinline__ void epi_fold_amax(const ConvArgs& a, int ng, EpiRegs& r) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const bool to_y0 = (ng * NT + nt) * 32 < a.cout0;
+    r.amax0 = fmaxf(r.amax0, to_y0 ? r.amax_nt[nt] : 0.f);
+    r.amax1 = fmaxf(r.amax1, to_y0 ? 0.f : r.amax_nt[nt]);
+    r.amax_nt[nt] = 0.f;
+  }
+}
 
 __device__ __forceinline__ unsigned epi_slot_off(int u) {          // parked voxel row u (128 B): 10 per halo row
   const int row = (int)(((unsigned)u * 205u) >> 11);               // u / 10 for u < 1024
@@ -121,9 +138,7 @@ __device__ __forceinline__ void h2_epi_compute(const ConvArgs& a, const EpiTile&
     float m = fabsf(v[0]);
 #pragma unroll
     for (int e = 1; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
-    m = r.vbase == PIPE_OOB ? 0.f : m;
-    r.amax0 = fmaxf(r.amax0, to_y0 ? m : 0.f);        // selects, not a branch: this runs inside the MFMA scheduling region
-    r.amax1 = fmaxf(r.amax1, to_y0 ? 0.f : m);
+    r.amax_nt[nt] = fmaxf(r.amax_nt[nt], r.vbase == PIPE_OOB ? 0.f : m);       // a select, not a branch: this runs inside the MFMA scheduling region
   }
   const unsigned second = r.vbase == PIPE_OOB ? PIPE_OOB : r.vbase + 16u;
   if constexpr (EPI == 3) {
@@ -132,12 +147,7 @@ __device__ __forceinline__ void h2_epi_compute(const ConvArgs& a, const EpiTile&
     buf_store4(yr, second, r.soff, vb);
   } else {
     h8 oh, ol;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      _Float16 th, tl;
-      h2_split1(v[e], th, tl);
-      oh[e] = th; ol[e] = tl;
-    }
+    h2_split8(v, oh, ol);
     const v4f wh = __builtin_bit_cast(v4f, oh), wl = __builtin_bit_cast(v4f, ol);
     const float va[4] = {wh[0], wh[1], wh[2], wh[3]}, vb[4] = {wl[0], wl[1], wl[2], wl[3]};
     buf_store4(yr, r.vbase, r.soff, va);
@@ -351,12 +361,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&ac
         buf_store4(yr, ok ? obase + 16u : PIPE_OOB, soff, vb);
       } else {
         h8 oh, ol;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          _Float16 th, tl;
-          h2_split1(v[e], th, tl);
-          oh[e] = th; ol[e] = tl;
-        }
+        h2_split8(v, oh, ol);
         const v4f wh = __builtin_bit_cast(v4f, oh), wl = __builtin_bit_cast(v4f, ol);
         const float va[4] = {wh[0], wh[1], wh[2], wh[3]}, vb[4] = {wl[0], wl[1], wl[2], wl[3]};
         buf_store4(yr, obase, soff, va);
@@ -379,17 +384,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   const int ntiles_total = a.cout_total >> 5;
   const int nchunk = a.Cin / KC;
 
-  // folded-BN scale / bias of every packed column -> LDS (read back as float4 per channel group in the epilogue), with the
-  // operands' range exponents folded in (pw_h2.h "Range": powers of two, exact)
+  // the operands' range exponents (pw_h2.h "Range"): the loads go out here, their first use is behind the prologue's halo DMA
   const RngScale rs = rng_scales(a);
-  {
-    float* sb = lds + H2_SB_OFF / 4;
-    for (int n = tid; n < a.cout_total; n += 256) {
-      const bool to_y0 = n < a.cout0;
-      sb[n] = (a.scale ? a.scale[n] : 1.f) * (to_y0 ? rs.s0 : rs.s1);
-      sb[H2_MAX_COUT + n] = (a.bias ? a.bias[n] : 0.f) * (to_y0 ? rs.b0 : rs.b1);
-    }
-  }
 
   const int nslots = (int)gridDim.x >> 3;
   const int per = (p.n_items + 7) >> 3;
@@ -418,7 +414,6 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   c.wave = wave; c.lane = lane;
   c.ldsg = reinterpret_cast<const char*>(lds);
   c.epi.pending = false; c.epi.b = c.epi.d0 = c.epi.h0 = c.epi.w0 = c.epi.ng = 0; c.epi.bufoff = 0;
-  c.res_mul = rs.res;
 
   constexpr int NW = WR ? 27 : 1;
   v4f wres[NW][2] = {};
@@ -460,6 +455,15 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     pipe_dma_row<10>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<11>(a, c.xr, c.lds3, dm, wave);
     pipe_dma_row<12>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<13>(a, c.xr, c.lds3, dm, wave);
     pipe_dma_row<14>(a, c.xr, c.lds3, dm, wave);
+    // folded-BN scale / bias of every packed column -> LDS (read back as float4 per channel group in the epilogue), with the
+    // range exponents folded in (powers of two, exact) -- in the shadow of the halo loads just issued
+    float* sb = lds + H2_SB_OFF / 4;
+    for (int n = tid; n < a.cout_total; n += 256) {
+      const bool to_y0 = n < a.cout0;
+      sb[n] = (a.scale ? a.scale[n] : 1.f) * (to_y0 ? rs.s0 : rs.s1);
+      sb[H2_MAX_COUT + n] = (a.bias ? a.bias[n] : 0.f) * (to_y0 ? rs.b0 : rs.b1);
+    }
+    c.res_mul = rs.res;
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
   }
@@ -501,6 +505,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     __syncthreads();                   // everyone's have; everyone is done with this buffer
     if (a.probe) ts2 = __builtin_readcyclecounter();
 
+    if constexpr (EPI > 0) { if (c.epi.pending) epi_fold_amax<NT>(a, c.epi.ng, er); }
     c.epi.pending = false;               // its passes ran inside this stage's taps
     if (ch == nchunk - 1) {
       char* stg = reinterpret_cast<char*>(lds) + bufoff + (unsigned)wave * (TW * 128);
@@ -532,9 +537,17 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     if (c.epi.pending)
       h2_epi_rest<NT, EPI, 0>(a, c.epi, reinterpret_cast<const char*>(lds) + c.epi.bufoff + (unsigned)wave * (TW * 128),
                               lds + H2_SB_OFF / 4, wave, lane, er, rs.res);
+    if (c.epi.pending) epi_fold_amax<NT>(a, c.epi.ng, er);
   }
-  if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(er.amax0), rs.e0);
-  if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(er.amax1), rs.e1);
+  {
+    // The slot pointers and exponents are needed once more, here.  Re-read them from the kernel-argument segment instead of
+    // keeping 10 SGPRs alive across the tap loop, where the allocator already spills scalars into VGPR lanes (ConvArgs is the
+    // first kernel argument; the empty asm makes the pointer opaque so that the loads are not merged with the prologue's)
+    const ConvArgs* ka = reinterpret_cast<const ConvArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("" : "+s"(ka));
+    if (ka->fmt_y0) rng_note(ka->y0_rng, __float_as_uint(er.amax0), rng_exp(ka->y0_rng));
+    if (ka->fmt_y1 && ka->y1) rng_note(ka->y1_rng, __float_as_uint(er.amax1), rng_exp(ka->y1_rng));
+  }
 }
 
 // ------------------------------------------------------------------------------------

@@ -126,6 +126,8 @@ __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3
   const int b = t / a.tiles_d;
   const int d0 = td * S2_TD, h0 = th * S2_TH, w0 = tw * S2_TW;
   const int ntiles_total = a.cout_total >> 5, nchunk = a.Cin / KC;
+  // range exponents of x / y0 / y1 (pw_h2.h "Range"), folded into scale / bias in the epilogue: loaded here, first used there
+  const RngScale rs = rng_scales(a);
 
   const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
   S2Ctx c;
@@ -207,7 +209,6 @@ __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3
   // 16 bytes per lane with 8 consecutive lanes covering one voxel's 128-byte chunk: whole lines per store.
   __syncthreads();                                   // every wave is done with the halo
   char* const stg = my_lds + wave * 4096;
-  const RngScale rs = rng_scales(a);                 // range exponents of x / y0 / y1 (pw_h2.h "Range") folded into scale / bias
   float amax0 = 0.f, amax1 = 0.f;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {

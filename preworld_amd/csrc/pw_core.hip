@@ -23,7 +23,12 @@ void pw_note_kernel(const char* fmt, ...) {
 
 PW_API const char* pw_last_kernel(void) { return g_kernel; }
 
-PW_API int pw_version(void) { return 200; }
+PW_API int pw_version(void) { return 300; }
+
+// sha256 (first 16 hex digits) of the sources this binary was built from -- written by preworld_amd/build.py just before
+// compiling; __graft_entry__.smoke() recomputes it from the tree next to the library and refuses a mismatch
+#include "pw_build_id.inc"
+PW_API const char* pw_build_id(void) { return PW_BUILD_ID; }
 
 PW_API const char* pw_last_error(void) { return g_err; }
 

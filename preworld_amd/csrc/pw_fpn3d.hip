@@ -41,6 +41,10 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
   const int half = lane >> 5, i = lane & 31;
   const long long m0 = ((long long)blockIdx.x * 4 + wave) * 32;
   if (m0 >= n_vox) return;
+  // range exponents (pw_h2.h "Range"): x8 is read under x_rng (y16 / y32 are fp32, true units), out is written under y0_rng.
+  // Loaded here, first used in the epilogue.
+  const int e_out = a.fmt_y0 ? rng_exp(a.y0_rng) : 0;
+  const int e_x = a.dma_stage ? rng_exp(a.x_rng) : 0;
   long long m = m0 + i;
   if (m >= n_vox) m = n_vox - 1;
   f32x16 acc;
@@ -75,9 +79,7 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
     }
     }
   }
-  // range exponents (pw_h2.h "Range"): x8 is read under x_rng (y16 / y32 are fp32, true units), out is written under y0_rng
-  const int e_out = a.fmt_y0 ? rng_exp(a.y0_rng) : 0;
-  const float xmul = rng_pow2(a.dma_stage ? rng_exp(a.x_rng) : 0), omul = rng_pow2(-e_out);
+  const float xmul = rng_pow2(e_x), omul = rng_pow2(-e_out);
   const float sc = (a.scale ? a.scale[i] : 1.f) * omul;
   const float bi = (a.bias ? a.bias[i] : 0.f) * omul;
   float amax = 0.f;

@@ -51,6 +51,23 @@ __device__ __forceinline__ void h2_split1(float x, _Float16& h, _Float16& l) {
   l = (_Float16)__builtin_amdgcn_fmed3f(x - (float)h, -H2_MAX, H2_MAX);
 }
 
+// 8 values at once, written pair-wise so that the conversions become v_cvt_pk_f16_f32 and the residual a v_pk_add_f32
+typedef float h2_f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void h2_split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const h2_f2 x = {v[2 * p], v[2 * p + 1]};
+    const h2_h2 h = __builtin_convertvector(x, h2_h2);
+    h2_f2 d = x - __builtin_convertvector(h, h2_f2);
+    d[0] = __builtin_amdgcn_fmed3f(d[0], -H2_MAX, H2_MAX);
+    d[1] = __builtin_amdgcn_fmed3f(d[1], -H2_MAX, H2_MAX);
+    const h2_h2 l = __builtin_convertvector(d, h2_h2);
+    hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+    lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
+  }
+}
+
 __device__ __forceinline__ void h2_split4(const float (&v)[4], u2& hi, u2& lo) {
   h4 h, l;
 #pragma unroll
@@ -69,15 +86,33 @@ __device__ __forceinline__ void h2_split4(const float (&v)[4], u2& hi, u2& lo) {
 // device-scope atomics on ONE address serialise at ~100 ns each -- 8 192 waves raising one word cost the pooling
 // kernel 150 us; spread over 1 024 words, without a returned value, they cost nothing measurable.  pw_rng_fold (one small
 // launch per pass) folds them into rng[1] and clears them.  A null slot = exponent 0, nothing recorded.
+#ifdef PW_RNG_EXP0        // experiment builds only (tools/build_variant.py): how much do the exponent loads cost?
+__device__ __forceinline__ int rng_exp(const int*) { return 0; }
+#else
 __device__ __forceinline__ int rng_exp(const int* r) { return r ? __builtin_amdgcn_readfirstlane(r[0]) : 0; }
+#endif
 __device__ __forceinline__ float rng_pow2(int e) { return __builtin_ldexpf(1.0f, e); }
 __device__ __forceinline__ unsigned rng_absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
-// every lane of a wave calls this once, at the end of the kernel: bits = |largest STORED value| of the lane, e = the exponent
-// it was stored under
+// maximum over the 64 lanes, as a wave-uniform value: 4 DPP steps inside the rows of 16 lanes (xor 1, xor 2, half-row mirror, row
+// mirror), then the four row results through v_readlane + s_max -- no LDS round trips (six ds_bpermute cost ~1 k cycles at
+// the tail of every kernel)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));     // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));     // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+// every lane of a wave calls this once, at the end of the kernel (all 64 lanes active): bits = |largest STORED value| of the lane,
+// e = the exponent it was stored under
 __device__ __forceinline__ void rng_note(int* r, unsigned bits, int e) {
+#ifdef PW_RNG_NOAMAX      // experiment builds only: how much does recording the maxima cost?
+  return;
+#endif
   if (!r) return;
-#pragma unroll
-  for (int off = 32; off; off >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
+  bits = wave_umax(bits);
   if ((threadIdx.x & 63) == 0 && bits) {
     const unsigned m = rng_absbits(__builtin_ldexpf(__uint_as_float(bits), e));
     const unsigned w = ((unsigned)blockIdx.x * 16u + (threadIdx.x >> 6)) & (unsigned)(PW_RNG_WORDS - 1);

@@ -244,24 +244,7 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
   c.geor = make_rsrc(tail.geo, tail.geo ? nvox : 0u);
   c.lgr = make_rsrc(tail.logits, tail.logits ? nvox * 72u : 0u);
   c.wave = wave; c.g = g;
-  // Range (pw_h2.h "Range").  x is read under its slot's exponent e_in.  The two hidden layers are split in registers, so their
-  // units are chosen from A-PRIORI bounds: |mid| <= mid_a 2^(16 + e_in) + mid_b (mid_a = max_c |scale_c| ||S w_c||_1: every
-  // stored input is below 2^16) and |hid| <= hid_a |mid|_max + hid_b; each layer is computed directly in units that put its
-  // bound at 2^15.  Powers of two, folded into the BN constants below; the logits come back in true units through inv2.
-  const int e_in = rng_exp(a.x_rng);
-  int e_mid, e_hid;
-  {
-    const float midb = fmaf(bd.mid_a, rng_pow2(16 + e_in), bd.mid_b);
-    const float hidb = fmaf(bd.hid_a, midb, bd.hid_b);
-    int ex;
-    (void)frexpf(midb, &ex);
-    e_mid = midb > 0.f ? __builtin_amdgcn_readfirstlane(ex) - 15 : 0;
-    (void)frexpf(hidb, &ex);
-    e_hid = hidb > 0.f ? __builtin_amdgcn_readfirstlane(ex) - 15 : 0;
-    e_mid = e_mid < -100 ? -100 : (e_mid > 100 ? 100 : e_mid);
-    e_hid = e_hid < -100 ? -100 : (e_hid > 100 ? 100 : e_hid);
-  }
-  c.inv2 = inv2 * rng_pow2(e_hid);
+  const int e_in = rng_exp(a.x_rng);        // (the load goes out here; first use behind the prologue's halo DMA)
 
   // fragment addresses: [kw][j >= 4][plane] for halo rows {j, j + 4} (row-pair base at j = 0 / immediates add (kd, j))
   unsigned ad0[3][2][2];
@@ -307,16 +290,16 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
     tw.w2h[1] = __builtin_bit_cast(h4, f4); tw.w2l[1] = __builtin_bit_cast(h4, f5);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      tw.s1[r] = tailpk[768 + 4 * g + r] * rng_pow2(e_mid - e_hid);
-      tw.b1[r] = tailpk[784 + 4 * g + r] * rng_pow2(-e_hid);
+      tw.s1[r] = tailpk[768 + 4 * g + r];
+      tw.b1[r] = tailpk[784 + 4 * g + r];
     }
   }
   // folded BN of the conv for this lane's 4 channels (4 g + r); the weights' power-of-two pre-scale is folded into scale
   float sc[4], bi[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    sc[r] = a.scale[4 * g + r] * rng_pow2(e_in - e_mid);
-    bi[r] = a.bias[4 * g + r] * rng_pow2(-e_mid);
+    sc[r] = a.scale[4 * g + r];
+    bi[r] = a.bias[4 * g + r];
   }
 
   PipeTile t = pipe_decode(a, p, item);
@@ -329,6 +312,28 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
     oh_dma_row<6>(a, c.xr, c.lds3, dm, wave); oh_dma_row<7>(a, c.xr, c.lds3, dm, wave); oh_dma_row<8>(a, c.xr, c.lds3, dm, wave);
     oh_dma_row<9>(a, c.xr, c.lds3, dm, wave); oh_dma_row<10>(a, c.xr, c.lds3, dm, wave); oh_dma_row<11>(a, c.xr, c.lds3, dm, wave);
     oh_dma_row<12>(a, c.xr, c.lds3, dm, wave); oh_dma_row<13>(a, c.xr, c.lds3, dm, wave); oh_dma_row<14>(a, c.xr, c.lds3, dm, wave);
+    // Range (pw_h2.h "Range").  x is read under its slot's exponent e_in.  The two hidden layers are split in registers, so their
+    // units are chosen from A-PRIORI bounds: |mid| <= mid_a 2^(16 + e_in) + mid_b (mid_a = max_c |scale_c| ||S w_c||_1: every
+    // stored input is below 2^16) and |hid| <= hid_a |mid|_max + hid_b; each layer is computed directly in units that put its
+    // bound at 2^15.  Powers of two, folded into the BN constants below; the logits come back in true units through inv2.
+    int e_mid, e_hid;
+    {
+      const float midb = fmaf(bd.mid_a, rng_pow2(16 + e_in), bd.mid_b);
+      const float hidb = fmaf(bd.hid_a, midb, bd.hid_b);
+      int ex;
+      (void)frexpf(midb, &ex);
+      e_mid = midb > 0.f ? __builtin_amdgcn_readfirstlane(ex) - 15 : 0;
+      (void)frexpf(hidb, &ex);
+      e_hid = hidb > 0.f ? __builtin_amdgcn_readfirstlane(ex) - 15 : 0;
+      e_mid = e_mid < -100 ? -100 : (e_mid > 100 ? 100 : e_mid);
+      e_hid = e_hid < -100 ? -100 : (e_hid > 100 ? 100 : e_hid);
+    }
+    c.inv2 = inv2 * rng_pow2(e_hid);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[r] *= rng_pow2(e_in - e_mid); bi[r] *= rng_pow2(-e_mid);
+      tw.s1[r] *= rng_pow2(e_mid - e_hid); tw.b1[r] *= rng_pow2(-e_hid);
+    }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
   }

@@ -69,6 +69,67 @@ def test_mini_split_states_and_miou_match_oracle():
     assert len(metric.count_iou()) == 3
 
 
+def _oracle_sample_full(seed, sd):
+    """one FULL-SIZE C3 sample (6 cameras, 200x200x16, key + adjacent frame) through the oracle: states 0/2/4/6 + their logits"""
+    gc = S.GRID_CONFIG_FULL
+    bevs = []
+    for f in range(2):
+        depth, feat = S.lift_inputs(seed * 16 + f, N=6)
+        r = S.synthetic_rig(6, dx=-2.5 * f)
+        bev = O.lss_view_transform(depth, feat, r['sensor2ego'], r['intrin'], r['post_rot'], r['post_tran'], r['bda'], gc,
+                                   S.INPUT_SIZE, S.DOWNSAMPLE)
+        bevs.append(O.pre_process(bev, sd))
+    vf = O.final_conv(O.encoder_forward(bevs[1], bevs[0], sd), sd)
+    states, feats = O.preworld4d_decode(vf, S.ego_state(seed), sd, n_steps=6, post_finetune=True)
+    return {h: states[h] for h in (0, 2, 4, 6)}, {h: O.occ_decode(feats[h], sd)[1] for h in (0, 2, 4, 6)}
+
+
+def test_fullsize_mini_split_miou_reproduces_the_oracle():
+    """north_star: "mIoU on a fixed mini-split is reproduced" -- a split that can FAIL: 8 full-size C3
+    samples (6 cameras, 200x200x16, 7 states).  Ground truth = the occupancy a PERTURBED copy of the weights predicts for the
+    same inputs, so the model under test scores a two-digit mIoU that depends on its predictions (a wrong model lands
+    somewhere else entirely; random labels would give ~1/18 whatever the model does).  The drop-in's temporal mIoU per
+    horizon (occ_metrics.py:413-594 through harness.evaluate) must equal the oracle pipeline's to 0.01, and every voxel the
+    two disagree on must be a near-tie of the oracle's logits."""
+    gc = S.GRID_CONFIG_FULL
+    sd = S.synth_state_dict(0)
+    net = harness.build_model(harness.model_cfg(gc), sd, DEV)
+    rs = np.random.RandomState(123)
+    sd_gt = dict(sd)
+    for k in sd:
+        if k.startswith(('occupancy_head.occ_pred_conv', 'fusion_head.2', 'final_conv.conv.weight')) and k.endswith('weight'):
+            sd_gt[k] = (sd[k] + 0.25 * float(np.abs(sd[k]).mean()) * rs.standard_normal(sd[k].shape)).astype(np.float32)
+    net_gt = harness.build_model(harness.model_cfg(gc), sd_gt, DEV)
+    seeds = list(range(1, 9))
+    samples = []
+    for seed in seeds:
+        frames = harness.lifted_frames(seed, 6, DEV)
+        ego = torch.from_numpy(S.ego_state(seed)).to(DEV)
+        with torch.no_grad():
+            lab = net_gt.simple_test_from_lift(frames, ego, n_steps=6)
+        gt = {h: lab['semantic_occ_%ds' % h][0].cpu().numpy() for h in (0, 2, 4, 6)}
+        samples.append(dict(frames=frames, ego=ego, gt=gt, mask_camera=rs.rand(200, 200, 16) < 0.7))
+    del net_gt
+    miou, stacks, metric = harness.evaluate(net, samples, DEV)
+    assert metric.cnt == len(seeds)
+    want = {h: O.MetricMIoU(num_classes=18, use_image_mask=True) for h in (0, 2, 4, 6)}
+    flips = 0
+    for i, (seed, s) in enumerate(zip(seeds, samples)):
+        ost, olg = _oracle_sample_full(seed, sd)
+        for j, h in enumerate((0, 2, 4, 6)):
+            check_argmax('mini-split sample %d state %ds' % (seed, h), stacks[i][j], ost[h], olg[h], LOGIT_TIE, floor=0.99999)
+            flips += int((stacks[i][j] != ost[h]).sum())
+            want[h].add_batch(ost[h], s['gt'][h], None, s['mask_camera'])
+    got = {h: miou[h] for h in (0, 2, 4, 6)}
+    ref = {h: want[h].count_miou()[0] for h in (0, 2, 4, 6)}
+    print('[mini-split] 8 full-size samples: temporal mIoU drop-in %s, oracle %s, %d of %d voxels differ'
+          % (got, ref, flips, 8 * 4 * 640000))
+    for h in (0, 2, 4, 6):
+        assert 20.0 <= ref[h] <= 95.0, ('the split must discriminate', h, ref[h])
+        assert abs(got[h] - ref[h]) <= 0.01, (h, got[h], ref[h])
+    assert abs(miou['avg_future'] - round(float(np.mean([ref[2], ref[4], ref[6]])), 2)) <= 0.01
+
+
 def test_geo_occ_comes_from_the_same_kernel():
     """preworld_temporal_traj.py:313-319: geo_occ = 0 where the argmax is not the empty class, 17 elsewhere."""
     sd = S.synth_state_dict(0)
