@@ -539,15 +539,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
                               lds + H2_SB_OFF / 4, wave, lane, er, rs.res);
     if (c.epi.pending) epi_fold_amax<NT>(a, c.epi.ng, er);
   }
-  {
-    // The slot pointers and exponents are needed once more, here.  Re-read them from the kernel-argument segment instead of
-    // keeping 10 SGPRs alive across the tap loop, where the allocator already spills scalars into VGPR lanes (ConvArgs is the
-    // first kernel argument; the empty asm makes the pointer opaque so that the loads are not merged with the prologue's)
-    const ConvArgs* ka = reinterpret_cast<const ConvArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
-    asm volatile("" : "+s"(ka));
-    if (ka->fmt_y0) rng_note(ka->y0_rng, __float_as_uint(er.amax0), rng_exp(ka->y0_rng));
-    if (ka->fmt_y1 && ka->y1) rng_note(ka->y1_rng, __float_as_uint(er.amax1), rng_exp(ka->y1_rng));
-  }
+  if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(er.amax0), rs.e0);
+  if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(er.amax1), rs.e1);
 }
 
 // ------------------------------------------------------------------------------------
