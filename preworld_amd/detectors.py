@@ -177,6 +177,47 @@ class BEVStereo4DOCC(nn.Module):
             return self.forward_train(**kwargs)
         return self.forward_test(**kwargs)
 
+    # ---- the runner-facing API of mmdet 2.24.0 BaseDetector (mmdet/models/detectors/base.py; third-party, not in the tree, restated
+    # from its published code): tools/train.py:244 calls model.init_weights() after build_model and mmcv's EpochBasedRunner calls
+    # model.train_step(data, optimizer) / val_step on every iteration
+    def init_weights(self):
+        """mmcv BaseModule.init_weights applies `init_cfg`; the PreWorld configs give none for these modules, so the
+        constructors' default initialisation stands (checkpoints are loaded afterwards by the runner / load_from)"""
+        for m in self.children():
+            if hasattr(m, 'init_weights') and m is not self:
+                m.init_weights()
+
+    @staticmethod
+    def _parse_losses(losses):
+        """dict of loss tensors / lists of tensors -> (total loss = sum of the entries whose key contains 'loss', log_vars of
+        python floats averaged over the ranks of an initialised process group)"""
+        from collections import OrderedDict
+        import torch.distributed as dist
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError('%s is not a tensor or list of tensors' % name)
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        for name, value in log_vars.items():
+            if dist.is_available() and dist.is_initialized():
+                value = value.data.clone()
+                dist.all_reduce(value.div_(dist.get_world_size()))
+            log_vars[name] = value.item()
+        return loss, log_vars
+
+    def train_step(self, data, optimizer=None):
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+    def val_step(self, data, optimizer=None):
+        return self.train_step(data, optimizer)
+
     def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
         """bevdet_occ.py:303-327 (module in .train()): depth loss + `loss_occ` on the predicter's logits.  `loss_occ` is built by
         mmdet's registry in the reference (third-party, not in the tree); the configs use

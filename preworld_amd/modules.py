@@ -328,6 +328,7 @@ class ConvModule3d(nn.Module):
         if self.with_norm:
             assert norm_cfg['type'] in ('BN3d', 'SyncBN', 'BN')
             self.bn = nn.BatchNorm3d(out_channels)
+            self.bn.pw_sync = norm_cfg['type'] == 'SyncBN'        # training: statistics over all ranks (train.BatchNormCL)
         self.with_activation = act_cfg is not None
         if self.with_activation:
             assert act_cfg['type'] == 'ReLU'
@@ -659,10 +660,17 @@ class OccHead(nn.Module):
             nn.Conv3d(mid // 2, out_channel, 1, bias=False))
         self.soft_weights = soft_weights
         self.num_point_sampling_feat = num_level
+        self.norm_type = norm_cfg['type']
         if soft_weights:
             self.voxel_soft_weights = nn.Sequential(
                 nn.Conv3d(mid, mid // 2, 1, bias=False), nn.BatchNorm3d(mid // 2),
                 nn.ReLU(inplace=True), nn.Conv3d(mid // 2, self.num_point_sampling_feat, 1, bias=False))
+        # norm_cfg type 'SyncBN' (every PreWorld config: preworld-7frame-finetune.py:39): in a multi-process training run the batch
+        # statistics and the backward sums of these layers are all-reduced over the ranks (train.BatchNormCL, sync=True); eval mode
+        # is plain BatchNorm with the running statistics either way
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm3d):
+                m.pw_sync = norm_cfg['type'] == 'SyncBN'
         self._cache = _PackedCache()
 
     def _folded(self, transposed=False, wino=False):

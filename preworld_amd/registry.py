@@ -44,8 +44,11 @@ REGISTRY_OF = {
 
 
 def replacements():
-    """{type name: (registry key, class)} -- the image-side stand-ins (SwinTransformer, FPN_LSS) are NOT registered: with
-    mmcv present the reference's own classes serve the image side."""
+    """{type name: (registry key, class)} -- the image-side stand-ins (SwinTransformer, FPN_LSS) are NOT registered.  Note that
+    the drop-in DETECTORS build their sub-modules through preworld_amd.builder (its own type table), so a detector built from
+    a config gets the plain-PyTorch SwinTransformer / FPN_LSS of image_encoder.py (same state-dict keys as the reference's, so
+    the same checkpoint loads); to keep the reference's own image modules, pass them as already-built nn.Modules
+    (builder.build returns non-dict arguments unchanged)."""
     tab = builder.table()
     return {name: (key, tab[name]) for name, (key, _) in REGISTRY_OF.items()}
 

@@ -140,35 +140,93 @@ class Conv3dCL(torch.autograd.Function):
         return dx, dw, None
 
 
+def _sync_world(sync):
+    """process group size when this BatchNorm is a SyncBN (norm_cfg type 'SyncBN', configs/preworld/**: OccHead) and a group is up"""
+    import torch.distributed as dist
+    return dist.get_world_size() if (sync and dist.is_available() and dist.is_initialized()) else 1
+
+
+def _all_reduce_sum(t):
+    """in-place SUM over the ranks; RCCL takes the device tensor, gloo (CPU tests) goes through host memory"""
+    import torch.distributed as dist
+    if dist.get_backend() == 'gloo' and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
 class BatchNormCL(torch.autograd.Function):
-    """y = relu?(batch_norm(x; batch statistics) * gamma + beta (+ residual)) -> (y, batch mean, biased batch variance)"""
+    """y = relu?(batch_norm(x; batch statistics) * gamma + beta (+ residual)) -> (y, batch mean, biased batch variance, count).
+    sync: SyncBatchNorm semantics (torch/nn/modules/_functions.py SyncBatchNorm, what mmcv builds for norm_cfg 'SyncBN'): the
+    statistics are those of the batch over ALL ranks -- one all-reduce of [sum x, sum x^2, n] per channel in the forward pass,
+    one of [sum dz, sum dz x_hat] in the backward pass; d gamma / d beta stay per rank (DDP averages parameter gradients)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, eps, relu):
+    def forward(ctx, x, gamma, beta, residual, eps, relu, sync=False):
         mean, var, rstd = bn_stats(x, eps)
+        n_local = float(x.numel() // x.shape[-1])
+        n_total = n_local
+        if _sync_world(sync) > 1:
+            C = x.shape[-1]
+            st = torch.cat([mean.double() * n_local, (var.double() + mean.double() ** 2) * n_local,
+                            torch.full((1,), n_local, dtype=torch.float64, device=x.device)])
+            _all_reduce_sum(st)
+            n_total = float(st[-1])
+            m64 = st[:C] / n_total
+            v64 = (st[C:2 * C] / n_total - m64 ** 2).clamp_min(0)
+            mean, var = m64.float(), v64.float()
+            rstd = torch.rsqrt(v64 + eps).float()
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = bn_apply(x, mean, rstd, g, b, residual, relu)
         ctx.save_for_backward(x, y, mean, rstd, g)
-        ctx.relu, ctx.has_res = bool(relu), residual is not None
-        ctx.mark_non_differentiable(mean, var)
-        return y, mean, var
+        ctx.relu, ctx.has_res, ctx.sync, ctx.n_ratio = bool(relu), residual is not None, bool(sync), n_local / n_total
+        cnt = torch.full((1,), n_total, dtype=torch.float32, device=x.device)
+        ctx.mark_non_differentiable(mean, var, cnt)
+        return y, mean, var, cnt
 
     @staticmethod
-    def backward(ctx, dy, _dm, _dv):
+    def backward(ctx, dy, _dm, _dv, _dc):
         x, y, mean, rstd, g = ctx.saved_tensors
+        if _sync_world(ctx.sync) > 1:
+            return BatchNormCL._backward_sync(ctx, x, dy.contiguous(), y, mean, rstd, g)
         dx, dgamma, dbeta, dres = bn_backward(x, dy.contiguous(), y, mean, rstd, g, ctx.relu, ctx.has_res and ctx.needs_input_grad[3])
-        return dx, dgamma, dbeta, dres, None, None
+        return dx, dgamma, dbeta, dres, None, None, None
+
+    @staticmethod
+    def _backward_sync(ctx, x, dy, y, mean, rstd, g):
+        """bn_backward with the two per-channel sums taken over all ranks.  pw_bn_bwd_apply divides the sums by its row count
+        (the local N); handing it the global sums scaled by N_local / N_total makes that the global mean."""
+        C = x.shape[-1]
+        N = x.numel() // C
+        nbytes = _lib.call_size('pw_bn_workspace_bytes', C)
+        ws = ops._workspace(nbytes, x.device)
+        s0, s1 = torch.empty(C, device=x.device, dtype=_f32), torch.empty(C, device=x.device, dtype=_f32)
+        yp = ops._p(_cl(y, 'y')) if ctx.relu else None
+        _lib.call('pw_bn_bwd_reduce', ops._p(_cl(x, 'x')), ops._p(_cl(dy, 'dy')), yp, N, C, ops._p(mean), ops._p(rstd), int(ctx.relu),
+                  ops._p(ws), nbytes, ops._p(s0), ops._p(s1), ops._stream())
+        tot = _all_reduce_sum(torch.cat([s0, s1]).double()) * ctx.n_ratio
+        g0, g1 = tot[:C].float().contiguous(), tot[C:].float().contiguous()
+        dx = torch.empty_like(x)
+        want_dres = ctx.has_res and ctx.needs_input_grad[3]
+        dres = torch.empty_like(x) if want_dres else None
+        _lib.call('pw_bn_bwd_apply', ops._p(x), ops._p(dy), yp, N, C, ops._p(mean), ops._p(rstd), ops._p(_cl(g, 'gamma')),
+                  ops._p(g0), ops._p(g1), int(ctx.relu), ops._p(dx), ops._p(dres), ops._stream())
+        return dx, s1, s0, dres, None, None, None
 
 
 def _update_running(bn, mean, var, n):
-    """nn.BatchNorm3d bookkeeping (torch/nn/modules/batchnorm.py): exponential average with the UNBIASED batch variance"""
+    """nn.BatchNorm3d bookkeeping (torch/nn/modules/batchnorm.py): exponential average with the UNBIASED batch variance;
+    n: (1,) device tensor, the number of rows the statistics were taken over (all ranks for a SyncBN) -- no host sync"""
     if not bn.track_running_stats or bn.running_mean is None:
         return
     with torch.no_grad():
         bn.num_batches_tracked += 1
         m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
-        bn.running_var.mul_(1.0 - m).add_(var * (n / max(n - 1.0, 1.0)), alpha=m)
+        bn.running_var.mul_(1.0 - m).add_(var * (n / (n - 1.0).clamp_min(1.0)), alpha=m)
 
 
 # ------------------------------------------------------------------------------ module-level training forwards
@@ -179,8 +237,8 @@ def conv_module_forward(m, x, residual=None, relu=None):
         raise NotImplementedError('training path: bias-free conv + BatchNorm3d modules only (the encoder blocks)')
     y = Conv3dCL.apply(x.contiguous(), m.conv.weight, m.stride)
     relu = m.with_activation if relu is None else relu
-    out, mean, var = BatchNormCL.apply(y, m.bn.weight, m.bn.bias, residual, m.bn.eps, relu)
-    _update_running(m.bn, mean, var, float(y.numel() // y.shape[-1]))
+    out, mean, var, cnt = BatchNormCL.apply(y, m.bn.weight, m.bn.bias, residual, m.bn.eps, relu, getattr(m.bn, 'pw_sync', False))
+    _update_running(m.bn, mean, var, cnt)
     return out
 
 
@@ -258,8 +316,8 @@ def fpn_forward(neck, feats):
     y16 = Conv3dCL.apply(x16, w[:, c8:c8 + c16], 1)
     y32 = Conv3dCL.apply(x32, w[:, c8 + c16:], 1)
     pre = UpsampleSumCL.apply(y8, y16, y32)
-    out, mean, var = BatchNormCL.apply(pre, cm.bn.weight, cm.bn.bias, None, cm.bn.eps, cm.with_activation)
-    _update_running(cm.bn, mean, var, float(pre.numel() // pre.shape[-1]))
+    out, mean, var, cnt = BatchNormCL.apply(pre, cm.bn.weight, cm.bn.bias, None, cm.bn.eps, cm.with_activation, getattr(cm.bn, 'pw_sync', False))
+    _update_running(cm.bn, mean, var, cnt)
     return out
 
 
@@ -273,8 +331,8 @@ def conv_bias_act_forward(m, x):
 
 
 def _bn_cl(bn, x, relu):
-    out, mean, var = BatchNormCL.apply(x.contiguous(), bn.weight, bn.bias, None, bn.eps, relu)
-    _update_running(bn, mean, var, float(x.numel() // x.shape[-1]))
+    out, mean, var, cnt = BatchNormCL.apply(x.contiguous(), bn.weight, bn.bias, None, bn.eps, relu, getattr(bn, 'pw_sync', False))
+    _update_running(bn, mean, var, cnt)
     return out
 
 

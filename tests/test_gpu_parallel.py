@@ -99,3 +99,60 @@ def test_rccl_device_tensor_all_gathers_world_size_1():
     p.join(60)
     assert p.exitcode == 0
     assert backend == 'nccl' and on_dev and all(same), (backend, same)
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    from preworld_amd import train
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        rs = np.random.RandomState(3)
+        x_all = torch.from_numpy(rs.standard_normal((2, 4, 6, 8, 16)).astype(np.float32)).cuda()
+        dy_all = torch.from_numpy(rs.standard_normal((2, 4, 6, 8, 16)).astype(np.float32)).cuda()
+        gamma = torch.from_numpy(rs.uniform(0.5, 1.5, 16).astype(np.float32)).cuda().requires_grad_()
+        beta = torch.from_numpy(rs.standard_normal(16).astype(np.float32)).cuda().requires_grad_()
+        x = x_all[rank:rank + 1].clone().requires_grad_()
+        y, mean, var, cnt = train.BatchNormCL.apply(x, gamma, beta, None, 1e-5, True, True)
+        (y * dy_all[rank:rank + 1]).sum().backward()
+        q.put((rank, y.detach().cpu().numpy(), x.grad.cpu().numpy(), gamma.grad.cpu().numpy(), beta.grad.cpu().numpy(),
+               mean.cpu().numpy(), var.cpu().numpy(), float(cnt)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_two_ranks_equal_one_process_on_the_whole_batch():
+    """OccHead is built with norm_cfg SyncBN in every PreWorld config (preworld-7frame-finetune.py:39) and trained on 8 GPUs:
+    the reference all-reduces the batch statistics (and the backward sums) over the ranks.  train.BatchNormCL(sync=True) on two
+    ranks holding one sample each must equal ordinary batch-statistics BatchNorm over the two-sample batch."""
+    import torch.nn.functional as F
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(3)
+    x_all = torch.from_numpy(rs.standard_normal((2, 4, 6, 8, 16)).astype(np.float32)).double().requires_grad_()
+    dy_all = torch.from_numpy(rs.standard_normal((2, 4, 6, 8, 16)).astype(np.float32)).double()
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, 16).astype(np.float32)).double().requires_grad_()
+    beta = torch.from_numpy(rs.standard_normal(16).astype(np.float32)).double().requires_grad_()
+    xf = x_all.reshape(-1, 16)
+    yf = torch.relu(F.batch_norm(xf, None, None, gamma, beta, training=True, eps=1e-5)).reshape(x_all.shape)
+    (yf * dy_all).sum().backward()
+    for r in range(2):
+        _, y, dx, dg, db, mean, var, cnt = res[r]
+        assert cnt == 2 * 4 * 6 * 8
+        np.testing.assert_allclose(y, yf[r:r + 1].detach().numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dx, x_all.grad[r:r + 1].numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(mean, xf.mean(0).detach().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(var, xf.var(0, unbiased=False).detach().numpy(), rtol=1e-5, atol=1e-6)
+    # parameter gradients stay per rank (DDP averages them): their sum is the whole batch's gradient
+    np.testing.assert_allclose(res[0][3] + res[1][3], gamma.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(res[0][4] + res[1][4], beta.grad.numpy(), rtol=2e-4, atol=2e-4)

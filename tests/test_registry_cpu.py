@@ -219,3 +219,29 @@ def test_prepare_inputs_pose_algebra():
     ref_c2a = np.linalg.inv(a[1] @ c[1]) @ a[0] @ c[0]
     np.testing.assert_allclose(c2a[0][0].numpy(), ref_c2a, rtol=1e-4, atol=1e-4)
     assert c2a[2] is None and len(c2a) == T
+
+
+def test_detectors_expose_the_runner_api():
+    """tools/train.py:244 calls model.init_weights(); mmcv's runner calls model.train_step(data, optimizer) and reads
+    outputs['loss'] / ['log_vars'] / ['num_samples'] (mmdet 2.24.0 BaseDetector.train_step / _parse_losses): the drop-in detectors
+    provide the same API.  The loss dict is stubbed here -- the kernels need a GPU; tests/test_gpu_train.py runs
+    the real forward_train."""
+    import torch
+    from preworld_amd import harness
+    from preworld_amd import synth as S
+    for det in ('PreWorld4DTraj', 'PreWorld', 'BEVStereo4DOCC'):
+        cfg = harness.model_cfg(S.GRID_CONFIG_C1, detector=det)
+        if det == 'BEVStereo4DOCC':
+            cfg.pop('occupancy_head'); cfg.pop('if_post_finetune')
+        from preworld_amd import builder
+        net = builder.build(cfg)
+        net.init_weights()
+        w = torch.nn.Parameter(torch.tensor(2.0))
+        net.forward_train = lambda **kw: {'loss_a': w * 3.0, 'loss_list': [w * 1.0, w * 0.5], 'acc': w.detach() * 0 + 0.25}
+        out = net.train_step(dict(img_metas=[{}, {}], img_inputs=None), None)
+        assert set(out) == {'loss', 'log_vars', 'num_samples'} and out['num_samples'] == 2
+        assert abs(float(out['loss']) - 9.0) < 1e-6                        # 'acc' has no 'loss' in its key: logged, not summed
+        assert out['log_vars'] == {'loss_a': 6.0, 'loss_list': 3.0, 'acc': 0.25, 'loss': 9.0}
+        out['loss'].backward()
+        assert abs(float(w.grad) - 4.5) < 1e-6
+        assert set(net.val_step(dict(img_metas=[{}]), None)) == {'loss', 'log_vars', 'num_samples'}
