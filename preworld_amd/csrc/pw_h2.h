@@ -71,10 +71,15 @@ __device__ __forceinline__ void h2_split8(const float (&v)[8], h8& hi, h8& lo) {
 __device__ __forceinline__ void h2_split4(const float (&v)[4], u2& hi, u2& lo) {
   h4 h, l;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    _Float16 a, b;
-    h2_split1(v[e], a, b);
-    h[e] = a; l[e] = b;
+  for (int p = 0; p < 2; ++p) {                      // pair-wise, like h2_split8
+    const h2_f2 x = {v[2 * p], v[2 * p + 1]};
+    const h2_h2 a = __builtin_convertvector(x, h2_h2);
+    h2_f2 d = x - __builtin_convertvector(a, h2_f2);
+    d[0] = __builtin_amdgcn_fmed3f(d[0], -H2_MAX, H2_MAX);
+    d[1] = __builtin_amdgcn_fmed3f(d[1], -H2_MAX, H2_MAX);
+    const h2_h2 b = __builtin_convertvector(d, h2_h2);
+    h[2 * p] = a[0]; h[2 * p + 1] = a[1];
+    l[2 * p] = b[0]; l[2 * p + 1] = b[1];
   }
   hi = __builtin_bit_cast(u2, h);
   lo = __builtin_bit_cast(u2, l);
