@@ -338,8 +338,10 @@ class BEVStereo4DOCC(nn.Module):
         # The frames' lift chains (voxel index, sort, pooling, pre_process_net) are independent until the encoder reads the
         # buffer: the adjacent frames run on a side stream (fork / join; captured into the hipGraph as two branches), so that
         # one frame's small latency-bound LSS kernels hide under the other's convolutions.  PW_LIFT_STREAMS=0: one stream.
+        # (not on the first call: the packed / folded weights both branches share are built lazily by torch ops on whichever
+        # stream reaches them first, and the other branch would read them without an event dependency -- ADVICE r02)
         fork = (x.is_cuda and not torch.is_grad_enabled() and self.with_prev and len(frames) > 1
-                and os.environ.get('PW_LIFT_STREAMS', '1') != '0')
+                and os.environ.get('PW_LIFT_STREAMS', '1') != '0' and self.__dict__.get('_lift_warm', False))
         if fork:
             main = torch.cuda.current_stream(x.device)
             side = self.__dict__.get('_lift_stream')
@@ -359,6 +361,7 @@ class BEVStereo4DOCC(nn.Module):
         self.lift_frame_cl(out=sl((n - 1) * C, n * C), out_h2=h2, **f0)
         if fork:
             main.wait_stream(side)
+        self.__dict__['_lift_warm'] = True
         return self.bev_encoder_cl(ops.H2(x, xslot) if h2 else x, out_h2=out_h2)
 
     def extract_voxel_feat_cl(self, frames, out_h2=False):

@@ -91,12 +91,15 @@ class LSSViewTransformer(nn.Module):
         the reference's accelerate flag, view_transformer.py:155-174,263-267, assumes a fixed rig and never checks)."""
         key = None
         if self.accelerate:
-            key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (sensor2ego, cam2imgs, post_rots, post_trans, bda))
+            tensors = (sensor2ego, cam2imgs, post_rots, post_trans, bda)
+            # identity + version counter of the tensor OBJECTS, which the cache entry keeps alive: a freed tensor's address can be
+            # handed to a new one by the caching allocator (with _version 0 again), so addresses alone would alias (ADVICE r02)
+            key = tuple((id(t), t._version) for t in tensors)
             if self._cache is not None and self._cache[0] == key:
-                return self._cache[1]
+                return self._cache[2]
         vs = self._sort_now(sensor2ego, cam2imgs, post_rots, post_trans, bda)
         if key is not None:
-            self._cache = (key, vs)
+            self._cache = (key, tensors, vs)
         return vs
 
     def _sort_now(self, sensor2ego, cam2imgs, post_rots, post_trans, bda):
@@ -301,13 +304,16 @@ class _PackedCache:
     def __init__(self):
         self._key = None
         self._val = None
+        self._live = None
 
     def get(self, tensors, build):
-        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors if t is not None)
+        # identity + version of the parameter OBJECTS (kept alive by the entry; see LSSViewTransformer._sort for why not addresses)
+        live = [t for t in tensors if t is not None]
+        key = tuple((id(t), t._version, t.device) for t in live)
         if key != self._key:
             with torch.no_grad():
                 self._val = build()
-            self._key = key
+            self._key, self._live = key, live
         return self._val
 
 

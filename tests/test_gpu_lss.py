@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import oracle as O
+from preworld_amd import modules as M
 from preworld_amd import ops
 from preworld_amd import synth as S
 
@@ -302,3 +303,49 @@ def test_edge_cases():
     # bad arguments raise (no silent fallback)
     with pytest.raises(Exception):
         ops.bev_pool_dense(depth.cpu(), feat, vs)
+
+
+def test_accelerate_reuses_the_sort_and_notices_new_camera_tensors():
+    """accelerate=True (view_transformer.py:155-174,263-267: the reference precomputes the ranks once for a fixed rig): the second
+    call with the SAME camera tensors skips geometry + sort and gives the same bits; new tensor objects (a new sample's poses
+    -- even when the allocator hands them the old addresses) or an in-place update rebuild the sort (ADVICE)."""
+    gc = S.GRID_CONFIG_C1
+    calls = []
+
+    def make(accelerate):
+        vt = M.LSSViewTransformer(grid_config=gc, input_size=S.INPUT_SIZE, downsample=S.DOWNSAMPLE, in_channels=8, out_channels=32,
+                                  collapse_z=False, accelerate=accelerate).to(DEV)
+        orig = vt._sort_now
+        vt._sort_now = lambda *a: (calls.append(1), orig(*a))[1]
+        return vt
+
+    def inputs(dx):
+        rig = S.synthetic_rig(1, dx=dx)
+        return [torch.empty(1, 1, 8, 32, 88, device=DEV), T(rig['sensor2ego']), None] + [T(rig[k]) for k in ('intrin', 'post_rot', 'post_tran', 'bda')]
+    depth, feat = S.lift_inputs(3, N=1)
+    d, f = T(depth).view(1, 88, 32, 88), T(feat).view(1, 32, 32, 88)
+    ref_vt = make(False)
+    vt = make(True)
+    inp = inputs(0.0)
+    with torch.no_grad():
+        want, _ = ref_vt.view_transform(inp, d, f)
+        n0 = len(calls)
+        a, _ = vt.view_transform(inp, d, f)
+        b, _ = vt.view_transform(inp, d, f)
+        assert len(calls) == n0 + 1, 'second call with the same camera tensors must reuse the sort'
+        assert torch.equal(a, want) and torch.equal(b, want)
+        # a new sample: new tensor objects with different poses.  Free the old ones first so that the caching allocator is
+        # likely to return the very same addresses -- the cache must still notice
+        old_ptrs = [t.data_ptr() for t in inp if t is not None]
+        del inp
+        inp2 = inputs(-2.5)
+        want2, _ = ref_vt.view_transform(inp2, d, f)
+        n1 = len(calls)
+        c, _ = vt.view_transform(inp2, d, f)
+        assert len(calls) == n1 + 1 and torch.equal(c, want2) and not torch.equal(c, want)
+        print('accelerate: %d of the new sample\\'s tensors reuse an old address' % sum(t.data_ptr() in old_ptrs for t in inp2 if t is not None))
+        # in-place update of a cached tensor
+        inp2[1].copy_(T(S.synthetic_rig(1, dx=0.0)['sensor2ego']))
+        n2 = len(calls)
+        e, _ = vt.view_transform(inp2, d, f)
+        assert len(calls) == n2 + 1 and torch.equal(e, want)
