@@ -343,7 +343,7 @@ def test_accelerate_reuses_the_sort_and_notices_new_camera_tensors():
         n1 = len(calls)
         c, _ = vt.view_transform(inp2, d, f)
         assert len(calls) == n1 + 1 and torch.equal(c, want2) and not torch.equal(c, want)
-        print('accelerate: %d of the new sample\\'s tensors reuse an old address' % sum(t.data_ptr() in old_ptrs for t in inp2 if t is not None))
+        print('accelerate: %d tensors of the new sample reuse an old address' % sum(t.data_ptr() in old_ptrs for t in inp2 if t is not None))
         # in-place update of a cached tensor
         inp2[1].copy_(T(S.synthetic_rig(1, dx=0.0)['sensor2ego']))
         n2 = len(calls)
