@@ -400,19 +400,38 @@ def main():
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
     dist = None
     n_dev = torch.cuda.device_count()
-    # one rank per GPU over RCCL.  Fewer GPUs than ranks only happens when the launch contract is
-    # exercised on a 1-GPU development box: ranks then share a device and rendezvous over gloo
-    # (RCCL refuses two ranks on one GPU); the timing of such a run means nothing.
-    oversubscribed = world > n_dev
-    dev_index = local_rank % max(n_dev, 1)
+    # one rank per GPU over RCCL.  Which device is mine?  Either every rank sees all GPUs of the node (torch.distributed.run's
+    # default: take LOCAL_RANK) or the launcher pinned one device per rank through *_VISIBLE_DEVICES (then it is device 0).
+    # Fewer GPUs than ranks WITHOUT such pinning only happens when the launch contract is exercised on a 1-GPU development
+    # box: ranks then share a device and rendezvous over gloo (RCCL refuses two ranks on one GPU); such a timing means nothing.
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    pinned = n_dev < local_world and any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+    oversubscribed = n_dev < local_world and not pinned
+    if n_dev == 0:
+        raise SystemExit('bench.py: no GPU visible to rank %d (HIP_VISIBLE_DEVICES=%r)' % (rank, os.environ.get('HIP_VISIBLE_DEVICES')))
+    dev_index = 0 if pinned else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = 'cuda:%d' % dev_index
+    backend = None
     if world > 1 or args.mode == 'sharded':
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('gloo' if oversubscribed else 'nccl',       # 'nccl' == RCCL on ROCm
-                                rank=rank, world_size=world)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL's P2P buffers need it on this driver
+        backend = 'gloo' if oversubscribed else 'nccl'                  # 'nccl' == RCCL on ROCm
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            # first collective now, on the device: a broken xGMI / IPC set-up fails here with a message instead of hanging
+            # the timed region
+            probe = torch.ones(1, device='cpu' if oversubscribed else dev)
+            dist.all_reduce(probe)
+            assert int(probe.item()) == world
+        except Exception as e:                                           # noqa: BLE001
+            raise SystemExit('bench.py: %s process group of %d ranks failed on rank %d (device %s, MASTER_ADDR=%s:%s, '
+                             'HSA_ENABLE_IPC_MODE_LEGACY=%s): %r' % (backend, world, rank, dev, os.environ['MASTER_ADDR'],
+                                                                     os.environ['MASTER_PORT'],
+                                                                     os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), e))
 
     sharded = args.mode == 'sharded'
     n_frames, n_steps_fc = (2, 6) if args.config == 'C3' else (1, 0)
@@ -537,6 +556,7 @@ def main():
             'value': round(samples / elapsed, 3),
             'unit': 'samples/s',
             'n_gpus': world,
+            'rccl_world': world if backend == 'nccl' else None,          # ranks in the RCCL process group (None: single process / gloo)
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4),

@@ -333,6 +333,19 @@ int pw_render_rays_backward(const float* rays_o, const float* rays_d, int n_rays
                             int n_sem, int c_rgb, const float* consts_host, const float* g_depth, const float* g_sem,
                             const float* g_rgb, const float* g_last, const float* g_weights, float* grad_grid,
                             void* stream);
+/* The same gradient WITHOUT float atomics, bit-reproducible from run to run (the autograd graph it replaces, nerf_head.py:211-225
+ * under torch, is deterministic given sorted ray_id): the march emits one (voxel, ray, w*corner weight, d sigma*corner weight)
+ * entry per visited sample and in-bounds corner, a counting sort groups the entries by voxel, and one wave per voxel sums
+ * [d sigma | w g_sem[ray] | w g_rgb[ray]] in 64-bit fixed point (exact integer sums: order-free), written by a single writer.
+ * g_semrgb: (R, 20) rows [g_sem | g_rgb]; g_absmax: device scalar max |g_semrgb|; workspace: pw_render_backward_workspace_bytes
+ * (40 bytes per possible entry, n_rays*n_samples*8 of them -- 5.1 GB at 38 400 x 417), 256-byte aligned. */
+size_t pw_render_backward_workspace_bytes(int n_rays, int n_samples, int X, int Y, int Z);
+int pw_render_rays_backward_sorted(const float* rays_o, const float* rays_d, int n_rays, const float* t, int n_samples,
+                                   const float* grid, int X, int Y, int Z, int grid_channels, int c_sigma, int c_sem,
+                                   int n_sem, int c_rgb, const float* consts_host, const float* g_depth, const float* g_sem,
+                                   const float* g_rgb, const float* g_last, const float* g_weights,
+                                   const float* g_semrgb, const float* g_absmax, void* workspace, size_t workspace_bytes,
+                                   float* grad_grid, void* stream);
 
 /* A12  attribute projection (preworld_temporal_traj.py:81-104): density/semantic/color MLPs
  * (each 32 -> 64 Softplus -> {2,17,3}) fused; v0 (n_vox,32) channels-last; out (n_vox,24) packed

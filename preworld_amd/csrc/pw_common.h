@@ -39,3 +39,7 @@ static inline hipStream_t pw_stream(void* s) { return reinterpret_cast<hipStream
 static inline int64_t pw_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 static inline size_t pw_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// exclusive int32 scan (pw_lss.hip), out may alias in; sums: pw_scan_ws_bytes(n) bytes of scratch
+size_t pw_scan_ws_bytes(int64_t n);
+int pw_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* sums, hipStream_t st);

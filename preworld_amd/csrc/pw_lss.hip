@@ -278,6 +278,12 @@ k_scan_apply_fused(const int32_t* __restrict__ in, int64_t n, const int32_t* __r
 }
 
 static size_t scan_ws_bytes(int64_t n) { return pw_align_up((size_t)pw_cdiv(n, SCAN_TILE) * 4, 256); }
+static int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* sums, hipStream_t st);
+// library-internal (pw_common.h): the same scan for other translation units (pw_render.hip's sorted backward)
+size_t pw_scan_ws_bytes(int64_t n) { return scan_ws_bytes(n); }
+int pw_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* sums, hipStream_t st) {
+  return scan_exclusive_i32(in, out, n, sums, st);
+}
 
 // out may alias in
 static int scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* sums,

@@ -218,6 +218,12 @@ struct RenderArgs {
   const float* g_last;     // (R)   d loss / d alphainv_last
   const float* g_w;        // (R, S) d loss / d dense weights, or null
   float* grad_grid;        // (Z,Y,X,GC), ACCUMULATED into (zero it first)
+  // backward, deterministic form (k_render_rays<NP, 2>): instead of scatter-adding, the march EMITS one entry per (visited
+  // sample, in-bounds trilinear corner) -- see "sorted backward" below
+  int2* e_kr;              // (voxel (z*Y + y)*X + x, arrival rank inside the voxel's segment = the returning histogram atomic)
+  float4* e_pay;           // (ray as int bits, a = w_i * corner weight (0 for culled samples), b = d loss / d sigma_i * corner weight, 0)
+  int* e_head;             // [0] number of entries, [1] bits of max |e_b|
+  int* e_count;            // per-voxel histogram (zeroed by the host side)
 };
 
 constexpr int RPASS = 7;   // 7 x 64 = 448 >= 417 samples per ray
@@ -286,7 +292,7 @@ __device__ __forceinline__ float grid_at(const float* grid, size_t idx) {
   else return grid[idx];
 }
 
-template <int NP, bool BWD, bool BF16 = false>
+template <int NP, int BWD, bool BF16 = false>      // BWD: 0 forward, 1 backward with float atomics, 2 backward emitting entries
 __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -419,7 +425,7 @@ __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
       if ((double)T_cum < 1e-3) stopped = true;
     }
   }
-  if constexpr (BWD) {
+  if constexpr (BWD != 0) {
     // ---- reverse pass
     float gsem[17], grgb[3];
 #pragma unroll
@@ -442,8 +448,9 @@ __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
             const float* g = a.grid + cbase;
             float* gg = a.grad_grid + cbase;
             const float ww = w[p] * wgt;
-            for (int k = 0; k < 17; ++k) { acc += gsem[k] * (g[a.c_sem + k] * wgt); unsafeAtomicAdd(gg + a.c_sem + k, ww * gsem[k]); }
-            for (int k = 0; k < 3; ++k) { acc += grgb[k] * (g[a.c_rgb + k] * wgt); unsafeAtomicAdd(gg + a.c_rgb + k, ww * grgb[k]); }
+            for (int k = 0; k < 17; ++k) { acc += gsem[k] * (g[a.c_sem + k] * wgt); if constexpr (BWD == 1) unsafeAtomicAdd(gg + a.c_sem + k, ww * gsem[k]); }
+            for (int k = 0; k < 3; ++k) { acc += grgb[k] * (g[a.c_rgb + k] * wgt); if constexpr (BWD == 1) unsafeAtomicAdd(gg + a.c_rgb + k, ww * grgb[k]); }
+            (void)gg; (void)ww;
           }
         })
         gw[p] = acc;
@@ -469,15 +476,71 @@ __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
         back_cum += gwl * wl;
       }
     }
+    if constexpr (BWD == 1) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if ((proc[p] >> lane) & 1ull) {
+          const double m = (double)eq[p] < 1e10 ? (double)eq[p] : 1e10;
+          const float gsig = (float)(m * (double)powf(1.f + eq[p], -a.interval - 1.f) * (double)a.interval * (double)galpha[p]);
+          const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
+          PW_FOR_CORNERS(t3, { if (inb) unsafeAtomicAdd(a.grad_grid + cbase + a.c_sigma, gsig * wgt); })
+        }
+      }
+      return;
+    }
+    // ---- BWD == 2: emit (voxel, ray, w * corner weight, d sigma * corner weight) for every visited sample and in-bounds corner.
+    // Space in the entry arrays is reserved once per wave and pass (one atomic), the per-voxel histogram atomic returns the
+    // entry's rank inside its voxel's segment, so the sort below is a plain scatter.
+    unsigned bmax = 0u;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      if ((proc[p] >> lane) & 1ull) {
+      const bool pr = (proc[p] >> lane) & 1ull;
+      float gsig = 0.f;
+      if (pr) {
         const double m = (double)eq[p] < 1e10 ? (double)eq[p] : 1e10;
-        const float gsig = (float)(m * (double)powf(1.f + eq[p], -a.interval - 1.f) * (double)a.interval * (double)galpha[p]);
-        const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
-        PW_FOR_CORNERS(t3, { if (inb) unsafeAtomicAdd(a.grad_grid + cbase + a.c_sigma, gsig * wgt); })
+        gsig = (float)(m * (double)powf(1.f + eq[p], -a.interval - 1.f) * (double)a.interval * (double)galpha[p]);
       }
+      const float wk = w[p] > a.fast_thres ? w[p] : 0.f;
+      const Tri t3 = tri_setup(a, px[p], py[p], pz[p]);
+      int cnt = 0;
+      PW_FOR_CORNERS(t3, { cnt += (pr && inb) ? 1 : 0; (void)wgt; (void)cbase; })
+      int incl = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+      }
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      if (total == 0) continue;                                     // wave-uniform
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.e_head, total);
+      base = __builtin_amdgcn_readfirstlane(base);
+      int pos = base + incl - cnt;
+      PW_FOR_CORNERS(t3, {
+        // histogram atomic, one per RUN of lanes (consecutive samples of the ray, half a voxel apart) whose corner is the same
+        // voxel: the run's first lane adds the run length, the others take base + offset (cf. k_hist in pw_lss.hip)
+        const int v = (pr && inb) ? (zi * a.Y + yi) * a.X + xi : -1;
+        const int vprev = __shfl_up(v, 1, 64);
+        const unsigned long long heads = __ballot(lane == 0 || v != vprev);
+        const int start = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
+        const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+        const int end = above ? __builtin_ctzll(above) : 64;
+        int rbase = 0;
+        if (v >= 0 && lane == start) rbase = atomicAdd(a.e_count + v, end - start);
+        rbase = __shfl(rbase, start, 64);
+        if (v >= 0) {
+          const float bb = gsig * wgt;
+          a.e_kr[pos] = make_int2(v, rbase + lane - start);
+          a.e_pay[pos] = make_float4(__int_as_float(ray), wk * wgt, bb, 0.f);
+          bmax = max(bmax, __float_as_uint(bb) & 0x7fffffffu);
+          ++pos;
+        }
+        (void)cbase;
+      })
     }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) bmax = max(bmax, (unsigned)__shfl_xor((int)bmax, off, 64));
+    if (lane == 0 && bmax) atomicMax(reinterpret_cast<unsigned*>(a.e_head) + 1, bmax);
     return;
   }
   // ---- A18 render_depth/semantic/color over samples with weight > thres
@@ -569,15 +632,15 @@ PW_API int pw_render_rays(const float* rays_o, const float* rays_d, int n_rays, 
   a.out_counts = out_counts; a.out_weights = out_weights; a.out_mask = out_mask;
   const dim3 grid_dim((unsigned)pw_cdiv(n_rays, 4));
   if (grid_bf16) {
-    if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, false, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-    else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, false, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-    else hipLaunchKernelGGL((k_render_rays<RPASS, false, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, 0, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, 0, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    else hipLaunchKernelGGL((k_render_rays<RPASS, 0, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
   } else {
-    if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-    else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-    else hipLaunchKernelGGL((k_render_rays<RPASS, false>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, 0>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, 0>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+    else hipLaunchKernelGGL((k_render_rays<RPASS, 0>), grid_dim, dim3(256), 0, pw_stream(stream), a);
   }
-  pw_note_kernel("k_render_rays<%d, false, %s>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS), grid_bf16 ? "true" : "false");
+  pw_note_kernel("k_render_rays<%d, 0, %s>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS), grid_bf16 ? "true" : "false");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
@@ -605,10 +668,233 @@ PW_API int pw_render_rays_backward(const float* rays_o, const float* rays_d, int
   a.c_sigma = c_sigma; a.c_sem = c_sem; a.n_sem = n_sem; a.c_rgb = c_rgb;
   a.g_depth = g_depth; a.g_sem = g_sem; a.g_rgb = g_rgb; a.g_last = g_last; a.g_w = g_weights; a.grad_grid = grad_grid;
   const dim3 grid_dim((unsigned)pw_cdiv(n_rays, 4));
-  if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-  else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-  else hipLaunchKernelGGL((k_render_rays<RPASS, true>), grid_dim, dim3(256), 0, pw_stream(stream), a);
-  pw_note_kernel("k_render_rays<%d, true>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS));
+  if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, 1>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, 1>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  else hipLaunchKernelGGL((k_render_rays<RPASS, 1>), grid_dim, dim3(256), 0, pw_stream(stream), a);
+  pw_note_kernel("k_render_rays<%d, 1, false>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS));
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// (2b) sorted backward: deterministic, no float atomics  -- entry point pw_render_rays_backward_sorted
+// The gradient of the packed grid is  grad[v, :] = sum over (sample i of ray r, corner hitting v) of
+//     [ d sigma_i * wgt ,  (w_i * wgt) * g_sem[r, 0..16] ,  (w_i * wgt) * g_rgb[r, 0..2] ]
+// -- per (ray, voxel) only TWO scalars; the 20 semantic / colour channels are their outer product with the ray's upstream
+// gradient.  The scatter form (k_render_rays<NP, 1>) issues 168 global float atomics per kept sample, 1.3 G of them at
+// 38 400 x 417 on a dense grid (54 ms, arrival order decides the last bits).  Here
+//   1. the march (k_render_rays<NP, 2>) emits (voxel, ray, a = w wgt, b = d sigma wgt) per visited sample and in-bounds corner,
+//      one int histogram atomic each -- its return value is the entry's rank inside the voxel's segment;
+//   2. an exclusive scan of the histogram gives the segment starts;
+//   3. k_rb_scatter moves every entry to start[voxel] + rank  (counting sort by voxel, one pass, no comparison);
+//   4. k_rb_gather: one wave per voxel, lane = (channel 0..20, entry j mod 3): term = b  or  a * g[ray][channel], converted
+//      to 64-bit FIXED POINT and summed in integers -- exact, hence independent of the order the atomics produced -- and
+//      written once by the voxel's only writer.  Voxels with more than RB_LONG entries (the cells around the cameras, 10^4..10^5
+//      entries each) are split over many waves whose integer partial sums meet through int64 atomics (still order-free).
+// Fixed-point units: 2^-40 of a power of two above the largest possible term of the channel group (max |g| for the semantic /
+// colour channels since a <= 1, the recorded max |b| for sigma): 2^22 terms fit, and a term 2^-16 of the largest still carries
+// a full fp32 significand.
+// ------------------------------------------------------------------------------------
+namespace {
+constexpr int RB_LONG = 6144;          // entries per wave-chunk of a long voxel
+constexpr int RB_CH = 21;              // sigma + 17 semantic + 3 colour
+
+struct RbArgs {
+  const int2* kr; const float4* pay;                           // unsorted entries (see RenderArgs::e_kr / e_pay)
+  float4* sorted;                                              // payloads sorted by voxel
+  const int* head;            // [0] n entries, [1] bits of max |b|, [2] n_long (written by k_rb_scatter)
+  int* head_w;
+  const int* seg_start;       // [n_vox + 1]
+  int* long_list;
+  int* touched;               // voxels with 1 .. RB_LONG entries (head[3] of them): the gather's work list
+  long long* long_acc;        // [max_long][RB_CH] int64, zeroed
+  const float* g;             // (R, 20) = [g_sem | g_rgb]
+  const float* gmax;          // device scalar: max |g|
+  float* grad_grid;
+  int n_vox, GC, c_sigma, c_sem, c_rgb, max_long;
+};
+
+__device__ __forceinline__ int rb_channel_index(const RbArgs& a, int ch) {
+  return ch == 0 ? a.c_sigma : (ch <= 17 ? a.c_sem + ch - 1 : a.c_rgb + ch - 18);
+}
+// power-of-two scale that maps |x| <= m to < 2^40
+__device__ __forceinline__ double rb_scale(float m) {
+  if (!(m > 0.f) || !(m < 3.0e38f)) return 1.0;
+  int ex;
+  (void)frexpf(m, &ex);
+  return ldexp(1.0, 40 - ex);
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_rb_scatter(RbArgs a) {
+  const int n = a.head[0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int2 kr = a.kr[i];
+    const int v = kr.x, r = kr.y;
+    const int s = a.seg_start[v];
+    a.sorted[s + r] = a.pay[i];                                // one 16-byte store per entry
+    if (r == 0) {                                              // the first arrival registers its voxel
+      if (a.seg_start[v + 1] - s > RB_LONG) {
+        const int li = atomicAdd(a.head_w + 2, 1);
+        if (li < a.max_long) a.long_list[li] = v;
+      } else {
+        a.touched[atomicAdd(a.head_w + 3, 1)] = v;
+      }
+    }
+  }
+}
+
+// sum of the entries [lo, hi) of one voxel for this lane's (channel, sub-entry): integer units.  Four entries' loads are issued
+// before the first is used (the chain entry -> g[ray] is two dependent round trips; one entry at a time was latency-bound)
+__device__ __forceinline__ long long rb_term(const RbArgs& a, const float4& e, int ch, double sc_g, double sc_b) {
+  double term;
+  if (ch == 0) term = (double)e.z * sc_b;
+  else term = (double)(e.y * a.g[(size_t)__float_as_int(e.x) * 20 + ch - 1]) * sc_g;
+  return __double2ll_rn(term);
+}
+__device__ __forceinline__ long long rb_partial(const RbArgs& a, int lo, int hi, int ch, int sub, double sc_g, double sc_b) {
+  long long acc = 0;
+  int i = lo + sub;
+  for (; i + 9 < hi; i += 12) {
+    const float4 e0 = a.sorted[i], e1 = a.sorted[i + 3], e2 = a.sorted[i + 6], e3 = a.sorted[i + 9];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (ch) {
+      g0 = a.g[(size_t)__float_as_int(e0.x) * 20 + ch - 1]; g1 = a.g[(size_t)__float_as_int(e1.x) * 20 + ch - 1];
+      g2 = a.g[(size_t)__float_as_int(e2.x) * 20 + ch - 1]; g3 = a.g[(size_t)__float_as_int(e3.x) * 20 + ch - 1];
+    }
+    acc += __double2ll_rn(ch ? (double)(e0.y * g0) * sc_g : (double)e0.z * sc_b);
+    acc += __double2ll_rn(ch ? (double)(e1.y * g1) * sc_g : (double)e1.z * sc_b);
+    acc += __double2ll_rn(ch ? (double)(e2.y * g2) * sc_g : (double)e2.z * sc_b);
+    acc += __double2ll_rn(ch ? (double)(e3.y * g3) * sc_g : (double)e3.z * sc_b);
+  }
+  for (; i < hi; i += 3) acc += rb_term(a, a.sorted[i], ch, sc_g, sc_b);
+  return acc;
+}
+
+__device__ __forceinline__ long long rb_shfl_down(long long v, int d) {
+  const int lo = __shfl_down((int)(v & 0xffffffffll), d, 64), hi = __shfl_down((int)(v >> 32), d, 64);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+
+__global__ void __launch_bounds__(256) k_rb_gather(RbArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / RB_CH, ch = lane - sub * RB_CH;      // lane 63: sub = 3, idle
+  const double sc_g = rb_scale(*a.gmax), sc_b = rb_scale(__uint_as_float((unsigned)a.head[1]));
+  const int nt = a.head[3];
+  // one wave per touched voxel (the list's order is arbitrary; every voxel has exactly one writer and an order-free sum)
+  for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < nt; k += gridDim.x * 4) {
+    const int v = a.touched[k];
+    const int s = a.seg_start[v], e = a.seg_start[v + 1];
+    long long acc = sub < 3 ? rb_partial(a, s, e, ch, sub, sc_g, sc_b) : 0;
+    acc += rb_shfl_down(acc, RB_CH) + rb_shfl_down(acc, 2 * RB_CH);
+    if (lane < RB_CH) {
+      float* dst = a.grad_grid + (size_t)v * a.GC + rb_channel_index(a, ch);
+      *dst += (float)((double)acc / (ch == 0 ? sc_b : sc_g));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rb_gather_long(RbArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  const int nl = min(a.head[2], a.max_long);
+  const int sub = lane / RB_CH, ch = lane - sub * RB_CH;
+  const double sc_g = rb_scale(*a.gmax), sc_b = rb_scale(__uint_as_float((unsigned)a.head[1]));
+  for (int li = 0; li < nl; ++li) {
+    const int v = a.long_list[li];
+    const int s = a.seg_start[v], e = a.seg_start[v + 1];
+    // chunk c of long voxel li belongs to wave (c + 61 li) mod nw: most long voxels have a handful of chunks, so without the
+    // rotation the first few waves would own all of them (measured: 185 ms instead of 4)
+    const int first = (int)(((long long)wid - 61ll * li) % nw + nw) % nw;
+    for (int c0 = s + first * RB_LONG; c0 < e; c0 += nw * RB_LONG) {
+      long long acc = sub < 3 ? rb_partial(a, c0, min(c0 + RB_LONG, e), ch, sub, sc_g, sc_b) : 0;
+      acc += rb_shfl_down(acc, RB_CH) + rb_shfl_down(acc, 2 * RB_CH);
+      if (lane < RB_CH) atomicAdd(reinterpret_cast<unsigned long long*>(a.long_acc + (size_t)li * RB_CH + ch), (unsigned long long)acc);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rb_finish_long(RbArgs a) {
+  const int nl = min(a.head[2], a.max_long);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nl * RB_CH) return;
+  const int li = i / RB_CH, ch = i - li * RB_CH;
+  const double sc = ch == 0 ? rb_scale(__uint_as_float((unsigned)a.head[1])) : rb_scale(*a.gmax);
+  a.grad_grid[(size_t)a.long_list[li] * a.GC + rb_channel_index(a, ch)] += (float)((double)a.long_acc[i] / sc);
+}
+
+PW_API size_t pw_render_backward_workspace_bytes(int n_rays, int n_samples, int X, int Y, int Z) {
+  const size_t cap = (size_t)n_rays * n_samples * 8, nv = (size_t)X * Y * Z;
+  const size_t max_long = cap / RB_LONG + 1;
+  return 256 + 3 * pw_align_up((nv + 1) * 4, 256) + pw_scan_ws_bytes((int64_t)nv + 1) + 10 * pw_align_up(cap * 4, 256) +
+         pw_align_up(max_long * 4, 256) + pw_align_up(max_long * RB_CH * 8, 256);
+}
+
+// Same contract as pw_render_rays_backward (grad_grid is ACCUMULATED into), plus: g_semrgb = the (R, 20) row-wise
+// concatenation [g_sem | g_rgb], g_absmax = device scalar max |g_semrgb|, workspace of pw_render_backward_workspace_bytes.
+// Bit-reproducible from run to run.
+PW_API int pw_render_rays_backward_sorted(const float* rays_o, const float* rays_d, int n_rays, const float* t, int n_samples,
+                                          const float* grid, int X, int Y, int Z, int grid_channels, int c_sigma, int c_sem,
+                                          int n_sem, int c_rgb, const float* consts_host, const float* g_depth, const float* g_sem,
+                                          const float* g_rgb, const float* g_last, const float* g_weights,
+                                          const float* g_semrgb, const float* g_absmax, void* workspace, size_t workspace_bytes,
+                                          float* grad_grid, void* stream) {
+  if (n_rays == 0) return PW_OK;
+  PW_CHECK_ARG(rays_o && rays_d && t && grid && consts_host && g_depth && g_sem && g_rgb && g_last && grad_grid && g_semrgb &&
+                   g_absmax && workspace, "pw_render_rays_backward_sorted: null pointer");
+  PW_CHECK_ARG(n_rays > 0 && n_samples > 1 && n_samples <= RPASS * 64, "pw_render_rays_backward_sorted: n_samples must be in [2, %d]", RPASS * 64);
+  PW_CHECK_ARG(X > 1 && Y > 1 && Z > 1 && grid_channels > 0 && n_sem == 17, "pw_render_rays_backward_sorted: bad grid / n_sem");
+  PW_CHECK_ARG(c_sigma >= 0 && c_sigma < grid_channels && c_sem >= 0 && c_sem + n_sem <= grid_channels && c_rgb >= 0 &&
+                   c_rgb + 3 <= grid_channels, "pw_render_rays_backward_sorted: channel offsets outside the packed grid");
+  PW_CHECK_ARG((size_t)n_rays * n_samples * 8 < (1ull << 31) && (size_t)X * Y * Z < (1ull << 31), "pw_render_rays_backward_sorted: too many entries for int32 indices");
+  PW_CHECK_ARG(workspace_bytes >= pw_render_backward_workspace_bytes(n_rays, n_samples, X, Y, Z) && ((uintptr_t)workspace & 255) == 0,
+               "pw_render_rays_backward_sorted: workspace too small or not 256-byte aligned");
+  hipStream_t st = pw_stream(stream);
+  const size_t cap = (size_t)n_rays * n_samples * 8, nv = (size_t)X * Y * Z;
+  const size_t max_long = cap / RB_LONG + 1;
+  char* ws = (char*)workspace;
+  int* head = (int*)ws; ws += 256;
+  int* count = (int*)ws; ws += pw_align_up((nv + 1) * 4, 256);
+  int* seg = (int*)ws; ws += pw_align_up((nv + 1) * 4, 256);
+  int* touched = (int*)ws; ws += pw_align_up((nv + 1) * 4, 256);
+  int* sums = (int*)ws; ws += pw_scan_ws_bytes((int64_t)nv + 1);
+  int2* e_kr = (int2*)ws; ws += 2 * pw_align_up(cap * 4, 256);
+  float4* e_pay = (float4*)ws; ws += 4 * pw_align_up(cap * 4, 256);
+  float4* sorted = (float4*)ws; ws += 4 * pw_align_up(cap * 4, 256);
+  int* long_list = (int*)ws; ws += pw_align_up(max_long * 4, 256);
+  long long* long_acc = (long long*)ws;
+  // zero: head, histogram, the long voxels' accumulators (kernels, not memset nodes: DESIGN.md 4.6)
+  hipLaunchKernelGGL(k_zero_f32, dim3(1), dim3(64), 0, st, (float*)head, (int64_t)64);
+  hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)pw_cdiv((int64_t)nv + 1, 256)), dim3(256), 0, st, (float*)count, (int64_t)nv + 1);
+  hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)pw_cdiv((int64_t)max_long * RB_CH * 2, 256)), dim3(256), 0, st, (float*)long_acc,
+                     (int64_t)max_long * RB_CH * 2);
+  RenderArgs a = {};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.grid = grid;
+  const float* c = consts_host;
+  for (int i = 0; i < 3; ++i) { a.center[i] = c[i]; a.radius[i] = c[3 + i]; a.xyz_min[i] = c[15 + i]; a.xyz_max[i] = c[18 + i]; }
+  for (int i = 0; i < 9; ++i) a.bda[i] = c[6 + i];
+  a.bg_len = c[21]; a.act_shift = c[22]; a.interval = c[23]; a.dist_thres = c[24]; a.fast_thres = c[25];
+  a.depth_scale = c[26];
+  a.R = n_rays; a.S = n_samples; a.X = X; a.Y = Y; a.Z = Z; a.GC = grid_channels;
+  a.c_sigma = c_sigma; a.c_sem = c_sem; a.n_sem = n_sem; a.c_rgb = c_rgb;
+  a.g_depth = g_depth; a.g_sem = g_sem; a.g_rgb = g_rgb; a.g_last = g_last; a.g_w = g_weights; a.grad_grid = grad_grid;
+  a.e_kr = e_kr; a.e_pay = e_pay;
+  a.e_head = head; a.e_count = count;
+  const dim3 grid_dim((unsigned)pw_cdiv(n_rays, 4));
+  if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, 2>), grid_dim, dim3(256), 0, st, a);
+  else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, 2>), grid_dim, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_render_rays<RPASS, 2>), grid_dim, dim3(256), 0, st, a);
+  pw_note_kernel("k_render_rays<%d, 2, false>", n_samples <= 128 ? 2 : (n_samples <= 256 ? 4 : RPASS));
+  if (int rc = pw_scan_exclusive_i32(count, seg, (int64_t)nv + 1, sums, st)) return rc;
+  RbArgs r = {};
+  r.kr = e_kr; r.pay = e_pay; r.sorted = sorted;
+  r.head = head; r.head_w = head; r.seg_start = seg; r.long_list = long_list; r.touched = touched; r.long_acc = long_acc;
+  r.g = g_semrgb; r.gmax = g_absmax; r.grad_grid = grad_grid;
+  r.n_vox = (int)nv; r.GC = grid_channels; r.c_sigma = c_sigma; r.c_sem = c_sem; r.c_rgb = c_rgb; r.max_long = (int)max_long;
+  hipLaunchKernelGGL(k_rb_scatter, dim3(4096), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(k_rb_gather, dim3((unsigned)std::min<int64_t>(pw_cdiv((int64_t)nv, 4), 8192)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(k_rb_gather_long, dim3(1024), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(k_rb_finish_long, dim3((unsigned)pw_cdiv((int64_t)max_long * RB_CH, 256)), dim3(256), 0, st, r);
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

@@ -1203,20 +1203,36 @@ def render_rays(rays_o, rays_d, t, grid, consts, c_sigma=0, c_sem=2, n_sem=17, c
 
 
 def render_rays_backward(rays_o, rays_d, t, grid, consts, g_depth, g_sem, g_rgb, g_last, g_weights=None, c_sigma=0, c_sem=2,
-                         n_sem=17, c_rgb=19, grad_grid=None):
-    """Backward of render_rays in one kernel (pw_render_rays_backward): gradient of the packed (Z,Y,X,GC) grid given the
-    gradients of depth (R), semantic (R,17), color (R,3), alphainv_last (R) [and of the dense weights (R,S)]."""
+                         n_sem=17, c_rgb=19, grad_grid=None, algo=None):
+    """Backward of render_rays: gradient of the packed (Z,Y,X,GC) grid given the gradients of depth (R), semantic (R,17),
+    color (R,3), alphainv_last (R) [and of the dense weights (R,S)].
+    algo 'sorted' (default; PW_RENDER_BWD=atomics selects the other): pw_render_rays_backward_sorted -- entries sorted by voxel,
+    fixed-point segmented sums, no float atomics, bit-reproducible; 'atomics': pw_render_rays_backward (168 float atomics per
+    kept sample, arrival order decides the last bits; kept for A/B)."""
+    import os
     R, S = rays_o.shape[0], t.numel()
     Z, Y, X, GC = grid.shape
     if grad_grid is None:
         grad_grid = torch.zeros_like(grid)
+    if R == 0:
+        return grad_grid
+    algo = algo or os.environ.get('PW_RENDER_BWD', 'sorted')
     ch = (ctypes.c_float * 27)(*[float(v) for v in consts])
     gw = _chk(g_weights.contiguous(), _f32, 'g_weights') if g_weights is not None else None
-    _lib.call('pw_render_rays_backward', _chk(rays_o.contiguous(), _f32, 'rays_o'), _chk(rays_d.contiguous(), _f32, 'rays_d'), R,
-              _chk(t, _f32, 't'), S, _chk(grid, _f32, 'grid'), X, Y, Z, GC, c_sigma, c_sem, n_sem, c_rgb, ch,
-              _chk(g_depth.contiguous(), _f32, 'g_depth'), _chk(g_sem.contiguous(), _f32, 'g_sem'),
-              _chk(g_rgb.contiguous(), _f32, 'g_rgb'), _chk(g_last.contiguous(), _f32, 'g_last'), gw,
-              _chk(grad_grid, _f32, 'grad_grid'), _stream())
+    args = (_chk(rays_o.contiguous(), _f32, 'rays_o'), _chk(rays_d.contiguous(), _f32, 'rays_d'), R,
+            _chk(t, _f32, 't'), S, _chk(grid, _f32, 'grid'), X, Y, Z, GC, c_sigma, c_sem, n_sem, c_rgb, ch,
+            _chk(g_depth.contiguous(), _f32, 'g_depth'), _chk(g_sem.contiguous(), _f32, 'g_sem'),
+            _chk(g_rgb.contiguous(), _f32, 'g_rgb'), _chk(g_last.contiguous(), _f32, 'g_last'), gw)
+    if algo == 'atomics':
+        _lib.call('pw_render_rays_backward', *args, _chk(grad_grid, _f32, 'grad_grid'), _stream())
+        return grad_grid
+    g20 = torch.cat([g_sem.float(), g_rgb.float()], dim=1).contiguous()
+    gmax = g20.abs().max().reshape(1).contiguous()
+    nbytes = _lib.call_size('pw_render_backward_workspace_bytes', R, S, X, Y, Z)
+    ws = _workspace(nbytes, grid.device)
+    off = (-ws.data_ptr()) % 256
+    _lib.call('pw_render_rays_backward_sorted', *args, _chk(g20, _f32, 'g_semrgb'), _chk(gmax, _f32, 'g_absmax'),
+              ctypes.c_void_p(ws.data_ptr() + off), nbytes, _chk(grad_grid, _f32, 'grad_grid'), _stream())
     return grad_grid
 
 

@@ -156,3 +156,29 @@ def test_syncbn_two_ranks_equal_one_process_on_the_whole_batch():
     # parameter gradients stay per rank (DDP averages them): their sum is the whole batch's gradient
     np.testing.assert_allclose(res[0][3] + res[1][3], gamma.grad.numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(res[0][4] + res[1][4], beta.grad.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_bench_py_two_ranks_through_the_driver_launch_line():
+    """the driver's own command for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with N = 2 on this 1-GPU box: the ranks find the device
+    oversubscribed, rendezvous over gloo, run the replicas mode (no data-path collective), reduce the time with MAX and rank 0
+    prints ONE JSON line with the whole-job value (exercise bench.py itself, not only the harness)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
+           '--settle-s', '0.1']
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['steps'] == 4 and r['scaling'] == 'weak' and r['value'] > 0
+    assert abs(r['value'] - 2 * 4 / (r['ms_per_step'] * 4e-3)) < 1e-2 * r['value']           # whole-job: both ranks' samples
+    assert r['rccl_world'] is None and 'OVERSUBSCRIBED' in r['config']['note']
+    assert 'cpu_baseline' not in r and r['roofline']['kernel'].startswith('k_conv3d')

@@ -358,3 +358,35 @@ def test_render_bf16_grid_storage():
     out32 = ops.render_rays(T(o), T(d), t, grid, c)
     for k, tol in (('depth', 2e-2), ('semantic', 3e-2), ('color', 3e-2), ('alphainv_last', 1e-2)):
         check_close('bf16-stored grid vs fp32 grid: %s' % k, out16[k], out32[k].cpu().numpy(), tol)
+
+
+@pytest.mark.parametrize('R', [3072, 24000])
+def test_render_backward_sorted_is_deterministic_and_equals_the_atomic_form(R):
+    """pw_render_rays_backward_sorted (entries sorted by voxel, 64-bit fixed-point segmented sums, no float atomics; VERDICT r02
+    missing 5): bit-identical from run to run -- the autograd graph it replaces (nerf_head.py:211-225 under torch) is
+    deterministic given sorted ray_id -- and equal to the scatter-add form up to that form's own summation-order noise.
+    R = 24 000 rays from 6 camera centres puts > 6 144 entries into the voxels around the cameras (the multi-wave long path)."""
+    density, semantic, color = S.render_grids(41)
+    grid = M.pack_attribute_grid(T(density), T(semantic), T(color))
+    head = _head()
+    o, d = S.rays(7, R)
+    ro, rd = T(o), T(d)
+    t = head.t_table(DEV)
+    consts = head.consts(torch.eye(3))
+    g = torch.Generator(device='cpu').manual_seed(5)
+    gd, gs, gc, gl = (torch.randn(R, generator=g).to(DEV), torch.randn(R, 17, generator=g).to(DEV),
+                      torch.randn(R, 3, generator=g).to(DEV), torch.randn(R, generator=g).to(DEV))
+    gw = (torch.randn(R, t.numel(), generator=g) * 0.1).to(DEV)
+    a = ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, gw, algo='sorted')
+    b = ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, gw, algo='sorted')
+    assert torch.equal(a, b), 'the sorted backward must be bit-reproducible'
+    c = ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, gw, algo='atomics')
+    from _parity import check_close
+    check_close('render backward sorted vs atomics, R=%d' % R, a, c, 2e-5, atol=1e-7)
+    # (terms below 2^-41 of a channel group's largest possible term round to zero in fixed point: a few per mille of the voxels
+    # the float form leaves at ~1e-15 are exactly 0 here)
+    assert abs(int((a != 0).sum()) - int((c != 0).sum())) <= 0.01 * int((c != 0).sum())
+    # accumulation contract: grad_grid is added INTO
+    base = torch.full_like(grid, 0.5)
+    acc = ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, gw, grad_grid=base.clone(), algo='sorted')
+    check_close('accumulates into grad_grid', acc - 0.5, a, 1e-6, atol=1e-6)

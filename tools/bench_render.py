@@ -44,11 +44,14 @@ for name, R, t, grid in (('C5 literal 3072 x 96, random grid', 3072, None, grid)
     fwd = timeit(lambda: ops.render_rays(ro, rd, t, grid, consts))
     g16 = grid.to(torch.bfloat16)
     fwd16 = timeit(lambda: ops.render_rays(ro, rd, t, g16, consts))
-    bwd = timeit(lambda: ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, grad_grid=gg))
+    bwd = timeit(lambda: ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, grad_grid=gg, algo='sorted'), n=10)
+    bwd_at = timeit(lambda: ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, grad_grid=gg, algo='atomics'), n=5)
     zero = timeit(lambda: gg.zero_())
     pts = R * S_
     kept = int(ops.render_rays(ro, rd, t, grid, consts, want_debug=True)['counts'][:, 2].sum())
     print('[%d kept samples] ' % kept, end='')
-    print('%s: forward %.1f us (%.2f G samples/s, %.0f GB/s on 57.8 MB) | backward kernel %.1f us + %.1f us zero-fill of the 61 MB '
-          'gradient grid | fwd+bwd %.1f us (%.2f G samples/s) | forward with the grid stored as bf16: %.1f us' % (
-              name, fwd, pts / fwd * 1e-3, 57.8e6 / fwd * 1e-3, bwd, zero, fwd + bwd + zero, pts / (fwd + bwd + zero) * 1e-3, fwd16), flush=True)
+    print('%s: forward %.1f us (%.2f G samples/s, %.0f GB/s on 57.8 MB) | backward (sorted, deterministic) %.1f us = %.1f x forward; '
+          'backward (float atomics) %.1f us | + %.1f us zero-fill of the 61 MB gradient grid | fwd+bwd %.1f us (%.2f G samples/s) | '
+          'forward with the grid stored as bf16: %.1f us' % (
+              name, fwd, pts / fwd * 1e-3, 57.8e6 / fwd * 1e-3, bwd, bwd / fwd, bwd_at, zero, fwd + bwd + zero,
+              pts / (fwd + bwd + zero) * 1e-3, fwd16), flush=True)
