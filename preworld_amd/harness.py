@@ -44,7 +44,8 @@ def build_model(cfg, state_dict, device='cuda:0'):
     net = builder.build(cfg, 'PreWorld4DTraj')
     sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in state_dict.items()}
     missing, _ = net.load_state_dict(sd, strict=False)
-    image_side = ('depth_net', 'img_backbone', 'img_neck', 'num_batches_tracked')
+    # (nerf_head.*: five registered buffers the constructor recomputes from the config, nerf_head.py:134-144)
+    image_side = ('depth_net', 'img_backbone', 'img_neck', 'num_batches_tracked', 'nerf_head.')
     bad = [k for k in missing if not any(t in k for t in image_side)]
     if bad:
         raise KeyError('state dict lacks hot-path keys: %s' % bad[:8])
