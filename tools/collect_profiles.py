@@ -32,7 +32,7 @@ def main(v, what):
         o.write('# %s — PMC passes over one eager, strictly serial C3 step (separate passes: FETCH_SIZE | WRITE_SIZE | MFMA busy + GUI '
                 'active | SQ mix)\n\nCommand: `rocprofv3 --pmc <counters> --kernel-trace -d ... -- python bench.py --no-graph --in-flight 1 '
                 '--steps 4 --warmup 1 --settle-s 0 --no-cpu-baseline`; tables by tools/rocpd_pmc.py (KB per dispatch for the TCC counters). '
-                'FETCH_SIZE is reported at half the bytes for 16 B/lane reads on gfx950 (doubled in profiles/r02_pmc_traffic.json for the '
+                'FETCH_SIZE is reported at half the bytes for 16 B/lane reads on gfx950 (doubled in profiles/rNN_pmc_traffic.json for the '
                 'MFMA kernels); WRITE_SIZE exact. Matrix-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).\n\n' % v)
         for c in ('FETCH_SIZE', 'WRITE_SIZE', 'MFMA', 'SQ'):
             o.write('## %s\n%s\n' % (c, rd('pmc_%s.md' % c)))
@@ -40,7 +40,7 @@ def main(v, what):
     shutil.copy(os.path.join(src, 'bench.json'), os.path.join(dst, v + '_bench.json'))
     if os.path.exists(os.path.join(src, 'bench_c5.json')):
         shutil.copy(os.path.join(src, 'bench_c5.json'), os.path.join(dst, v + '_bench_c5.json'))
-    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'make_pmc_json.py'), src, os.path.join(dst, 'r02_pmc_traffic.json')])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'make_pmc_json.py'), src, os.path.join(dst, v[:3] + '_pmc_traffic.json')])
 
 
 if __name__ == '__main__':
