@@ -128,9 +128,11 @@ int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_
  * mmdet3d/models/backbones/resnet.py:88-184, necks/lss_fpn.py:120-129,
  * detectors/preworld.py:72-79, heads/occupancy_head.py:80-105.
  *   x        (B, D, H, W, Cin) fp32, Cin % 32 == 0
- *   wpk      packed weights, float[Cin/32][ksize^3][cout_total/32][64][16] with
- *            wpk[ch][tap][nt][h*32+j][s] = w[nt*32+j][ch*32+h*16+s][tap]  (w = torch
- *            (Cout,Cin,kD,kH,kW); columns >= Cout zero) -- built by preworld_amd.ops.pack_conv_weight
+ *   wpk      packed weights, float[Cin/32][ksize^3][cout_total/32][4][64][4] with
+ *            wpk[ch][tap][nt][q][h*32+j][e] = w[nt*32+j][ch*32+h*16+4*q+e][tap]  (w = torch
+ *            (Cout,Cin,kD,kH,kW); columns >= Cout zero) -- built by preworld_amd.ops.pack_conv_weight.
+ *            (A 4096-byte tile is four 1024-byte pieces of 64 lanes x 16 B, so that one wave-wide 16-byte load
+ *            reads 8 consecutive cache lines.)
  *   scale,bias  float[cout_total] or NULL: y = acc*scale + bias  (BatchNorm eval folded, or conv bias)
  *   residual    same layout as y0 or NULL (added before ReLU; BasicBlock3D.forward resnet.py:120-123)
  *   y0 (B,Do,Ho,Wo,cout0) gets packed columns [0,cout0); y1 (B,Do,Ho,Wo,cout1) gets columns
@@ -149,7 +151,7 @@ int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const 
 /* A8  LSSFPN3D fused (mmdet3d/models/necks/lss_fpn.py:132-148): out = ReLU(BN(W8 x8 +
  * up2(y16) + up4(y32))) where y16/y32 are the 1x1x1 conv already applied at 1/2 and 1/4
  * resolution (32 channels each; interpolation and 1x1x1 conv commute).  trilinear,
- * align_corners=True.  x8 (B,D,H,W,Cin8), wpk8 packed [Cin8/32][1][1][64][16], out (B,D,H,W,32).
+ * align_corners=True.  x8 (B,D,H,W,Cin8), wpk8 packed [Cin8/32][1][1][4][64][4], out (B,D,H,W,32).
  * x_h2 != 0: x8 is in split-fp16 "h2" storage and wpk8 comes from pack_conv_weight_h2 (its inv_scale folded into `scale`);
  * out_h2 != 0: out is written in h2 storage (see pw_conv3d_h2).  y16 / y32 are always fp32.  x_rng / out_rng: range slots
  * of x8 / out when they are h2 (see pw_f32_to_h2; NULL = exponent 0). */
@@ -205,9 +207,9 @@ int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int l
  * row strides -- for ksize 3 (stride 1: persistent LDS-tiled kernel; stride 2: gather kernel) and ksize 1 (stride 1); algo 2 / 3
  * force the gather kernel (3 = input-channel chunks split over the 4 waves, tiny grids), with
  *   x        (B, D, H, W, Cin) in h2 storage;
- *   wpk      split-fp16 packed weights float[Cin/32][ksize^3][cout_total/32][64 lanes][16]: lane (j = l & 31, h = l >> 5) holds,
- *            for q = 2*ks + p, the 8 halves plane p of S[n] * w[n = nt*32 + j][c = ch*32 + 16*ks + 8*h + 0..7][tap], S[n] a
- *            power of two that the caller folds back into scale[n] (preworld_amd.ops.pack_conv_weight_h2);
+ *   wpk      split-fp16 packed weights float[Cin/32][ksize^3][cout_total/32][4 pieces][64 lanes][4]: piece q = 2*ks + p of
+ *            lane l (j = l & 31, h = l >> 5) holds the 8 halves plane p of S[n] * w[n = nt*32 + j][c = ch*32 + 16*ks + 8*h + 0..7][tap],
+ *            S[n] a power of two that the caller folds back into scale[n] (preworld_amd.ops.pack_conv_weight_h2);
  *   cout0 / cout1 / ld_y0 / ld_y1 multiples of 32;
  *   fmt_y0 / fmt_y1 / fmt_res: 0 = fp32, 1 = h2 storage of y0 / y1 / residual (the residual shares y0's row stride and
  *   may be y0 itself);

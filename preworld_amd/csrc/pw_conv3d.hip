@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
       for (int q = 0; q < 4; ++q)
         aaddr[khp][kw][q] = (unsigned)((((wave * TH + pr) * TW + ww) * 8 + ((half * 4 + q) ^ f)) * 16);
     }
-  const unsigned lane_off = (unsigned)lane * 64u;
+  const unsigned lane_off = (unsigned)lane * 16u;
   const unsigned wstride = (unsigned)ntiles_total * 4096u;           // bytes per tap
   const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
   const rsrc_t wr = make_rsrc(a.wpk, (unsigned)((size_t)(a.Cin / KC) * 27 * ntiles_total * 4096));
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_k3s1_pipe(ConvArgs a, PipeArg
   c.lds3 = (lds3_t)lds;
   c.xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
   c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 27 * ntiles_total * 4096));
-  c.lane_off = (unsigned)lane * 64u;
+  c.lane_off = (unsigned)lane * 16u;
   c.wstride = (unsigned)ntiles_total * 4096u;
   c.wave = wave; c.lane = lane;
 

@@ -13,6 +13,7 @@ namespace {
 constexpr int BD = 4, BH = 8, BW = 8;
 constexpr int TD = BD + 2, TH = BH + 2, TW = BW + 2;
 constexpr int TV = TD * TH * TW;                 // 600 halo voxels
+constexpr unsigned WPIECE = 1024u;               // bytes per piece of a packed weight tile (4 pieces x 64 lanes x 16 B)
 constexpr int KC = 32;                           // input channels per LDS chunk
 }  // namespace
 
@@ -226,11 +227,13 @@ __device__ __forceinline__ void stage_halo_chunk(const ConvArgs& a, rsrc_t xr, f
 
 template <int NT>
 __device__ __forceinline__ void load_b(rsrc_t wr, unsigned wsoff, unsigned lane_off, float4 (&b)[NT][4]) {
-  // wsoff: wave-uniform byte offset of this (chunk, tap, N-group); lane_off = lane*64 bytes
+  // wsoff: wave-uniform byte offset of this (chunk, tap, N-group) tile; lane_off = lane*16 bytes.  A 4096-byte weight tile is
+  // four 1024-byte pieces of 64 lanes x 16 B (WPIECE): one instruction reads 1 KB of consecutive bytes = 8 cache lines, where
+  // the 64-bytes-per-lane order of rounds 1-2 touched 32 lines per instruction (the vector L1 looks up one line per cycle)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b[nt][q] = buf_load4(wr, lane_off + (unsigned)(q * 16), wsoff + (unsigned)(nt * 4096));
+    for (int q = 0; q < 4; ++q) b[nt][q] = buf_load4(wr, lane_off + (unsigned)q * WPIECE, wsoff + (unsigned)(nt * 4096));
 }
 
 // one tap: 2 M-tiles x NT N-tiles x 16 k-steps of v_mfma_f32_32x32x2_f32.

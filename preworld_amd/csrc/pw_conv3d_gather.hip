@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
     }
     const int nchunk = a.Cin / KC;
     c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * TAPS * ntiles_total * 4096));
-    c.lane_off = (unsigned)lane * 64u;
+    c.lane_off = (unsigned)lane * 16u;
     c.wstride = (unsigned)ntiles_total * 4096u;
 
     float4 a0[MT][4], a1[MT][4], b0[NT][4], b1[NT][4];

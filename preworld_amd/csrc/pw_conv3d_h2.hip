@@ -94,10 +94,12 @@ __device__ __forceinline__ void h2_epi_load(const ConvArgs& a, const EpiTile& t,
   const int o = lane & 3;
   const int u = 16 * P + (lane >> 2), sv = u & 63;
   const int mt = sv >> 5, vr = (sv >> 3) & 3, vc = sv & 7;
-  const bool ok = t.pending && od < a.Do && (t.h0 + mt * 4 + vr) < a.Ho && (t.w0 + vc) < a.Wo;
+  // (no short-circuit: the pass lives inside a tap's scheduling region, a branch would cut that region in two)
+  const bool ok = (int)t.pending & (int)(od < a.Do) & (int)((t.h0 + mt * 4 + vr) < a.Ho) & (int)((t.w0 + vc) < a.Wo);
   r.soff = (unsigned)(((((t.b * a.Do + od) * a.Ho + t.h0) * a.Wo + t.w0) * ld) * 4);
   const unsigned pos = (EPI == 3 ? (unsigned)(32 * o) : (unsigned)((4 * (o & 1) + 2 * (o >> 1)) * 16));
-  r.vbase = ok ? (unsigned)(((mt * 4 + vr) * a.Wo + vc) * ld) * 4u + (unsigned)col0 * 4u + pos : PIPE_OOB;
+  const unsigned vin = (unsigned)(((mt * 4 + vr) * a.Wo + vc) * ld) * 4u + (unsigned)col0 * 4u + pos;
+  r.vbase = ok ? vin : PIPE_OOB;
   const char* src = stg + epi_slot_off(u);
   const int sw = (u >> 1) & 7;
   r.x0 = *reinterpret_cast<const v4f*>(src + (((2 * o) ^ sw) * 16));
@@ -165,11 +167,28 @@ __device__ __forceinline__ void h2_epi_rest(const ConvArgs& a, const EpiTile& t,
   }
 }
 
-// halo row this wave's DMA issues at tap TAP of a stage (or -1): parking rows (< S) go out after the epilogue passes
+// halo rows (K = first, count) this wave's DMA issues at tap TAP of a stage: the whole next halo goes out as ONE burst
+// right after the epilogue passes (taps 2 .. 4 NT + 1, which read the parked rows K < 7 / 13).  The memory counter is in
+// order: a weight load (L2 latency, needed two taps later) cannot be waited for without also waiting for every halo row
+// issued before it (HBM latency, longer than three taps).  One row per tap over 13-15 taps therefore stalled almost every
+// tap (profiles/r03_conv_h2_ablation.txt: the same DMA instructions with every lane out of range, i.e. returning at once,
+// took 23 % off the kernel); as a burst the queue behind the weights is clear again a few taps later, for the rest of the stage.
+#ifndef PW_DMA_ROWS_PER_TAP_NT1
+#define PW_DMA_ROWS_PER_TAP_NT1 3
+#endif
+#ifndef PW_DMA_ROWS_PER_TAP_NT2
+#define PW_DMA_ROWS_PER_TAP_NT2 5
+#endif
 template <int NT, int TAP>
-__device__ __forceinline__ constexpr int h2_dma_row_of_tap() {
-  if constexpr (NT == 1) return (TAP >= 1 && TAP <= 8) ? TAP + 6 : ((TAP >= 9 && TAP <= 15) ? TAP - 9 : -1);
-  else return (TAP >= 1 && TAP <= 2) ? TAP + 12 : ((TAP >= 10 && TAP <= 22) ? TAP - 10 : -1);
+__device__ __forceinline__ constexpr int h2_dma_first_row() {
+  constexpr int per = NT == 1 ? PW_DMA_ROWS_PER_TAP_NT1 : PW_DMA_ROWS_PER_TAP_NT2, t0 = 4 * NT + 2;
+  return TAP < t0 ? PIPE_ROWS_PER_WAVE : (TAP - t0) * per;
+}
+template <int NT, int TAP>
+__device__ __forceinline__ constexpr int h2_dma_row_count() {
+  constexpr int per = NT == 1 ? PW_DMA_ROWS_PER_TAP_NT1 : PW_DMA_ROWS_PER_TAP_NT2;
+  constexpr int k0 = h2_dma_first_row<NT, TAP>();
+  return k0 >= PIPE_ROWS_PER_WAVE ? 0 : (k0 + per <= PIPE_ROWS_PER_WAVE ? per : PIPE_ROWS_PER_WAVE - k0);
 }
 
 template <int NT>
@@ -180,6 +199,7 @@ struct H2Ctx {
   unsigned wsoff, wsoff_next;
   bool has_next;
   PipeDma dm;
+  unsigned dm_base, dm_pitch;  // next stage's halo: byte offset of row (d0-1, h0-1) at wbase / chunk ch; bytes per h row
   int wave, lane;
   long long* tap_probe;
   EpiTile epi;                 // tile parked by the previous stage, written out during this one
@@ -207,7 +227,7 @@ __device__ __forceinline__ void h2_load_b(rsrc_t wr, unsigned wsoff, unsigned la
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int q = WR ? 1 : 0; q < 4; q += WR ? 2 : 1) {
-      const auto v = __builtin_amdgcn_raw_buffer_load_b128(wr, lane_off + (unsigned)(q * 16), wsoff + (unsigned)(nt * 4096), 0);
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(wr, lane_off + (unsigned)q * H2W_PIECE, wsoff + (unsigned)(nt * 4096), 0);
       v4f o;
       o[0] = __uint_as_float(v[0]); o[1] = __uint_as_float(v[1]); o[2] = __uint_as_float(v[2]); o[3] = __uint_as_float(v[3]);
       b[nt][q] = o;
@@ -240,37 +260,102 @@ __device__ __forceinline__ void h2_mfma(const v4f (&aq)[2][4], const v4f (&b)[NT
   h2_mfma<NT, false, 0, 1>(aq, b, acc, none);
 }
 
+// ---- issue order inside a tap.  One wave per SIMD means nothing else fills the matrix pipe while this wave issues its own
+// loads and address arithmetic: with the tap's side work (weight loads two taps ahead, next tap's A fragments, the halo row
+// DMA with its ~25 scalar instructions, an epilogue pass) in front of the MFMAs, a 768-cycle tap (NT 2) took 930 .. 1600 cycles
+// (profiles/r03_conv_h2_stage_probe_64to64.txt; leaving each piece out in turn: profiles/r03_conv_h2_ablation.txt).  So the
+// whole tap is ONE scheduling region and the pipeline below spreads the side work over the shadows of the 12 NT MFMAs
+// (32 cycles each = ~7 issue slots): slot i gets its share of the VMEM reads, LDS reads, SALU and VALU instructions.
+__device__ __forceinline__ constexpr int h2_share(int i, int slots, int n) { return ((i + 1) * n) / slots - (i * n) / slots; }
+
+template <int I, int S, int NVM, int NDS, int NSA, int NVA>
+__device__ __forceinline__ void h2_pipeline() {
+  if constexpr (I < S) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (h2_share(I, S, NDS) > 0) __builtin_amdgcn_sched_group_barrier(0x100, h2_share(I, S, NDS), 0);
+    if constexpr (h2_share(I, S, NVM) > 0) __builtin_amdgcn_sched_group_barrier(0x020, h2_share(I, S, NVM), 0);
+    if constexpr (h2_share(I, S, NSA) > 0) __builtin_amdgcn_sched_group_barrier(0x004, h2_share(I, S, NSA), 0);
+    if constexpr (h2_share(I, S, NVA) > 0) __builtin_amdgcn_sched_group_barrier(0x002, h2_share(I, S, NVA), 0);
+    h2_pipeline<I + 1, S, NVM, NDS, NSA, NVA>();
+  }
+}
+
+// halo row `wave + 4 K` of the next stage (pipe_dma_row of pw_conv3d_common.h with the per-stage part of the address
+// arithmetic hoisted into H2Ctx and no branch: the row's scalar code has to sit inside the tap's scheduling region)
+struct H2DmaView { rsrc_t xr; lds3_t lds3; unsigned base, pitch; int wave; };
+template <int K>
+__device__ __forceinline__ void h2_dma_row(const ConvArgs& a, const PipeDma& dm, const H2DmaView& c) {
+  constexpr int c1 = (4 * K) / TH, c2 = (4 * K) % TH;
+  const int t = c2 + c.wave;                               // wave-uniform
+  const int carry = t >= TH ? 1 : 0;
+  const int dd = c1 + carry, hh = t - TH * carry;
+  const bool rok = (int)dm.live & (int)((unsigned)(dm.d0 - 1 + dd) < (unsigned)a.D) & (int)((unsigned)(dm.h0 - 1 + hh) < (unsigned)a.H);
+  const unsigned soff = c.base + (unsigned)(dd * a.H + hh) * c.pitch;      // rows outside the volume: every lane is out of range
+#ifdef PW_X_DMAOOB
+  const unsigned v0 = rok ? PIPE_OOB : PIPE_OOB - 16u, v1 = v0;
+#else
+  const unsigned v0 = rok ? ((hh & 1) ? dm.voff[1][0] : dm.voff[0][0]) : PIPE_OOB;
+  const unsigned v1 = rok ? ((hh & 1) ? dm.voff[1][1] : dm.voff[0][1]) : PIPE_OOB;
+#endif
+  lds3_t dst = c.lds3 + (dm.ldsbuf + (unsigned)(c1 * TH + c2) * (TW * 128) + (unsigned)c.wave * (TW * 128));
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, dst, 16, v0, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, dst + 1024, 4, v1, soff, 0, 0);
+}
+
+template <int K0, int N>
+__device__ __forceinline__ void h2_dma_rows(const ConvArgs& a, const PipeDma& dm, const H2DmaView& c) {
+  if constexpr (N > 0) {
+    h2_dma_row<K0>(a, dm, c);
+    h2_dma_rows<K0 + 1, N - 1>(a, dm, c);
+  }
+}
+
 template <int NT, int EPI, int TAP, bool WR = false, int NW = 1>
 __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, const unsigned (&aaddr)[2][3][4],
                                         v4f (&ac)[2][4], v4f (&an)[2][4], v4f (&b0)[NT][4], v4f (&b1)[NT][4],
                                         v4f (&b2)[NT][4], f32x16 (&acc)[2][NT], EpiRegs& er, const v4f (&wres)[NW][2]) {
-  if (c.tap_probe) {                       // development aid: cycle counter at every tap of one stage
+#ifdef PW_CONV_TAP_PROBE                   // development aid: cycle counter at every tap of one stage
+  if (c.tap_probe) {
     if (c.lane == 0) c.tap_probe[c.wave * 27 + TAP] = __builtin_readcyclecounter();
   }
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+  constexpr int dma_k0 = h2_dma_first_row<NT, TAP>(), dma_n = h2_dma_row_count<NT, TAP>();
+#ifdef PW_X_NOEPI
+  constexpr bool epi_tap = false, epi_ld = false;
+#else
+  constexpr bool epi_tap = EPI > 0 && TAP >= 2 && TAP <= 4 * NT + 1;      // pass TAP-2 of the previous tile (loaded last tap)
+  constexpr bool epi_ld = EPI > 0 && TAP >= 1 && TAP <= 4 * NT;           // loads of pass TAP-1
+#endif
+#ifdef PW_X_BSAME
+  h2_load_b<NT, WR>(c.wr, c.wsoff, c.lane_off, b2);
+#elif !defined(PW_X_NOB)
   if constexpr (TAP + 2 < 27) {
     h2_load_b<NT, WR>(c.wr, c.wsoff + (unsigned)(TAP + 2) * c.wstride, c.lane_off, b2);
   } else {
     h2_load_b<NT, WR>(c.wr, c.wsoff_next + (unsigned)(TAP + 2 - 27) * c.wstride, c.lane_off, b2);
   }
-  if constexpr (h2_dma_row_of_tap<NT, TAP>() >= 0) pipe_dma_row<h2_dma_row_of_tap<NT, TAP>()>(a, c.xr, c.lds3, c.dm, c.wave);
+#endif
+#ifndef PW_X_NODMA
+  h2_dma_rows<dma_k0, dma_n>(a, c.dm, H2DmaView{c.xr, c.lds3, c.dm_base, c.dm_pitch, c.wave});
+#endif
+#ifndef PW_X_NOA
   if constexpr (TAP < 26) h2_read_a_tap<TAP + 1>(c.lds3, aaddr, an);
-  __builtin_amdgcn_sched_barrier(0);
-  constexpr bool epi_tap = EPI > 0 && TAP >= 2 && TAP <= 4 * NT + 1;
-  if constexpr (epi_tap) h2_epi_compute<NT, EPI, TAP - 2>(a, c.epi, er, c.res_mul);      // pass TAP-2 of the previous tile (loaded last tap)
-  h2_mfma<NT, WR, TAP, NW>(ac, b0, acc, wres);
-  if constexpr (epi_tap) {
-    // interleave: one MFMA, then a handful of the pass's VALU instructions in its shadow; the two stores last
-#pragma unroll
-    for (int i = 0; i < 12 * NT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, NT == 1 ? 6 : 3, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (EPI > 0 && TAP >= 1 && TAP <= 4 * NT)
+#endif
+  if constexpr (epi_tap) h2_epi_compute<NT, EPI, TAP - 2>(a, c.epi, er, c.res_mul);
+  if constexpr (epi_ld)
     h2_epi_load<NT, EPI, TAP - 1>(a, c.epi, c.ldsg + c.epi.bufoff + (unsigned)c.wave * (TW * 128),
                                   reinterpret_cast<const float*>(c.ldsg + H2_SB_OFF), c.wave, c.lane, er);
+  h2_mfma<NT, WR, TAP, NW>(ac, b0, acc, wres);
+  {
+    constexpr int n_vm = (WR ? 2 : 4) * NT + 2 * dma_n + ((epi_ld && EPI == 2) ? 2 : 0);
+    constexpr int n_ds = (TAP < 26 ? 8 : 0) + (epi_ld ? 6 : 0);
+    constexpr int n_sa = 4 + 26 * dma_n + (epi_ld ? 12 : 0);
+    constexpr int n_va = 5 * dma_n + (epi_tap ? (EPI == 2 ? 100 : 76) : 0) + (epi_ld ? 36 : 0);
+    h2_pipeline<0, 12 * NT, n_vm, n_ds, n_sa, n_va>();
+    if constexpr (epi_tap) __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   if constexpr (TAP < 26) h2_step<NT, EPI, TAP + 1, WR, NW>(a, c, aaddr, an, ac, b1, b2, b0, acc, er, wres);
 }
 
@@ -409,7 +494,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   c.lds3 = (lds3_t)lds;
   c.xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
   c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 27 * ntiles_total * 4096));
-  c.lane_off = (unsigned)lane * 64u;
+  c.lane_off = (unsigned)lane * 16u;
   c.wstride = (unsigned)ntiles_total * 4096u;
   c.wave = wave; c.lane = lane;
   c.ldsg = reinterpret_cast<const char*>(lds);
@@ -422,7 +507,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     for (int tp = 0; tp < 27; ++tp)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(c.wr, c.lane_off + (unsigned)(ks * 32), (unsigned)tp * c.wstride, 0);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(c.wr, c.lane_off + (unsigned)(2 * ks) * H2W_PIECE, (unsigned)tp * c.wstride, 0);
         v4f o;
         o[0] = __uint_as_float(v[0]); o[1] = __uint_as_float(v[1]); o[2] = __uint_as_float(v[2]); o[3] = __uint_as_float(v[3]);
         wres[tp][ks] = o;
@@ -496,6 +581,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
     pipe_lane_offsets(a, tn.w0, lane, c.dm.voff);
     c.dm.b = tn.b; c.dm.d0 = tn.d0; c.dm.h0 = tn.h0; c.dm.wbase = tn.w0 > 0 ? tn.w0 - 1 : 0;
     c.dm.ch = chn; c.dm.ldsbuf = (unsigned)PIPE_BUF_BYTES - bufoff; c.dm.live = c.has_next;
+    c.dm_pitch = (unsigned)(a.W * a.Cin) * 4u;
+    c.dm_base = (unsigned)(((((tn.b * a.D + tn.d0 - 1) * a.H + tn.h0 - 1) * a.W + c.dm.wbase) * a.Cin + chn * KC) * 4);
 
     c.tap_probe = (a.probe && blockIdx.x == 17 && stage == 3) ? a.probe + 256 * 8 * 16 * 4 : nullptr;
     h2_step<NT, EPI, 0, WR, NW>(a, c, aaddr, a0, a1, b0, b1, b2, acc, er, wres);
@@ -584,7 +671,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3d_h2_tile(ConvArgs a) {
       for (int q = 0; q < 4; ++q)
         aaddr[khp][kw][q] = (unsigned)((((wave * TH + pr) * TW + ww) * 8 + ((half * 4 + q) ^ f)) * 16);
     }
-  const unsigned lane_off = (unsigned)lane * 64u;
+  const unsigned lane_off = (unsigned)lane * 16u;
   const unsigned wstride = (unsigned)ntiles_total * 4096u;
   const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
   const rsrc_t wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 27 * ntiles_total * 4096));

@@ -56,7 +56,7 @@ __device__ __forceinline__ v4f s2_load4(rsrc_t r, unsigned voff, unsigned soff) 
 struct S2Ctx {
   const char* lds;
   rsrc_t wr;
-  unsigned lane_off, tile_off, wstride;        // lane * 64 (+ k-step); first cout tile of the wave x 4096; bytes per tap
+  unsigned lane_off, tile_off, wstride;        // lane * 16 (+ k-step pieces); first cout tile of the wave x 4096; bytes per tap
   unsigned ra[2][2];                           // fragment addresses [kh >> 1][plane]
 };
 
@@ -65,7 +65,7 @@ __device__ __forceinline__ void s2_load_w(const S2Ctx& c, unsigned wsoff, v4f (&
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) bw[nt][p] = s2_load4(c.wr, c.lane_off + (unsigned)(p * 16), wsoff + c.tile_off + (unsigned)(nt * 4 * 4096));
+    for (int p = 0; p < 2; ++p) bw[nt][p] = s2_load4(c.wr, c.lane_off + (unsigned)p * H2W_PIECE, wsoff + c.tile_off + (unsigned)(nt * 4 * 4096));
 }
 
 template <int TAP>
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256 * S2_NG<NTW>, S2_NG_V == 1 ? (NTW == 1 ? 3
     if (a.probe && pass == 0) ts[1] = __builtin_readcyclecounter();
     if (S2_PREFETCH && pass + 1 < 2 * nchunk) issue_halo(pass + 1);
     // ---- 27 taps of this k-step
-    c.lane_off = (unsigned)lane * 64u + (unsigned)(ks * 32);
+    c.lane_off = (unsigned)lane * 16u + (unsigned)(2 * ks) * H2W_PIECE;
     const unsigned wsoff = (unsigned)(ch * 27) * c.wstride;
     v4f ax[2][2][2], bw[S2_WD][NTW][2];
 #pragma unroll

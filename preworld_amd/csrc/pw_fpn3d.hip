@@ -53,12 +53,14 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
   const int nchunk = a.Cin / KC;
   for (int ch = 0; ch < nchunk; ++ch) {
     const float* src = a.x + (size_t)m * a.Cin + ch * KC + half * 16;
-    const float* wt = a.wpk + (size_t)ch * 1024 + lane * 16;
+    // a weight tile = four 1024-byte pieces of 64 lanes x 16 B (pw_conv3d_common.h WPIECE), fp32 and split-fp16 alike
+    const float* wt = a.wpk + (size_t)ch * 1024 + lane * 4;
+    constexpr int wq = (int)(WPIECE / 4);
     float4 aq[4], bq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       aq[q] = *reinterpret_cast<const float4*>(src + q * 4);
-      bq[q] = *reinterpret_cast<const float4*>(wt + q * 4);
+      bq[q] = *reinterpret_cast<const float4*>(wt + q * wq);
     }
     if (a.dma_stage) {
       // x8 and wpk8 in split-fp16 storage (pw_h2.h): the lane's four 16-byte pieces are {hi, lo} x {k-step 0, 1}

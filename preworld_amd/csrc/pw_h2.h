@@ -32,6 +32,13 @@
 #define PW_H2_H_
 #include "pw_conv3d_common.h"
 
+// Packed split-fp16 weight tile (ops.pack_conv_weight_h2): 4096 B per (chunk, tap, 32-column tile) = four 1024-byte PIECES
+// q = 2 ks + p (k-step, hi / lo plane), a piece = 64 lanes x 16 B in lane order.  One load instruction of a wave therefore reads
+// 1 KB of consecutive bytes = 8 cache lines.  (Rounds 1-2 kept a lane's four pieces together, 64 B per lane: every instruction
+// then touched 32 lines for the same 1 KB, and the vector L1 looks up one line per cycle -- 0.82 lookups per cycle over the whole
+// 64->64 kernel, 62 % TA busy, a quarter of the wave cycles in s_waitcnt: profiles/r03_conv_h2_pmc.md.)
+constexpr unsigned H2W_PIECE = WPIECE;
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));

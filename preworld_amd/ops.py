@@ -234,8 +234,8 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
 # ------------------------------------------------------------------------------ conv3d
 def pack_conv_weight(w, cout_total=None):
     """torch Conv3d weight (Cout, Cin, k, k, k) -> the MFMA operand order documented in
-    include/preworld_hip.h: float[Cin/32][k^3][cout_total/32][64][16] with
-    wpk[ch][tap][nt][h*32+j][s] = w[nt*32+j][ch*32+h*16+s][tap]; columns >= Cout are zero."""
+    include/preworld_hip.h: float[Cin/32][k^3][cout_total/32][4 pieces][64 lanes][4] with
+    wpk[ch][tap][nt][q][h*32+j][e] = w[nt*32+j][ch*32+h*16+4*q+e][tap]; columns >= Cout are zero."""
     Cout, Cin, k = w.shape[0], w.shape[1], w.shape[2]
     if Cin % 32:
         raise _lib.PreworldHipError('Cin must be a multiple of 32, got %d' % Cin)
@@ -245,8 +245,8 @@ def pack_conv_weight(w, cout_total=None):
     wp = w.new_zeros(cout_total, Cin, taps)
     wp[:Cout] = w.reshape(Cout, Cin, taps)
     nt, nch = cout_total // 32, Cin // 32
-    wp = wp.view(nt, 32, nch, 2, 16, taps)              # (nt, j, ch, h, s, tap)
-    wp = wp.permute(2, 5, 0, 3, 1, 4).contiguous()      # (ch, tap, nt, h, j, s)
+    wp = wp.view(nt, 32, nch, 2, 4, 4, taps)            # (nt, j, ch, h, q, e, tap): s = 4 q + e
+    wp = wp.permute(2, 6, 0, 4, 3, 1, 5).contiguous()   # (ch, tap, nt, q, h, j, e): piece-major, a piece = 64 lanes x 16 B
     return wp.view(nch, taps, nt, 64, 16).float().contiguous()
 
 
@@ -618,7 +618,7 @@ def h2_to_f32(x, out=None):
 
 def pack_conv_weight_h2(w, cout_total=None):
     """torch Conv3d weight (Cout, Cin, 3,3,3) -> (wpk, inv_scale): split-fp16 weights in the operand order of
-    pw_conv3d_h2 (include/preworld_hip.h) as a float32-typed tensor [Cin/32][27][cout_total/32][64][16], and the
+    pw_conv3d_h2 (include/preworld_hip.h) as a float32-typed tensor [Cin/32][27][cout_total/32][4 pieces][64 lanes][4], and the
     per-column factor (cout_total,) = 1 / S[n] to multiply into the epilogue scale.  S[n] = 2^k puts the largest
     |w[n]| in [512, 1024): both halves of the split are then normal fp16 numbers for every weight above 2^-13 of it."""
     Cout, Cin = w.shape[:2]
@@ -637,8 +637,8 @@ def pack_conv_weight_h2(w, cout_total=None):
     planes = torch.stack([hi, lo], 0)                                            # (p, n, c, tap)
     nt, nch = cout_total // 32, Cin // 32
     t = planes.view(2, nt, 32, nch, 2, 2, 8, taps)                               # (p, nt, j, ch, ks, h, e, tap)
-    t = t.permute(3, 7, 1, 5, 2, 4, 0, 6).contiguous()                           # (ch, tap, nt, h, j, ks, p, e)
-    wpk = t.view(nch, taps, nt, 64, 32).view(torch.float32).view(nch, taps, nt, 64, 16).contiguous()
+    t = t.permute(3, 7, 1, 4, 0, 5, 2, 6).contiguous()                           # (ch, tap, nt, ks, p, h, j, e): piece-major
+    wpk = t.view(nch, taps, nt, 4 * 64 * 8).view(torch.float32).view(nch, taps, nt, 64, 16).contiguous()
     inv = torch.ones(cout_total, dtype=torch.float64, device=w.device)
     inv[:Cout] = 1.0 / S
     return wpk, inv.float()

@@ -219,14 +219,15 @@ class BatchNormCL(torch.autograd.Function):
 
 def _update_running(bn, mean, var, n):
     """nn.BatchNorm3d bookkeeping (torch/nn/modules/batchnorm.py): exponential average with the UNBIASED batch variance;
-    n: (1,) device tensor, the number of rows the statistics were taken over (all ranks for a SyncBN) -- no host sync"""
+    n: (1,) device tensor (or a plain number), the number of rows the statistics were taken over (all ranks for a SyncBN) -- no host sync"""
     if not bn.track_running_stats or bn.running_mean is None:
         return
     with torch.no_grad():
         bn.num_batches_tracked += 1
         m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
-        bn.running_var.mul_(1.0 - m).add_(var * (n / (n - 1.0).clamp_min(1.0)), alpha=m)
+        unbias = n / (n - 1.0).clamp_min(1.0) if torch.is_tensor(n) else float(n) / max(float(n) - 1.0, 1.0)
+        bn.running_var.mul_(1.0 - m).add_(var * unbias, alpha=m)
 
 
 # ------------------------------------------------------------------------------ module-level training forwards

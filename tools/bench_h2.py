@@ -28,7 +28,8 @@ def timeit(fn, secs=0.4):
 
 
 def main():
-  for (B, D, H, W), cin, cout in SHAPES:
+  shapes = [SHAPES[int(os.environ['SHAPE'])]] if os.environ.get('SHAPE') else SHAPES
+  for (B, D, H, W), cin, cout in shapes:
       torch.manual_seed(0)
       x = torch.randn(B, D, H, W, cin, device=DEV)
       w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
@@ -43,6 +44,10 @@ def main():
           t = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(fmt, fmt)))
           res['h2->h2' if fmt else 'h2->f32'] = t
       kern = _lib.lib().pw_last_kernel().decode()
+      if os.environ.get('QUICK'):          # pipelined kernel only (variant A/B runs)
+          print('%dx%dx%dx%d %d->%d %6.1f GF  %s' % (B, D, H, W, cin, cout, gf, kern),
+                '  '.join('%s %.1f us (%.0f TF direct)' % (k, v, gf / v * 1e3) for k, v in res.items()), flush=True)
+          continue
       os.environ['PW_H2_TILE'] = '1'
       res['tile h2->h2'] = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(True, True)))
       for nt in ('1', '2'):
