@@ -167,12 +167,11 @@ __device__ __forceinline__ void h2_epi_rest(const ConvArgs& a, const EpiTile& t,
   }
 }
 
-// halo rows (K = first, count) this wave's DMA issues at tap TAP of a stage: the whole next halo goes out as ONE burst
-// right after the epilogue passes (taps 2 .. 4 NT + 1, which read the parked rows K < 7 / 13).  The memory counter is in
-// order: a weight load (L2 latency, needed two taps later) cannot be waited for without also waiting for every halo row
-// issued before it (HBM latency, longer than three taps).  One row per tap over 13-15 taps therefore stalled almost every
-// tap (profiles/r03_conv_h2_ablation.txt: the same DMA instructions with every lane out of range, i.e. returning at once,
-// took 23 % off the kernel); as a burst the queue behind the weights is clear again a few taps later, for the rest of the stage.
+// halo rows (K = first, count) this wave's DMA issues at tap TAP of a stage: a few rows per tap right after the epilogue
+// passes (taps 2 .. 4 NT + 1, which read the parked rows K < 7 / 13), so that the parked rows are never refilled under a pass
+// and the whole halo has the rest of the stage to land.  (One row per tap over 13-15 taps, 5 or 15 per tap: the same time within
+// noise, profiles/r03_conv_h2_ablation.txt section 3.  That file's "DMA with every lane out of range" variant is 23 % faster
+// only because an all-zero halo stops the operand bits toggling on a power-capped chip -- profiles/r03_power_wall.txt.)
 #ifndef PW_DMA_ROWS_PER_TAP_NT1
 #define PW_DMA_ROWS_PER_TAP_NT1 3
 #endif
@@ -261,11 +260,13 @@ __device__ __forceinline__ void h2_mfma(const v4f (&aq)[2][4], const v4f (&b)[NT
 }
 
 // ---- issue order inside a tap.  One wave per SIMD means nothing else fills the matrix pipe while this wave issues its own
-// loads and address arithmetic: with the tap's side work (weight loads two taps ahead, next tap's A fragments, the halo row
-// DMA with its ~25 scalar instructions, an epilogue pass) in front of the MFMAs, a 768-cycle tap (NT 2) took 930 .. 1600 cycles
-// (profiles/r03_conv_h2_stage_probe_64to64.txt; leaving each piece out in turn: profiles/r03_conv_h2_ablation.txt).  So the
-// whole tap is ONE scheduling region and the pipeline below spreads the side work over the shadows of the 12 NT MFMAs
-// (32 cycles each = ~7 issue slots): slot i gets its share of the VMEM reads, LDS reads, SALU and VALU instructions.
+// loads and address arithmetic: with the tap's side work (weight loads two taps ahead, next tap's A fragments, halo row DMA with its
+// ~25 scalar instructions, an epilogue pass) in front of the MFMAs, a 768-cycle tap (NT 2) took 930 .. 1600 cycles
+// (profiles/r03_conv_h2_stage_probe_64to64.txt).  So the whole tap is ONE scheduling region, branch-free, and the pipeline below
+// spreads the side work over the shadows of the 12 NT MFMAs (32 cycles each = ~7 issue slots): slot i gets its share of the LDS
+// reads, VMEM reads, SALU and VALU instructions.  64 -> 64 stage: 35.4 k -> 28.4 k cycles, barrier wait 1.2 k -> 0.2 k
+// (profiles/r03_conv_h2_stage_probe_64to64_v2.txt).  The WALL time moved by 5 % only: with real operand data the socket is at its
+// 1400 W cap and fewer idle cycles are answered with a lower clock (profiles/r03_power_wall.txt).
 __device__ __forceinline__ constexpr int h2_share(int i, int slots, int n) { return ((i + 1) * n) / slots - (i * n) / slots; }
 
 template <int I, int S, int NVM, int NDS, int NSA, int NVA>
@@ -630,359 +631,10 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
   if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(er.amax1), rs.e1);
 }
 
-// ------------------------------------------------------------------------------------
-// paired-wave variant (k_conv3d_h2p): the same persistent pipeline with EIGHT waves per block, two per SIMD.
-// Why: with one wave per SIMD every cycle that wave spends issuing (or waiting for) its own operand loads is a cycle the matrix
-// pipe of that SIMD idles -- 58 % pipe occupancy over the 64 -> 64 layer, a quarter of the wave cycles in s_waitcnt
-// (profiles/r03_conv_h2_pmc.md); the probes of DESIGN 4.8 put the same operand mix at +26 % wall with a second wave per SIMD.
-// Wave (ds, kp) = (wave & 3, wave >> 2) works on d-slice ds like before but only on k-step kp of the 32-channel chunk: per tap
-// 4 ds_read_b128 + 2 NT weight pieces feed 6 NT MFMAs, the same operand bytes per MFMA, the same LDS and L1 traffic per block, and
-// 32 NT accumulator registers -- which is what makes 256 registers per wave enough.  The two partial sums of a d-slice meet in LDS
-// when the tile is parked (kp 1 writes, kp 0 reads, adds its own and writes the sum: one rounding, a fixed order), the 4 NT epilogue passes are shared
-// (wave kp runs passes P = 2 J + kp), and each wave both parks its passes' rows in, and refills by DMA, only halo rows
-// wave + 8 K of its own -- so no wave ever waits for another inside a stage.
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned epi_slot_off_p(int u) {        // parked voxel row u of a d-slice -> byte offset in its rows ds + 4 K
-  const int P = u >> 4, kp = P & 1;
-  const int v = 16 * (P >> 1) + (u & 15);                          // index among the rows of wave (ds, kp): 10 per halo row
-  const int i = (int)(((unsigned)v * 205u) >> 11);
-  return (unsigned)((2 * i + kp) * (4 * TW * 128) + (v - i * 10) * 128);
-}
-
-// MODE 0 (kp 1, first): store the raw accumulators.  MODE 1 (kp 0, after a barrier): read the partner's, add its own, store the
-// sum -- one rounding in a fixed order; no LDS float atomics (without -munsafe-fp-atomics they are compare-and-swap loops: the
-// first version of this phase took 52 k cycles per tile).
-template <int NT, int MODE>
-__device__ __forceinline__ void h2p_park(const f32x16 (&acc)[2][NT], char* stg, int lane) {
-  const int half = lane >> 5, pj = patch_of_row(lane & 31);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int u = nt * 64 + mt * 32 + pj;
-      char* dst = stg + epi_slot_off_p(u);
-      const int sw = (u >> 1) & 7;
-      v4f o[4];
-      if constexpr (MODE == 1) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) o[g] = *reinterpret_cast<const v4f*>(dst + (((2 * g + half) ^ sw) * 16));
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        v4f v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = MODE == 1 ? o[g][e] + acc[mt][nt][4 * g + e] : acc[mt][nt][4 * g + e];
-        *reinterpret_cast<v4f*>(dst + (((2 * g + half) ^ sw) * 16)) = v;
-      }
-    }
-}
-
-// own pass J of 2 NT of wave (ds, kp) = pass P = 2 J + kp of the d-slice (h2_epi_load with the paired row mapping)
-template <int NT, int EPI, int J>
-__device__ __forceinline__ void h2p_epi_load(const ConvArgs& a, const EpiTile& t, const char* stg, const float* sb, int ds, int kp,
-                                             int lane, EpiRegs& r) {
-  constexpr int nt = J >> 1;
-  const int P = 2 * J + kp;
-  const int n0 = (t.ng * NT + nt) * 32;
-  const bool to_y0 = n0 < a.cout0;
-  const int ld = to_y0 ? a.ld0 : a.ld1;
-  const int col0 = to_y0 ? n0 : n0 - a.n1_start;
-  const int od = t.d0 + ds;
-  const int o = lane & 3;
-  const int u = 16 * P + (lane >> 2), sv = u & 63;
-  const int mt = sv >> 5, vr = (sv >> 3) & 3, vc = sv & 7;
-  const bool ok = (int)t.pending & (int)(od < a.Do) & (int)((t.h0 + mt * 4 + vr) < a.Ho) & (int)((t.w0 + vc) < a.Wo);
-  r.soff = (unsigned)(((((t.b * a.Do + od) * a.Ho + t.h0) * a.Wo + t.w0) * ld) * 4);
-  const unsigned pos = (EPI == 3 ? (unsigned)(32 * o) : (unsigned)((4 * (o & 1) + 2 * (o >> 1)) * 16));
-  const unsigned vin = (unsigned)(((mt * 4 + vr) * a.Wo + vc) * ld) * 4u + (unsigned)col0 * 4u + pos;
-  r.vbase = ok ? vin : PIPE_OOB;
-  const char* src = stg + epi_slot_off_p(u);
-  const int sw = (u >> 1) & 7;
-  r.x0 = *reinterpret_cast<const v4f*>(src + (((2 * o) ^ sw) * 16));
-  r.x1 = *reinterpret_cast<const v4f*>(src + (((2 * o + 1) ^ sw) * 16));
-  r.s0 = *reinterpret_cast<const v4f*>(sb + n0 + 8 * o);
-  r.s1 = *reinterpret_cast<const v4f*>(sb + n0 + 8 * o + 4);
-  r.b0 = *reinterpret_cast<const v4f*>(sb + H2_MAX_COUT + n0 + 8 * o);
-  r.b1 = *reinterpret_cast<const v4f*>(sb + H2_MAX_COUT + n0 + 8 * o + 4);
-  if constexpr (EPI == 2) {
-    const unsigned out_vox = (unsigned)((size_t)a.B * a.Do * a.Ho * a.Wo);
-    const rsrc_t rr = make_rsrc(a.residual, out_vox * (unsigned)ld * 4u);
-    r.r0 = buf_load4(rr, r.vbase, r.soff);
-    r.r1 = buf_load4(rr, r.vbase == PIPE_OOB ? PIPE_OOB : r.vbase + 16u, r.soff);
-  }
-}
-
-template <int NT, int EPI, int J>
-__device__ __forceinline__ void h2p_epi_rest(const ConvArgs& a, const EpiTile& t, const char* stg, const float* sb, int ds, int kp,
-                                             int lane, EpiRegs& r, float res_mul) {
-  if constexpr (J < 2 * NT) {
-    h2p_epi_load<NT, EPI, J>(a, t, stg, sb, ds, kp, lane, r);
-    h2_epi_compute<NT, EPI, 2 * J>(a, t, r, res_mul);            // (only P >> 2 = J >> 1 matters there)
-    h2p_epi_rest<NT, EPI, J + 1>(a, t, stg, sb, ds, kp, lane, r, res_mul);
-  }
-}
-
-// halo row min(wave + 8 K, 59) of the next stage (waves 4 .. 7 repeat row 59 for K = 7: same bytes, no branch)
-template <int K>
-__device__ __forceinline__ void h2p_dma_row(const ConvArgs& a, const PipeDma& dm, const H2DmaView& c) {
-  const int r0 = c.wave + 8 * K;
-  const int row = K == 7 ? (r0 < TD * TH - 1 ? r0 : TD * TH - 1) : r0;
-  const int dd = (int)(((unsigned)row * 205u) >> 11), hh = row - dd * TH;
-  const bool rok = (int)dm.live & (int)((unsigned)(dm.d0 - 1 + dd) < (unsigned)a.D) & (int)((unsigned)(dm.h0 - 1 + hh) < (unsigned)a.H);
-  const unsigned soff = c.base + (unsigned)(dd * a.H + hh) * c.pitch;
-  const unsigned v0 = rok ? ((hh & 1) ? dm.voff[1][0] : dm.voff[0][0]) : PIPE_OOB;
-  const unsigned v1 = rok ? ((hh & 1) ? dm.voff[1][1] : dm.voff[0][1]) : PIPE_OOB;
-  lds3_t dst = c.lds3 + (dm.ldsbuf + (unsigned)row * (TW * 128));
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, dst, 16, v0, soff, 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, dst + 1024, 4, v1, soff, 0, 0);
-}
-template <int K0, int N>
-__device__ __forceinline__ void h2p_dma_rows(const ConvArgs& a, const PipeDma& dm, const H2DmaView& c) {
-  if constexpr (N > 0) {
-    h2p_dma_row<K0>(a, dm, c);
-    h2p_dma_rows<K0 + 1, N - 1>(a, dm, c);
-  }
-}
-
-struct H2pCtx {
-  lds3_t lds3;
-  rsrc_t xr, wr;
-  unsigned lane_off, wstride, wsoff, wsoff_next;
-  bool has_next;
-  PipeDma dm;
-  unsigned dm_base, dm_pitch;
-  int wave, ds, kp, lane;
-  EpiTile epi;
-  const char* ldsg;
-  float res_mul;
-};
-
-template <int TAP>
-__device__ __forceinline__ void h2p_read_a_tap(lds3_t lds3, const unsigned (&aaddr)[2][3][2], v4f (&aq)[2][2]) {
-  constexpr int kd = TAP / 9, kh = (TAP / 3) % 3, kw = TAP % 3;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    constexpr unsigned imm0 = (unsigned)(((kd * TH + kh) * TW) * 128);
-    const unsigned imm = imm0 + (unsigned)(mt * 4 * TW * 128);
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-      aq[mt][p] = *reinterpret_cast<const __attribute__((address_space(3))) v4f*>(lds3 + aaddr[kh & 1][kw][p] + imm);
-  }
-}
-
-template <int NT>
-__device__ __forceinline__ void h2p_load_b(rsrc_t wr, unsigned wsoff, unsigned lane_off, v4f (&b)[NT][2]) {
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const auto v = __builtin_amdgcn_raw_buffer_load_b128(wr, lane_off + (unsigned)p * H2W_PIECE, wsoff + (unsigned)(nt * 4096), 0);
-      v4f o;
-      o[0] = __uint_as_float(v[0]); o[1] = __uint_as_float(v[1]); o[2] = __uint_as_float(v[2]); o[3] = __uint_as_float(v[3]);
-      b[nt][p] = o;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void h2p_mfma(const v4f (&aq)[2][2], const v4f (&b)[NT][2], f32x16 (&acc)[2][NT]) {
-#pragma unroll
-  for (int prod = 0; prod < 3; ++prod) {            // hi_w.hi_x, lo_w.hi_x, hi_w.lo_x
-    const int pw = prod == 1 ? 1 : 0, px = prod == 2 ? 1 : 0;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, b[nt][pw]), __builtin_bit_cast(h8, aq[mt][px]),
-                                                             acc[mt][nt], 0, 0, 0);
-  }
-}
-
-// DMA rows of a tap: the wave's 8 rows go out after its 2 NT passes (taps 2 .. 2 NT + 1)
-template <int NT, int TAP>
-__device__ __forceinline__ constexpr int h2p_dma_first_row() {
-  constexpr int per = NT == 1 ? 1 : 2, t0 = 2 * NT + 2;
-  return TAP < t0 ? 8 : (TAP - t0) * per;
-}
-template <int NT, int TAP>
-__device__ __forceinline__ constexpr int h2p_dma_row_count() {
-  constexpr int per = NT == 1 ? 1 : 2, k0 = h2p_dma_first_row<NT, TAP>();
-  return k0 >= 8 ? 0 : (k0 + per <= 8 ? per : 8 - k0);
-}
-
-template <int NT, int EPI, int TAP>
-__device__ __forceinline__ void h2p_step(const ConvArgs& a, const H2pCtx& c, const unsigned (&aaddr)[2][3][2],
-                                         v4f (&ac)[2][2], v4f (&an)[2][2], v4f (&b0)[NT][2], v4f (&b1)[NT][2],
-                                         v4f (&b2)[NT][2], f32x16 (&acc)[2][NT], EpiRegs& er) {
-  __builtin_amdgcn_sched_barrier(0);
-  constexpr int dma_k0 = h2p_dma_first_row<NT, TAP>(), dma_n = h2p_dma_row_count<NT, TAP>();
-  constexpr bool epi_tap = TAP >= 2 && TAP <= 2 * NT + 1;       // own pass TAP-2 of the previous tile (loaded last tap)
-  constexpr bool epi_ld = TAP >= 1 && TAP <= 2 * NT;            // loads of own pass TAP-1
-  if constexpr (TAP + 2 < 27) {
-    h2p_load_b<NT>(c.wr, c.wsoff + (unsigned)(TAP + 2) * c.wstride, c.lane_off, b2);
-  } else {
-    h2p_load_b<NT>(c.wr, c.wsoff_next + (unsigned)(TAP + 2 - 27) * c.wstride, c.lane_off, b2);
-  }
-  h2p_dma_rows<dma_k0, dma_n>(a, c.dm, H2DmaView{c.xr, c.lds3, c.dm_base, c.dm_pitch, c.wave});
-  if constexpr (TAP < 26) h2p_read_a_tap<TAP + 1>(c.lds3, aaddr, an);
-  if constexpr (epi_tap) h2_epi_compute<NT, EPI, 2 * (TAP - 2)>(a, c.epi, er, c.res_mul);
-  if constexpr (epi_ld)
-    h2p_epi_load<NT, EPI, TAP - 1>(a, c.epi, c.ldsg + c.epi.bufoff + (unsigned)c.ds * (TW * 128),
-                                   reinterpret_cast<const float*>(c.ldsg + H2_SB_OFF), c.ds, c.kp, c.lane, er);
-  h2p_mfma<NT>(ac, b0, acc);
-  {
-    constexpr int n_vm = 2 * NT + 2 * dma_n + ((epi_ld && EPI == 2) ? 2 : 0);
-    constexpr int n_ds = (TAP < 26 ? 4 : 0) + (epi_ld ? 6 : 0);
-    constexpr int n_sa = 4 + 20 * dma_n + (epi_ld ? 12 : 0);
-    constexpr int n_va = 5 * dma_n + (epi_tap ? (EPI == 2 ? 100 : 76) : 0) + (epi_ld ? 40 : 0);
-    h2_pipeline<0, 6 * NT, n_vm, n_ds, n_sa, n_va>();
-    if constexpr (epi_tap) __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (TAP < 26) h2p_step<NT, EPI, TAP + 1>(a, c, aaddr, an, ac, b1, b2, b0, acc, er);
-}
-
-template <int NT, int EPI>
-__global__ void __launch_bounds__(512, 1) k_conv3d_h2p(ConvArgs a, PipeArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  const int ds = wave & 3, kp = wave >> 2;         // d-slice of the tile, k-step of the chunk
-  const int half = lane >> 5, j = lane & 31;
-  const int pj = patch_of_row(j), pr = pj >> 3, pc = pj & 7;
-  const int ntiles_total = a.cout_total >> 5;
-  const int nchunk = a.Cin / KC;
-  const RngScale rs = rng_scales(a);
-
-  const int nslots = (int)gridDim.x >> 3;
-  const int per = (p.n_items + 7) >> 3;
-  const int it_end = min(((int)blockIdx.x & 7) * per + per, p.n_items);
-  int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  if (item >= it_end) return;
-
-  unsigned aaddr0[2][3][2];
-#pragma unroll
-  for (int khp = 0; khp < 2; ++khp)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int ww = pc + kw;
-      const int f = ((ww >> 1) & 3) | (((pr + khp) & 1) << 2);
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        aaddr0[khp][kw][pl] = (unsigned)((((ds * TH + pr) * TW + ww) * 8 + ((half * 4 + 2 * kp + pl) ^ f)) * 16);
-    }
-
-  H2pCtx c;
-  c.lds3 = (lds3_t)lds;
-  c.xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
-  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 27 * ntiles_total * 4096));
-  c.lane_off = (unsigned)lane * 16u + (unsigned)(2 * kp) * H2W_PIECE;
-  c.wstride = (unsigned)ntiles_total * 4096u;
-  c.wave = wave; c.ds = ds; c.kp = kp; c.lane = lane;
-  c.ldsg = reinterpret_cast<const char*>(lds);
-  c.epi.pending = false; c.epi.b = c.epi.d0 = c.epi.h0 = c.epi.w0 = c.epi.ng = 0; c.epi.bufoff = 0;
-  c.dm_pitch = (unsigned)(a.W * a.Cin) * 4u;
-
-  PipeTile t = pipe_decode(a, p, item);
-  int ch = 0;
-  v4f a0[2][2], a1[2][2], b0[NT][2], b1[NT][2], b2[NT][2];
-  EpiRegs er = {};
-  f32x16 acc[2][NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  {  // prologue: the first stage's halo goes out in one burst
-    PipeDma dm;
-    pipe_lane_offsets(a, t.w0, lane, dm.voff);
-    dm.b = t.b; dm.d0 = t.d0; dm.h0 = t.h0; dm.wbase = t.w0 > 0 ? t.w0 - 1 : 0; dm.ch = 0; dm.ldsbuf = 0;
-    dm.live = true;
-    h2p_load_b<NT>(c.wr, (unsigned)((t.ng * NT) * 4096), c.lane_off, b0);
-    h2p_load_b<NT>(c.wr, (unsigned)((t.ng * NT) * 4096) + c.wstride, c.lane_off, b1);
-    const H2DmaView dv{c.xr, c.lds3, (unsigned)(((((t.b * a.D + t.d0 - 1) * a.H + t.h0 - 1) * a.W + dm.wbase) * a.Cin) * 4), c.dm_pitch, wave};
-    h2p_dma_rows<0, 8>(a, dm, dv);
-    float* sb = lds + H2_SB_OFF / 4;
-    for (int n = tid; n < a.cout_total; n += 512) {
-      const bool to_y0 = n < a.cout0;
-      sb[n] = (a.scale ? a.scale[n] : 1.f) * (to_y0 ? rs.s0 : rs.s1);
-      sb[H2_MAX_COUT + n] = (a.bias ? a.bias[n] : 0.f) * (to_y0 ? rs.b0 : rs.b1);
-    }
-    c.res_mul = rs.res;
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-  }
-
-  for (int stage = 0;; ++stage) {
-    const unsigned bufoff = (stage & 1) ? (unsigned)PIPE_BUF_BYTES : 0u;
-    unsigned aaddr[2][3][2];
-#pragma unroll
-    for (int khp = 0; khp < 2; ++khp)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          aaddr[khp][kw][pl] = aaddr0[khp][kw][pl] + bufoff;
-          asm volatile("" : "+v"(aaddr[khp][kw][pl]));
-        }
-    long long ts0 = 0, ts1 = 0, ts2 = 0;
-    if (a.probe) ts0 = __builtin_readcyclecounter();
-    h2p_read_a_tap<0>(c.lds3, aaddr, a0);
-
-    PipeTile tn = t;
-    int chn = ch + 1, itemn = item;
-    if (chn == nchunk) { chn = 0; itemn = item + nslots; }
-    c.has_next = itemn < it_end;
-    if (c.has_next && chn == 0) tn = pipe_decode(a, p, itemn);
-    if (!c.has_next) chn = 0;
-    c.wsoff = (unsigned)((ch * 27 * ntiles_total + t.ng * NT) * 4096);
-    c.wsoff_next = (unsigned)((chn * 27 * ntiles_total + tn.ng * NT) * 4096);
-    pipe_lane_offsets(a, tn.w0, lane, c.dm.voff);
-    c.dm.b = tn.b; c.dm.d0 = tn.d0; c.dm.h0 = tn.h0; c.dm.wbase = tn.w0 > 0 ? tn.w0 - 1 : 0;
-    c.dm.ch = chn; c.dm.ldsbuf = (unsigned)PIPE_BUF_BYTES - bufoff; c.dm.live = c.has_next;
-    c.dm_base = (unsigned)(((((tn.b * a.D + tn.d0 - 1) * a.H + tn.h0 - 1) * a.W + c.dm.wbase) * a.Cin + chn * KC) * 4);
-
-    h2p_step<NT, EPI, 0>(a, c, aaddr, a0, a1, b0, b1, b2, acc, er);
-    if (a.probe) ts1 = __builtin_readcyclecounter();
-
-    __builtin_amdgcn_s_waitcnt(0);     // my DMA rows of the next stage have landed
-    __syncthreads();                   // everyone's have; everyone is done with this buffer
-    if (a.probe) ts2 = __builtin_readcyclecounter();
-
-    if (c.epi.pending) epi_fold_amax<NT>(a, c.epi.ng, er);
-    c.epi.pending = false;
-    if (ch == nchunk - 1) {
-      // the two k-step halves of every d-slice meet in its rows of the consumed buffer: kp 0 stores, kp 1 adds
-      char* stg = reinterpret_cast<char*>(lds) + bufoff + (unsigned)ds * (TW * 128);
-      if (kp == 1) h2p_park<NT, 0>(acc, stg, lane);
-      __syncthreads();
-      if (kp == 0) h2p_park<NT, 1>(acc, stg, lane);
-      __syncthreads();
-      c.epi.b = t.b; c.epi.d0 = t.d0; c.epi.h0 = t.h0; c.epi.w0 = t.w0; c.epi.ng = t.ng; c.epi.bufoff = bufoff;
-      c.epi.pending = true;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    }
-    if (a.probe && lane == 0 && stage < 16) {
-      long long* pp = a.probe + (((size_t)blockIdx.x * 8 + wave) * 16 + stage) * 4;
-      pp[0] = ts0; pp[1] = ts1; pp[2] = ts2; pp[3] = __builtin_readcyclecounter();
-    }
-    if (!c.has_next) break;
-    t = tn; ch = chn; item = itemn;
-  }
-  if (c.epi.pending) {
-    h2p_epi_rest<NT, EPI, 0>(a, c.epi, reinterpret_cast<const char*>(lds) + c.epi.bufoff + (unsigned)ds * (TW * 128),
-                             lds + H2_SB_OFF / 4, ds, kp, lane, er, rs.res);
-    epi_fold_amax<NT>(a, c.epi.ng, er);
-  }
-  if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(er.amax0), rs.e0);
-  if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(er.amax1), rs.e1);
-}
+// (A paired-wave variant of this kernel -- 8 waves per block, two per SIMD, wave pairs splitting the two k-steps of a chunk and
+// meeting in LDS when the tile is parked -- was built and measured in round 3, commit 578d615: 29.4 k instead of 35.4 k cycles
+// per 64 -> 64 stage, and the SAME wall time: with real data the socket sits at its 1400 W cap and the shader clock drops to
+// match, 1.87 -> 1.69 GHz.  profiles/r03_power_wall.txt; DESIGN.md 4.13.  It was removed again.)
 
 // ------------------------------------------------------------------------------------
 // tile-per-block variant: one 4x8x8 tile x N-group per 4-wave block, single 76.8 KB halo buffer -> TWO blocks per CU.
@@ -1307,23 +959,6 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
     hipLaunchKernelGGL((k_conv3d_h2<NTv, EPIv>), dim3(nb), dim3(256), H2_LDS, st, a, p);  \
     pw_note_kernel("k_conv3d_h2<%d, %d, false>", NTv, EPIv);                                     \
   } while (0)
-  // paired-wave kernel (two waves per SIMD): default wherever a pipelined epilogue variant applies; PW_H2_PAIR=0 keeps one wave per SIMD
-  bool pair = epi > 0;
-  if (const char* e = getenv("PW_H2_PAIR")) pair = atoi(e) != 0 && epi > 0;
-#define PW_H2_LAUNCH_P(NTv, EPIv)                                                          \
-  do {                                                                                     \
-    static int once = set_lds_limit(k_conv3d_h2p<NTv, EPIv>, H2_LDS);                       \
-    if (once) return once;                                                                 \
-    hipLaunchKernelGGL((k_conv3d_h2p<NTv, EPIv>), dim3(nb), dim3(512), H2_LDS, st, a, p);   \
-    pw_note_kernel("k_conv3d_h2p<%d, %d>", NTv, EPIv);                                     \
-  } while (0)
-  if (pair) {
-    if (NT == 2) { if (epi == 1) PW_H2_LAUNCH_P(2, 1); else if (epi == 2) PW_H2_LAUNCH_P(2, 2); else PW_H2_LAUNCH_P(2, 3); }
-    else { if (epi == 1) PW_H2_LAUNCH_P(1, 1); else if (epi == 2) PW_H2_LAUNCH_P(1, 2); else PW_H2_LAUNCH_P(1, 3); }
-    PW_CHECK_LAUNCH();
-    return PW_OK;
-  }
-#undef PW_H2_LAUNCH_P
   // resident hi planes: one chunk, one cout tile (PW_H2_WR=0 keeps the streaming variant)
   bool wres = NT == 1 && ntiles == 1 && Cin == KC && epi > 0;
   if (const char* e = getenv("PW_H2_WR")) { if (atoi(e) == 0) wres = false; }
