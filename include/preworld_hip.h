@@ -49,6 +49,10 @@ const char* pw_last_error(void);
 /* name, as rocprofv3 --kernel-trace prints it, of the dominant kernel the calling thread's last pw_* compute call
  * launched (which variant the library picked); measurement aid for bench.py's roofline object */
 const char* pw_last_kernel(void);
+/* measurement aid (bench.py): TFLOP/s a bare v_mfma_f32_32x32x16_f16 stream sustains on the current device for `seconds`
+ * (<= 10) of wall time -- random fp16 operands in registers, no memory traffic, one wave per SIMD on every CU: what the socket's
+ * power cap leaves of the 2.5 PFLOP/s data-sheet peak (profiles/r03_power_wall.txt).  Synchronous, default stream. */
+int pw_probe_mfma_f16(double seconds, double* tflops);
 /* device the library was built for / runs on: fills CU count, returns 0 */
 int pw_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
 

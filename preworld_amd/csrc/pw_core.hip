@@ -1,6 +1,7 @@
 // Error state, version and device query for libpreworld_hip.so.
 #include "pw_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -44,4 +45,74 @@ PW_API int pw_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name,
     arch_name[arch_name_len - 1] = 0;
   }
   return PW_OK;
+}
+
+// ---- measurement aid: what the socket's power cap leaves of the fp16 matrix pipe on THIS box.
+// A bare v_mfma_f32_32x32x16_f16 stream -- operands in registers, 8 x 8 different register pairs of random fp16 values, no memory
+// traffic in the loop -- for `seconds` of wall time at one wave per SIMD on every CU (tools/probes/mfma_power.hip is the
+// stand-alone version with the constant-operand and two-waves-per-SIMD cases).  With real operand data an MI355X sustains
+// ~1.7 PFLOP/s of it, not the 2.5 PFLOP/s of the data sheet (profiles/r03_power_wall.txt); bench.py prints the number next to
+// `roofline.peak` so that a reader can tell a scheduling gap from the power wall.
+typedef float pw_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 pw_h8 __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(256) k_probe_mfma_f16(float* __restrict__ out, const pw_h8* __restrict__ src, int iters) {
+  pw_f32x16 acc[4];
+  for (int c = 0; c < 4; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  pw_h8 a[8], b[8];
+  for (int i = 0; i < 8; ++i) {
+    a[i] = src[i * 64 + (threadIdx.x & 63)];
+    b[i] = src[(8 + i) * 64 + (threadIdx.x & 63)];
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u)
+      acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 7], b[(u >> 3) & 7], acc[u & 3], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int c = 0; c < 4; ++c) for (int r = 0; r < 16; ++r) s += acc[c][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+PW_API int pw_probe_mfma_f16(double seconds, double* tflops) {
+  PW_CHECK_ARG(tflops && seconds > 0 && seconds <= 10, "pw_probe_mfma_f16: bad arguments");
+  int dev = 0;
+  PW_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  PW_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  const int nblk = prop.multiProcessorCount, iters = 2000;
+  const size_t n_src = 16 * 64 * 8;
+  _Float16* hsrc = (_Float16*)malloc(n_src * 2);
+  unsigned long long st = 0x9E3779B97F4A7C15ull;
+  for (size_t i = 0; i < n_src; ++i) {                     // sum of 12 uniforms: random signs, exponents and mantissas
+    float s = 0.f;
+    for (int k = 0; k < 12; ++k) { st = st * 6364136223846793005ull + 1442695040888963407ull; s += (float)(st >> 40) * (1.f / 16777216.f); }
+    hsrc[i] = (_Float16)((s - 6.f) * 0.125f);
+  }
+  pw_h8* src = nullptr; float* out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = PW_OK;
+  do {
+    if (hipMalloc(&src, n_src * 2) != hipSuccess || hipMalloc(&out, (size_t)nblk * 256 * 4) != hipSuccess ||
+        hipMemcpy(src, hsrc, n_src * 2, hipMemcpyHostToDevice) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess) { pw_set_error("pw_probe_mfma_f16: HIP allocation failed"); rc = PW_EHIP; break; }
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(k_probe_mfma_f16, dim3(nblk), dim3(256), 0, 0, out, src, iters);
+    (void)hipDeviceSynchronize();
+    double total_ms = 0.0; long long launches = 0;
+    while (total_ms < seconds * 1e3) {
+      (void)hipEventRecord(e0, 0);
+      for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(k_probe_mfma_f16, dim3(nblk), dim3(256), 0, 0, out, src, iters);
+      (void)hipEventRecord(e1, 0);
+      if (hipEventSynchronize(e1) != hipSuccess) { pw_set_error("pw_probe_mfma_f16: kernel failed"); rc = PW_EHIP; break; }
+      float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+      total_ms += ms; launches += 10;
+    }
+    if (rc == PW_OK) *tflops = (double)launches * iters * 64.0 * 4.0 * nblk * 32768.0 / (total_ms * 1e-3) * 1e-12;
+  } while (0);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (src) (void)hipFree(src);
+  if (out) (void)hipFree(out);
+  free(hsrc);
+  return rc;
 }
