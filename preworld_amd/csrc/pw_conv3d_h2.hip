@@ -311,6 +311,9 @@ __device__ __forceinline__ void h2_dma_rows(const ConvArgs& a, const PipeDma& dm
   }
 }
 
+// (PW_X_*: timing-only ablation switches -- each leaves one piece of a tap's side work out, or makes it trivial, and computes
+// WRONG results; built by tools/build_variant.py into variant libraries, never into libpreworld_hip.so.  Their table, and why half
+// of it measures the power cap rather than the piece left out: profiles/r03_conv_h2_ablation.txt.)
 template <int NT, int EPI, int TAP, bool WR = false, int NW = 1>
 __device__ __forceinline__ void h2_step(const ConvArgs& a, const H2Ctx<NT>& c, const unsigned (&aaddr)[2][3][4],
                                         v4f (&ac)[2][4], v4f (&an)[2][4], v4f (&b0)[NT][4], v4f (&b1)[NT][4],
