@@ -416,7 +416,7 @@ def pretrain_step_ms(dev, args):
         torch.cuda.synchronize()
         return {'ms': round((time.perf_counter() - t0) / n * 1e3, 2), 'rays': R, 'samples_per_ray': 417,
                 'what': 'final_conv + OccHead + attribute MLPs + NerfHead losses, forward + backward, 1 sample, eager',
-                'losses': {k: round(float(v), 4) for k, v in losses.items() if 'sup' not in k}}
+                'losses': {k: round(float(v.detach()), 4) for k, v in losses.items() if 'sup' not in k}}
     except Exception as e:                                            # noqa: BLE001  (an extra figure must not take the bench line down)
         return {'error': repr(e)[:300]}
 

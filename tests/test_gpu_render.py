@@ -333,7 +333,8 @@ def test_nerf_head_forward_is_differentiable():
                             torch.from_numpy(rays[0, :, 3]), torch.from_numpy(rays[0, :, 13:16]))
     sum(ref.values()).backward()
     for k in ref:
-        assert abs(float(losses[k]) - float(ref[k])) <= 2e-4 * abs(float(ref[k])) + 1e-6, (k, float(losses[k]), float(ref[k]))
+        got, want = float(losses[k].detach()), float(ref[k].detach())
+        assert abs(got - want) <= 2e-4 * abs(want) + 1e-6, (k, got, want)
     from _parity import check_close
     for name, a, b in zip(('density', 'semantic', 'color'), g, cg):
         check_close('NerfHead d loss / d %s' % name, a.grad[0], b.grad.numpy(), 5e-5, atol=1e-8)
