@@ -21,6 +21,7 @@
 //     8) outputs it contributes to -- 8 x 4 accumulator registers per lane hold the whole output tile;
 //   * epilogue = the direct kernels' (scale/bias, residual, ReLU, two destinations, row stride).
 #include "pw_wino_common.h"
+#include "pw_h2.h"
 
 // Points are processed a ROW (4 points = 4 independent MFMA chains, interleaved) at a time; the operands
 // of the next row are requested before this row's MFMAs, and the output transform of a row's products is
@@ -109,9 +110,13 @@ __device__ __forceinline__ void wino_chunk(const WinoCtx& c, unsigned r_base, un
 }
 
 // scale/bias, residual, ReLU and the two destinations for the wave's 16 tiles (d-pair mh) x 16 couts (half nh)
+// re (split-fp16 Winograd): destinations may be in h2 storage (a.fmt_y0 / a.fmt_y1); scb then already carries the range factors
+// and the largest stored magnitude per destination is recorded in *re
+// stage (with re): 4 KB of LDS owned by this wave -- an h2 destination is written through it as whole 16-byte slots (below)
 template <int NG>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y)[NG][8], int b, int d0, int h0, int w0,
-                                              int mh, int nh, int lane, int ng0 = 0, const float* scb = nullptr) {
+                                              int mh, int nh, int lane, int ng0 = 0, const float* scb = nullptr,
+                                              RngEpi* re = nullptr, float* stage = nullptr) {
   // ---- epilogue: lane holds cout l&15 for tiles (l>>4)*4 + r of its half; output o = (od, oh, ow)
   // scb: {scale, bias} per column group already in registers (the persistent kernel requests them at the start of the
   // tile, a global-load latency before they are needed)
@@ -145,6 +150,43 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y
         const int od = d0 + 2 * mh + (o >> 2), oh = (o >> 1) & 1, ow = o & 1;
         so[o] = (unsigned)((((b * a.Do + od) * a.Ho + h0 + oh) * a.Wo + w0 + ow) * ld) * 4u;
       }
+      if (re && (to_y0 ? a.fmt_y0 : a.fmt_y1)) {
+        // h2 destination.  The accumulator layout gives a lane ONE output channel of 32 voxels; an h2 slot is 8 consecutive
+        // channels of one voxel (two-byte stores straight from the registers: +21 us on the 64 -> 64 layer).  So the finished
+        // values of four outputs x 16 tiles x 16 channels go through the wave's 4 KB of LDS as [voxel][16 channels] rows --
+        // voxel row = ol * 16 + r * 4 + g, so that the four lane groups g write four consecutive rows = 64 banks -- and come
+        // back as 8 channels of one voxel per lane: split, two 16-byte stores.  Wave-local: LDS operations of a wave execute
+        // in program order, no barrier.
+        const int g = lane >> 4, j = lane & 15;
+        float am = 0.f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+          for (int ol = 0; ol < 4; ++ol)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(ol * 16 + r * 4 + g) * 16 + j] = fmaxf(Y[ng][4 * hf + ol][r] * sc + bi, lo);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int item = lane + 64 * i, v = item >> 1, hg = item & 1;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(stage + v * 16 + hg * 8);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(stage + v * 16 + hg * 8 + 4);
+            const int ol = v >> 4, r = (v >> 2) & 3, gg = v & 3, o = 4 * hf + ol;
+            const int od = d0 + 2 * mh + (o >> 2), oh = h0 + 2 * gg + ((o >> 1) & 1), ow = w0 + 2 * r + (o & 1);
+            const unsigned voff = (unsigned)((((b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * ld) * 4u + (unsigned)h2_elem_off(col0 + 8 * hg);
+            const float v8[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v8[e]));
+            h8 o_hi, o_lo;
+            h2_split8(v8, o_hi, o_lo);
+            const v4f wh = __builtin_bit_cast(v4f, o_hi), wl = __builtin_bit_cast(v4f, o_lo);
+            const float va[4] = {wh[0], wh[1], wh[2], wh[3]}, vb[4] = {wl[0], wl[1], wl[2], wl[3]};
+            buf_store4(yr, voff, 0u, va);
+            buf_store4(yr, voff + 16u, 0u, vb);
+          }
+        }
+        if (to_y0) re->amax0 = fmaxf(re->amax0, am); else re->amax1 = fmaxf(re->amax1, am);
+        continue;
+      }
       float rv[8][4];
       if (has_res) {
 #pragma unroll
@@ -169,7 +211,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y
           const int od = d0 + 2 * mh + (o >> 2), oh = h0 + 2 * tth_e + ((o >> 1) & 1), ow = w0 + 2 * r + (o & 1);
           if (od < a.Do && oh < a.Ho && ow < a.Wo) {
             const size_t vox = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-            store_out(a, n, vox, Y[ng][o][r] * sc + bi);
+            store_out(a, n, vox, Y[ng][o][r] * sc + bi, re);
           }
         }
     }
@@ -282,13 +324,14 @@ __device__ __forceinline__ void ws_load_a(const WinoCtx& c, f32x4 (&aq)[4][2]) {
     for (int q = 0; q < 2; ++q) aq[k][q] = lds_read4(c.lds3, c.a_addr[q] + WsRow<R, NG>::a_off + (unsigned)k * 4096u);
 }
 
-template <int R, int NG>
+// F16: a 2048-byte block = planes {hi, lo} x 64 lanes x 8 halves (lane_off = lane * 16, the plane 1024 bytes on)
+template <int R, int NG, bool F16 = false>
 __device__ __forceinline__ void ws_load_b(const WinoCtx& c, unsigned ubase, f32x4 (&bq)[4][2]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const float4 w = buf_load4(c.wr, c.lane_off + (unsigned)(q * 16),
+      const float4 w = buf_load4(c.wr, c.lane_off + (unsigned)(q * (F16 ? 1024 : 16)),
                                  ubase + (WsRow<R, NG>::point + (unsigned)k) * c.ustep + (unsigned)WsRow<R, NG>::ng * 4096u);
       bq[k][q] = f32x4{w.x, w.y, w.z, w.w};
     }
@@ -297,7 +340,7 @@ __device__ __forceinline__ void ws_load_b(const WinoCtx& c, unsigned ubase, f32x
 // rows R .. 16 NG - 1 of one chunk; bc holds row R's weights on entry; on exit of the last row bc/ac of the
 // CALLER hold the first row of the next chunk (ubase_next) again -- the row count is even, so the ping-pong
 // ends where it started
-template <int R, int NG>
+template <int R, int NG, bool F16 = false>
 __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsigned ubase_next, f32x4 (&ac)[4][2],
                                         f32x4 (&bc)[4][2], f32x4 (&an)[4][2], f32x4 (&bn)[4][2], f32x4 (&Mp)[4],
                                         f32x4 (&Y)[NG][8]) {
@@ -309,15 +352,31 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
   f32x4 (&acur)[4][2] = NG == 1 ? ac : (W::ng == 0 ? ac : an);
   if constexpr (NG == 1 ? W::first : W::ng == 0) ws_load_a<R, NG>(c, acur);
   if constexpr (R + 1 < TOTAL) {
-    ws_load_b<R + 1, NG>(c, ubase, bn);
+    ws_load_b<R + 1, NG, F16>(c, ubase, bn);
     if constexpr (NG == 1 && !W::last) ws_load_a<R + 1, NG>(c, an);
   } else {
-    ws_load_b<0, NG>(c, ubase_next, bn);
+    ws_load_b<0, NG, F16>(c, ubase_next, bn);
   }
   __builtin_amdgcn_sched_barrier(0);
   f32x4 M[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) M[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (F16) {
+    // one v_mfma_f32_16x16x32_f16 covers the whole 32-channel chunk: hi.hi, hi_v.lo_u, lo_v.hi_u
+    typedef _Float16 wh8 __attribute__((ext_vector_type(8)));
+    wh8 vh[4], vl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      vh[k] = __builtin_bit_cast(wh8, f32x4{acur[k][0][0], acur[k][0][1], acur[k][1][0], acur[k][1][1]});
+      vl[k] = __builtin_bit_cast(wh8, f32x4{acur[k][0][2], acur[k][0][3], acur[k][1][2], acur[k][1][3]});
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) M[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[k], __builtin_bit_cast(wh8, bc[k][0]), M[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) M[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[k], __builtin_bit_cast(wh8, bc[k][1]), M[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) M[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[k], __builtin_bit_cast(wh8, bc[k][0]), M[k], 0, 0, 0);
+  } else {
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -325,6 +384,7 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         M[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[k][q][e], bc[k][q][e], M[k], 0, 0, 0);
+  }
   if constexpr (R >= 1) {
     typedef WsRow<R - 1, NG> P;
     wino_scatter_row<P::ID, P::IH>(Mp, Y[P::ng]);               // the previous row's products, under this row's MFMAs
@@ -333,10 +393,10 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
 #pragma unroll
   for (int k = 0; k < 4; ++k) Mp[k] = M[k];
   if constexpr (W::last) __syncthreads();                       // end of the half-step
-  if constexpr (R + 1 < TOTAL) ws_rows<R + 1, NG>(c, ubase, ubase_next, an, bn, ac, bc, Mp, Y);
+  if constexpr (R + 1 < TOTAL) ws_rows<R + 1, NG, F16>(c, ubase, ubase_next, an, bn, ac, bc, Mp, Y);
 }
 
-template <int NG>
+template <int NG, bool F16 = false, bool H2IN = false>
 __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs p, int n16_total) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -350,12 +410,15 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
   const lds3_t lds3 = (lds3_t)lds;
 
   if (wave >= 4) {
-    ws_transform_role(a, p, lds3, item, it_end, nslots, nchunk, wave - 4, tid - 256, lane);
+    ws_transform_role<F16, H2IN>(a, p, lds3, item, it_end, nslots, nchunk, wave - 4, tid - 256, lane);
     return;
   }
 
   // -------------------------------------------------------------------- GEMM + output transform role
   const int mh = wave & 1, nh = wave >> 1;            // tile half (d-pair) and cout half of this wave
+  RngScale rs = {0, 0, 1.f, 1.f, 1.f, 1.f, 1.f};      // split-fp16 Winograd: range exponents of x / y0 / y1 (pw_h2.h "Range")
+  if constexpr (F16) rs = rng_scales(a);
+  RngEpi re = {1.f, 0.f, 0.f};
   WinoCtx c;
   c.lds3 = lds3;
   {
@@ -365,14 +428,14 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
       c.a_addr[q] = (unsigned)WINO_R_BYTES + (unsigned)(((mh * 16 + wino_row16(lt)) * 8 + ((g * 2 + q) ^ (lt & 7))) * 16);
   }
   c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 64 * n16_total * 2048));
-  c.lane_off = (unsigned)lane * 32u;
+  c.lane_off = (unsigned)lane * (F16 ? 16u : 32u);
   c.ustep = (unsigned)n16_total * 2048u;
   const unsigned chunk_bytes = 64u * c.ustep;
   f32x4 a0[4][2], a1[4][2], b0[4][2], b1[4][2], Mp[4];
   // work item = (tile, group of NG x 32 couts); the group's weights start (group * 2 NG + nh) n16-blocks in
   PipeTile t = pipe_decode(a, p, item);
   unsigned gbase = (unsigned)((t.ng * 2 * NG + nh) * 2048);
-  ws_load_b<0, NG>(c, gbase, b0);
+  ws_load_b<0, NG, F16>(c, gbase, b0);
   __syncthreads();                                              // barrier A
   __syncthreads();                                              // barrier B
   for (; item < it_end; item += nslots) {
@@ -387,17 +450,27 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
       const int n = (t.ng * NG + ng) * 32 + nh * 16 + (lane & 15);
       scb[2 * ng] = a.scale ? a.scale[n] : 1.f;
       scb[2 * ng + 1] = a.bias ? a.bias[n] : 0.f;
+      if constexpr (F16) {
+        const bool to_y0 = (t.ng * NG + ng) * 32 + nh * 16 < a.cout0;
+        scb[2 * ng] *= to_y0 ? rs.s0 : rs.s1;
+        scb[2 * ng + 1] *= to_y0 ? rs.b0 : rs.b1;
+      }
     }
     const PipeTile tn = pipe_decode(a, p, item + nslots < it_end ? item + nslots : item);
     const unsigned gnext = (unsigned)((tn.ng * 2 * NG + nh) * 2048);
     for (int ch = 0; ch < nchunk; ++ch) {
       const unsigned ubase = (unsigned)ch * chunk_bytes + gbase;
       const unsigned unext = ch + 1 < nchunk ? (unsigned)(ch + 1) * chunk_bytes + gbase : gnext;
-      ws_rows<0, NG>(c, ubase, unext, a0, b0, a1, b1, Mp, Y);
+      ws_rows<0, NG, F16>(c, ubase, unext, a0, b0, a1, b1, Mp, Y);
       wino_scatter_row<3, 3>(Mp, Y[NG - 1]);
     }
-    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane, t.ng * NG, scb);
+    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane, t.ng * NG, scb, F16 ? &re : nullptr,
+                      F16 ? lds + (WINO_LDS + wave * 4096) / 4 : nullptr);
     t = tn; gbase = gnext;
+  }
+  if constexpr (F16) {
+    if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(re.amax0), rs.e0);
+    if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(re.amax1), rs.e1);
   }
 }
 
@@ -463,6 +536,62 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
   } while (0)
   if (NG == 1) PW_WINO(1); else PW_WINO(2);
 #undef PW_WINO
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// Winograd F(2x2x2, 3x3x3) with SPLIT-FP16 operands in the transform domain (round 3): the wave-specialised kernel above with
+//   * the transformed input written to LDS as hi + lo halves of value / 8 and the transformed weights pre-split on the host
+//     (ops.pack_conv_weight_wino_h2): three v_mfma_f32_16x16x32_f16 per point and 32-channel chunk instead of eight fp32 MFMAs --
+//     0.89 executed MFMA-FLOPs per direct-form FLOP where the direct split-fp16 kernel executes 3;
+//   * x in h2 storage (fmt_x = 1: hi + lo joined by one v_fma_mix_f32 per channel as the transform role reads the halo) or fp32;
+//   * y0 / y1 in h2 storage under their range slots, or fp32.
+// Same error class as the direct split-fp16 form (tools/study_wino_h2.py; tests/test_gpu_encoder.py).  No residual input.
+PW_API int pw_conv3d_wino_h2(const float* x, int fmt_x, const float* uwpk, const float* scale, const float* bias, float* y0,
+                             float* y1, int B, int D, int H, int W, int Cin, int cout_total, int cout0, int cout1, int ld_y0,
+                             int ld_y1, int relu0, int relu1, int fmt_y0, int fmt_y1, const int32_t* x_rng, int32_t* y0_rng,
+                             int32_t* y1_rng, void* stream) {
+  PW_CHECK_ARG(x && uwpk && y0, "pw_conv3d_wino_h2: null pointer");
+  PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cin % KC == 0, "pw_conv3d_wino_h2: bad shape");
+  PW_CHECK_ARG(cout_total > 0 && cout_total % 32 == 0 && cout0 > 0 && cout0 <= cout_total && cout1 >= 0,
+               "pw_conv3d_wino_h2: bad cout split");
+  PW_CHECK_ARG(!(cout1 > 0 && !y1), "pw_conv3d_wino_h2: cout1 > 0 needs y1");
+  PW_CHECK_ARG((fmt_x == 0 || fmt_x == 1) && (fmt_y0 == 0 || fmt_y0 == 1) && (fmt_y1 == 0 || fmt_y1 == 1),
+               "pw_conv3d_wino_h2: formats are 0 (fp32) or 1 (h2)");
+  PW_CHECK_ARG(!(fmt_y0 && (cout0 % 32)) && !(fmt_y1 && cout1 && (cout1 % 32)), "pw_conv3d_wino_h2: h2 destinations need multiples of 32 channels");
+  ConvArgs a = {};
+  a.x = x; a.wpk = uwpk; a.scale = scale; a.bias = bias; a.y0 = y0; a.y1 = y1;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Do = D; a.Ho = H; a.Wo = W;
+  a.cout_total = cout_total; a.cout0 = cout0; a.cout1 = cout1;
+  a.ld0 = ld_y0 > 0 ? ld_y0 : cout0; a.ld1 = ld_y1 > 0 ? ld_y1 : cout1;
+  a.n1_start = (cout0 + 31) / 32 * 32;
+  a.relu0 = relu0; a.relu1 = relu1;
+  a.fmt_y0 = fmt_y0; a.fmt_y1 = fmt_y1;
+  a.x_rng = fmt_x ? x_rng : nullptr; a.y0_rng = y0_rng; a.y1_rng = y1_rng;
+  a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
+  PW_CHECK_ARG((size_t)B * D * H * W * Cin * 4 < (1ull << 32) &&
+                   (size_t)B * D * H * W * (a.ld0 > a.ld1 ? a.ld0 : a.ld1) * 4 < (1ull << 32),
+               "pw_conv3d_wino_h2: tensors must be < 4 GiB (32-bit buffer addressing)");
+  const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
+  const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
+  int NG = (cout_total % 64 == 0 && nblk * (cout_total / 64) >= 2ll * nb) ? 2 : 1;
+  if (const char* g = getenv("PW_WINO_NG")) NG = (atoi(g) == 2 && cout_total % 64 == 0) ? 2 : 1;
+  PipeArgs p = {};
+  p.ngroups = cout_total / (32 * NG);
+  PW_CHECK_ARG(nblk * p.ngroups < (1ll << 20), "pw_conv3d_wino_h2: too many work items");
+  p.n_items = (int)nblk * p.ngroups;
+  p.m_ng = magic_of(p.ngroups); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
+#define PW_WINO_H2(NGv, INv)                                                                                        \
+  do {                                                                                                              \
+    static int once = set_lds_limit(k_conv3d_wino_ws<NGv, true, INv>, WINO_LDS + 16384);                             \
+    if (once) return once;                                                                                          \
+    hipLaunchKernelGGL((k_conv3d_wino_ws<NGv, true, INv>), dim3(nb), dim3(512), WINO_LDS + 16384, pw_stream(stream), a, p, \
+                       cout_total / 16);                                                                            \
+    pw_note_kernel("k_conv3d_wino_ws<%d, true, %s>", NGv, INv ? "true" : "false");                                 \
+  } while (0)
+  if (NG == 1) { if (fmt_x) PW_WINO_H2(1, true); else PW_WINO_H2(1, false); }
+  else { if (fmt_x) PW_WINO_H2(2, true); else PW_WINO_H2(2, false); }
+#undef PW_WINO_H2
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

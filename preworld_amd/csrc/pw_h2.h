@@ -58,15 +58,24 @@ __device__ __forceinline__ void h2_split1(float x, _Float16& h, _Float16& l) {
   l = (_Float16)__builtin_amdgcn_fmed3f(x - (float)h, -H2_MAX, H2_MAX);
 }
 
-// 8 values at once, written pair-wise so that the conversions become v_cvt_pk_f16_f32 and the residual a v_pk_add_f32
+// 8 values at once, written pair-wise: v_cvt_pk_f16_f32 for the two hi halves, the residual x - hi as ONE v_fma_mix_f32 per
+// value (hi * -1 + x with hi read as the low / high half of the packed register: exact, like the convert + subtract pair it
+// replaces -- hipcc does not form the mixed-precision FMA by itself), clamp, v_cvt_pk_f16_f32 for the two lo halves
 typedef float h2_f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2_f2 h2_residual2(h2_h2 h, h2_f2 x) {
+  const unsigned hp = __builtin_bit_cast(unsigned, h);
+  h2_f2 d;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d[0]) : "v"(hp), "v"(x[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d[1]) : "v"(hp), "v"(x[1]));
+  return d;
+}
 __device__ __forceinline__ void h2_split8(const float (&v)[8], h8& hi, h8& lo) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const h2_f2 x = {v[2 * p], v[2 * p + 1]};
     const h2_h2 h = __builtin_convertvector(x, h2_h2);
-    h2_f2 d = x - __builtin_convertvector(h, h2_f2);
+    h2_f2 d = h2_residual2(h, x);
     d[0] = __builtin_amdgcn_fmed3f(d[0], -H2_MAX, H2_MAX);
     d[1] = __builtin_amdgcn_fmed3f(d[1], -H2_MAX, H2_MAX);
     const h2_h2 l = __builtin_convertvector(d, h2_h2);
@@ -81,7 +90,7 @@ __device__ __forceinline__ void h2_split4(const float (&v)[4], u2& hi, u2& lo) {
   for (int p = 0; p < 2; ++p) {                      // pair-wise, like h2_split8
     const h2_f2 x = {v[2 * p], v[2 * p + 1]};
     const h2_h2 a = __builtin_convertvector(x, h2_h2);
-    h2_f2 d = x - __builtin_convertvector(a, h2_f2);
+    h2_f2 d = h2_residual2(a, x);
     d[0] = __builtin_amdgcn_fmed3f(d[0], -H2_MAX, H2_MAX);
     d[1] = __builtin_amdgcn_fmed3f(d[1], -H2_MAX, H2_MAX);
     const h2_h2 b = __builtin_convertvector(d, h2_h2);
