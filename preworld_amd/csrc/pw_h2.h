@@ -64,6 +64,9 @@ __device__ __forceinline__ void h2_split1(float x, _Float16& h, _Float16& l) {
 typedef float h2_f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2_f2 h2_residual2(h2_h2 h, h2_f2 x) {
+#ifdef PW_SPLIT_NOMIX                      // A/B: the convert + subtract form
+  return x - __builtin_convertvector(h, h2_f2);
+#endif
   const unsigned hp = __builtin_bit_cast(unsigned, h);
   h2_f2 d;
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d[0]) : "v"(hp), "v"(x[0]));
