@@ -357,7 +357,10 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
   } else {
     ws_load_b<0, NG, F16>(c, ubase_next, bn);
   }
-  __builtin_amdgcn_sched_barrier(0);
+  // fp32: a row's 32 MFMAs of 64 cycles hide the load issue in front of them.  F16: the 12 MFMAs of a row are 192 cycles and the
+  // 16 loads in front of them ~500 -- the row is ONE scheduling region and the loads / the previous row's output transform are
+  // spread over the MFMA shadows (below), like a tap of k_conv3d_h2
+  if constexpr (!(F16 && NG == 1)) __builtin_amdgcn_sched_barrier(0);      // (NG 2 as one region: 150 -> 170 us at 32 -> 64, measured)
   f32x4 M[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) M[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -388,6 +391,17 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
   if constexpr (R >= 1) {
     typedef WsRow<R - 1, NG> P;
     wino_scatter_row<P::ID, P::IH>(Mp, Y[P::ng]);               // the previous row's products, under this row's MFMAs
+  }
+  if constexpr (F16 && NG == 1) {
+    constexpr bool own_a = NG == 1 ? W::first : W::ng == 0;     // this row's V fragments are read by this row itself
+    if constexpr (own_a) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (!own_a && i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
