@@ -523,18 +523,6 @@ def main():
             else:
                 os.environ['PW_LIFT_STREAMS'] = lift_streams
         roofline = roofline_object(probe.summary(), n_probe)
-        if roofline.get('bound') == 'mfma':
-            # what the 1400 W socket cap leaves of the matrix pipe on this box: a bare fp16 MFMA stream on random operands
-            # (pw_probe_mfma_f16, ~0.5 s).  `peak` / `frac` stay the data-sheet figures SURVEY 8(d) asks for.
-            import ctypes
-            from preworld_amd import _lib as L
-            tf = ctypes.c_double(0.0)
-            L.call('pw_probe_mfma_f16', 0.5, ctypes.byref(tf))
-            roofline['sustained_mfma'] = dict(
-                tflops=round(tf.value, 1), frac_of_it=round(roofline['executed_tflops'] / tf.value, 4),
-                how='bare v_mfma_f32_32x32x16_f16 stream, random fp16 operands in registers, no memory traffic, one wave per SIMD, '
-                    '0.5 s on this box just before the timed region; frac_of_it = executed_tflops / tflops '
-                    '(profiles/r03_power_wall.txt: with real data the socket sits at its power cap and the clock follows)')
 
     graph = None
     latency_ms = None
@@ -589,6 +577,20 @@ def main():
         t = torch.tensor([elapsed], device='cpu' if oversubscribed else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    if roofline is not None and roofline.get('bound') == 'mfma':
+        # what the 1400 W socket cap leaves of the matrix pipe on this box: a bare fp16 MFMA stream on random operands
+        # (pw_probe_mfma_f16, ~0.5 s), run AFTER the timed region so that it cannot warm the chip for it.  `peak` / `frac` stay the
+        # data-sheet figures SURVEY 8(d) asks for.
+        import ctypes
+        from preworld_amd import _lib as L
+        tf = ctypes.c_double(0.0)
+        L.call('pw_probe_mfma_f16', 0.5, ctypes.byref(tf))
+        roofline['sustained_mfma'] = dict(
+            tflops=round(tf.value, 1), frac_of_it=round(roofline['executed_tflops'] / tf.value, 4),
+            how='bare v_mfma_f32_32x32x16_f16 stream, random fp16 operands in registers, no memory traffic, one wave per SIMD, '
+                '0.5 s on this box right after the timed region; frac_of_it = executed_tflops / tflops '
+                '(profiles/r03_power_wall.txt: with real data the socket sits at its power cap and the clock follows)')
 
     # every replay of the timed region stayed inside its calibrated activation ranges (pipeline.CapturedSample.ranges_ok: the
     # exponent table + recorded maxima the replays delivered to pinned host memory)
