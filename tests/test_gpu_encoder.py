@@ -814,3 +814,14 @@ def test_conv3d_wino_h2_scale_sweep():
         print('[parity] conv3d_wino_h2 64->64 x 2^%d: worst element %.2f of (4e-6 |ref| + 3e-6 rms)' % (k, q))
         worst.append(q)
     assert max(worst) <= 1.0 and max(worst) <= 1.5 * min(worst) + 0.05, worst
+
+
+def test_sustained_mfma_probe_reports_a_plausible_rate():
+    """pw_probe_mfma_f16 (bench.py's roofline.sustained_mfma): a bare fp16 MFMA stream on random operands -- above the split-fp16
+    conv kernels' executed rate, below the 2.5 PFLOP/s data-sheet peak."""
+    import ctypes
+    from preworld_amd import _lib as L
+    tf = ctypes.c_double(0.0)
+    L.call('pw_probe_mfma_f16', 0.2, ctypes.byref(tf))
+    print('[probe] bare v_mfma_f32_32x32x16_f16 stream, random operands: %.0f TFLOP/s' % tf.value)
+    assert 600.0 < tf.value < 2600.0, tf.value
