@@ -126,6 +126,20 @@ int pw_bev_pool_dense(const float* depth, const float* feat, const int32_t* seg_
                       int long_threshold, const int32_t* long_list, const int32_t* n_long,
                       float* out, int out_h2, int32_t* out_rng, void* stream);
 
+/* A1-A4 in one call (inference, C == 32): camera tensors + frustum + (depth, feat) of one batch of frames -> pooled grid
+ * out (B,Z,Y,X,C), every voxel written (sum in ascending point order, or zero); fp32 or (out_h2) split-fp16 under out_rng.
+ * Same results, bit for bit, as pw_lss_camera_matrices + pw_lss_voxel_index + pw_segment_sort + pw_bev_pool_dense
+ * (view_transformer.py:114-153, :203-261; bev_pool_cuda.cu:21-48) in 5 launches instead of 11: a voxel's first eight points are
+ * listed by the counting atomics themselves and sorted inside the pooling sweep; only voxels with more points take a scatter.
+ * sensor2ego (B,N,4,4), cam2imgs / post_rots (B,N,3,3), post_trans (B,N,3), bda (B,3,3), frustum (D,H,W,3), depth (B,N,D,H,W),
+ * feat (B,N,H,W,C) device; lower3_host / interval3_host host float[3].  workspace: 256-byte aligned scratch, no state kept. */
+size_t pw_lss_lift_pool_workspace_bytes(int64_t n_points, int64_t n_voxels, int BN);
+int pw_lss_lift_pool(int B, int N, int D, int H, int W, const float* frustum, const float* sensor2ego,
+                     const float* cam2imgs, const float* post_rots, const float* post_trans, const float* bda,
+                     const float* lower3_host, const float* interval3_host, int gx, int gy, int gz, const float* depth,
+                     const float* feat, int c, void* workspace, size_t workspace_bytes, float* out, int out_h2,
+                     int32_t* out_rng, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A6-A9, A11  3-D convolution on channels-last activations, exact-fp32 MFMA implicit GEMM.
  * Replaces torch Conv3d(+BatchNorm3d eval)(+residual)(+ReLU) as composed by

@@ -22,6 +22,7 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fvisibility=
 EXTRA = {
     # geometry / pooling must round exactly like the oracle: no FMA contraction
     'pw_lss.hip': ['-ffp-contract=off'],
+    'pw_lss_fused.hip': ['-ffp-contract=off'],
     'pw_render.hip': ['-ffp-contract=off'],
     'pw_stereo.hip': ['-ffp-contract=off'],
 }

@@ -17,47 +17,18 @@
 //   * pooling is voxel-driven: each group of C/4 lanes owns one voxel, walks its segment
 //     with float4 gathers of feat, and writes the (Z,Y,X,C) row once (sum or zeros):
 //     coalesced 1 KiB per wave-store, no memset pass, no permute pass.
-#include "pw_common.h"
-#include "pw_h2.h"
+#include "pw_lss_common.h"
 
 // ------------------------------------------------------------------------------------
 // camera matrices (closed-form 3x3 inverse, same op order as oracle inv3x3_f32)
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void inv3x3(const float* m, float* o) {
-  float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
-  float A = e * i - f * h, B = c * h - b * i, C = b * f - c * e;
-  float D = f * g - d * i, E = a * i - c * g, F = c * d - a * f;
-  float G = d * h - e * g, H = b * g - a * h, I = a * e - b * d;
-  float det = (a * A + b * D) + c * G;
-  float r = 1.0f / det;
-  o[0] = A * r; o[1] = B * r; o[2] = C * r;
-  o[3] = D * r; o[4] = E * r; o[5] = F * r;
-  o[6] = G * r; o[7] = H * r; o[8] = I * r;
-}
-
 __global__ void k_camera_matrices(int BN, const float* __restrict__ s2e,
                                   const float* __restrict__ K, const float* __restrict__ pr,
                                   float* __restrict__ ipr, float* __restrict__ comb,
                                   float* __restrict__ tr) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= BN) return;
-  float R[9], Kin[9], Kinv[9], P[9], Pinv[9];
-  const float* S = s2e + c * 16;
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) R[i * 3 + j] = S[i * 4 + j];
-  for (int i = 0; i < 9; ++i) { Kin[i] = K[c * 9 + i]; P[i] = pr[c * 9 + i]; }
-  inv3x3(P, Pinv);
-  inv3x3(Kin, Kinv);
-  for (int i = 0; i < 9; ++i) ipr[c * 9 + i] = Pinv[i];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      float acc = 0.f;
-      for (int k = 0; k < 3; ++k) acc += R[i * 3 + k] * Kinv[k * 3 + j];
-      comb[c * 9 + i * 3 + j] = acc;
-    }
-  tr[c * 3 + 0] = S[3];
-  tr[c * 3 + 1] = S[7];
-  tr[c * 3 + 2] = S[11];
+  lss_camera_matrix_one(c, s2e, K, pr, ipr, comb, tr);
 }
 
 PW_API int pw_lss_camera_matrices(int BN, const float* sensor2ego, const float* cam2imgs,
@@ -74,11 +45,6 @@ PW_API int pw_lss_camera_matrices(int BN, const float* sensor2ego, const float* 
 // ------------------------------------------------------------------------------------
 // frustum point -> voxel id
 // ------------------------------------------------------------------------------------
-struct GridParams {
-  float lx, ly, lz, ix, iy, iz;
-  int gx, gy, gz;
-};
-
 __global__ void __launch_bounds__(256)
 k_voxel_index(int N, int64_t DHW, int64_t total, const float* __restrict__ frustum,
               const float* __restrict__ ipr, const float* __restrict__ ptr,
@@ -87,59 +53,7 @@ k_voxel_index(int N, int64_t DHW, int64_t total, const float* __restrict__ frust
               float* __restrict__ coor_out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  int cam = (int)(i / DHW);
-  int64_t p = i - (int64_t)cam * DHW;
-  int b = cam / N;
-  const float* fr = frustum + p * 3;
-  const float* M = ipr + cam * 9;
-  const float* C = comb + cam * 9;
-  const float* T = trn + cam * 3;
-  const float* PT = ptr + cam * 3;
-  const float* A = bda + b * 9;
-  float p0 = fr[0] - PT[0], p1 = fr[1] - PT[1], p2 = fr[2] - PT[2];
-  float q[3], r[3], o[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float acc = 0.f;
-    acc += M[k * 3 + 0] * p0;
-    acc += M[k * 3 + 1] * p1;
-    acc += M[k * 3 + 2] * p2;
-    q[k] = acc;
-  }
-  float u0 = q[0] * q[2], u1 = q[1] * q[2], u2 = q[2];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float acc = 0.f;
-    acc += C[k * 3 + 0] * u0;
-    acc += C[k * 3 + 1] * u1;
-    acc += C[k * 3 + 2] * u2;
-    r[k] = acc + T[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float acc = 0.f;
-    acc += A[k * 3 + 0] * r[0];
-    acc += A[k * 3 + 1] * r[1];
-    acc += A[k * 3 + 2] * r[2];
-    o[k] = acc;
-  }
-  if (coor_out) {
-    coor_out[i * 3 + 0] = o[0];
-    coor_out[i * 3 + 1] = o[1];
-    coor_out[i * 3 + 2] = o[2];
-  }
-  float fx = (o[0] - gp.lx) / gp.ix;
-  float fy = (o[1] - gp.ly) / gp.iy;
-  float fz = (o[2] - gp.lz) / gp.iz;
-  // .long() truncates toward zero (view_transformer.py:228): trunc(f) in [0,g) <=> -1 < f < g
-  bool in = fx > -1.f && fx < (float)gp.gx && fy > -1.f && fy < (float)gp.gy && fz > -1.f &&
-            fz < (float)gp.gz;
-  int32_t v = -1;
-  if (in) {
-    int x = (int)fx, y = (int)fy, z = (int)fz;
-    v = ((b * gp.gz + z) * gp.gy + y) * gp.gx + x;
-  }
-  vox[i] = v;
+  vox[i] = lss_voxel_of_point(i, N, DHW, frustum, ipr, ptr, comb, trn, bda, gp, coor_out);
 }
 
 PW_API int pw_lss_voxel_index(int B, int N, int D, int H, int W, const float* frustum,
@@ -378,19 +292,6 @@ k_ranksort(const int32_t* __restrict__ keys, const int32_t* __restrict__ seg_sta
 // long segments: one block per segment, ids staged in LDS, rank = #smaller ids (LDS broadcast
 // reads, no global traffic in the O(n^2) part).  Segments beyond SORT_LDS_MAX ids are processed
 // in LDS-sized passes (rank accumulates over passes).
-__device__ __forceinline__ int count_smaller_lds(const int32_t* ids, int m16, int id) {
-  const int4* ids4 = reinterpret_cast<const int4*>(ids);
-  int r = 0;
-  for (int j = 0; j < m16 / 4; j += 4) {                  // 4 x ds_read_b128 (broadcast) per trip
-    const int4 a = ids4[j], b = ids4[j + 1], c = ids4[j + 2], d = ids4[j + 3];
-    r += (a.x < id) + (a.y < id) + (a.z < id) + (a.w < id);
-    r += (b.x < id) + (b.y < id) + (b.z < id) + (b.w < id);
-    r += (c.x < id) + (c.y < id) + (c.z < id) + (c.w < id);
-    r += (d.x < id) + (d.y < id) + (d.z < id) + (d.w < id);
-  }
-  return r;
-}
-
 __device__ __forceinline__ void sort_long_blocks(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ tmp,
                                                  const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
                                                  int32_t* __restrict__ order, int aux_div, int aux_mod,
@@ -592,13 +493,6 @@ PW_API int pw_lss_ranks(int64_t n_voxels, const int32_t* seg_start, const int32_
 // ------------------------------------------------------------------------------------
 constexpr int POOL_UNROLL = 8;
 
-__device__ __forceinline__ void fma4_nc(float4& acc, const float4& f, float d) {
-  acc.x = acc.x + f.x * d;
-  acc.y = acc.y + f.y * d;
-  acc.z = acc.z + f.z * d;
-  acc.w = acc.w + f.w * d;
-}
-
 // dense, voxel-driven: writes every voxel row once.  order_feat[pos] is the feat-pixel index
 // of sorted point pos.  Segments longer than long_threshold (a few hundred near-camera voxels
 // hold up to ~1300 points) are taken by whole waves in the first LONG_BLOCKS blocks, which
@@ -608,26 +502,6 @@ constexpr int LONG_BLOCKS = 128;    // x 4 waves
 #ifndef PW_POOL_WAVES
 #define PW_POOL_WAVES 5
 #endif
-
-// one lane's 4 channels (quad `sub`) of voxel row v: fp32, or split-fp16 (h2, pw_h2.h) for the fp16-matrix-core encoder
-template <int LPV>
-__device__ __forceinline__ void pool_store(float4* __restrict__ out, int64_t v, int sub, const float4& acc, int out_h2,
-                                           float mul, unsigned& amax) {
-  if (!out_h2) {
-    out[v * LPV + sub] = acc;
-  } else {
-    // h2: the sums are stored divided by 2^e of the destination's range slot (mul = 2^-e, exact) and their largest magnitude
-    // is recorded (pw_h2.h "Range"); bit-pattern maximum, so a NaN among the inputs shows up in the slot
-    const float f[4] = {acc.x * mul, acc.y * mul, acc.z * mul, acc.w * mul};
-    amax = max(max(amax, rng_absbits(f[0])), max(rng_absbits(f[1]), max(rng_absbits(f[2]), rng_absbits(f[3]))));
-    u2 hi, lo;
-    h2_split4(f, hi, lo);
-    char* row = reinterpret_cast<char*>(out + v * LPV) + (sub >> 3) * 128;
-    const int c = (sub & 7) * 4;
-    *reinterpret_cast<u2*>(row + h2_group_off(c, 0)) = hi;
-    *reinterpret_cast<u2*>(row + h2_group_off(c, 1)) = lo;
-  }
-}
 
 template <int LPV>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_POOL_WAVES, 8)))

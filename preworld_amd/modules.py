@@ -6,10 +6,16 @@ preworld_amd.registry.  All hot arithmetic goes through libpreworld_hip.so (prew
 torch only provides parameters, device memory and the stream.  Modules raise if the HIP
 library is missing or if asked to run on CPU tensors -- there is no fallback path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
+
+# PW_LSS=sort keeps the sort-based lift (pw_segment_sort + pw_bev_pool_dense) on the inference path: A/B switch for
+# ops.lss_lift_pool, which is the default for C == 32 (same bits either way, tests/test_gpu_lss.py)
+_LSS_FORM = os.environ.get('PW_LSS', 'slots')
 
 
 def create_frustum(depth_cfg, input_size, downsample):
@@ -133,14 +139,26 @@ class LSSViewTransformer(nn.Module):
     def view_transform_core(self, input, depth, tran_feat):
         B, N, C, H, W = input[0].shape
         _, _, size = self._grid()
-        vs = self._sort(input[1], input[3], input[4], input[5], input[6])
-        seg_start, order, n_vox = vs.seg_start, vs.order, vs.n_keys
         if getattr(tran_feat, '_pw_channels_last', False):        # already (B*N,H,W,C) from ops.depthnet_tail
             feat = tran_feat.view(B, N, H, W, self.out_channels)
         else:
             feat = tran_feat.view(B, N, self.out_channels, H, W).permute(0, 1, 3, 4, 2).contiguous().float()
         dep = depth.view(B, N, self.D, H, W).contiguous().float()
-        if (dep.requires_grad or feat.requires_grad) and torch.is_grad_enabled():
+        train = (dep.requires_grad or feat.requires_grad) and torch.is_grad_enabled()
+        if not train and not self.accelerate and self.out_channels == 32 and _LSS_FORM != 'sort':
+            # one frame's lift + pooling without a sort (ops.lss_lift_pool): same bits, 5 launches
+            lower, interval, _ = self._grid()
+            out = ops.lss_lift_pool(self._frustum_on(input[1]), input[1], input[3], input[4], input[5], input[6], lower,
+                                    interval, size, dep, feat, out_h2=getattr(self, '_pool_h2', False))
+            if isinstance(out, ops.H2):
+                self._pool_rng, out = out.rng, out.buf
+            bev = out.view(B, size[2], size[1], size[0], self.out_channels).permute(0, 4, 1, 2, 3)
+            if self.collapse_z:
+                bev = torch.cat(bev.unbind(dim=2), 1)
+            return bev, depth
+        vs = self._sort(input[1], input[3], input[4], input[5], input[6])
+        seg_start, order, n_vox = vs.seg_start, vs.order, vs.n_keys
+        if train:
             rb, rd, rf, st, ln = ops.lss_ranks(seg_start, order, n_vox, self.D, H * W)
             if rb is None:
                 out = feat.new_zeros(B, size[2], size[1], size[0], self.out_channels)

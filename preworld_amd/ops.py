@@ -156,6 +156,33 @@ def bev_pool_dense(depth, feat, vs, out=None, out_h2=False):
     return H2(out, orng) if out_h2 else out
 
 
+def lss_lift_pool(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, lower, interval, grid_size, depth, feat,
+                  out=None, out_h2=False):
+    """get_lidar_coor + voxel_pooling_prepare_v2 + bev_pool_v2 forward of one batch of frames in one call (inference, C == 32;
+    view_transformer.py:114-153, :203-261, bev_pool_cuda.cu:21-48): the same bits as lss_camera_matrices -> lss_voxel_index ->
+    segment_sort -> bev_pool_dense in 5 launches.  depth (B,N,D,H,W), feat (B,N,H,W,C) fp32; returns (n_voxels, C) fp32 or an
+    ops.H2 (out_h2)."""
+    B, N = sensor2ego.shape[:2]
+    D, H, W, _ = frustum.shape
+    C = feat.shape[-1]
+    dev = feat.device
+    n_vox = B * int(grid_size[0]) * int(grid_size[1]) * int(grid_size[2])
+    if out is None:
+        out = torch.empty(n_vox, C, device=dev, dtype=_f32)
+    orng = None
+    if out_h2:
+        out, orng = _out_h2(out, dev)
+    nbytes = _lib.call_size('pw_lss_lift_pool_workspace_bytes', B * N * D * H * W, n_vox, B * N)
+    ws = _workspace(nbytes, dev)
+    f = lambda t: t.contiguous().float()
+    _lib.call('pw_lss_lift_pool', B, N, D, H, W, _chk(frustum, _f32, 'frustum'), _chk(f(sensor2ego), _f32, 'sensor2ego'),
+              _chk(f(cam2imgs), _f32, 'cam2imgs'), _chk(f(post_rots), _f32, 'post_rots'), _chk(f(post_trans), _f32, 'post_trans'),
+              _chk(f(bda), _f32, 'bda'), _host3(lower), _host3(interval), int(grid_size[0]), int(grid_size[1]),
+              int(grid_size[2]), _chk(depth, _f32, 'depth'), _chk(feat, _f32, 'feat'), C, _p(ws), nbytes,
+              _chk(out, _f32, 'out'), int(bool(out_h2)), _p(orng), _stream())
+    return H2(out, orng) if out_h2 else out
+
+
 # ------------------------------------------------------------------------------ bev_pool_v2
 def bev_pool_v2_forward(depth, feat, out, ranks_depth, ranks_feat, ranks_bev, interval_lengths,
                         interval_starts):

@@ -144,6 +144,83 @@ def test_full_size_bit_exact_vs_oracle(cfg):
     np.testing.assert_array_equal(ref_abi, o_bev)
 
 
+def _rig_cfg(cfg):
+    if cfg == 'C1':
+        return S.GRID_CONFIG_C1, 1, 1, S.synthetic_rig(1)
+    if cfg == 'full':
+        return S.GRID_CONFIG_FULL, 6, 1, S.synthetic_rig(6)
+    r0, r1 = S.synthetic_rig(6), S.synthetic_rig(6, dx=-2.5)
+    rig = {k: np.concatenate([r0[k], r1[k]], 0) for k in r0}
+    rig['bda'][1] = np.array([[0.99, 0.1, 0], [-0.1, 0.99, 0], [0, 0, 1.0]], np.float32)
+    return S.GRID_CONFIG_FULL, 6, 2, rig
+
+
+@pytest.mark.parametrize('cfg', ['C1', 'full', 'full_adj_b2'])
+def test_lift_pool_slots_bit_exact_vs_oracle_and_sort_path(cfg):
+    """ops.lss_lift_pool (id slots + in-group sort, no sort kernels) at the BASELINE sizes: the pooled fp32 sums equal the oracle's
+    and the sort-based path's bit for bit; the h2 form equals the sort-based path's h2 bytes and range maximum; two runs agree
+    (the slot arrival order differs from run to run, the result must not)."""
+    gc, N, B, rig = _rig_cfg(cfg)
+    fr, lower, interval, size, vox, coor = _prepare(gc, S.INPUT_SIZE, S.DOWNSAMPLE, rig, B, N)
+    n_vox = B * size[0] * size[1] * size[2]
+    D, H, W = fr.shape[:3]
+    want = O.voxel_pooling_prepare_v2(coor.cpu().numpy(), lower, interval, size)
+    depth, feat = S.lift_inputs(7, B=B, N=N)
+    featc = np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2))
+    o_bev = O.bev_pool_v2(depth, featc, want[1], want[2], want[0], (B, size[2], size[1], size[0], 32), want[3], want[4])
+    d_t, f_t = T(depth), T(featc)
+    cams = [T(rig[k]) for k in ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda')]
+    out = torch.full((n_vox, 32), float('nan'), device=DEV)          # every voxel must be written
+    got = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t, out=out)
+    np.testing.assert_array_equal(got.view(B, size[2], size[1], size[0], 32).permute(0, 4, 1, 2, 3).cpu().numpy(), o_bev)
+    again = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t)
+    assert torch.equal(got, again)
+    vs = vsort(vox, n_vox, D, H * W)
+    ref_h2 = ops.bev_pool_dense(d_t, f_t, vs, out_h2=True)
+    got_h2 = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t, out_h2=True)
+    assert torch.equal(got_h2.buf.view(torch.int32), ref_h2.buf.view(torch.int32))
+    a, b = ops.slot_state(ref_h2.rng), ops.slot_state(got_h2.rng)
+    assert a == b and b[1] > 0
+
+
+@pytest.mark.parametrize('case', ['one_voxel', 'ragged', 'all_outside'])
+def test_lift_pool_slots_edge_cases(case):
+    """the heavy-voxel classes of ops.lss_lift_pool at their extremes: every frustum point in ONE voxel (a 5 632-point segment:
+    block sort in two LDS passes), a ragged tiny frustum (point count not a multiple of 64, voxel count not a multiple of 64),
+    and a rig that looks away from the grid (nothing kept: all zeros)."""
+    rs = np.random.RandomState(3)
+    if case == 'one_voxel':
+        gc = dict(x=[-400., 400., 800.], y=[-400., 400., 800.], z=[-100., 100., 200.], depth=[1.0, 9.0, 1.0])   # a 1x1x1 grid
+        N, input_size, ds = 2, (16, 22), 1
+    elif case == 'ragged':
+        gc = dict(x=[-10., 10., 4.0], y=[-10., 10., 2.5], z=[-1., 5.4, 0.8], depth=[1.0, 14.0, 1.0])
+        N, input_size, ds = 3, (80, 176), 16
+    else:
+        gc = dict(x=[500., 540., 0.4], y=[500., 540., 0.4], z=[-1., 5.4, 0.4], depth=[1.0, 45.0, 0.5])
+        N, input_size, ds = 2, (256, 704), 16
+    rig = S.synthetic_rig(N)
+    fr = O.create_frustum(gc['depth'], input_size, ds)
+    lower, interval, size = O.grid_infos(gc)
+    D, H, W = fr.shape[:3]
+    depth = rs.random_sample((1, N, D, H, W)).astype(np.float32)
+    featc = rs.standard_normal((1, N, H, W, 32)).astype(np.float32)
+    cams = [T(rig[k]) for k in ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda')]
+    got = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, T(depth), T(featc))
+    ipr, comb, tr = O.camera_matrices(rig['sensor2ego'], rig['intrin'], rig['post_rot'])
+    coor = O.lidar_coor(fr, ipr, rig['post_tran'].reshape(-1, 3), comb, tr, rig['bda'], 1, N)
+    want = O.voxel_pooling_prepare_v2(coor, lower, interval, size)
+    shape = (1, size[2], size[1], size[0], 32)
+    if want[0] is None or len(want[0]) == 0:
+        assert case == 'all_outside'
+        o_bev = np.zeros((1, 32, size[2], size[1], size[0]), np.float32)
+    else:
+        assert case != 'all_outside'
+        o_bev = O.bev_pool_v2(depth, featc, want[1], want[2], want[0], shape, want[3], want[4])
+        if case == 'one_voxel':
+            assert len(want[0]) == N * D * H * W > 4096
+    np.testing.assert_array_equal(got.view(*shape).permute(0, 4, 1, 2, 3).cpu().numpy(), o_bev)
+
+
 def test_full_size_properties(golden):
     """Size-independent properties at BASELINE's full size: linearity in feat, conservation
     (sum of pooled == sum over kept points of depth*feat), idempotent re-run, golden stats."""

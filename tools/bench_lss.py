@@ -40,3 +40,12 @@ vs0 = ops.VoxelSort(vs.seg_start, vs.order, vs.order_feat, None, None, vs.n_keys
 t0 = timeit(lambda: ops.bev_pool_dense(d_t, f_t, vs0, out=out))
 print('pool fp32 without the long-segment blocks (same result, long segments inside the sweep): %.1f us; long segments: %d' % (
     t0, int(vs.n_long.item())), flush=True)
+# the slot-based single-call form (ops.lss_lift_pool): camera matrices + index + lists + pooling in 5 launches
+cams = (s2e, K, pr, pt, bda)
+d5 = d_t.view(1, 6, 88, 32, 88)
+t_fused = timeit(lambda: ops.lss_lift_pool(fr, *cams, lower, interval, size, d5, f_t, out=out))
+t_fused_h2 = timeit(lambda: ops.lss_lift_pool(fr, *cams, lower, interval, size, d5, f_t, out=out, out_h2=True))
+ref = ops.bev_pool_dense(d_t, f_t, vs)
+got = ops.lss_lift_pool(fr, *cams, lower, interval, size, d5, f_t)
+print('lss_lift_pool (5 launches, whole frame): fp32 %.1f us | h2 %.1f us | same bits as the sort path: %s' % (
+    t_fused, t_fused_h2, bool(torch.equal(ref, got))), flush=True)
