@@ -181,9 +181,9 @@ constexpr int HC_ROWS = 128;          // rows per LDS chunk of the block-pooled 
 //     chunk's rows are in flight while the first half wave adds this chunk's, lane c = channel c.
 //   other blocks: voxels of 9 .. 64 points, HALF a wave each: lane c of the half ranks the c-th and (c + 32)-th arrival with 64
 //     shuffles at most, the half's LDS strip then lists (pixel, depth) in order, all rows are requested, lane c adds channel c.
-__global__ void __launch_bounds__(256)
-k_lss_pool_heavy(const float* __restrict__ depth, const float4* __restrict__ feat, const int32_t* __restrict__ slots,
-                 const int32_t* __restrict__ cur, const int4* __restrict__ list_b, const int4* __restrict__ list_c,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_lss_pool_slots(const float* __restrict__ depth, const float4* __restrict__ feat, const int32_t* __restrict__ count,
+                 const int32_t* __restrict__ slots, int64_t n_vox, const int32_t* __restrict__ cur, const int4* __restrict__ list_b, const int4* __restrict__ list_c,
                  const int32_t* __restrict__ tmp, int32_t* __restrict__ sorted_pf, float* __restrict__ sorted_d, FeatIdx fi,
                  float4* __restrict__ out, int out_h2, int* __restrict__ out_rng, int dbg) {
   extern __shared__ __attribute__((aligned(16))) int32_t ids[];
@@ -290,13 +290,13 @@ k_lss_pool_heavy(const float* __restrict__ depth, const float4* __restrict__ fea
         if (lane < LPV) pool_store<LPV>(out, k, sub, acc, out_h2, omul, amax);
       }
     }
-  } else {
+  } else if ((int)blockIdx.x < C_BLOCKS + B_BLOCKS) {
     const int nb = (dbg & 2) ? 0 : cur[CUR_B];
     const int hb = lane & 32, c = lane & 31;
     int32_t* lpf = ids + (wave * 2 + (lane >> 5)) * 128;          // 64 pixels + 64 depths per half: 4 KB of the block's LDS
     float* ld = reinterpret_cast<float*>(lpf + 64);
     const float* __restrict__ featf = reinterpret_cast<const float*>(feat);
-    for (int t = ((int)blockIdx.x - C_BLOCKS) * 4 + wave; 2 * t < nb; t += ((int)gridDim.x - C_BLOCKS) * 4) {
+    for (int t = ((int)blockIdx.x - C_BLOCKS) * 4 + wave; 2 * t < nb; t += B_BLOCKS * 4) {
       const int li = 2 * t + (lane >> 5);
       const bool on = li < nb;
       const int4 e = on ? list_b[li] : make_int4(0, 0, 0, 0);
@@ -318,45 +318,37 @@ k_lss_pool_heavy(const float* __restrict__ depth, const float4* __restrict__ fea
       }
       if (c < n) { lpf[ra] = feat_index(a, fi); ld[ra] = da; }
       if (c + 32 < n) { lpf[rb] = feat_index(b, fi); ld[rb] = db; }
-      float x[HEAVY_WAVE_MAX];
-#pragma unroll
-      for (int p = 0; p < HEAVY_WAVE_MAX; ++p) {
-        x[p] = 0.f;
-        if (p < nmax) {                                    // wave-uniform
-          const int pf = p < n ? lpf[p] : 0;
-          if (p < n) x[p] = featf[(unsigned)(pf * 32 + c)];
-        }
-      }
       float acc1 = 0.f;
 #pragma unroll
-      for (int p = 0; p < HEAVY_WAVE_MAX; ++p)
-        if (p < nmax) {
-          const float d = p < n ? ld[p] : 0.f;
-          if (p < n) acc1 = acc1 + x[p] * d;
+      for (int h = 0; h < HEAVY_WAVE_MAX; h += 32)
+        if (h < nmax) {                                    // wave-uniform: rows of 32 points requested together
+          float x[32];
+#pragma unroll
+          for (int p = 0; p < 32; ++p) {
+            x[p] = 0.f;
+            if (h + p < nmax) {
+              const int pf = h + p < n ? lpf[h + p] : 0;
+              if (h + p < n) x[p] = featf[(unsigned)(pf * 32 + c)];
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < 32; ++p)
+            if (h + p < nmax) {
+              const float d = h + p < n ? ld[h + p] : 0.f;
+              if (h + p < n) acc1 = acc1 + x[p] * d;
+            }
         }
       const float4 acc = half_to_quads(acc1, lane);
       if (on && c < LPV) pool_store<LPV>(out, k, sub, acc, out_h2, omul, amax);
     }
-  }
-  if (out_h2) rng_note(out_rng, amax, e_out);
-}
-
-// The light voxels (1 .. 8 points).  A wave reads the counters of 64 consecutive voxels, moves the (voxel, count) pairs of the
-// non-empty light ones to its first lanes (ds_permute over a full permutation), and its eight lane groups take eight of them at a
-// time: the group sorts the voxel's ids (8 shuffles + one ds_permute), gathers the rows, adds them in order.  Empty voxels were
-// zero-filled by k_lss_index_slots, heavy ones written by k_lss_pool_heavy.
-__global__ void __launch_bounds__(256)
-k_lss_pool_slots(const float* __restrict__ depth, const float4* __restrict__ feat, const int32_t* __restrict__ count,
-                 const int32_t* __restrict__ slots, int64_t n_vox, FeatIdx fi, float4* __restrict__ out, int out_h2,
-                 int* __restrict__ out_rng, int dbg) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane % LPV, grp = lane / LPV, gbase = lane - sub;
-  const int e_out = out_h2 ? rng_exp(out_rng) : 0;
-  const float omul = rng_pow2(-e_out);
-  unsigned amax = 0u;
-  {
-    const int64_t wid = (int64_t)((int)blockIdx.x) * 4 + wave;
-    const int64_t nw = (int64_t)((int)gridDim.x) * 4;
+  } else {
+    // ---- the light voxels (1 .. 8 points).  A wave reads the counters of 64 consecutive voxels, moves the (voxel, count) pairs
+    // of the non-empty light ones to its first lanes (ds_permute over a full permutation), and its eight lane groups take eight of
+    // them at a time: the group sorts the voxel's ids (8 shuffles + one ds_permute), gathers the rows, adds them in order.  Empty
+    // voxels were zero-filled by k_lss_index_slots.
+    const int grp = lane / LPV, gbase = lane - sub;
+    const int64_t wid = (int64_t)((int)blockIdx.x - C_BLOCKS - B_BLOCKS) * 4 + wave;
+    const int64_t nw = (int64_t)((int)gridDim.x - C_BLOCKS - B_BLOCKS) * 4;
     for (int64_t v0 = wid * 64; v0 < ((dbg & 4) ? 0 : n_vox); v0 += nw * 64) {
       const int c = v0 + lane < n_vox ? count[v0 + lane] : 0;
       const bool light = c > 0 && c <= LS;
@@ -481,11 +473,10 @@ PW_API int pw_lss_lift_pool(int B, int N, int D, int H, int W, const float* frus
                      w.hstart, w.list_b, w.list_c);
   hipLaunchKernelGGL(k_lss_ovf_scatter, dim3((unsigned)pw_cdiv(total, 256)), dim3(256), 0, st, total, w.kr, w.hstart, w.tmp);
   const FeatIdx fi{(int)DHW, H * W, 1.0f / (float)DHW, 1.0f / (float)(H * W)};
-  hipLaunchKernelGGL(k_lss_pool_heavy, dim3(C_BLOCKS + B_BLOCKS), dim3(256), SORT_LDS_IDS * 4, st, depth, (const float4*)feat, w.slots,
-                     cur, w.list_b, w.list_c, w.tmp, w.sorted_pf, w.sorted_d, fi, (float4*)out, out_h2, out_rng, dbg);
   const int64_t want = pw_cdiv(pw_cdiv(n_vox, 64), 4);
-  hipLaunchKernelGGL(k_lss_pool_slots, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, st, depth, (const float4*)feat,
-                     w.count, w.slots, n_vox, fi, (float4*)out, out_h2, out_rng, dbg);
+  hipLaunchKernelGGL(k_lss_pool_slots, dim3((unsigned)(want < 4096 ? want : 4096) + C_BLOCKS + B_BLOCKS), dim3(256), SORT_LDS_IDS * 4,
+                     st, depth, (const float4*)feat, w.count, w.slots, n_vox, cur, w.list_b, w.list_c, w.tmp, w.sorted_pf, w.sorted_d,
+                     fi, (float4*)out, out_h2, out_rng, dbg);
   pw_note_kernel("k_lss_pool_slots");
   PW_CHECK_LAUNCH();
   return PW_OK;
