@@ -72,7 +72,7 @@ class KernelProbe:
     the stream passed through the C ABI) and asks the library which kernel it picked (pw_last_kernel)."""
 
     OPS = ('conv3d_ndhwc', 'conv3d_wino', 'conv3d_h2', 'occ_head_fused', 'occ_head_h2', 'forecast_steps', 'forecast_steps_h2', 'fpn3d_fuse', 'bev_pool_dense',
-           'segment_sort', 'lss_voxel_index', 'f32_to_h2', 'h2_to_f32')
+           'segment_sort', 'lss_voxel_index', 'lss_lift_pool', 'f32_to_h2', 'h2_to_f32')
 
     def __init__(self):
         self.records = []
@@ -171,6 +171,16 @@ class KernelProbe:
             C = feat.shape[-1]
             w.update(label='bev_pool_dense', flops=2.0 * C * kept, exec_flops=0.0, mfma=None,
                      bytes=4.0 * (vs.n_keys * C + depth.numel() + feat.numel() + (vs.n_keys + 1) + 2 * kept))
+        elif name == 'lss_lift_pool':
+            # one frame's whole lift (camera matrices, voxel ids, point lists, pooling: 5 launches, timed together).  Algorithmic
+            # bytes = what the stage must touch: the pooled grid written once, depth and context read once, the frustum table read
+            # once per camera; the id slots and lists are the implementation's own traffic and are not counted
+            fr, depth, feat = args[0], args[9], args[10]
+            size = args[8]
+            n_vox = int(args[1].shape[0]) * int(size[0]) * int(size[1]) * int(size[2])
+            C = feat.shape[-1]
+            w.update(label='lss_lift_pool (whole frame, 5 launches)', flops=2.0 * C * depth.numel(), exec_flops=0.0, mfma=None,
+                     bytes=4.0 * (n_vox * C + depth.numel() + feat.numel() + 3 * depth.numel()))
         elif name == 'segment_sort':
             keys, n_keys = args[0], args[1]
             w.update(label='segment_sort', mfma=None, bytes=4.0 * (3 * keys.numel() + 2 * n_keys))
@@ -238,7 +248,7 @@ def roofline_object(agg, n_probe_steps):
         return ent
     order = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])
     dom = entry(*order[0])
-    dom['also'] = [entry(k, a) for k, a in order[1:] if k.startswith('k_pool_dense')]
+    dom['also'] = [entry(k, a) for k, a in order[1:] if k.startswith(('k_pool_dense', 'k_lss_pool'))]
     dom['all_kernels'] = {k: dict(us_per_step=round(a['ms'] * 1e3 / n_probe_steps, 1), launches=a['launches'] // n_probe_steps,
                                   tflops=round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2),
                                   alg_GBps=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1)) for k, a in order}
