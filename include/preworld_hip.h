@@ -531,6 +531,13 @@ int pw_lovasz_softmax(const float* probas, const uint8_t* target, const uint8_t*
 size_t pw_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int ksize, int stride);
 int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int B, int D, int H,
                     int W, int Cin, int Cout, int ksize, int stride, void* stream);
+
+/* the same gradient for 3x3x3 stride-1 layers with Cin, Cout multiples of 32 on the fp16 matrix cores with split-fp16 operands
+ * (22-bit products, fp32 accumulation; operands transposed through LDS, three input rows resident): 3-4x pw_conv3d_wgrad.
+ * amax2: device float[2] = {max |x|, max |dy|} (per-tensor power-of-two pre-scales; NULL = none).  Deterministic. */
+size_t pw_conv3d_wgrad_h2_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const float* amax2, void* workspace, size_t workspace_bytes,
+                       int B, int D, int H, int W, int Cin, int Cout, void* stream);
 /* dX of Conv3d(k=3, stride=2, padding=1): dy (B,Do,Ho,Wo,Cout) with Do = (D-1)/2+1 .., wt float[3][3][3][Cout][Cin] (torch's
  * weight.permute(2,3,4,0,1)), dx (B,D,H,W,Cin), Cin % 4 == 0.  (Stride-1 and 1x1x1 data gradients are forward convolutions
  * with flipped / transposed weights: pw_conv3d_ndhwc.) */

@@ -1,0 +1,328 @@
+// Weight gradient of the 3x3x3 stride-1 pad-1 convolutions on the fp16 matrix cores with split-fp16 operands (pw_h2.h):
+//   dW[co][ci][kd][kh][kw] = sum over output voxels v of dY[v][co] * X[v + (kd, kh, kw) - 1][ci]
+// (what torch autograd computes for mmdet3d/models/backbones/resnet.py:88-123's Conv3d in training).  pw_train.hip's
+// k_conv3d_wgrad does this with v_mfma_f32_32x32x2_f32 and both operands straight from global memory (65-83 TFLOP/s); here
+// K = 16 output voxels of a row per v_mfma_f32_32x32x16_f16 and three MFMAs per product block (hi*hi + lo*hi + hi*lo, 22-bit
+// significands, fp32 accumulation), 5.3x the matrix rate of the fp32 instruction.
+//
+// The MFMA wants 8 CONSECUTIVE K per lane, i.e. 8 consecutive voxels of ONE channel, and the tensors are channels-last: operands
+// go through LDS transposed.  A block walks a strip of 64 output columns down the rows (b, od, oh0 .. oh1) for one kd:
+//   * per row it stages dY[row][strip][co tile(s)] and the ONE new input row X[id][oh + 1][strip -1 .. +64][ci tile(s)] -- the rows
+//     oh - 1 and oh are still in LDS from the previous steps (ring of three), so every X row is read from global memory once per
+//     kd instead of once per (kd, kh) -- split into hi / lo fp16 planes, stored channel-major: [plane][channel][position], two
+//     voxels per 32-bit write, row stride 176 B = 4 x 11 dwords so that the 16 lanes of a ds_read_b128 phase cover all 64 banks;
+//   * a wave owns one (32 co x 32 ci) pair of the block's tile and keeps its 9 accumulator tiles (kh, kw) of this kd in registers
+//     (144 AGPRs).  Per K-step: 2 ds_read_b128 of dY (hi, lo), per kh 2 ds_read_b128 of X (hi, lo) + 4 ds_read_b32 (the halves
+//     before and after the lane's block); the kw = 0 / 2 operands are the block shifted by one half, built with 4 v_alignbit each;
+//     27 MFMAs per (K-step, wave).
+// Tiles narrower than 64 x 64 (Cin or Cout == 32) give the spare waves every second / fourth K-step of the same pair; they write
+// their own partial tiles.  Values are scaled by a per-tensor power of two taken from the tensors' largest magnitudes (amax2, device
+// memory, no host sync) so that they sit in fp16's range whatever the scale of the gradients; the product of the two is taken out
+// again when the partial tile is written.  Partial tiles per (chunk, tap, co block, ci block) are summed in a fixed order by
+// pw_train.hip's k_wgrad_reduce: deterministic, no atomics.
+#include "pw_h2.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int WG_NS = 4;                       // K-steps of 16 output columns per strip
+constexpr int WG_COLS = 16 * WG_NS;            // 64
+constexpr int WG_STRIDE = 176;                 // bytes per channel row of a plane: (8 + 64 + 8) halves = 160 B, padded to 4 x 11 dwords
+constexpr int WG_PLANE = 32 * WG_STRIDE;       // one plane (hi or lo) of a 32-channel tile
+constexpr int WG_TILE = 2 * WG_PLANE;          // 11 264 B
+
+struct WgH2Args {
+  const float* x;
+  const float* dy;
+  float* partial;            // [chunk * ksub_n + ksub][27][co_blocks][ci_blocks][32 * 32]
+  const float* amax2;        // {max |x|, max |dy|} or null
+  int B, D, H, W, Cin, Cout;
+  int co_t, ci_t;            // 32-channel tiles per block along co / ci (1 or 2)
+  int cog, cig;              // tile groups along co / ci
+  int n_strips, oh_splits, rows_per_split;
+  int co_blocks, ci_blocks;
+};
+
+// exponent e such that amax * 2^-e lies in [2^12, 2^13) (0 for zero / non-finite / absent)
+__device__ __forceinline__ int wg_exp(const float* amax2, int i) {
+  if (!amax2) return 0;
+  const unsigned bits = __float_as_uint(amax2[i]) & 0x7fffffffu;
+  return rng_ideal_exp(bits);
+}
+
+// two voxels' values of one channel -> packed hi pair, packed lo pair (low half = first voxel)
+__device__ __forceinline__ void wg_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const h2_f2 x = {a, b};
+  const h2_h2 h = __builtin_convertvector(x, h2_h2);
+  h2_f2 d = h2_residual2(h, x);
+  d[0] = __builtin_amdgcn_fmed3f(d[0], -H2_MAX, H2_MAX);
+  d[1] = __builtin_amdgcn_fmed3f(d[1], -H2_MAX, H2_MAX);
+  const h2_h2 l = __builtin_convertvector(d, h2_h2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+__device__ __forceinline__ h8 wg_as_h8(const wg_u4& v) { return __builtin_bit_cast(h8, v); }
+}  // namespace
+
+template <int CO_T, int CI_T>
+__global__ void __launch_bounds__(256) k_conv3d_wgrad_h2(WgH2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int P = CO_T * CI_T;               // (co tile, ci tile) pairs of the block
+  constexpr int KSUB = 4 / P;                  // waves per pair, each taking every KSUB-th K-step
+  constexpr int X_TASKS = 34 * 8 * CI_T, Y_TASKS = 32 * 8 * CO_T;
+  constexpr int X_ROUNDS = (X_TASKS + 255) / 256, Y_ROUNDS = (Y_TASKS + 255) / 256;
+  unsigned char* xring = lds;                                  // [3][CI_T] tiles
+  unsigned char* ybuf = lds + 3 * CI_T * WG_TILE;              // [CO_T] tiles
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = wave % P, ksub = wave / P;
+  const int ct = pair / CI_T, it = pair % CI_T;
+  int bid = blockIdx.x;
+  const int ig = bid % a.cig; bid /= a.cig;
+  const int cg = bid % a.cog; bid /= a.cog;
+  const int kd = bid;
+  const int strip = blockIdx.y;
+  const int split = blockIdx.z % a.oh_splits, bd = blockIdx.z / a.oh_splits;
+  const int od = bd % a.D, b = bd / a.D;
+  const int id = od + kd - 1;
+  const int ow0 = strip * WG_COLS;
+  const int ns = min(WG_NS, (a.W - ow0 + 15) / 16);
+  const int oh0 = split * a.rows_per_split, oh1 = min(a.H, oh0 + a.rows_per_split);
+  const int ex = wg_exp(a.amax2, 0), ey = wg_exp(a.amax2, 1);
+  const float sx = rng_pow2(-ex), sy = rng_pow2(-ey);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if ((unsigned)id < (unsigned)a.D && oh0 < oh1) {
+    const float* xplane = a.x + (((size_t)b * a.D + id) * a.H) * (size_t)a.W * a.Cin + (size_t)(ig * CI_T) * 32;
+    const float* yplane = a.dy + (((size_t)b * a.D + od) * a.H) * (size_t)a.W * a.Cout + (size_t)(cg * CO_T) * 32;
+    float4 xr[X_ROUNDS][2], yr[Y_ROUNDS][2];
+    // global loads of one input row (ih) / one dY row (oh) into registers; rows / columns outside the volume load as zero
+    auto load_x = [&](int ih) {
+      const bool row_ok = (unsigned)ih < (unsigned)a.H;
+      const float* row = xplane + (size_t)(row_ok ? ih : 0) * a.W * a.Cin;
+#pragma unroll
+      for (int r = 0; r < X_ROUNDS; ++r) {
+        const int t = r * 256 + (int)threadIdx.x;
+        const int cq = t & 7, tile = (t >> 3) % CI_T, pp = t / (8 * CI_T);
+        const int w = ow0 - 2 + 2 * pp;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const bool ok = row_ok && t < X_TASKS && (unsigned)(w + e) < (unsigned)a.W;
+          xr[r][e] = ok ? *reinterpret_cast<const float4*>(row + (size_t)(w + e) * a.Cin + tile * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    };
+    auto load_y = [&](int oh) {
+      const float* row = yplane + (size_t)oh * a.W * a.Cout;
+#pragma unroll
+      for (int r = 0; r < Y_ROUNDS; ++r) {
+        const int t = r * 256 + (int)threadIdx.x;
+        const int cq = t & 7, tile = (t >> 3) % CO_T, pp = t / (8 * CO_T);
+        const int w = ow0 + 2 * pp;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const bool ok = t < Y_TASKS && (w + e) < a.W;
+          yr[r][e] = ok ? *reinterpret_cast<const float4*>(row + (size_t)(w + e) * a.Cout + tile * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    };
+    // registers -> LDS, split and transposed: channel c of the tile at row c of both planes, position pair pp at half index
+    // 6 + 2 pp (X: column ow0 - 2 + 2 pp) resp. 8 + 2 pp (dY: column ow0 + 2 pp)
+    auto store_task = [&](unsigned char* base, const float4 (&reg)[2], int t, int nt, int idx0, float s) {
+      const int cq = t & 7, tile = (t >> 3) % nt, pp = t / (8 * nt);
+      const float v0[4] = {reg[0].x * s, reg[0].y * s, reg[0].z * s, reg[0].w * s};
+      const float v1[4] = {reg[1].x * s, reg[1].y * s, reg[1].z * s, reg[1].w * s};
+      unsigned char* p = base + tile * WG_TILE + (cq * 4) * WG_STRIDE + (idx0 + 2 * pp) * 2;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned hi, lo;
+        wg_split_pair(v0[c], v1[c], hi, lo);
+        *reinterpret_cast<unsigned*>(p + c * WG_STRIDE) = hi;
+        *reinterpret_cast<unsigned*>(p + c * WG_STRIDE + WG_PLANE) = lo;
+      }
+    };
+    auto store_x = [&](int ih) {
+      unsigned char* base = xring + ((ih + 3) % 3) * CI_T * WG_TILE;
+#pragma unroll
+      for (int r = 0; r < X_ROUNDS; ++r) {
+        const int t = r * 256 + (int)threadIdx.x;
+        if (t < X_TASKS) store_task(base, xr[r], t, CI_T, 6, sx);
+      }
+    };
+    auto store_y = [&]() {
+#pragma unroll
+      for (int r = 0; r < Y_ROUNDS; ++r) {
+        const int t = r * 256 + (int)threadIdx.x;
+        if (t < Y_TASKS) store_task(ybuf, yr[r], t, CO_T, 8, sy);
+      }
+    };
+    // prologue: input rows oh0 - 1 and oh0 into ring slots, row oh0 + 1 and dY row oh0 in flight
+    load_x(oh0 - 1);
+    store_x(oh0 - 1);
+    load_x(oh0);
+    store_x(oh0);
+    load_x(oh0 + 1);
+    load_y(oh0);
+    const int m = lane & 31, h = lane >> 5;
+    for (int oh = oh0; oh < oh1; ++oh) {
+      __syncthreads();                                   // every wave is done with row oh - 2's slot and the previous dY row
+      store_x(oh + 1);
+      store_y();
+      __syncthreads();
+      if (oh + 1 < oh1) {                                // next step's rows travel while this step's MFMAs run
+        load_x(oh + 2);
+        load_y(oh + 1);
+      }
+      const unsigned char* yt = ybuf + ct * WG_TILE + m * WG_STRIDE;
+      for (int s = ksub; s < ns; s += KSUB) {
+        const int off = (8 + 16 * s + 8 * h) * 2;        // byte offset of the lane's 8-column block in a channel row
+        const wg_u4 ah = *reinterpret_cast<const wg_u4*>(yt + off);
+        const wg_u4 al = *reinterpret_cast<const wg_u4*>(yt + WG_PLANE + off);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int ih = oh + kh - 1;
+          if ((unsigned)ih >= (unsigned)a.H) continue;   // wave-uniform: the slot holds zeros anyway, skip the work
+          const unsigned char* xt = xring + (((ih + 3) % 3) * CI_T + it) * WG_TILE + m * WG_STRIDE + off;
+          wg_u4 bc[2];
+          unsigned bp[2], bn[2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            bc[pl] = *reinterpret_cast<const wg_u4*>(xt + pl * WG_PLANE);
+            bp[pl] = *reinterpret_cast<const unsigned*>(xt + pl * WG_PLANE - 4);
+            bn[pl] = *reinterpret_cast<const unsigned*>(xt + pl * WG_PLANE + 16);
+          }
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            wg_u4 bh, bl;
+            if (kw == 1) {
+              bh = bc[0]; bl = bc[1];
+            } else {
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl) {
+                const wg_u4 c = bc[pl];
+                wg_u4 r;
+                if (kw == 0) {                           // columns shifted by -1: halves [-1 .. 6]
+                  r = wg_u4{__builtin_amdgcn_alignbit(c.x, bp[pl], 16), __builtin_amdgcn_alignbit(c.y, c.x, 16),
+                            __builtin_amdgcn_alignbit(c.z, c.y, 16), __builtin_amdgcn_alignbit(c.w, c.z, 16)};
+                } else {                                 // +1: halves [1 .. 8]
+                  r = wg_u4{__builtin_amdgcn_alignbit(c.y, c.x, 16), __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                            __builtin_amdgcn_alignbit(c.w, c.z, 16), __builtin_amdgcn_alignbit(bn[pl], c.w, 16)};
+                }
+                if (pl == 0) bh = r; else bl = r;
+              }
+            }
+            f32x16& d = acc[kh * 3 + kw];
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_as_h8(ah), wg_as_h8(bh), d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_as_h8(al), wg_as_h8(bh), d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_as_h8(ah), wg_as_h8(bl), d, 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // partial tiles of this (chunk, K-subset): D row (co) = (r & 3) + 8 (r >> 2) + 4 h, column (ci) = lane & 31
+  const float unscale = rng_pow2(ex + ey);
+  const int chunk = ((int)blockIdx.z * a.n_strips + strip) * KSUB + ksub;
+  const int cob = cg * CO_T + ct, cib = ig * CI_T + it;
+  const int i = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int tap = kd * 9 + t;
+    float* dst = a.partial + ((((size_t)chunk * 27 + tap) * a.co_blocks + cob) * a.ci_blocks + cib) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + i] = acc[t][r] * unscale;
+  }
+}
+
+// sum of the per-chunk partial tiles in a fixed order -> torch's [Cout][Cin][kd][kh][kw] (same as pw_train.hip's k_wgrad_reduce;
+// device code is per translation unit)
+__global__ void __launch_bounds__(256) k_wgrad_h2_reduce(const float* __restrict__ partial, float* __restrict__ dw, int n_chunks,
+                                                         int taps, int co_blocks, int ci_blocks, int Cout, int Cin) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // over [tap][cob][cib][32][32]
+  const size_t per_chunk = (size_t)taps * co_blocks * ci_blocks * 1024;
+  if (idx >= per_chunk) return;
+  float s = 0.f;
+  for (int c = 0; c < n_chunks; ++c) s += partial[(size_t)c * per_chunk + idx];
+  const int j = (int)(idx & 31), i = (int)((idx >> 5) & 31);
+  size_t t = idx >> 10;
+  const int cib = (int)(t % ci_blocks); t /= ci_blocks;
+  const int cob = (int)(t % co_blocks); t /= co_blocks;
+  const int tap = (int)t;
+  dw[((size_t)(cob * 32 + i) * Cin + cib * 32 + j) * taps + tap] = s;
+}
+
+namespace {
+struct WgPlan {
+  int co_t, ci_t, cog, cig, n_strips, oh_splits, rows_per_split, ksub, n_chunks;
+  size_t lds;
+};
+WgPlan wg_plan(int B, int D, int H, int W, int Cin, int Cout) {
+  WgPlan p;
+  p.co_t = Cout % 64 == 0 ? 2 : 1;
+  p.ci_t = Cin % 64 == 0 ? 2 : 1;
+  p.cog = Cout / (32 * p.co_t);
+  p.cig = Cin / (32 * p.ci_t);
+  p.n_strips = (W + WG_COLS - 1) / WG_COLS;
+  p.ksub = 4 / (p.co_t * p.ci_t);
+  // enough blocks for ~4 per CU: 3 kd x tile groups x strips x (b, od) x row splits
+  const int base = 3 * p.cog * p.cig * p.n_strips * B * D;
+  int splits = (1024 + base - 1) / base;
+  if (splits > H / 8) splits = H / 8;
+  if (splits < 1) splits = 1;
+  p.rows_per_split = (H + splits - 1) / splits;
+  p.oh_splits = (H + p.rows_per_split - 1) / p.rows_per_split;
+  p.n_chunks = B * D * p.oh_splits * p.n_strips * p.ksub;
+  p.lds = (size_t)(3 * p.ci_t + p.co_t) * WG_TILE;
+  return p;
+}
+}  // namespace
+
+PW_API size_t pw_conv3d_wgrad_h2_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return 0;
+  const WgPlan p = wg_plan(B, D, H, W, Cin, Cout);
+  return (size_t)p.n_chunks * 27 * (Cout / 32) * (Cin / 32) * 1024 * 4;
+}
+
+PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const float* amax2, void* workspace,
+                              size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
+  PW_CHECK_ARG(x && dy && dw && workspace, "pw_conv3d_wgrad_h2: null pointer");
+  PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0,
+               "pw_conv3d_wgrad_h2: 3x3x3 stride 1, Cin and Cout multiples of 32 (pw_conv3d_wgrad takes everything else)");
+  PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy) & 15) == 0, "pw_conv3d_wgrad_h2: x / dy must be 16-byte aligned");
+  PW_CHECK_ARG(workspace_bytes >= pw_conv3d_wgrad_h2_workspace_bytes(B, D, H, W, Cin, Cout), "pw_conv3d_wgrad_h2: workspace too small");
+  const WgPlan p = wg_plan(B, D, H, W, Cin, Cout);
+  WgH2Args a;
+  a.x = x; a.dy = dy; a.partial = (float*)workspace; a.amax2 = amax2;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.co_t = p.co_t; a.ci_t = p.ci_t; a.cog = p.cog; a.cig = p.cig;
+  a.n_strips = p.n_strips; a.oh_splits = p.oh_splits; a.rows_per_split = p.rows_per_split;
+  a.co_blocks = Cout / 32; a.ci_blocks = Cin / 32;
+  hipStream_t st = pw_stream(stream);
+  const dim3 grid((unsigned)(3 * p.cog * p.cig), (unsigned)p.n_strips, (unsigned)(B * D * p.oh_splits));
+#define PW_WG_LAUNCH(CO, CI)                                                                                                    \
+  do {                                                                                                                          \
+    static bool attr_set = false;                                                                                               \
+    if (!attr_set) {                                                                                                            \
+      PW_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3d_wgrad_h2<CO, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      attr_set = true;                                                                                                          \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((k_conv3d_wgrad_h2<CO, CI>), grid, dim3(256), p.lds, st, a);                                             \
+  } while (0)
+  if (p.co_t == 2 && p.ci_t == 2) PW_WG_LAUNCH(2, 2);
+  else if (p.co_t == 2) PW_WG_LAUNCH(2, 1);
+  else if (p.ci_t == 2) PW_WG_LAUNCH(1, 2);
+  else PW_WG_LAUNCH(1, 1);
+#undef PW_WG_LAUNCH
+  const size_t per_chunk = (size_t)27 * a.co_blocks * a.ci_blocks * 1024;
+  hipLaunchKernelGGL(k_wgrad_h2_reduce, dim3((unsigned)pw_cdiv((int64_t)per_chunk, 256)), dim3(256), 0, st, a.partial, dw, p.n_chunks, 27,
+                     a.co_blocks, a.ci_blocks, Cout, Cin);
+  pw_note_kernel("k_conv3d_wgrad_h2<%d, %d>", p.co_t, p.ci_t);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

@@ -24,6 +24,8 @@ import torch
 from . import _lib, ops
 
 _f32 = torch.float32
+# PW_WGRAD=f32 keeps the exact-fp32 MFMA weight-gradient kernel for the 3x3x3 stride-1 layers too (default: split-fp16, pw_train_h2.hip)
+_WGRAD = __import__('os').environ.get('PW_WGRAD', 'h2')
 
 
 def _cl(t, name):
@@ -76,6 +78,16 @@ def conv3d_wgrad(x, dy, w_shape, stride=1):
     """d loss / d w of conv3d_raw, torch layout (Cout,Cin,k,k,k)."""
     Cout, Cin, k = w_shape[0], w_shape[1], w_shape[2]
     B, D, H, W, _ = x.shape
+    if k == 3 and stride == 1 and Cin % 32 == 0 and Cout % 32 == 0 and _WGRAD != 'f32':
+        # split-fp16 operands on the fp16 matrix cores (pw_conv3d_wgrad_h2): 22-bit products, fp32 accumulation; the two maxima
+        # (device side, no sync) give the per-tensor power-of-two pre-scales
+        amax2 = torch.stack([x.detach().abs().amax(), dy.detach().abs().amax()]).float()
+        nbytes = _lib.call_size('pw_conv3d_wgrad_h2_workspace_bytes', B, D, H, W, Cin, Cout)
+        ws = ops._workspace(nbytes, x.device)
+        dw = torch.empty(tuple(w_shape), device=x.device, dtype=_f32)
+        _lib.call('pw_conv3d_wgrad_h2', ops._p(_cl(x, 'x')), ops._p(_cl(dy, 'dy')), ops._p(dw), ops._p(amax2), ops._p(ws), nbytes,
+                  B, D, H, W, Cin, Cout, ops._stream())
+        return dw
     nbytes = _lib.call_size('pw_conv3d_wgrad_workspace_bytes', B, D, H, W, Cin, Cout, k, stride)
     ws = ops._workspace(nbytes, x.device)
     dw = torch.empty(tuple(w_shape), device=x.device, dtype=_f32)
