@@ -31,17 +31,19 @@ constexpr int WG_COLS = 16 * WG_NS;            // 64
 constexpr int WG_STRIDE = 176;                 // bytes per channel row of a plane: (8 + 64 + 8) halves = 160 B, padded to 4 x 11 dwords
 constexpr int WG_PLANE = 32 * WG_STRIDE;       // one plane (hi or lo) of a 32-channel tile
 constexpr int WG_TILE = 2 * WG_PLANE;          // 11 264 B
+constexpr int WG_THREADS = 768;                // 12 waves: 3 kh x 4 (pair, K-subset) -- three per SIMD, so one wave's staging VALU work runs under another's MFMAs
 
 struct WgH2Args {
   const float* x;
   const float* dy;
-  float* partial;            // [chunk * ksub_n + ksub][27][co_blocks][ci_blocks][32 * 32]
+  float* partial;            // [chunk][27][co_blocks][ci_blocks][32 * 32]
   const float* amax2;        // {max |x|, max |dy|} or null
   int B, D, H, W, Cin, Cout;
   int co_t, ci_t;            // 32-channel tiles per block along co / ci (1 or 2)
   int cog, cig;              // tile groups along co / ci
   int n_strips, oh_splits, rows_per_split;
   int co_blocks, ci_blocks;
+  int dbg;                   // timing experiments (PW_WG_DEBUG): 1 = no MFMA phase, 2 = no LDS stores, 4 = no global loads
 };
 
 // exponent e such that amax * 2^-e lies in [2^12, 2^13) (0 for zero / non-finite / absent)
@@ -67,16 +69,16 @@ __device__ __forceinline__ h8 wg_as_h8(const wg_u4& v) { return __builtin_bit_ca
 }  // namespace
 
 template <int CO_T, int CI_T>
-__global__ void __launch_bounds__(256) k_conv3d_wgrad_h2(WgH2Args a) {
+__global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int P = CO_T * CI_T;               // (co tile, ci tile) pairs of the block
   constexpr int KSUB = 4 / P;                  // waves per pair, each taking every KSUB-th K-step
   constexpr int X_TASKS = 34 * 8 * CI_T, Y_TASKS = 32 * 8 * CO_T;
-  constexpr int X_ROUNDS = (X_TASKS + 255) / 256, Y_ROUNDS = (Y_TASKS + 255) / 256;
-  unsigned char* xring = lds;                                  // [3][CI_T] tiles
-  unsigned char* ybuf = lds + 3 * CI_T * WG_TILE;              // [CO_T] tiles
+  constexpr int X_ROUNDS = (X_TASKS + WG_THREADS - 1) / WG_THREADS, Y_ROUNDS = (Y_TASKS + WG_THREADS - 1) / WG_THREADS;
+  unsigned char* xring = lds;                                  // [4][CI_T] tiles: input rows oh - 1 .. oh + 2
+  unsigned char* ybuf = lds + 4 * CI_T * WG_TILE;              // [2][CO_T] tiles: dY rows oh, oh + 1
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = wave % P, ksub = wave / P;
+  const int kh = wave % 3, pair = (wave / 3) % P, ksub = wave / (3 * P);
   const int ct = pair / CI_T, it = pair % CI_T;
   int bid = blockIdx.x;
   const int ig = bid % a.cig; bid /= a.cig;
@@ -92,23 +94,23 @@ __global__ void __launch_bounds__(256) k_conv3d_wgrad_h2(WgH2Args a) {
   const int ex = wg_exp(a.amax2, 0), ey = wg_exp(a.amax2, 1);
   const float sx = rng_pow2(-ex), sy = rng_pow2(-ey);
 
-  f32x16 acc[9];
+  f32x16 acc[3];                                 // kw = 0, 1, 2 of this wave's kh
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   if ((unsigned)id < (unsigned)a.D && oh0 < oh1) {
     const float* xplane = a.x + (((size_t)b * a.D + id) * a.H) * (size_t)a.W * a.Cin + (size_t)(ig * CI_T) * 32;
     const float* yplane = a.dy + (((size_t)b * a.D + od) * a.H) * (size_t)a.W * a.Cout + (size_t)(cg * CO_T) * 32;
-    float4 xr[X_ROUNDS][2], yr[Y_ROUNDS][2];
+    float4 xr0[X_ROUNDS][2], yr0[Y_ROUNDS][2], xr1[X_ROUNDS][2], yr1[Y_ROUNDS][2];     // two row sets in flight
     // global loads of one input row (ih) / one dY row (oh) into registers; rows / columns outside the volume load as zero
-    auto load_x = [&](int ih) {
+    auto load_x = [&](float4 (&xr)[X_ROUNDS][2], int ih) {
       const bool row_ok = (unsigned)ih < (unsigned)a.H;
       const float* row = xplane + (size_t)(row_ok ? ih : 0) * a.W * a.Cin;
 #pragma unroll
       for (int r = 0; r < X_ROUNDS; ++r) {
-        const int t = r * 256 + (int)threadIdx.x;
+        const int t = r * WG_THREADS + (int)threadIdx.x;
         const int cq = t & 7, tile = (t >> 3) % CI_T, pp = t / (8 * CI_T);
         const int w = ow0 - 2 + 2 * pp;
 #pragma unroll
@@ -118,11 +120,11 @@ __global__ void __launch_bounds__(256) k_conv3d_wgrad_h2(WgH2Args a) {
         }
       }
     };
-    auto load_y = [&](int oh) {
+    auto load_y = [&](float4 (&yr)[Y_ROUNDS][2], int oh) {
       const float* row = yplane + (size_t)oh * a.W * a.Cout;
 #pragma unroll
       for (int r = 0; r < Y_ROUNDS; ++r) {
-        const int t = r * 256 + (int)threadIdx.x;
+        const int t = r * WG_THREADS + (int)threadIdx.x;
         const int cq = t & 7, tile = (t >> 3) % CO_T, pp = t / (8 * CO_T);
         const int w = ow0 + 2 * pp;
 #pragma unroll
@@ -147,114 +149,146 @@ __global__ void __launch_bounds__(256) k_conv3d_wgrad_h2(WgH2Args a) {
         *reinterpret_cast<unsigned*>(p + c * WG_STRIDE + WG_PLANE) = lo;
       }
     };
-    auto store_x = [&](int ih) {
-      unsigned char* base = xring + ((ih + 3) % 3) * CI_T * WG_TILE;
+    auto store_x = [&](const float4 (&xr)[X_ROUNDS][2], int ih) {
+      unsigned char* base = xring + ((ih + 4) & 3) * CI_T * WG_TILE;
 #pragma unroll
       for (int r = 0; r < X_ROUNDS; ++r) {
-        const int t = r * 256 + (int)threadIdx.x;
+        const int t = r * WG_THREADS + (int)threadIdx.x;
         if (t < X_TASKS) store_task(base, xr[r], t, CI_T, 6, sx);
       }
     };
-    auto store_y = [&]() {
+    auto store_y = [&](const float4 (&yr)[Y_ROUNDS][2], int oh) {
+      unsigned char* ybase = ybuf + (oh & 1) * CO_T * WG_TILE;
 #pragma unroll
       for (int r = 0; r < Y_ROUNDS; ++r) {
-        const int t = r * 256 + (int)threadIdx.x;
-        if (t < Y_TASKS) store_task(ybuf, yr[r], t, CO_T, 8, sy);
+        const int t = r * WG_THREADS + (int)threadIdx.x;
+        if (t < Y_TASKS) store_task(ybase, yr[r], t, CO_T, 8, sy);
       }
     };
-    // prologue: input rows oh0 - 1 and oh0 into ring slots, row oh0 + 1 and dY row oh0 in flight
-    load_x(oh0 - 1);
-    store_x(oh0 - 1);
-    load_x(oh0);
-    store_x(oh0);
-    load_x(oh0 + 1);
-    load_y(oh0);
     const int m = lane & 31, h = lane >> 5;
-    for (int oh = oh0; oh < oh1; ++oh) {
-      __syncthreads();                                   // every wave is done with row oh - 2's slot and the previous dY row
-      store_x(oh + 1);
-      store_y();
-      __syncthreads();
-      if (oh + 1 < oh1) {                                // next step's rows travel while this step's MFMAs run
-        load_x(oh + 2);
-        load_y(oh + 1);
-      }
-      const unsigned char* yt = ybuf + ct * WG_TILE + m * WG_STRIDE;
+    // the MFMAs of output row oh: dY slot oh & 1, input rows oh - 1 .. oh + 1 in slots (row & 3)
+    auto compute = [&](int oh) {
+      const int ih = oh + kh - 1;
+      if ((unsigned)ih >= (unsigned)a.H) return;         // wave-uniform: this wave's input row lies outside the volume
+      const unsigned char* yt = ybuf + ((oh & 1) * CO_T + ct) * WG_TILE + m * WG_STRIDE;
       for (int s = ksub; s < ns; s += KSUB) {
         const int off = (8 + 16 * s + 8 * h) * 2;        // byte offset of the lane's 8-column block in a channel row
         const wg_u4 ah = *reinterpret_cast<const wg_u4*>(yt + off);
         const wg_u4 al = *reinterpret_cast<const wg_u4*>(yt + WG_PLANE + off);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int ih = oh + kh - 1;
-          if ((unsigned)ih >= (unsigned)a.H) continue;   // wave-uniform: the slot holds zeros anyway, skip the work
-          const unsigned char* xt = xring + (((ih + 3) % 3) * CI_T + it) * WG_TILE + m * WG_STRIDE + off;
-          wg_u4 bc[2];
-          unsigned bp[2], bn[2];
+        {
+          const unsigned char* xt = xring + (((ih + 4) & 3) * CI_T + it) * WG_TILE + m * WG_STRIDE + off;
+          wg_u4 bv[3][2];                                // [kw][plane]
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
-            bc[pl] = *reinterpret_cast<const wg_u4*>(xt + pl * WG_PLANE);
-            bp[pl] = *reinterpret_cast<const unsigned*>(xt + pl * WG_PLANE - 4);
-            bn[pl] = *reinterpret_cast<const unsigned*>(xt + pl * WG_PLANE + 16);
+            const wg_u4 c = *reinterpret_cast<const wg_u4*>(xt + pl * WG_PLANE);
+            const unsigned bp = *reinterpret_cast<const unsigned*>(xt + pl * WG_PLANE - 4);
+            const unsigned bn = *reinterpret_cast<const unsigned*>(xt + pl * WG_PLANE + 16);
+            bv[1][pl] = c;
+            // columns shifted by -1: halves [-1 .. 6]; by +1: halves [1 .. 8]
+            bv[0][pl] = wg_u4{__builtin_amdgcn_alignbit(c.x, bp, 16), __builtin_amdgcn_alignbit(c.y, c.x, 16),
+                              __builtin_amdgcn_alignbit(c.z, c.y, 16), __builtin_amdgcn_alignbit(c.w, c.z, 16)};
+            bv[2][pl] = wg_u4{__builtin_amdgcn_alignbit(c.y, c.x, 16), __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                              __builtin_amdgcn_alignbit(c.w, c.z, 16), __builtin_amdgcn_alignbit(bn, c.w, 16)};
           }
+          // product-major: the three MFMAs into one accumulator are two other accumulators apart
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            wg_u4 bh, bl;
-            if (kw == 1) {
-              bh = bc[0]; bl = bc[1];
-            } else {
+          for (int prod = 0; prod < 3; ++prod)
 #pragma unroll
-              for (int pl = 0; pl < 2; ++pl) {
-                const wg_u4 c = bc[pl];
-                wg_u4 r;
-                if (kw == 0) {                           // columns shifted by -1: halves [-1 .. 6]
-                  r = wg_u4{__builtin_amdgcn_alignbit(c.x, bp[pl], 16), __builtin_amdgcn_alignbit(c.y, c.x, 16),
-                            __builtin_amdgcn_alignbit(c.z, c.y, 16), __builtin_amdgcn_alignbit(c.w, c.z, 16)};
-                } else {                                 // +1: halves [1 .. 8]
-                  r = wg_u4{__builtin_amdgcn_alignbit(c.y, c.x, 16), __builtin_amdgcn_alignbit(c.z, c.y, 16),
-                            __builtin_amdgcn_alignbit(c.w, c.z, 16), __builtin_amdgcn_alignbit(bn[pl], c.w, 16)};
-                }
-                if (pl == 0) bh = r; else bl = r;
-              }
-            }
-            f32x16& d = acc[kh * 3 + kw];
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_as_h8(ah), wg_as_h8(bh), d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_as_h8(al), wg_as_h8(bh), d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_as_h8(ah), wg_as_h8(bl), d, 0, 0, 0);
-          }
+            for (int kw = 0; kw < 3; ++kw)
+              acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg_as_h8(prod == 1 ? al : ah), wg_as_h8(bv[kw][prod == 2 ? 1 : 0]), acc[kw], 0, 0, 0);
         }
       }
+    };
+    // prologue: input rows oh0 - 1 .. oh0 + 1 and dY row oh0 into their slots (exposed, once per block); the rows of step
+    // oh0 + 1 in flight in set 0
+    load_x(xr0, oh0 - 1); load_x(xr1, oh0); load_y(yr0, oh0);
+    store_x(xr0, oh0 - 1); store_x(xr1, oh0); store_y(yr0, oh0);
+    load_x(xr0, oh0 + 1); store_x(xr0, oh0 + 1);
+    if (oh0 + 1 < oh1) { load_x(xr0, oh0 + 2); load_y(yr0, oh0 + 1); }
+    __syncthreads();
+    // step oh: request the rows of step oh + 2 (other register set), run row oh's MFMAs, then split the rows of step oh + 1
+    // (requested one step ago) into the slots row oh does not read.  One barrier per step; loads are in flight for two steps.
+    auto step = [&](int oh, float4 (&xa)[X_ROUNDS][2], float4 (&ya)[Y_ROUNDS][2], float4 (&xb)[X_ROUNDS][2], float4 (&yb)[Y_ROUNDS][2]) {
+      if (oh + 2 < oh1 && !(a.dbg & 4)) { load_x(xb, oh + 3); load_y(yb, oh + 2); }
+      // the stores fill slots this step's MFMAs do not read, so their order is free: waves 4 .. 7 store first, the others compute
+      // first -- on every SIMD one wave's staging VALU work meets the other two's MFMAs
+      const bool store_first = (wave >> 2) & 1;
+      if (store_first && oh + 1 < oh1 && !(a.dbg & 2)) { store_x(xa, oh + 2); store_y(ya, oh + 1); }
+      if (!(a.dbg & 1)) compute(oh);
+      if (!store_first && oh + 1 < oh1 && !(a.dbg & 2)) { store_x(xa, oh + 2); store_y(ya, oh + 1); }
+      __syncthreads();
+    };
+    for (int oh = oh0; oh < oh1; oh += 2) {
+      step(oh, xr0, yr0, xr1, yr1);
+      if (oh + 1 < oh1) step(oh + 1, xr1, yr1, xr0, yr0);
     }
+  }
+  // narrow tiles: the KSUB waves of a (pair, kh) add their tiles through LDS in a fixed order (wave 0 + 1 (+ 2 + 3)), one kw at a time
+  if constexpr (KSUB > 1) {
+    float* red = reinterpret_cast<float*>(lds);          // [pair][kh][KSUB - 1][64 lanes x 16] floats
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      __syncthreads();
+      if (ksub > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((((pair * 3 + kh) * (KSUB - 1) + ksub - 1)) * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (ksub == 0) {
+#pragma unroll
+        for (int q = 0; q < KSUB - 1; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += red[((((pair * 3 + kh) * (KSUB - 1) + q)) * 16 + r) * 64 + lane];
+      }
+    }
+    if (ksub > 0) return;
   }
   // partial tiles of this (chunk, K-subset): D row (co) = (r & 3) + 8 (r >> 2) + 4 h, column (ci) = lane & 31
   const float unscale = rng_pow2(ex + ey);
-  const int chunk = ((int)blockIdx.z * a.n_strips + strip) * KSUB + ksub;
+  const int chunk = (int)blockIdx.z * a.n_strips + strip;
   const int cob = cg * CO_T + ct, cib = ig * CI_T + it;
   const int i = lane & 31, hh = lane >> 5;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int tap = kd * 9 + t;
+  for (int t = 0; t < 3; ++t) {
+    const int tap = kd * 9 + kh * 3 + t;
     float* dst = a.partial + ((((size_t)chunk * 27 + tap) * a.co_blocks + cob) * a.ci_blocks + cib) * 1024;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + i] = acc[t][r] * unscale;
   }
 }
 
-// sum of the per-chunk partial tiles in a fixed order -> torch's [Cout][Cin][kd][kh][kw] (same as pw_train.hip's k_wgrad_reduce;
-// device code is per translation unit)
+// sum of the per-chunk partial tiles -> torch's [Cout][Cin][kd][kh][kw].  A block owns 32 consecutive elements of a tile; its 8
+// groups of 32 threads each add every 8th chunk (four loads in flight), the 8 sums meet in LDS and are added in group order:
+// a fixed order, so the result is deterministic.
 __global__ void __launch_bounds__(256) k_wgrad_h2_reduce(const float* __restrict__ partial, float* __restrict__ dw, int n_chunks,
                                                          int taps, int co_blocks, int ci_blocks, int Cout, int Cin) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // over [tap][cob][cib][32][32]
+  __shared__ float part[8][32];
   const size_t per_chunk = (size_t)taps * co_blocks * ci_blocks * 1024;
-  if (idx >= per_chunk) return;
-  float s = 0.f;
-  for (int c = 0; c < n_chunks; ++c) s += partial[(size_t)c * per_chunk + idx];
-  const int j = (int)(idx & 31), i = (int)((idx >> 5) & 31);
-  size_t t = idx >> 10;
-  const int cib = (int)(t % ci_blocks); t /= ci_blocks;
-  const int cob = (int)(t % co_blocks); t /= co_blocks;
-  const int tap = (int)t;
-  dw[((size_t)(cob * 32 + i) * Cin + cib * 32 + j) * taps + tap] = s;
+  const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const size_t idx = (size_t)blockIdx.x * 32 + e;                         // over [tap][cob][cib][32][32]
+  const float* src = partial + idx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = q;
+  for (; c + 24 < n_chunks; c += 32) {
+    s0 += src[(size_t)c * per_chunk];
+    s1 += src[(size_t)(c + 8) * per_chunk];
+    s2 += src[(size_t)(c + 16) * per_chunk];
+    s3 += src[(size_t)(c + 24) * per_chunk];
+  }
+  for (; c < n_chunks; c += 8) s0 += src[(size_t)c * per_chunk];
+  part[q][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0) {
+    float s = part[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += part[k][e];
+    const int j = (int)(idx & 31), i = (int)((idx >> 5) & 31);
+    size_t t = idx >> 10;
+    const int cib = (int)(t % ci_blocks); t /= ci_blocks;
+    const int cob = (int)(t % co_blocks); t /= co_blocks;
+    const int tap = (int)t;
+    dw[((size_t)(cob * 32 + i) * Cin + cib * 32 + j) * taps + tap] = s;
+  }
 }
 
 namespace {
@@ -272,13 +306,13 @@ WgPlan wg_plan(int B, int D, int H, int W, int Cin, int Cout) {
   p.ksub = 4 / (p.co_t * p.ci_t);
   // enough blocks for ~4 per CU: 3 kd x tile groups x strips x (b, od) x row splits
   const int base = 3 * p.cog * p.cig * p.n_strips * B * D;
-  int splits = (1024 + base - 1) / base;
+  int splits = (640 + base - 1) / base;
   if (splits > H / 8) splits = H / 8;
   if (splits < 1) splits = 1;
   p.rows_per_split = (H + splits - 1) / splits;
   p.oh_splits = (H + p.rows_per_split - 1) / p.rows_per_split;
-  p.n_chunks = B * D * p.oh_splits * p.n_strips * p.ksub;
-  p.lds = (size_t)(3 * p.ci_t + p.co_t) * WG_TILE;
+  p.n_chunks = B * D * p.oh_splits * p.n_strips;
+  p.lds = (size_t)(4 * p.ci_t + 2 * p.co_t) * WG_TILE;
   return p;
 }
 }  // namespace
@@ -303,6 +337,8 @@ PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const 
   a.co_t = p.co_t; a.ci_t = p.ci_t; a.cog = p.cog; a.cig = p.cig;
   a.n_strips = p.n_strips; a.oh_splits = p.oh_splits; a.rows_per_split = p.rows_per_split;
   a.co_blocks = Cout / 32; a.ci_blocks = Cin / 32;
+  static const int dbg = [] { const char* e = getenv("PW_WG_DEBUG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   hipStream_t st = pw_stream(stream);
   const dim3 grid((unsigned)(3 * p.cog * p.cig), (unsigned)p.n_strips, (unsigned)(B * D * p.oh_splits));
 #define PW_WG_LAUNCH(CO, CI)                                                                                                    \
@@ -312,7 +348,7 @@ PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const 
       PW_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3d_wgrad_h2<CO, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
       attr_set = true;                                                                                                          \
     }                                                                                                                           \
-    hipLaunchKernelGGL((k_conv3d_wgrad_h2<CO, CI>), grid, dim3(256), p.lds, st, a);                                             \
+    hipLaunchKernelGGL((k_conv3d_wgrad_h2<CO, CI>), grid, dim3(WG_THREADS), p.lds, st, a);                                             \
   } while (0)
   if (p.co_t == 2 && p.ci_t == 2) PW_WG_LAUNCH(2, 2);
   else if (p.co_t == 2) PW_WG_LAUNCH(2, 1);
@@ -320,7 +356,7 @@ PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const 
   else PW_WG_LAUNCH(1, 1);
 #undef PW_WG_LAUNCH
   const size_t per_chunk = (size_t)27 * a.co_blocks * a.ci_blocks * 1024;
-  hipLaunchKernelGGL(k_wgrad_h2_reduce, dim3((unsigned)pw_cdiv((int64_t)per_chunk, 256)), dim3(256), 0, st, a.partial, dw, p.n_chunks, 27,
+  hipLaunchKernelGGL(k_wgrad_h2_reduce, dim3((unsigned)(per_chunk / 32)), dim3(256), 0, st, a.partial, dw, p.n_chunks, 27,
                      a.co_blocks, a.ci_blocks, Cout, Cin);
   pw_note_kernel("k_conv3d_wgrad_h2<%d, %d>", p.co_t, p.ci_t);
   PW_CHECK_LAUNCH();
