@@ -532,6 +532,11 @@ size_t pw_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int 
 int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int B, int D, int H,
                     int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
+/* per-voxel dense layer with few channels (OccHead's 1x1x1 convs in training, occupancy_head.py:124-161, and their data
+ * gradients): y[n][j] = sum_k x[n][k] w[j][k], x (n, K), w (N, K), y (n, N); built for (K, N) in {16x8, 8x18, 8x1, 8x16, 18x8, 1x8,
+ * 32x16, 16x32}, PW_EUNSUP otherwise. */
+int pw_linear_rows(const float* x, const float* w, float* y, int64_t n, int K, int N, void* stream);
+
 /* the same gradient for 3x3x3 stride-1 layers with Cin, Cout multiples of 32 on the fp16 matrix cores with split-fp16 operands
  * (22-bit products, fp32 accumulation; operands transposed through LDS, three input rows resident): 3-4x pw_conv3d_wgrad.
  * amax2: device float[2] = {max |x|, max |dy|} (per-tensor power-of-two pre-scales; NULL = none).  Deterministic. */

@@ -619,3 +619,65 @@ PW_API int pw_upsample_trilinear_adjoint(const float* dhi, float* dlo, int B, in
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Per-voxel dense layers with a handful of channels (OccHead's 1x1x1 convs 16 -> 8 -> 18 and its soft-weight branch 16 -> 8 -> 1,
+// heads/occupancy_head.py:124-161; their data gradients are the same op with the weight transposed).  y[n][j] = sum_k x[n][k] w[j][k].
+// As library GEMMs (M = 640 000, K = 16, N = 8) these took 1.0-1.5 ms each in the training step; they are a 60 MB stream:
+// one thread per row, the weights are wave-uniform (scalar loads), K x N FMAs per row.
+// ------------------------------------------------------------------------------------
+template <int K, int N>
+__global__ void __launch_bounds__(256) k_linear_rows(const float* __restrict__ x, const float* __restrict__ w,
+                                                     float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float xv[K];
+  if constexpr (K % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) {
+      const float4 v = reinterpret_cast<const float4*>(x + i * K)[q];
+      xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+    }
+  } else if constexpr (K % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < K / 2; ++q) {
+      const float2 v = reinterpret_cast<const float2*>(x + i * K)[q];
+      xv[2 * q] = v.x; xv[2 * q + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) xv[k] = x[i * K + k];
+  }
+  float out[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc = fmaf(xv[k], w[j * K + k], acc);
+    out[j] = acc;
+  }
+  if constexpr (N % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q)
+      reinterpret_cast<float4*>(y + i * N)[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+  } else if constexpr (N % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q) reinterpret_cast<float2*>(y + i * N)[q] = make_float2(out[2 * q], out[2 * q + 1]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) y[i * N + j] = out[j];
+  }
+}
+
+PW_API int pw_linear_rows(const float* x, const float* w, float* y, int64_t n, int K, int N, void* stream) {
+  PW_CHECK_ARG(x && w && y && n > 0, "pw_linear_rows: bad arguments");
+  PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "pw_linear_rows: x / y must be 16-byte aligned");
+  hipStream_t st = pw_stream(stream);
+  const dim3 grid((unsigned)pw_cdiv(n, 256));
+#define PW_LR(KK, NN) \
+  if (K == KK && N == NN) { hipLaunchKernelGGL((k_linear_rows<KK, NN>), grid, dim3(256), 0, st, x, w, y, n); PW_CHECK_LAUNCH(); return PW_OK; }
+  PW_LR(16, 8) PW_LR(8, 18) PW_LR(8, 1) PW_LR(8, 16) PW_LR(18, 8) PW_LR(1, 8) PW_LR(32, 16) PW_LR(16, 32)
+#undef PW_LR
+  pw_set_error("pw_linear_rows: (K, N) = (%d, %d) is not built (16x8, 8x18, 8x1, 8x16, 18x8, 1x8, 32x16, 16x32)", K, N);
+  return PW_EUNSUP;
+}

@@ -350,12 +350,50 @@ def _bn_cl(bn, x, relu):
     return out
 
 
+_LINEAR_ROWS = {(16, 8), (8, 18), (8, 1), (8, 16), (18, 8), (1, 8), (32, 16), (16, 32)}
+
+
+def _linear_rows(x, w):
+    """x (..., K) channels-last, w (N, K) -> (..., N) on pw_linear_rows"""
+    K, N = w.shape[1], w.shape[0]
+    y = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=_f32)
+    _lib.call('pw_linear_rows', ops._p(_cl(x, 'x')), ops._p(w.contiguous()), ops._p(y), x.numel() // K, K, N, ops._stream())
+    return y
+
+
+class LinearRowsCL(torch.autograd.Function):
+    """1x1x1 Conv3d without bias on a channels-last (B,Z,Y,X,K) tensor with a handful of channels (OccHead's occ_pred_conv /
+    voxel_soft_weights, occupancy_head.py:124-161): forward and data gradient on pw_linear_rows, weight gradient on
+    pw_conv3d_wgrad (ksize 1).  Replaces torch.matmul, whose GEMM kernels took 1.0-1.5 ms per call at M = 640 000, K = 16, N = 8."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _linear_rows(x, w.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _linear_rows(dy, w.detach().t().contiguous()) if ctx.needs_input_grad[0] else None
+        dw = conv3d_wgrad(x, dy, (w.shape[0], w.shape[1], 1, 1, 1), 1).reshape(w.shape) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def _conv1x1_cl(x, conv):
+    """x (B,Z,Y,X,K) @ the (N,K,1,1,1) weight of a bias-free 1x1x1 conv"""
+    w = conv.weight.reshape(conv.weight.shape[0], -1)
+    if x.dim() == 5 and (w.shape[1], w.shape[0]) in _LINEAR_ROWS and (w.shape[0], w.shape[1]) in _LINEAR_ROWS:
+        return LinearRowsCL.apply(x.contiguous(), w)
+    return torch.matmul(x, w.t())
+
+
 def occ_head_forward(head, x_cl, transposed=True):
     """OccHead.forward_coarse_voxel (occupancy_head.py:124-161) in training mode on channels-last x (B,Z,Y,X,32) -> logits
     (B,Z,Y,X,18).  transposed: x is the encoder's native (Z,Y,X) buffer while the reference convolves (X,Y,Z): the taps are
     permuted instead of the activation.  3x3x3 conv 32 -> 16 on the MFMA kernels (output columns zero-padded to 32 so that
     dgrad runs on them too), batch-statistics BatchNorm on the HIP kernels; the per-voxel 16 -> 8 -> 18 layers (and the soft-weight
-    branch) are plain library GEMMs (torch.matmul)."""
+    branch) on pw_linear_rows (LinearRowsCL)."""
     c0, bn0 = head.occ_convs[0][0], head.occ_convs[0][1]
     c1, bn1, c2 = head.occ_pred_conv[0], head.occ_pred_conv[1], head.occ_pred_conv[3]
     w0 = c0.weight.permute(0, 1, 4, 3, 2) if transposed else c0.weight
@@ -368,11 +406,11 @@ def occ_head_forward(head, x_cl, transposed=True):
         # receives exactly zero gradients -- but its BatchNorm sees the batch (running statistics move) and its parameters get
         # zero-valued .grad tensors (weight decay applies to them), so it is evaluated, not skipped
         s0, sbn, s3 = head.voxel_soft_weights[0], head.voxel_soft_weights[1], head.voxel_soft_weights[3]
-        sw = _bn_cl(sbn, torch.matmul(mid, s0.weight.reshape(s0.weight.shape[0], -1).t()), True)
-        sw = torch.softmax(torch.matmul(sw, s3.weight.reshape(s3.weight.shape[0], -1).t()), dim=-1)
+        sw = _bn_cl(sbn, _conv1x1_cl(mid, s0), True)
+        sw = torch.softmax(_conv1x1_cl(sw, s3), dim=-1)
         mid = mid * sw
-    hid = _bn_cl(bn1, torch.matmul(mid, c1.weight.reshape(c1.weight.shape[0], -1).t()), True)
-    return torch.matmul(hid, c2.weight.reshape(c2.weight.shape[0], -1).t())
+    hid = _bn_cl(bn1, _conv1x1_cl(mid, c1), True)
+    return _conv1x1_cl(hid, c2)
 
 
 def downscale_forward(mod, v_cl):
