@@ -455,9 +455,12 @@ class _PreWorldCommon(BEVStereo4DOCC):
         logits = torch.cat([train.occ_head_forward(head, voxel_feats_cl[b:b + 1], transposed=True)
                             for b in range(voxel_feats_cl.shape[0])], 0)           # (B,Z,Y,X,18)
         occ_preds = logits.permute(0, 4, 3, 2, 1)                                   # (B,18,X,Y,Z) view, as :240-247 stacks them
-        vf_xyz = voxel_feats_cl.permute(0, 3, 2, 1, 4)                              # (B,X,Y,Z,C) view (:238)
-        density_prob = self.density_mlp(vf_xyz)
-        density, semantic, color = density_prob[..., 0], self.semantic_mlp(vf_xyz), self.color_mlp(vf_xyz)
+        # the attribute MLPs act per voxel: applied to the (Z,Y,X) buffer as 1x1x1 convs on the MFMA kernels (train.mlp_cl), their
+        # outputs viewed as the reference's (B,X,Y,Z,.) (:238)
+        xyz = lambda t: t.permute(0, 3, 2, 1, 4)
+        density_prob = xyz(train.mlp_cl(self.density_mlp, voxel_feats_cl))
+        density, semantic = density_prob[..., 0], xyz(train.mlp_cl(self.semantic_mlp, voxel_feats_cl))
+        color = xyz(train.mlp_cl(self.color_mlp, voxel_feats_cl))
         out = {}
         cw17 = torch.from_numpy(1.0 / np.log(NUSC_CLASS_FREQUENCIES[:17] + 0.001)).float()
         if self.if_post_finetune:

@@ -388,6 +388,27 @@ def _conv1x1_cl(x, conv):
     return torch.matmul(x, w.t())
 
 
+def linear_cl(x_cl, lin):
+    """nn.Linear applied per voxel to a channels-last (B,Z,Y,X,K) tensor as a 1x1x1 convolution on the MFMA conv kernels (forward,
+    data and weight gradients: Conv3dCL), output columns zero-padded to a multiple of 32 and sliced back.  For K % 32 == 0 (the
+    attribute MLPs 32 -> 64 -> {2, 17, 3} of preworld.py:101-110, which the library GEMM ran at 1.0-1.5 ms per call on 640 000
+    voxels); anything else goes to F.linear."""
+    N, K = lin.weight.shape
+    if x_cl.dim() != 5 or K % 32 or not x_cl.is_cuda:
+        return torch.nn.functional.linear(x_cl, lin.weight, lin.bias)
+    pad = (-N) % 32
+    w = torch.cat([lin.weight, lin.weight.new_zeros(pad, K)], 0) if pad else lin.weight
+    y = Conv3dCL.apply(x_cl.contiguous(), w.reshape(N + pad, K, 1, 1, 1), 1)[..., :N]
+    return y + lin.bias if lin.bias is not None else y
+
+
+def mlp_cl(seq, x_cl):
+    """an nn.Sequential of Linear / activation modules per voxel of a channels-last tensor (Linear layers through linear_cl)"""
+    for m in seq:
+        x_cl = linear_cl(x_cl, m) if isinstance(m, torch.nn.Linear) else m(x_cl)
+    return x_cl
+
+
 def occ_head_forward(head, x_cl, transposed=True):
     """OccHead.forward_coarse_voxel (occupancy_head.py:124-161) in training mode on channels-last x (B,Z,Y,X,32) -> logits
     (B,Z,Y,X,18).  transposed: x is the encoder's native (Z,Y,X) buffer while the reference convolves (X,Y,Z): the taps are
