@@ -215,7 +215,13 @@ def _pmc_traffic(kernel):
     process; profiles/*_pmc_traffic.json says how they were collected and corrected), newest round first."""
     prof = os.path.join(ROOT, 'profiles')
     for name in sorted((f for f in os.listdir(prof) if f.endswith('_pmc_traffic.json')), reverse=True):
-        ent = json.load(open(os.path.join(prof, name))).get('by_kernel', {}).get(kernel)
+        by = json.load(open(os.path.join(prof, name))).get('by_kernel', {})
+        if kernel == 'k_lss_pool_slots':
+            # ops.lss_lift_pool is probed as ONE unit (5 launches, the library reports its last kernel): traffic of all five
+            ents = [v for k, v in by.items() if k.startswith('k_lss_')]
+            if ents:
+                return int(sum(e['fetch_bytes'] + e['write_bytes'] for e in ents)), name
+        ent = by.get(kernel)
         if ent:
             return int(ent['fetch_bytes'] + ent['write_bytes']), name
     return None, None
@@ -225,7 +231,8 @@ def roofline_object(agg, n_probe_steps):
     def entry(kernel, a):
         sec = a['ms'] * 1e-3
         traffic, src = _pmc_traffic(kernel)
-        ent = dict(kernel=kernel, launches_per_step=a['launches'] // n_probe_steps,
+        ent = dict(kernel=kernel if kernel != 'k_lss_pool_slots' else 'k_lss_prologue + k_lss_index_slots + k_lss_heavy_alloc + k_lss_ovf_scatter + k_lss_pool_slots',
+                   launches_per_step=a['launches'] // n_probe_steps,
                    avg_launch_us=round(a['ms'] * 1e3 / a['launches'], 2), us_per_step=round(a['ms'] * 1e3 / n_probe_steps, 1),
                    algorithmic_bytes=int(a['bytes'] / a['launches']), traffic=traffic,
                    traffic_unit='HBM bytes per launch (PMC, %s)' % src if src else None)
