@@ -20,6 +20,8 @@
 // memory, no host sync) so that they sit in fp16's range whatever the scale of the gradients; the product of the two is taken out
 // again when the partial tile is written.  Partial tiles per (chunk, tap, co block, ci block) are summed in a fixed order by
 // pw_train.hip's k_wgrad_reduce: deterministic, no atomics.
+#include <type_traits>
+
 #include "pw_h2.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,8 +31,13 @@ namespace {
 constexpr int WG_NS = 4;                       // K-steps of 16 output columns per strip
 constexpr int WG_COLS = 16 * WG_NS;            // 64
 constexpr int WG_STRIDE = 176;                 // bytes per channel row of a plane: (8 + 64 + 8) halves = 160 B, padded to 4 x 11 dwords
-constexpr int WG_PLANE = 32 * WG_STRIDE;       // one plane (hi or lo) of a 32-channel tile
-constexpr int WG_TILE = 2 * WG_PLANE;          // 11 264 B
+constexpr int WG_PLANE = 32 * WG_STRIDE + 16;  // one plane (hi or lo) of a 32-channel tile; rows 16..31 sit 16 B further (wg_row)
+constexpr int WG_TILE = 2 * WG_PLANE + 32;     // 11 328 B; the second tile of an operand sits 8 banks further
+// byte offset of channel row c inside a plane.  The 16 extra bytes after row 15 and the 32 after a tile are for the STAGING writes:
+// a wave writes 8 channel quads x 2 tiles x 4 position pairs per instruction, and with plain strides quads q / q + 4 and the two
+// tiles fell on the same banks (4-way conflicts on all 16 writes of a task); the ds_read_b128 phases (16 consecutive rows) are
+// unaffected.
+__host__ __device__ constexpr int wg_row(int c) { return c * WG_STRIDE + ((c >> 4) << 4); }
 constexpr int WG_THREADS = 768;                // 12 waves: 3 kh x 4 (pair, K-subset) -- three per SIMD, so one wave's staging VALU work runs under another's MFMAs
 
 struct WgH2Args {
@@ -43,7 +50,6 @@ struct WgH2Args {
   int cog, cig;              // tile groups along co / ci
   int n_strips, oh_splits, rows_per_split;
   int co_blocks, ci_blocks;
-  int dbg;                   // timing experiments (PW_WG_DEBUG): 1 = no MFMA phase, 2 = no LDS stores, 4 = no global loads
 };
 
 // exponent e such that amax * 2^-e lies in [2^12, 2^13) (0 for zero / non-finite / absent)
@@ -80,12 +86,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kh = wave % 3, pair = (wave / 3) % P, ksub = wave / (3 * P);
   const int ct = pair / CI_T, it = pair % CI_T;
-  int bid = blockIdx.x;
+  // one-dimensional grid, remapped so that an XCD works on a contiguous range of logical blocks (xcd_contiguous): the three kd
+  // blocks of a (strip, b, od, rows) -- which read the SAME dY rows in lockstep -- and their neighbours then share one L2; dealt
+  // round-robin they sat on three XCDs and every row crossed the fabric three times
+  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
   const int ig = bid % a.cig; bid /= a.cig;
   const int cg = bid % a.cog; bid /= a.cog;
-  const int kd = bid;
-  const int strip = blockIdx.y;
-  const int split = blockIdx.z % a.oh_splits, bd = blockIdx.z / a.oh_splits;
+  const int kd = bid % 3; bid /= 3;
+  const int strip = bid % a.n_strips;
+  const int zi = bid / a.n_strips;
+  const int split = zi % a.oh_splits, bd = zi / a.oh_splits;
   const int od = bd % a.D, b = bd / a.D;
   const int id = od + kd - 1;
   const int ow0 = strip * WG_COLS;
@@ -104,43 +114,59 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
     const float* xplane = a.x + (((size_t)b * a.D + id) * a.H) * (size_t)a.W * a.Cin + (size_t)(ig * CI_T) * 32;
     const float* yplane = a.dy + (((size_t)b * a.D + od) * a.H) * (size_t)a.W * a.Cout + (size_t)(cg * CO_T) * 32;
     float4 xr0[X_ROUNDS][2], yr0[Y_ROUNDS][2], xr1[X_ROUNDS][2], yr1[Y_ROUNDS][2];     // two row sets in flight
-    // global loads of one input row (ih) / one dY row (oh) into registers; rows / columns outside the volume load as zero
+    // A thread's staging tasks never change: (position pair, tile, channel quad) per round.  Everything that depends only on them
+    // is computed ONCE -- element offset inside a row, LDS byte offset, and a per-voxel scale that is the tensor's pre-scale or 0
+    // for a column outside the volume (the load then goes to a clamped column, unconditionally: no branches, no 64-bit address
+    // arithmetic in the loop -- the first version spent ~180 VALU instructions per task there and the staging phase, not the
+    // MFMAs, set the step time).
+    int xo[X_ROUNDS][2], yo[Y_ROUNDS][2], xl[X_ROUNDS], yl[Y_ROUNDS];
+    float xs[X_ROUNDS][2], ys[Y_ROUNDS][2];
+#pragma unroll
+    for (int r = 0; r < X_ROUNDS; ++r) {
+      const int t = (r * WG_THREADS + (int)threadIdx.x) % X_TASKS;      // surplus threads repeat a task: identical stores, no branch
+      const int cq = t & 7, tile = (t >> 3) % CI_T, pp = t / (8 * CI_T);
+      xl[r] = tile * WG_TILE + wg_row(cq * 4) + (6 + 2 * pp) * 2;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int w = ow0 - 2 + 2 * pp + e;
+        xs[r][e] = (unsigned)w < (unsigned)a.W ? sx : 0.f;
+        xo[r][e] = min(max(w, 0), a.W - 1) * a.Cin + tile * 32 + cq * 4;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < Y_ROUNDS; ++r) {
+      const int t = (r * WG_THREADS + (int)threadIdx.x) % Y_TASKS;
+      const int cq = t & 7, tile = (t >> 3) % CO_T, pp = t / (8 * CO_T);
+      yl[r] = tile * WG_TILE + wg_row(cq * 4) + (8 + 2 * pp) * 2;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int w = ow0 + 2 * pp + e;
+        ys[r][e] = w < a.W ? sy : 0.f;
+        yo[r][e] = min(w, a.W - 1) * a.Cout + tile * 32 + cq * 4;
+      }
+    }
+    // global loads of one input row (ih) / one dY row (oh) into registers: a uniform row base + the thread's offsets
     auto load_x = [&](float4 (&xr)[X_ROUNDS][2], int ih) {
-      const bool row_ok = (unsigned)ih < (unsigned)a.H;
-      const float* row = xplane + (size_t)(row_ok ? ih : 0) * a.W * a.Cin;
+      const float* row = xplane + (size_t)min(max(ih, 0), a.H - 1) * a.W * a.Cin;
 #pragma unroll
       for (int r = 0; r < X_ROUNDS; ++r) {
-        const int t = r * WG_THREADS + (int)threadIdx.x;
-        const int cq = t & 7, tile = (t >> 3) % CI_T, pp = t / (8 * CI_T);
-        const int w = ow0 - 2 + 2 * pp;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const bool ok = row_ok && t < X_TASKS && (unsigned)(w + e) < (unsigned)a.W;
-          xr[r][e] = ok ? *reinterpret_cast<const float4*>(row + (size_t)(w + e) * a.Cin + tile * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        xr[r][0] = *reinterpret_cast<const float4*>(row + xo[r][0]);
+        xr[r][1] = *reinterpret_cast<const float4*>(row + xo[r][1]);
       }
     };
     auto load_y = [&](float4 (&yr)[Y_ROUNDS][2], int oh) {
       const float* row = yplane + (size_t)oh * a.W * a.Cout;
 #pragma unroll
       for (int r = 0; r < Y_ROUNDS; ++r) {
-        const int t = r * WG_THREADS + (int)threadIdx.x;
-        const int cq = t & 7, tile = (t >> 3) % CO_T, pp = t / (8 * CO_T);
-        const int w = ow0 + 2 * pp;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const bool ok = t < Y_TASKS && (w + e) < a.W;
-          yr[r][e] = ok ? *reinterpret_cast<const float4*>(row + (size_t)(w + e) * a.Cout + tile * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        yr[r][0] = *reinterpret_cast<const float4*>(row + yo[r][0]);
+        yr[r][1] = *reinterpret_cast<const float4*>(row + yo[r][1]);
       }
     };
     // registers -> LDS, split and transposed: channel c of the tile at row c of both planes, position pair pp at half index
     // 6 + 2 pp (X: column ow0 - 2 + 2 pp) resp. 8 + 2 pp (dY: column ow0 + 2 pp)
-    auto store_task = [&](unsigned char* base, const float4 (&reg)[2], int t, int nt, int idx0, float s) {
-      const int cq = t & 7, tile = (t >> 3) % nt, pp = t / (8 * nt);
-      const float v0[4] = {reg[0].x * s, reg[0].y * s, reg[0].z * s, reg[0].w * s};
-      const float v1[4] = {reg[1].x * s, reg[1].y * s, reg[1].z * s, reg[1].w * s};
-      unsigned char* p = base + tile * WG_TILE + (cq * 4) * WG_STRIDE + (idx0 + 2 * pp) * 2;
+    auto store_task = [&](unsigned char* p, const float4 (&reg)[2], float s0, float s1) {
+      const float v0[4] = {reg[0].x * s0, reg[0].y * s0, reg[0].z * s0, reg[0].w * s0};
+      const float v1[4] = {reg[1].x * s1, reg[1].y * s1, reg[1].z * s1, reg[1].w * s1};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         unsigned hi, lo;
@@ -151,32 +177,29 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
     };
     auto store_x = [&](const float4 (&xr)[X_ROUNDS][2], int ih) {
       unsigned char* base = xring + ((ih + 4) & 3) * CI_T * WG_TILE;
+      const float rowf = (unsigned)ih < (unsigned)a.H ? 1.f : 0.f;          // a row outside the volume is stored as zeros
 #pragma unroll
-      for (int r = 0; r < X_ROUNDS; ++r) {
-        const int t = r * WG_THREADS + (int)threadIdx.x;
-        if (t < X_TASKS) store_task(base, xr[r], t, CI_T, 6, sx);
-      }
+      for (int r = 0; r < X_ROUNDS; ++r)
+        store_task(base + xl[r], xr[r], xs[r][0] * rowf, xs[r][1] * rowf);
     };
     auto store_y = [&](const float4 (&yr)[Y_ROUNDS][2], int oh) {
       unsigned char* ybase = ybuf + (oh & 1) * CO_T * WG_TILE;
 #pragma unroll
-      for (int r = 0; r < Y_ROUNDS; ++r) {
-        const int t = r * WG_THREADS + (int)threadIdx.x;
-        if (t < Y_TASKS) store_task(ybase, yr[r], t, CO_T, 8, sy);
-      }
+      for (int r = 0; r < Y_ROUNDS; ++r)
+        store_task(ybase + yl[r], yr[r], ys[r][0], ys[r][1]);
     };
     const int m = lane & 31, h = lane >> 5;
     // the MFMAs of output row oh: dY slot oh & 1, input rows oh - 1 .. oh + 1 in slots (row & 3)
     auto compute = [&](int oh) {
       const int ih = oh + kh - 1;
       if ((unsigned)ih >= (unsigned)a.H) return;         // wave-uniform: this wave's input row lies outside the volume
-      const unsigned char* yt = ybuf + ((oh & 1) * CO_T + ct) * WG_TILE + m * WG_STRIDE;
+      const unsigned char* yt = ybuf + ((oh & 1) * CO_T + ct) * WG_TILE + wg_row(m);
       for (int s = ksub; s < ns; s += KSUB) {
         const int off = (8 + 16 * s + 8 * h) * 2;        // byte offset of the lane's 8-column block in a channel row
         const wg_u4 ah = *reinterpret_cast<const wg_u4*>(yt + off);
         const wg_u4 al = *reinterpret_cast<const wg_u4*>(yt + WG_PLANE + off);
         {
-          const unsigned char* xt = xring + (((ih + 4) & 3) * CI_T + it) * WG_TILE + m * WG_STRIDE + off;
+          const unsigned char* xt = xring + (((ih + 4) & 3) * CI_T + it) * WG_TILE + wg_row(m) + off;
           wg_u4 bv[3][2];                                // [kw][plane]
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
@@ -205,23 +228,49 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
     store_x(xr0, oh0 - 1); store_x(xr1, oh0); store_y(yr0, oh0);
     load_x(xr0, oh0 + 1); store_x(xr0, oh0 + 1);
     if (oh0 + 1 < oh1) { load_x(xr0, oh0 + 2); load_y(yr0, oh0 + 1); }
+    if (oh0 + 2 < oh1) { load_x(xr1, oh0 + 3); load_y(yr1, oh0 + 2); }
     __syncthreads();
-    // step oh: request the rows of step oh + 2 (other register set), run row oh's MFMAs, then split the rows of step oh + 1
-    // (requested one step ago) into the slots row oh does not read.  One barrier per step; loads are in flight for two steps.
-    auto step = [&](int oh, float4 (&xa)[X_ROUNDS][2], float4 (&ya)[Y_ROUNDS][2], float4 (&xb)[X_ROUNDS][2], float4 (&yb)[Y_ROUNDS][2]) {
-      if (oh + 2 < oh1 && !(a.dbg & 4)) { load_x(xb, oh + 3); load_y(yb, oh + 2); }
-      // the stores fill slots this step's MFMAs do not read, so their order is free: waves 4 .. 7 store first, the others compute
-      // first -- on every SIMD one wave's staging VALU work meets the other two's MFMAs
-      const bool store_first = (wave >> 2) & 1;
-      if (store_first && oh + 1 < oh1 && !(a.dbg & 2)) { store_x(xa, oh + 2); store_y(ya, oh + 1); }
-      if (!(a.dbg & 1)) compute(oh);
-      if (!store_first && oh + 1 < oh1 && !(a.dbg & 2)) { store_x(xa, oh + 2); store_y(ya, oh + 1); }
-      __syncthreads();
+    // step oh: split the rows of step oh + 1 (requested a step ago, set a) into the slots row oh does not read, request the rows
+    // of step oh + 2 into the same registers, run row oh's MFMAs; one barrier per step.  The steady-state steps are BRANCH-FREE:
+    // with a condition around a load or a store the compiler's s_waitcnt bookkeeping merges a path on which the registers'
+    // earlier loads were never consumed and drains the (in-order) load counter before every new request -- each step then cost an
+    // exposed memory latency.  For the same reason the barrier is not __syncthreads() (its release fence waits for vmcnt(0)), and
+    // the store-first / compute-first order is a compile-time variant chosen once per wave.
+    auto run = [&](auto sf_tag) {
+      constexpr bool SF = decltype(sf_tag)::value;
+      auto step_u = [&](int oh, float4 (&xa)[X_ROUNDS][2], float4 (&ya)[Y_ROUNDS][2], float4 (&xb)[X_ROUNDS][2], float4 (&yb)[Y_ROUNDS][2]) {
+        if constexpr (SF) {
+          store_x(xa, oh + 2); store_y(ya, oh + 1);
+          load_x(xa, oh + 4); load_y(ya, oh + 3);
+          compute(oh);
+        } else {
+          compute(oh);
+          store_x(xa, oh + 2); store_y(ya, oh + 1);
+          load_x(xa, oh + 4); load_y(ya, oh + 3);
+        }
+        (void)xb; (void)yb;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      };
+      auto step_c = [&](int oh, float4 (&xa)[X_ROUNDS][2], float4 (&ya)[Y_ROUNDS][2]) {
+        if (SF && oh + 1 < oh1) { store_x(xa, oh + 2); store_y(ya, oh + 1); }
+        if (SF && oh + 3 < oh1) { load_x(xa, oh + 4); load_y(ya, oh + 3); }
+        compute(oh);
+        if (!SF && oh + 1 < oh1) { store_x(xa, oh + 2); store_y(ya, oh + 1); }
+        if (!SF && oh + 3 < oh1) { load_x(xa, oh + 4); load_y(ya, oh + 3); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      };
+      int oh = oh0;
+      for (; oh + 4 < oh1; oh += 2) {
+        step_u(oh, xr0, yr0, xr1, yr1);
+        step_u(oh + 1, xr1, yr1, xr0, yr0);
+      }
+      for (; oh < oh1; oh += 2) {                         // the last (up to four) steps
+        step_c(oh, xr0, yr0);
+        if (oh + 1 < oh1) step_c(oh + 1, xr1, yr1);
+      }
     };
-    for (int oh = oh0; oh < oh1; oh += 2) {
-      step(oh, xr0, yr0, xr1, yr1);
-      if (oh + 1 < oh1) step(oh + 1, xr1, yr1, xr0, yr0);
-    }
+    // waves 4 .. 7 store first, the others compute first: on every SIMD one wave's staging VALU work meets the other two's MFMAs
+    if ((wave >> 2) & 1) run(std::true_type{}); else run(std::false_type{});
   }
   // narrow tiles: the KSUB waves of a (pair, kh) add their tiles through LDS in a fixed order (wave 0 + 1 (+ 2 + 3)), one kw at a time
   if constexpr (KSUB > 1) {
@@ -245,7 +294,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
   }
   // partial tiles of this (chunk, K-subset): D row (co) = (r & 3) + 8 (r >> 2) + 4 h, column (ci) = lane & 31
   const float unscale = rng_pow2(ex + ey);
-  const int chunk = (int)blockIdx.z * a.n_strips + strip;
+  const int chunk = zi * a.n_strips + strip;
   const int cob = cg * CO_T + ct, cib = ig * CI_T + it;
   const int i = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -337,10 +386,8 @@ PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const 
   a.co_t = p.co_t; a.ci_t = p.ci_t; a.cog = p.cog; a.cig = p.cig;
   a.n_strips = p.n_strips; a.oh_splits = p.oh_splits; a.rows_per_split = p.rows_per_split;
   a.co_blocks = Cout / 32; a.ci_blocks = Cin / 32;
-  static const int dbg = [] { const char* e = getenv("PW_WG_DEBUG"); return e ? atoi(e) : 0; }();
-  a.dbg = dbg;
   hipStream_t st = pw_stream(stream);
-  const dim3 grid((unsigned)(3 * p.cog * p.cig), (unsigned)p.n_strips, (unsigned)(B * D * p.oh_splits));
+  const dim3 grid((unsigned)(3 * p.cog * p.cig * p.n_strips * B * D * p.oh_splits));
 #define PW_WG_LAUNCH(CO, CI)                                                                                                    \
   do {                                                                                                                          \
     static bool attr_set = false;                                                                                               \

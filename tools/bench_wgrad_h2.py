@@ -1,4 +1,6 @@
-"""pw_conv3d_wgrad_h2 alone (no amax passes) at the encoder's 3x3x3 stride-1 shapes; PW_WG_DEBUG selects timing experiments."""
+"""pw_conv3d_wgrad_h2 alone (no amax passes) at the encoder's 3x3x3 stride-1 shapes.  (The PW_WG_DEBUG phase switches the
+recorded staging-only / MFMA-only figures of profiles/r03_train.txt were taken with are no longer in the kernel: a condition around
+its loads or stores costs it the overlap they measure.)"""
 import os
 import sys
 
