@@ -539,7 +539,11 @@ int pw_linear_rows(const float* x, const float* w, float* y, int64_t n, int K, i
 
 /* the same gradient for 3x3x3 stride-1 layers with Cin, Cout multiples of 32 on the fp16 matrix cores with split-fp16 operands
  * (22-bit products, fp32 accumulation; operands transposed through LDS, three input rows resident): 3-4x pw_conv3d_wgrad.
- * amax2: device float[2] = {max |x|, max |dy|} (per-tensor power-of-two pre-scales; NULL = none).  Deterministic. */
+ * amax2: pw_absmax2(x, dy)'s 512 partial maxima (per-tensor power-of-two pre-scales; NULL = none).  Deterministic. */
+/* largest magnitudes of two fp32 tensors in one launch, as 2 x 256 partial maxima (no atomics): out (device float[512]) [0..255]
+ * over x, [256..511] over y; the maximum of a half is max |.|.  Element counts multiples of 4, 16-byte aligned.  Feeds
+ * pw_conv3d_wgrad_h2's amax2, which reduces the partials itself. */
+int pw_absmax2(const float* x, int64_t nx, const float* y, int64_t ny, float* out, void* stream);
 size_t pw_conv3d_wgrad_h2_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const float* amax2, void* workspace, size_t workspace_bytes,
                        int B, int D, int H, int W, int Cin, int Cout, void* stream);

@@ -44,7 +44,7 @@ struct WgH2Args {
   const float* x;
   const float* dy;
   float* partial;            // [chunk][27][co_blocks][ci_blocks][32 * 32]
-  const float* amax2;        // {max |x|, max |dy|} or null
+  const float* amax2;        // pw_absmax2's partial maxima [2][WG_AMAX_PARTS] (x, dy) or null
   int B, D, H, W, Cin, Cout;
   int co_t, ci_t;            // 32-channel tiles per block along co / ci (1 or 2)
   int cog, cig;              // tile groups along co / ci
@@ -52,13 +52,7 @@ struct WgH2Args {
   int co_blocks, ci_blocks;
 };
 
-// exponent e such that amax * 2^-e lies in [2^12, 2^13) (0 for zero / non-finite / absent)
-__device__ __forceinline__ int wg_exp(const float* amax2, int i) {
-  if (!amax2) return 0;
-  const unsigned bits = __float_as_uint(amax2[i]) & 0x7fffffffu;
-  return rng_ideal_exp(bits);
-}
-
+constexpr int WG_AMAX_PARTS = 256;             // partial maxima per tensor (pw_absmax2)
 // two voxels' values of one channel -> packed hi pair, packed lo pair (low half = first voxel)
 __device__ __forceinline__ void wg_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
   const h2_f2 x = {a, b};
@@ -101,7 +95,20 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
   const int ow0 = strip * WG_COLS;
   const int ns = min(WG_NS, (a.W - ow0 + 15) / 16);
   const int oh0 = split * a.rows_per_split, oh1 = min(a.H, oh0 + a.rows_per_split);
-  const int ex = wg_exp(a.amax2, 0), ey = wg_exp(a.amax2, 1);
+  // exponents e such that amax * 2^-e lies in [2^12, 2^13) (0 for zero / non-finite / absent): the block reduces pw_absmax2's partials
+  int ex = 0, ey = 0;
+  if (a.amax2) {
+    __shared__ unsigned amx[2][WG_THREADS / 64];
+    const unsigned* part = reinterpret_cast<const unsigned*>(a.amax2);
+    unsigned m0 = threadIdx.x < WG_AMAX_PARTS ? part[threadIdx.x] : 0u, m1 = threadIdx.x < WG_AMAX_PARTS ? part[WG_AMAX_PARTS + threadIdx.x] : 0u;
+    m0 = wave_umax(m0); m1 = wave_umax(m1);
+    if (lane == 0) { amx[0][wave] = m0; amx[1][wave] = m1; }
+    __syncthreads();
+    m0 = 0u; m1 = 0u;
+#pragma unroll
+    for (int w = 0; w < WG_THREADS / 64; ++w) { m0 = max(m0, amx[0][w]); m1 = max(m1, amx[1][w]); }
+    ex = rng_ideal_exp(m0); ey = rng_ideal_exp(m1);
+  }
   const float sx = rng_pow2(-ex), sy = rng_pow2(-ey);
 
   f32x16 acc[3];                                 // kw = 0, 1, 2 of this wave's kh
@@ -392,7 +399,7 @@ PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const 
   do {                                                                                                                          \
     static bool attr_set = false;                                                                                               \
     if (!attr_set) {                                                                                                            \
-      PW_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3d_wgrad_h2<CO, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      PW_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3d_wgrad_h2<CO, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
       attr_set = true;                                                                                                          \
     }                                                                                                                           \
     hipLaunchKernelGGL((k_conv3d_wgrad_h2<CO, CI>), grid, dim3(WG_THREADS), p.lds, st, a);                                             \
@@ -406,6 +413,35 @@ PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const 
   hipLaunchKernelGGL(k_wgrad_h2_reduce, dim3((unsigned)(per_chunk / 32)), dim3(256), 0, st, a.partial, dw, p.n_chunks, 27,
                      a.co_blocks, a.ci_blocks, Cout, Cin);
   pw_note_kernel("k_conv3d_wgrad_h2<%d, %d>", p.co_t, p.ci_t);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
+// largest magnitudes of two tensors in one launch (the per-tensor pre-scales of pw_conv3d_wgrad_h2): block b of tensor i leaves the
+// maximum of its grid-stride share at out[i * WG_AMAX_PARTS + b] as a float (bit-pattern maximum: a NaN ends above every number).
+// No atomics (2 x 8 192 same-address atomic maxima cost 50 us), no zero-initialised output; the consumer reduces the partials.
+__global__ void __launch_bounds__(256) k_absmax2(const float4* __restrict__ x, int64_t nx4, const float4* __restrict__ y, int64_t ny4,
+                                                 unsigned* __restrict__ out) {
+  __shared__ unsigned wm[4];
+  const bool second = blockIdx.y == 1;
+  const float4* p = second ? y : x;
+  const int64_t n4 = second ? ny4 : nx4;
+  unsigned m = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = p[i];
+    m = max(max(m, rng_absbits(v.x)), max(rng_absbits(v.y), max(rng_absbits(v.z), rng_absbits(v.w))));
+  }
+  m = wave_umax(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[(second ? WG_AMAX_PARTS : 0) + blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+}
+
+PW_API int pw_absmax2(const float* x, int64_t nx, const float* y, int64_t ny, float* out, void* stream) {
+  PW_CHECK_ARG(x && y && out && nx > 0 && ny > 0 && nx % 4 == 0 && ny % 4 == 0, "pw_absmax2: bad arguments (element counts must be multiples of 4)");
+  PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "pw_absmax2: x / y must be 16-byte aligned");
+  hipLaunchKernelGGL(k_absmax2, dim3(WG_AMAX_PARTS, 2), dim3(256), 0, pw_stream(stream), (const float4*)x, nx / 4, (const float4*)y, ny / 4,
+                     (unsigned*)out);
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

@@ -81,8 +81,8 @@ def conv3d_wgrad(x, dy, w_shape, stride=1):
     if k == 3 and stride == 1 and Cin % 32 == 0 and Cout % 32 == 0 and _WGRAD != 'f32':
         # split-fp16 operands on the fp16 matrix cores (pw_conv3d_wgrad_h2): 22-bit products, fp32 accumulation; the two maxima
         # (device side, no sync) give the per-tensor power-of-two pre-scales
-        ax, ay = torch.aminmax(x.detach()), torch.aminmax(dy.detach())         # one read pass each, no |x| temporary
-        amax2 = torch.stack([torch.maximum(-ax.min, ax.max), torch.maximum(-ay.min, ay.max)]).float()
+        amax2 = torch.empty(512, device=x.device, dtype=_f32)
+        _lib.call('pw_absmax2', ops._p(_cl(x, 'x')), x.numel(), ops._p(_cl(dy, 'dy')), dy.numel(), ops._p(amax2), ops._stream())
         nbytes = _lib.call_size('pw_conv3d_wgrad_h2_workspace_bytes', B, D, H, W, Cin, Cout)
         ws = ops._workspace(nbytes, x.device)
         dw = torch.empty(tuple(w_shape), device=x.device, dtype=_f32)
