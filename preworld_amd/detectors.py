@@ -390,6 +390,14 @@ class BEVStereo4DOCC(nn.Module):
         return [r.cpu().numpy().astype(np.uint8) for r in res]
 
 
+def _zero_weight(pred):
+    """`CrossEntropyLoss()(pred, ones) * 0.` of preworld.py:120-127 / :305-307 -- a zero-weight term whose only job is to keep the
+    attribute MLPs in the autograd graph (their parameters get zero-valued gradients).  Its value is 0 and its gradient is 0 for any
+    finite prediction, and so are this sum's: the soft-target cross entropy over 640 000 x {17, 3, 1} values (log-softmax and four
+    reductions, forward and backward: 3 ms of the training step) is not evaluated."""
+    return pred.sum() * 0.
+
+
 class _PreWorldCommon(BEVStereo4DOCC):
     """What preworld.py:24-120 and preworld_temporal_traj.py:27-118 share: final_conv (out_dim), the three attribute
     MLPs, nerf_head, occupancy_head and the flags."""
@@ -472,17 +480,16 @@ class _PreWorldCommon(BEVStereo4DOCC):
         else:
             cw = torch.cat([cw17, torch.zeros(1)]).to(occ_preds)
             out['loss_sup_voxel' + sfx] = L.CE_ssc_loss(occ_preds, voxel_semantics, cw, 255) * 0.
-        ce = nn.CrossEntropyLoss(reduction='mean')
         if self.if_render:
             extra = {} if interval is None else dict(if_temporal=True, interval=interval)
             out.update(self.nerf_head(density, semantic, color, if_pretrain=self.if_pretrain, dataset_type=self.dataset_type,
                                       rays=kwargs['rays'] if rays is None else rays, bda=kwargs.get('bda'), **extra))
         else:                                                         # loss_sup (:120-127): zero weight, keeps the MLPs in the graph
             for pred, tag, n in ((semantic, 'semantic', self.num_classes - 1), (color, 'color', 3), (density, 'density', 1)):
-                out['loss_sup_%s%s' % (tag, sfx)] = ce(pred.reshape(-1, n), torch.ones_like(pred).reshape(-1, n)) * 0.
+                out['loss_sup_%s%s' % (tag, sfx)] = _zero_weight(pred)
         if self.if_pretrain and interval is None:                      # preworld.py:305-307 (the temporal detector has no such term)
             n = self.num_classes - 1
-            out['loss_sup_semantic'] = ce(semantic.reshape(-1, n), torch.ones_like(semantic).reshape(-1, n)) * 0.
+            out['loss_sup_semantic'] = _zero_weight(semantic)
         return out
 
     def forward_train_from_feats(self, bev_feat_cl, **kwargs):
