@@ -221,6 +221,39 @@ def test_lift_pool_slots_edge_cases(case):
     np.testing.assert_array_equal(got.view(*shape).permute(0, 4, 1, 2, 3).cpu().numpy(), o_bev)
 
 
+def test_lift_pool_slots_class_boundaries():
+    """ops.lss_lift_pool at the exact boundaries of its voxel classes: voxels holding 0, 1, 7, 8 (all slots), 9 (first heavy one),
+    32, 33 (second shuffle round of the half-wave sort), 63, 64, 65 (first block-sorted one), 127, 128, 129 (LDS row chunks), 4096
+    and 4097 points (second LDS sort pass), their points scattered over the frustum in a random order.  With identity cameras a
+    frustum entry (x, y, 1) IS the point, so the counts are exact by construction."""
+    counts = [0, 1, 7, 8, 9, 32, 33, 63, 64, 65, 127, 128, 129, 4096, 4097, 2, 3, 0, 8, 9]
+    rs = np.random.RandomState(17)
+    gx, gy = 5, 4                                        # 20 voxels of size 1 in the z = [0.5, 1.5) slab
+    pts = []
+    for v, c in enumerate(counts):
+        x0, y0 = v % gx, v // gx
+        pts.append(np.stack([x0 + rs.uniform(0.05, 0.95, c), y0 + rs.uniform(0.05, 0.95, c), np.ones(c)], 1))
+    pts = np.concatenate(pts).astype(np.float32)
+    n = len(pts)
+    W = 97                                               # ragged: the frustum is padded with points outside the grid
+    H = (n + W - 1) // W
+    pad = np.tile(np.array([[-5.0, -5.0, 1.0]], np.float32), (H * W - n, 1))
+    fr = np.concatenate([pts, pad])[rs.permutation(H * W)].reshape(1, H, W, 3)
+    eye = np.eye(3, dtype=np.float32)
+    s2e = np.eye(4, dtype=np.float32)[None, None]
+    cams = [T(s2e), T(eye[None, None]), T(eye[None, None]), T(np.zeros((1, 1, 3), np.float32)), T(eye[None])]
+    lower, interval, size = [0.0, 0.0, 0.5], [1.0, 1.0, 1.0], [gx, gy, 1]
+    depth = rs.random_sample((1, 1, 1, H, W)).astype(np.float32)
+    featc = rs.standard_normal((1, 1, H, W, 32)).astype(np.float32)
+    got = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, T(depth), T(featc))
+    ipr, comb, tr = O.camera_matrices(s2e, eye[None, None], eye[None, None])
+    coor = O.lidar_coor(fr, ipr, np.zeros((1, 3), np.float32), comb, tr, eye[None], 1, 1)
+    want = O.voxel_pooling_prepare_v2(coor, np.array(lower, np.float32), np.array(interval, np.float32), size)
+    assert np.bincount(want[0], minlength=gx * gy).tolist() == counts
+    o_bev = O.bev_pool_v2(depth, featc, want[1], want[2], want[0], (1, 1, gy, gx, 32), want[3], want[4])
+    np.testing.assert_array_equal(got.view(1, 1, gy, gx, 32).permute(0, 4, 1, 2, 3).cpu().numpy(), o_bev)
+
+
 def test_full_size_properties(golden):
     """Size-independent properties at BASELINE's full size: linearity in feat, conservation
     (sum of pooled == sum over kept points of depth*feat), idempotent re-run, golden stats."""
