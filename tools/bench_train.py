@@ -113,3 +113,11 @@ for _ in range(n):
 torch.cuda.synchronize()
 print('PreWorld.forward_train voxel side, C3 shape (6 cams, 2 frames, 200x200x16), forward + backward: %.1f ms per step   losses: %s' % (
     (time.perf_counter() - t0) / n * 1e3, ', '.join('%s %.3f' % (k, float(v)) for k, v in out.items() if 'sup' not in k)), flush=True)
+
+if os.environ.get('PW_TORCH_PROFILE'):           # which torch ops (glue around the HIP kernels) the step spends device time in
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            train_step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by='self_cuda_time_total', row_limit=28, max_name_column_width=60), flush=True)
