@@ -532,6 +532,12 @@ size_t pw_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int 
 int pw_conv3d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int B, int D, int H,
                     int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
+/* torch Conv3d weight w (Cout, Cin, k, k, k) -> the packed operand layout of pw_conv3d_ndhwc (wino = 0: float[Cin'/32][k^3]
+ * [cout_total/32][4][64][4]) or of pw_conv3d_wino (wino = 1, k = 3: float[Cin'/32][64][cout_total/16][64][8], U = G w G^T in
+ * float64), in one launch.  flip_t != 0 packs w' = w.flip(2,3,4).transpose(0,1) -- the weight of the stride-1 data gradient --
+ * without materialising it (then Cin' = Cout, columns = Cin).  Training re-packs every weight every step. */
+int pw_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, int flip_t, int cout_total, float* out, int wino, void* stream);
+
 /* per-voxel dense layer with few channels (OccHead's 1x1x1 convs in training, occupancy_head.py:124-161, and their data
  * gradients): y[n][j] = sum_k x[n][k] w[j][k], x (n, K), w (N, K), y (n, N); built for (K, N) in {16x8, 8x18, 8x1, 8x16, 18x8, 1x8,
  * 32x16, 16x32}, PW_EUNSUP otherwise. */

@@ -701,3 +701,85 @@ PW_API int pw_linear_rows(const float* x, const float* w, float* y, int64_t n, i
   pw_set_error("pw_linear_rows: (K, N) = (%d, %d) is not built (16x8, 8x18, 8x1, 8x16, 18x8, 1x8, 32x16, 16x32)", K, N);
   return PW_EUNSUP;
 }
+
+// ------------------------------------------------------------------------------------
+// Weight packing for the fp32 conv kernels in ONE launch each (training re-packs every weight every step: as torch ops -- double(),
+// einsum, zeros, copy, permute, contiguous, float -- a pack cost ~10 launches and ~0.3 ms of host time, 60 packs per step made the
+// eager training step host-bound).  flip_t: pack w' = w.flip(2, 3, 4).transpose(0, 1), the weight of the stride-1 data gradient,
+// without materialising it.  Layouts: preworld_amd.ops.pack_conv_weight / pack_conv_weight_wino (include/preworld_hip.h).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float packed_w(const float* __restrict__ w, int Cout_w, int Cin_w, int k, int flip_t, int n, int c, int a,
+                                          int b, int cc) {
+  // element [n][c][a][b][cc] of w (flip_t = 0) or of w.flip(2,3,4).transpose(0,1) (flip_t = 1); zero outside
+  const int co = flip_t ? c : n, ci = flip_t ? n : c;
+  if (co >= Cout_w || ci >= Cin_w) return 0.f;
+  if (flip_t) { a = k - 1 - a; b = k - 1 - b; cc = k - 1 - cc; }
+  return w[((((size_t)co * Cin_w + ci) * k + a) * k + b) * k + cc];
+}
+
+__global__ void __launch_bounds__(256) k_pack_conv_weight(const float* __restrict__ w, int Cout_w, int Cin_w, int k, int flip_t,
+                                                          int cout_total, int cin_total, float* __restrict__ out) {
+  // out[ch][tap][nt][q][h * 32 + j][e] = w'[nt * 32 + j][ch * 32 + h * 16 + 4 q + e][tap]
+  const int taps = k * k * k, nt_n = cout_total / 32;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)cin_total * taps * cout_total;
+  if (idx >= total) return;
+  size_t t = idx;
+  const int e = (int)(t & 3); t >>= 2;
+  const int j = (int)(t & 31); t >>= 5;
+  const int h = (int)(t & 1); t >>= 1;
+  const int q = (int)(t & 3); t >>= 2;
+  const int nt = (int)(t % nt_n); t /= nt_n;
+  const int tap = (int)(t % taps);
+  const int ch = (int)(t / taps);
+  const int n = nt * 32 + j, c = ch * 32 + h * 16 + 4 * q + e;
+  out[idx] = packed_w(w, Cout_w, Cin_w, k, flip_t, n, c, tap / (k * k), (tap / k) % k, tap % k);
+}
+
+__global__ void __launch_bounds__(256) k_pack_conv_weight_wino(const float* __restrict__ w, int Cout_w, int Cin_w, int flip_t,
+                                                               int cout_total, int cin_total, float* __restrict__ out) {
+  // out[ch][p][n16][g][j][s] = U[n16 * 16 + j][ch * 32 + g * 8 + s][p], U = G w' G^T along d, h, w (float64, rounded once)
+  const int n16_n = cout_total / 16;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)cin_total * 64 * cout_total;
+  if (idx >= total) return;
+  size_t t = idx;
+  const int s = (int)(t & 7); t >>= 3;
+  const int j = (int)(t & 15); t >>= 4;
+  const int g = (int)(t & 3); t >>= 2;
+  const int n16 = (int)(t % n16_n); t /= n16_n;
+  const int p = (int)(t & 63);
+  const int ch = (int)(t >> 6);
+  const int n = n16 * 16 + j, c = ch * 32 + g * 8 + s;
+  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  const int pi = p >> 4, pj = (p >> 2) & 3, pk = p & 3;
+  double u = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        u += G[pi][a] * G[pj][b] * G[pk][cc] * (double)packed_w(w, Cout_w, Cin_w, 3, flip_t, n, c, a, b, cc);
+  out[idx] = (float)u;
+}
+
+PW_API int pw_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, int flip_t, int cout_total, float* out, int wino,
+                               void* stream) {
+  PW_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && ksize >= 1 && ksize <= 3 && cout_total > 0, "pw_pack_conv_weight: bad arguments");
+  const int cout_p = flip_t ? Cin : Cout, cin_p = flip_t ? Cout : Cin;         // shape of the packed (possibly transposed) weight
+  PW_CHECK_ARG(cin_p % 32 == 0 && cout_total % 32 == 0 && cout_total >= cout_p, "pw_pack_conv_weight: packed Cin and cout_total must be multiples of 32");
+  PW_CHECK_ARG(!wino || ksize == 3, "pw_pack_conv_weight: the Winograd layout is for 3x3x3 weights");
+  hipStream_t st = pw_stream(stream);
+  if (wino) {
+    const size_t total = (size_t)cin_p * 64 * cout_total;
+    hipLaunchKernelGGL(k_pack_conv_weight_wino, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, st, w, Cout, Cin, flip_t,
+                       cout_total, cin_p, out);
+  } else {
+    const size_t total = (size_t)cin_p * ksize * ksize * ksize * cout_total;
+    hipLaunchKernelGGL(k_pack_conv_weight, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, st, w, Cout, Cin, ksize, flip_t,
+                       cout_total, cin_p, out);
+  }
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

@@ -37,16 +37,33 @@ def _cl(t, name):
 
 
 # ------------------------------------------------------------------------------ raw ops
-def _conv_fwd(x, w, stride):
-    """bias-free conv of channels-last x with torch-layout w on the fp32 inference kernels: Winograd F(2x2x2,3x3x3) where the
-    module stack uses it (3x3x3 stride 1, enough tiles; PW_CONV_WINO=0 / PW_TRAIN_WINO=0 keep the direct MFMA kernel), else direct"""
+def pack_weight(w, wino, flip_t=False):
+    """ops.pack_conv_weight(w) / ops.pack_conv_weight_wino(w) -- or, with flip_t, of w.flip(2, 3, 4).transpose(0, 1) -- in one
+    launch (pw_pack_conv_weight): training re-packs every weight every step, and as a dozen torch ops per pack that made the eager
+    step host-bound."""
+    Cout, Cin, k = w.shape[0], w.shape[1], w.shape[2]
+    cout_p, cin_p = (Cin, Cout) if flip_t else (Cout, Cin)
+    cout_total = (cout_p + 31) // 32 * 32
+    if wino:
+        out = torch.empty(cin_p // 32, 64, cout_total // 16, 64, 8, device=w.device, dtype=_f32)
+    else:
+        out = torch.empty(cin_p // 32, k ** 3, cout_total // 32, 64, 16, device=w.device, dtype=_f32)
+    _lib.call('pw_pack_conv_weight', ops._p(_cl(w.detach().contiguous(), 'w')), Cout, Cin, k, int(bool(flip_t)), cout_total, ops._p(out),
+              int(bool(wino)), ops._stream())
+    return out
+
+
+def _conv_fwd(x, w, stride, flip_t=False):
+    """bias-free conv of channels-last x with torch-layout w (or, flip_t, with w.flip(2,3,4).transpose(0,1): the stride-1 data
+    gradient) on the fp32 inference kernels: Winograd F(2x2x2,3x3x3) where the module stack uses it (3x3x3 stride 1, enough tiles;
+    PW_CONV_WINO=0 / PW_TRAIN_WINO=0 keep the direct MFMA kernel), else direct"""
     import os
     from .modules import _use_wino
-    k, cout = w.shape[2], w.shape[0]
+    k, cout = w.shape[2], (w.shape[1] if flip_t else w.shape[0])
     cout_total = (cout + 31) // 32 * 32
     if os.environ.get('PW_TRAIN_WINO', '1') != '0' and _use_wino(x, cout_total, k, stride):
-        return ops.conv3d_wino(x, ops.pack_conv_weight_wino(w), cout0=cout)
-    return ops.conv3d_ndhwc(x, ops.pack_conv_weight(w), cout0=cout, ksize=k, stride=stride)
+        return ops.conv3d_wino(x, pack_weight(w, True, flip_t), cout0=cout)
+    return ops.conv3d_ndhwc(x, pack_weight(w, False, flip_t), cout0=cout, ksize=k, stride=stride)
 
 
 def conv3d_raw(x, w, stride=1):
@@ -66,8 +83,7 @@ def conv3d_dgrad(dy, w, x_shape, stride=1):
     if stride == 1:
         if Cout % 32:
             raise _lib.PreworldHipError('conv3d_dgrad: Cout %% 32 == 0 expected (encoder layers)')
-        wt = w.detach().flip(2, 3, 4).transpose(0, 1).contiguous() if k == 3 else w.detach().transpose(0, 1).contiguous()
-        return _conv_fwd(_cl(dy, 'dy'), wt, 1)
+        return _conv_fwd(_cl(dy, 'dy'), w, 1, flip_t=True)
     if stride != 2 or k not in (2, 3):
         raise _lib.PreworldHipError('conv3d_dgrad: only stride 1 (k 1 | 3), 3x3x3 stride 2 and 2x2x2 stride 2 are built')
     if k == 3 and Cout % 32 == 0 and Cin % 32 == 0 and _DGRAD_S2 != 'valu':
@@ -76,7 +92,7 @@ def conv3d_dgrad(dy, w, x_shape, stride=1):
         # it in half the time of the plain-VALU kernel below (12 TFLOP/s): 748 -> ~400 us at the encoder's first down-sampling stage.
         dyd = torch.zeros(B, D, H, W, Cout, device=dy.device, dtype=_f32)
         dyd[:, ::2, ::2, ::2] = dy
-        return _conv_fwd(dyd, w.detach().flip(2, 3, 4).transpose(0, 1).contiguous(), 1)
+        return _conv_fwd(dyd, w, 1, flip_t=True)
     dx = torch.empty(B, D, H, W, Cin, device=dy.device, dtype=_f32)
     _lib.call('pw_conv3d_dgrad_s2' if k == 3 else 'pw_conv3d_dgrad_k2s2', ops._p(_cl(dy, 'dy')),
               ops._p(_cl(w.detach().permute(2, 3, 4, 0, 1).contiguous(), 'w')), ops._p(dx), B, D, H, W, Cin, Cout, ops._stream())
