@@ -738,30 +738,42 @@ __global__ void __launch_bounds__(256) k_pack_conv_weight(const float* __restric
 
 __global__ void __launch_bounds__(256) k_pack_conv_weight_wino(const float* __restrict__ w, int Cout_w, int Cin_w, int flip_t,
                                                                int cout_total, int cin_total, float* __restrict__ out) {
-  // out[ch][p][n16][g][j][s] = U[n16 * 16 + j][ch * 32 + g * 8 + s][p], U = G w' G^T along d, h, w (float64, rounded once)
+  // out[ch][p][n16][g][j][s] = U[n16 * 16 + j][ch * 32 + g * 8 + s][p], U = G w' G^T along d, h, w in float64, rounded once.
+  // One thread per (output channel n, input channel c): 27 loads, the transform one axis at a time (G = [1 0 0; .5 .5 .5;
+  // .5 -.5 .5; 0 0 1]: halvings and sums), 64 stores.  (One thread per OUTPUT element with the 27-term triple sum: 1.1 ms per step.)
   const int n16_n = cout_total / 16;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)cin_total * 64 * cout_total;
-  if (idx >= total) return;
-  size_t t = idx;
-  const int s = (int)(t & 7); t >>= 3;
-  const int j = (int)(t & 15); t >>= 4;
-  const int g = (int)(t & 3); t >>= 2;
-  const int n16 = (int)(t % n16_n); t /= n16_n;
-  const int p = (int)(t & 63);
-  const int ch = (int)(t >> 6);
-  const int n = n16 * 16 + j, c = ch * 32 + g * 8 + s;
-  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
-  const int pi = p >> 4, pj = (p >> 2) & 3, pk = p & 3;
-  double u = 0.0;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // c fastest: 8 consecutive threads write 32 contiguous bytes
+  if (idx >= (size_t)cin_total * cout_total) return;
+  const int c = (int)(idx % cin_total), n = (int)(idx / cin_total);
+  double t0[3][3][4];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
+    for (int b = 0; b < 3; ++b) {
+      const double w0 = packed_w(w, Cout_w, Cin_w, 3, flip_t, n, c, a, b, 0), w1 = packed_w(w, Cout_w, Cin_w, 3, flip_t, n, c, a, b, 1),
+                   w2 = packed_w(w, Cout_w, Cin_w, 3, flip_t, n, c, a, b, 2);
+      t0[a][b][0] = w0; t0[a][b][1] = 0.5 * ((w0 + w1) + w2); t0[a][b][2] = 0.5 * ((w0 - w1) + w2); t0[a][b][3] = w2;
+    }
+  double t1[3][4][4];
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc)
-        u += G[pi][a] * G[pj][b] * G[pk][cc] * (double)packed_w(w, Cout_w, Cin_w, 3, flip_t, n, c, a, b, cc);
-  out[idx] = (float)u;
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double w0 = t0[a][0][k], w1 = t0[a][1][k], w2 = t0[a][2][k];
+      t1[a][0][k] = w0; t1[a][1][k] = 0.5 * ((w0 + w1) + w2); t1[a][2][k] = 0.5 * ((w0 - w1) + w2); t1[a][3][k] = w2;
+    }
+  const int ch = c >> 5, g = (c >> 3) & 3, s8 = c & 7, n16 = n >> 4, j = n & 15;
+  float* dst = out + ((((size_t)ch * 64 * n16_n + n16) * 4 + g) * 16 + j) * 8 + s8;          // point 0; points are n16_n * 512 floats apart
+  const size_t pstride = (size_t)n16_n * 512;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double w0 = t1[0][jj][k], w1 = t1[1][jj][k], w2 = t1[2][jj][k];
+      const double u[4] = {w0, 0.5 * ((w0 + w1) + w2), 0.5 * ((w0 - w1) + w2), w2};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[(size_t)(i * 16 + jj * 4 + k) * pstride] = (float)u[i];
+    }
 }
 
 PW_API int pw_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, int flip_t, int cout_total, float* out, int wino,
@@ -772,7 +784,7 @@ PW_API int pw_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, int
   PW_CHECK_ARG(!wino || ksize == 3, "pw_pack_conv_weight: the Winograd layout is for 3x3x3 weights");
   hipStream_t st = pw_stream(stream);
   if (wino) {
-    const size_t total = (size_t)cin_p * 64 * cout_total;
+    const size_t total = (size_t)cin_p * cout_total;
     hipLaunchKernelGGL(k_pack_conv_weight_wino, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, st, w, Cout, Cin, flip_t,
                        cout_total, cin_p, out);
   } else {
