@@ -16,7 +16,7 @@ Kernels:
   * BatchNorm3d    : pw_bn_stats / pw_bn_apply / pw_bn_bwd_reduce / pw_bn_bwd_apply (batch statistics in double, running
                      statistics updated like nn.BatchNorm3d: momentum, unbiased variance, num_batches_tracked)
   * up-sampling    : pw_upsample_trilinear_add / pw_upsample_trilinear_adjoint
-Everything is fp32 channels-last (B, D, H, W, C); the per-voxel / per-sample dense layers are library GEMMs (torch.matmul /
+Everything is fp32 channels-last (B, D, H, W, C); the per-sample dense layers (and per-voxel ones of unusual width) are library GEMMs (torch.matmul /
 F.linear).  `ConvModule3d.forward_cl`, `BasicBlock3D.forward_cl`, `CustomResNet3D`, `LSSFPN3D`, `OccHead.forward` dispatch here
 when the module is in training mode; `PreWorld.forward_train` / `PreWorld4DTraj.forward_train` (detectors.py) compose them."""
 import torch
