@@ -553,59 +553,3 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
   PW_CHECK_LAUNCH();
   return PW_OK;
 }
-
-// Winograd F(2x2x2, 3x3x3) with SPLIT-FP16 operands in the transform domain (round 3): the wave-specialised kernel above with
-//   * the transformed input written to LDS as hi + lo halves of value / 8 and the transformed weights pre-split on the host
-//     (ops.pack_conv_weight_wino_h2): three v_mfma_f32_16x16x32_f16 per point and 32-channel chunk instead of eight fp32 MFMAs --
-//     0.89 executed MFMA-FLOPs per direct-form FLOP where the direct split-fp16 kernel executes 3;
-//   * x in h2 storage (fmt_x = 1: hi + lo joined by one v_fma_mix_f32 per channel as the transform role reads the halo) or fp32;
-//   * y0 / y1 in h2 storage under their range slots, or fp32.
-// Same error class as the direct split-fp16 form (tools/study_wino_h2.py; tests/test_gpu_encoder.py).  No residual input.
-PW_API int pw_conv3d_wino_h2(const float* x, int fmt_x, const float* uwpk, const float* scale, const float* bias, float* y0,
-                             float* y1, int B, int D, int H, int W, int Cin, int cout_total, int cout0, int cout1, int ld_y0,
-                             int ld_y1, int relu0, int relu1, int fmt_y0, int fmt_y1, const int32_t* x_rng, int32_t* y0_rng,
-                             int32_t* y1_rng, void* stream) {
-  PW_CHECK_ARG(x && uwpk && y0, "pw_conv3d_wino_h2: null pointer");
-  PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cin % KC == 0, "pw_conv3d_wino_h2: bad shape");
-  PW_CHECK_ARG(cout_total > 0 && cout_total % 32 == 0 && cout0 > 0 && cout0 <= cout_total && cout1 >= 0,
-               "pw_conv3d_wino_h2: bad cout split");
-  PW_CHECK_ARG(!(cout1 > 0 && !y1), "pw_conv3d_wino_h2: cout1 > 0 needs y1");
-  PW_CHECK_ARG((fmt_x == 0 || fmt_x == 1) && (fmt_y0 == 0 || fmt_y0 == 1) && (fmt_y1 == 0 || fmt_y1 == 1),
-               "pw_conv3d_wino_h2: formats are 0 (fp32) or 1 (h2)");
-  PW_CHECK_ARG(!(fmt_y0 && (cout0 % 32)) && !(fmt_y1 && cout1 && (cout1 % 32)), "pw_conv3d_wino_h2: h2 destinations need multiples of 32 channels");
-  ConvArgs a = {};
-  a.x = x; a.wpk = uwpk; a.scale = scale; a.bias = bias; a.y0 = y0; a.y1 = y1;
-  a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Do = D; a.Ho = H; a.Wo = W;
-  a.cout_total = cout_total; a.cout0 = cout0; a.cout1 = cout1;
-  a.ld0 = ld_y0 > 0 ? ld_y0 : cout0; a.ld1 = ld_y1 > 0 ? ld_y1 : cout1;
-  a.n1_start = (cout0 + 31) / 32 * 32;
-  a.relu0 = relu0; a.relu1 = relu1;
-  a.fmt_y0 = fmt_y0; a.fmt_y1 = fmt_y1;
-  a.x_rng = fmt_x ? x_rng : nullptr; a.y0_rng = y0_rng; a.y1_rng = y1_rng;
-  a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
-  PW_CHECK_ARG((size_t)B * D * H * W * Cin * 4 < (1ull << 32) &&
-                   (size_t)B * D * H * W * (a.ld0 > a.ld1 ? a.ld0 : a.ld1) * 4 < (1ull << 32),
-               "pw_conv3d_wino_h2: tensors must be < 4 GiB (32-bit buffer addressing)");
-  const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
-  const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
-  int NG = (cout_total % 64 == 0 && nblk * (cout_total / 64) >= 2ll * nb) ? 2 : 1;
-  if (const char* g = getenv("PW_WINO_NG")) NG = (atoi(g) == 2 && cout_total % 64 == 0) ? 2 : 1;
-  PipeArgs p = {};
-  p.ngroups = cout_total / (32 * NG);
-  PW_CHECK_ARG(nblk * p.ngroups < (1ll << 20), "pw_conv3d_wino_h2: too many work items");
-  p.n_items = (int)nblk * p.ngroups;
-  p.m_ng = magic_of(p.ngroups); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
-#define PW_WINO_H2(NGv, INv)                                                                                        \
-  do {                                                                                                              \
-    static int once = set_lds_limit(k_conv3d_wino_ws<NGv, true, INv>, WINO_LDS + 16384);                             \
-    if (once) return once;                                                                                          \
-    hipLaunchKernelGGL((k_conv3d_wino_ws<NGv, true, INv>), dim3(nb), dim3(512), WINO_LDS + 16384, pw_stream(stream), a, p, \
-                       cout_total / 16);                                                                            \
-    pw_note_kernel("k_conv3d_wino_ws<%d, true, %s>", NGv, INv ? "true" : "false");                                 \
-  } while (0)
-  if (NG == 1) { if (fmt_x) PW_WINO_H2(1, true); else PW_WINO_H2(1, false); }
-  else { if (fmt_x) PW_WINO_H2(2, true); else PW_WINO_H2(2, false); }
-#undef PW_WINO_H2
-  PW_CHECK_LAUNCH();
-  return PW_OK;
-}

@@ -1,6 +1,6 @@
-"""EXPERIMENT: Winograd F(2x2x2,3x3x3) with split-fp16 operands in the transform domain (PW_WINO_F16=1, the
-wave-specialised kernel, fp32 input) next to the fp32 Winograd kernel and today's direct split-fp16 kernel: error against a
-float64 torch conv on a sub-volume, and sustained time per launch."""
+"""Winograd F(2x2x2,3x3x3) with split-fp16 operands on 32x32x16 MFMA tiles (pw_conv3d_wino_h2) next to the fp32 Winograd kernel
+and the direct split-fp16 kernel at the three full-resolution layer shapes: error against a float64 torch conv on two sub-volumes,
+and sustained time per launch."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -56,14 +56,16 @@ for cin, cout in ((32, 32), (32, 64), (64, 64)):
     f32 = lambda: ops.conv3d_wino(x, uw, sc, bi, relu0=False, out0=y)
     f32(); res['wino fp32'] = (err(y), timeit(f32))
     uwh, mul = ops.pack_conv_weight_wino_h2(w)
-    f16 = lambda: ops.conv3d_wino_h2(x, uwh, sc * mul, bi, out0=y, out_h2=(False, False))
-    f16(); res['wino h2 (f32 in, f32 out)'] = (err(y), timeit(f16))
     xh = ops.f32_to_h2(x)
     f16b = lambda: ops.conv3d_wino_h2(xh, uwh, sc * mul, bi, out0=y, out_h2=(False, False))
     f16b(); res['wino h2 (h2 in, f32 out)'] = (err(y), timeit(f16b))
-    yh = ops.H2(torch.empty(B, D, H, W, cout, device=DEV), ops.new_slot(DEV) if hasattr(ops, 'new_slot') else None)
+    yh = ops.H2(torch.empty(B, D, H, W, cout, device=DEV), ops.new_slot(DEV))
     f16c = lambda: ops.conv3d_wino_h2(xh, uwh, sc * mul, bi, out0=yh, out_h2=(True, True))
     f16c(); res['wino h2 (h2 in, h2 out)'] = (err(ops.h2_to_f32(yh)), timeit(f16c))
+    if cout == 32:
+        rr = ops.H2(torch.randn(B, D, H, W, cout, device=DEV), ops.new_slot(DEV))
+        f16d = lambda: ops.conv3d_wino_h2(xh, uwh, sc * mul, bi, residual=rr, relu0=True, out0=rr, out_h2=(True, True))
+        res['wino h2 (h2 in, h2 out, in-place residual)'] = (float('nan'), timeit(f16d))
     yd = ops.H2(torch.empty(B, D, H, W, cout, device=DEV), ops.new_slot(DEV))
     wpk0, inv0 = ops.pack_conv_weight_h2(w)
     h2b = lambda: ops.conv3d_h2(xh, wpk0, sc * inv0, bi, out0=yd, out_h2=(True, True))
