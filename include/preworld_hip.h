@@ -237,21 +237,6 @@ int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, const flo
                  int ld_y0, int ld_y1, int ksize, int stride, int relu0, int relu1, int algo, int fmt_y0, int fmt_y1,
                  int fmt_res, const int32_t* x_rng, const int32_t* res_rng, int32_t* y0_rng, int32_t* y1_rng, void* stream);
 
-/* Winograd F(2x2x2, 3x3x3) form of pw_conv3d_h2's 3x3x3 stride-1 case: three fp16 MFMAs (32x32x16) per transform-domain point,
- * k-step and 32-column group -- 0.89 executed MFMA-FLOPs per direct-form FLOP instead of 3.  Replaces the same torch
- * Conv3d(+BN eval)(+residual)(+ReLU) compositions (mmdet3d/models/backbones/resnet.py:88-184: conv1 + downsample of a BasicBlock3D
- * as one 2 x Cout pass, conv2 with the in-place residual; detectors/preworld.py:72-79 final_conv).  cout_total = 32 or 64.
- *   x       (B, D, H, W, Cin), fmt_x 0 = fp32, 1 = h2 storage under x_rng;
- *   uwpk    transform-domain weights float[Cin/32][64 points][cout_total/32][4 pieces][64 lanes][4]: piece q = 2*ks + p of lane l
- *           (i = l & 31, kg = l >> 5) holds the 8 halves plane p of S[n] * (G w G^T)[n = 32*g + i][c = ch*32 + 16*kg + 8*ks + 0..7][point]
- *           (preworld_amd.ops.pack_conv_weight_wino_h2); scale[n] must carry 8 / S[n] (the kernel stores the transformed input / 8);
- *   residual  NULL or y0's layout and format (fmt_res == fmt_y0; may be y0 itself), added before the ReLU;
- *   y0 / y1, cout0 / cout1 (multiples of 32, cout0 + cout1 == cout_total), ld_y0 / ld_y1, relu0 / relu1, fmt_*, range slots: as
- *   pw_conv3d_h2. */
-int pw_conv3d_wino_h2(const float* x, int fmt_x, const float* uwpk, const float* scale, const float* bias, const float* residual,
-                      float* y0, float* y1, int B, int D, int H, int W, int Cin, int cout_total, int cout0, int cout1, int ld_y0,
-                      int ld_y1, int relu0, int relu1, int fmt_y0, int fmt_y1, int fmt_res, const int32_t* x_rng,
-                      const int32_t* res_rng, int32_t* y0_rng, int32_t* y1_rng, void* stream);
 
 /* A11  OccHead fused (mmdet3d/models/heads/occupancy_head.py:124-177, num_level=1,
  * use_deblock=False): conv3x3x3 Cin->16 + BN + ReLU, 1x1x1 16->8 + BN + ReLU, 1x1x1 8->18,

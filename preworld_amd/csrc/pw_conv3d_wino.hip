@@ -21,7 +21,6 @@
 //     8) outputs it contributes to -- 8 x 4 accumulator registers per lane hold the whole output tile;
 //   * epilogue = the direct kernels' (scale/bias, residual, ReLU, two destinations, row stride).
 #include "pw_wino_common.h"
-#include "pw_h2.h"
 
 // Points are processed a ROW (4 points = 4 independent MFMA chains, interleaved) at a time; the operands
 // of the next row are requested before this row's MFMAs, and the output transform of a row's products is
@@ -110,13 +109,9 @@ __device__ __forceinline__ void wino_chunk(const WinoCtx& c, unsigned r_base, un
 }
 
 // scale/bias, residual, ReLU and the two destinations for the wave's 16 tiles (d-pair mh) x 16 couts (half nh)
-// re (split-fp16 Winograd): destinations may be in h2 storage (a.fmt_y0 / a.fmt_y1); scb then already carries the range factors
-// and the largest stored magnitude per destination is recorded in *re
-// stage (with re): 4 KB of LDS owned by this wave -- an h2 destination is written through it as whole 16-byte slots (below)
 template <int NG>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y)[NG][8], int b, int d0, int h0, int w0,
-                                              int mh, int nh, int lane, int ng0 = 0, const float* scb = nullptr,
-                                              RngEpi* re = nullptr, float* stage = nullptr) {
+                                              int mh, int nh, int lane, int ng0 = 0, const float* scb = nullptr) {
   // ---- epilogue: lane holds cout l&15 for tiles (l>>4)*4 + r of its half; output o = (od, oh, ow)
   // scb: {scale, bias} per column group already in registers (the persistent kernel requests them at the start of the
   // tile, a global-load latency before they are needed)
@@ -150,43 +145,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y
         const int od = d0 + 2 * mh + (o >> 2), oh = (o >> 1) & 1, ow = o & 1;
         so[o] = (unsigned)((((b * a.Do + od) * a.Ho + h0 + oh) * a.Wo + w0 + ow) * ld) * 4u;
       }
-      if (re && (to_y0 ? a.fmt_y0 : a.fmt_y1)) {
-        // h2 destination.  The accumulator layout gives a lane ONE output channel of 32 voxels; an h2 slot is 8 consecutive
-        // channels of one voxel (two-byte stores straight from the registers: +21 us on the 64 -> 64 layer).  So the finished
-        // values of four outputs x 16 tiles x 16 channels go through the wave's 4 KB of LDS as [voxel][16 channels] rows --
-        // voxel row = ol * 16 + r * 4 + g, so that the four lane groups g write four consecutive rows = 64 banks -- and come
-        // back as 8 channels of one voxel per lane: split, two 16-byte stores.  Wave-local: LDS operations of a wave execute
-        // in program order, no barrier.
-        const int g = lane >> 4, j = lane & 15;
-        float am = 0.f;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-          for (int ol = 0; ol < 4; ++ol)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(ol * 16 + r * 4 + g) * 16 + j] = fmaxf(Y[ng][4 * hf + ol][r] * sc + bi, lo);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int item = lane + 64 * i, v = item >> 1, hg = item & 1;
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(stage + v * 16 + hg * 8);
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(stage + v * 16 + hg * 8 + 4);
-            const int ol = v >> 4, r = (v >> 2) & 3, gg = v & 3, o = 4 * hf + ol;
-            const int od = d0 + 2 * mh + (o >> 2), oh = h0 + 2 * gg + ((o >> 1) & 1), ow = w0 + 2 * r + (o & 1);
-            const unsigned voff = (unsigned)((((b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * ld) * 4u + (unsigned)h2_elem_off(col0 + 8 * hg);
-            const float v8[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v8[e]));
-            h8 o_hi, o_lo;
-            h2_split8(v8, o_hi, o_lo);
-            const v4f wh = __builtin_bit_cast(v4f, o_hi), wl = __builtin_bit_cast(v4f, o_lo);
-            const float va[4] = {wh[0], wh[1], wh[2], wh[3]}, vb[4] = {wl[0], wl[1], wl[2], wl[3]};
-            buf_store4(yr, voff, 0u, va);
-            buf_store4(yr, voff + 16u, 0u, vb);
-          }
-        }
-        if (to_y0) re->amax0 = fmaxf(re->amax0, am); else re->amax1 = fmaxf(re->amax1, am);
-        continue;
-      }
       float rv[8][4];
       if (has_res) {
 #pragma unroll
@@ -211,7 +169,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y
           const int od = d0 + 2 * mh + (o >> 2), oh = h0 + 2 * tth_e + ((o >> 1) & 1), ow = w0 + 2 * r + (o & 1);
           if (od < a.Do && oh < a.Ho && ow < a.Wo) {
             const size_t vox = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-            store_out(a, n, vox, Y[ng][o][r] * sc + bi, re);
+            store_out(a, n, vox, Y[ng][o][r] * sc + bi);
           }
         }
     }
@@ -324,14 +282,13 @@ __device__ __forceinline__ void ws_load_a(const WinoCtx& c, f32x4 (&aq)[4][2]) {
     for (int q = 0; q < 2; ++q) aq[k][q] = lds_read4(c.lds3, c.a_addr[q] + WsRow<R, NG>::a_off + (unsigned)k * 4096u);
 }
 
-// F16: a 2048-byte block = planes {hi, lo} x 64 lanes x 8 halves (lane_off = lane * 16, the plane 1024 bytes on)
-template <int R, int NG, bool F16 = false>
+template <int R, int NG>
 __device__ __forceinline__ void ws_load_b(const WinoCtx& c, unsigned ubase, f32x4 (&bq)[4][2]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const float4 w = buf_load4(c.wr, c.lane_off + (unsigned)(q * (F16 ? 1024 : 16)),
+      const float4 w = buf_load4(c.wr, c.lane_off + (unsigned)(q * 16),
                                  ubase + (WsRow<R, NG>::point + (unsigned)k) * c.ustep + (unsigned)WsRow<R, NG>::ng * 4096u);
       bq[k][q] = f32x4{w.x, w.y, w.z, w.w};
     }
@@ -340,7 +297,7 @@ __device__ __forceinline__ void ws_load_b(const WinoCtx& c, unsigned ubase, f32x
 // rows R .. 16 NG - 1 of one chunk; bc holds row R's weights on entry; on exit of the last row bc/ac of the
 // CALLER hold the first row of the next chunk (ubase_next) again -- the row count is even, so the ping-pong
 // ends where it started
-template <int R, int NG, bool F16 = false>
+template <int R, int NG>
 __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsigned ubase_next, f32x4 (&ac)[4][2],
                                         f32x4 (&bc)[4][2], f32x4 (&an)[4][2], f32x4 (&bn)[4][2], f32x4 (&Mp)[4],
                                         f32x4 (&Y)[NG][8]) {
@@ -352,34 +309,15 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
   f32x4 (&acur)[4][2] = NG == 1 ? ac : (W::ng == 0 ? ac : an);
   if constexpr (NG == 1 ? W::first : W::ng == 0) ws_load_a<R, NG>(c, acur);
   if constexpr (R + 1 < TOTAL) {
-    ws_load_b<R + 1, NG, F16>(c, ubase, bn);
+    ws_load_b<R + 1, NG>(c, ubase, bn);
     if constexpr (NG == 1 && !W::last) ws_load_a<R + 1, NG>(c, an);
   } else {
-    ws_load_b<0, NG, F16>(c, ubase_next, bn);
+    ws_load_b<0, NG>(c, ubase_next, bn);
   }
-  // fp32: a row's 32 MFMAs of 64 cycles hide the load issue in front of them.  F16: the 12 MFMAs of a row are 192 cycles and the
-  // 16 loads in front of them ~500 -- the row is ONE scheduling region and the loads / the previous row's output transform are
-  // spread over the MFMA shadows (below), like a tap of k_conv3d_h2
-  if constexpr (!(F16 && NG == 1)) __builtin_amdgcn_sched_barrier(0);      // (NG 2 as one region: 150 -> 170 us at 32 -> 64, measured)
+  __builtin_amdgcn_sched_barrier(0);
   f32x4 M[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) M[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (F16) {
-    // one v_mfma_f32_16x16x32_f16 covers the whole 32-channel chunk: hi.hi, hi_v.lo_u, lo_v.hi_u
-    typedef _Float16 wh8 __attribute__((ext_vector_type(8)));
-    wh8 vh[4], vl[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      vh[k] = __builtin_bit_cast(wh8, f32x4{acur[k][0][0], acur[k][0][1], acur[k][1][0], acur[k][1][1]});
-      vl[k] = __builtin_bit_cast(wh8, f32x4{acur[k][0][2], acur[k][0][3], acur[k][1][2], acur[k][1][3]});
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) M[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[k], __builtin_bit_cast(wh8, bc[k][0]), M[k], 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) M[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[k], __builtin_bit_cast(wh8, bc[k][1]), M[k], 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) M[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[k], __builtin_bit_cast(wh8, bc[k][0]), M[k], 0, 0, 0);
-  } else {
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -387,30 +325,18 @@ __device__ __forceinline__ void ws_rows(const WinoCtx& c, unsigned ubase, unsign
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         M[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[k][q][e], bc[k][q][e], M[k], 0, 0, 0);
-  }
   if constexpr (R >= 1) {
     typedef WsRow<R - 1, NG> P;
     wino_scatter_row<P::ID, P::IH>(Mp, Y[P::ng]);               // the previous row's products, under this row's MFMAs
-  }
-  if constexpr (F16 && NG == 1) {
-    constexpr bool own_a = NG == 1 ? W::first : W::ng == 0;     // this row's V fragments are read by this row itself
-    if constexpr (own_a) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      if (!own_a && i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 4; ++k) Mp[k] = M[k];
   if constexpr (W::last) __syncthreads();                       // end of the half-step
-  if constexpr (R + 1 < TOTAL) ws_rows<R + 1, NG, F16>(c, ubase, ubase_next, an, bn, ac, bc, Mp, Y);
+  if constexpr (R + 1 < TOTAL) ws_rows<R + 1, NG>(c, ubase, ubase_next, an, bn, ac, bc, Mp, Y);
 }
 
-template <int NG, bool F16 = false, bool H2IN = false>
+template <int NG>
 __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs p, int n16_total) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -424,15 +350,12 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
   const lds3_t lds3 = (lds3_t)lds;
 
   if (wave >= 4) {
-    ws_transform_role<F16, H2IN>(a, p, lds3, item, it_end, nslots, nchunk, wave - 4, tid - 256, lane);
+    ws_transform_role(a, p, lds3, item, it_end, nslots, nchunk, wave - 4, tid - 256, lane);
     return;
   }
 
   // -------------------------------------------------------------------- GEMM + output transform role
   const int mh = wave & 1, nh = wave >> 1;            // tile half (d-pair) and cout half of this wave
-  RngScale rs = {0, 0, 1.f, 1.f, 1.f, 1.f, 1.f};      // split-fp16 Winograd: range exponents of x / y0 / y1 (pw_h2.h "Range")
-  if constexpr (F16) rs = rng_scales(a);
-  RngEpi re = {1.f, 0.f, 0.f};
   WinoCtx c;
   c.lds3 = lds3;
   {
@@ -442,14 +365,14 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
       c.a_addr[q] = (unsigned)WINO_R_BYTES + (unsigned)(((mh * 16 + wino_row16(lt)) * 8 + ((g * 2 + q) ^ (lt & 7))) * 16);
   }
   c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 64 * n16_total * 2048));
-  c.lane_off = (unsigned)lane * (F16 ? 16u : 32u);
+  c.lane_off = (unsigned)lane * 32u;
   c.ustep = (unsigned)n16_total * 2048u;
   const unsigned chunk_bytes = 64u * c.ustep;
   f32x4 a0[4][2], a1[4][2], b0[4][2], b1[4][2], Mp[4];
   // work item = (tile, group of NG x 32 couts); the group's weights start (group * 2 NG + nh) n16-blocks in
   PipeTile t = pipe_decode(a, p, item);
   unsigned gbase = (unsigned)((t.ng * 2 * NG + nh) * 2048);
-  ws_load_b<0, NG, F16>(c, gbase, b0);
+  ws_load_b<0, NG>(c, gbase, b0);
   __syncthreads();                                              // barrier A
   __syncthreads();                                              // barrier B
   for (; item < it_end; item += nslots) {
@@ -464,27 +387,17 @@ __global__ void __launch_bounds__(512, 1) k_conv3d_wino_ws(ConvArgs a, PipeArgs 
       const int n = (t.ng * NG + ng) * 32 + nh * 16 + (lane & 15);
       scb[2 * ng] = a.scale ? a.scale[n] : 1.f;
       scb[2 * ng + 1] = a.bias ? a.bias[n] : 0.f;
-      if constexpr (F16) {
-        const bool to_y0 = (t.ng * NG + ng) * 32 + nh * 16 < a.cout0;
-        scb[2 * ng] *= to_y0 ? rs.s0 : rs.s1;
-        scb[2 * ng + 1] *= to_y0 ? rs.b0 : rs.b1;
-      }
     }
     const PipeTile tn = pipe_decode(a, p, item + nslots < it_end ? item + nslots : item);
     const unsigned gnext = (unsigned)((tn.ng * 2 * NG + nh) * 2048);
     for (int ch = 0; ch < nchunk; ++ch) {
       const unsigned ubase = (unsigned)ch * chunk_bytes + gbase;
       const unsigned unext = ch + 1 < nchunk ? (unsigned)(ch + 1) * chunk_bytes + gbase : gnext;
-      ws_rows<0, NG, F16>(c, ubase, unext, a0, b0, a1, b1, Mp, Y);
+      ws_rows<0, NG>(c, ubase, unext, a0, b0, a1, b1, Mp, Y);
       wino_scatter_row<3, 3>(Mp, Y[NG - 1]);
     }
-    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane, t.ng * NG, scb, F16 ? &re : nullptr,
-                      F16 ? lds + (WINO_LDS + wave * 4096) / 4 : nullptr);
+    wino_epilogue<NG>(a, Y, t.b, t.d0, t.h0, t.w0, mh, nh, lane, t.ng * NG, scb);
     t = tn; gbase = gnext;
-  }
-  if constexpr (F16) {
-    if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(re.amax0), rs.e0);
-    if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(re.amax1), rs.e1);
   }
 }
 

@@ -98,32 +98,7 @@ __device__ __forceinline__ void wino_lane_offsets(const ConvArgs& a, int w0, int
 // resp. ID 0) and kept in registers (P1, P2: 2 x 16 float4), so a tile's 4x4x4 patch is read from LDS exactly once
 // per chunk (64 ds_read_b128 per thread instead of 128) -- LDS bandwidth, not the matrix pipe, is the busiest unit of
 // these kernels (R reads + V writes + A reads + halo DMA: ~1 MB per tile and chunk at 128 B/clk).
-// one (voxel, channel quad) of the raw halo as 4 fp32 values.  H2IN: the halo holds split-fp16 storage (pw_h2.h) -- `off` then
-// points at the quad's 4 hi halves, its 4 lo halves sit one 16-byte slot on; value = hi + lo, one v_fma_mix_f32 per channel
-template <bool H2IN>
-__device__ __forceinline__ f32x4 wino_read_quad(lds3_t lds3, unsigned off) {
-  if constexpr (!H2IN) {
-    return lds_read4(lds3, off);
-  } else {
-    // (spelled out: hipcc turns (float)hi * 1 + (float)lo into two converts and an add, three instructions per channel)
-    typedef unsigned wu2 __attribute__((ext_vector_type(2)));
-    const wu2 hi = *reinterpret_cast<const __attribute__((address_space(3))) wu2*>(lds3 + off);
-    const wu2 lo = *reinterpret_cast<const __attribute__((address_space(3))) wu2*>(lds3 + off + 16u);
-    f32x4 r;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r.x) : "v"(hi.x), "v"(lo.x));
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r.y) : "v"(hi.x), "v"(lo.x));
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r.z) : "v"(hi.y), "v"(lo.y));
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r.w) : "v"(hi.y), "v"(lo.y));
-    return r;
-  }
-}
-// byte offset of channel quad q (channels 4 q .. 4 q + 3) inside a voxel's 128-byte chunk: fp32, or the hi halves in h2 storage
-template <bool H2IN>
-__device__ __forceinline__ unsigned wino_quad_off(int q) {
-  return H2IN ? (unsigned)((4 * ((q >> 1) & 1) + 2 * (q >> 2)) * 16 + (q & 1) * 8) : (unsigned)(q * 16);
-}
-
-template <int ID, bool H2IN = false>
+template <int ID>
 __device__ __forceinline__ void ws_transform_read(lds3_t lds3, unsigned r_base, f32x4 (&y)[4][4], f32x4 (&P1)[4][4],
                                                   f32x4 (&P2)[4][4]) {
 #pragma unroll
@@ -132,17 +107,17 @@ __device__ __forceinline__ void ws_transform_read(lds3_t lds3, unsigned r_base, 
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh) {
       if constexpr (ID == 0) {
-        const f32x4 p0 = wino_read_quad<H2IN>(lds3, r_base + (unsigned)(((0 * TH + hh) * TW + ww) * 128));
-        P2[hh][ww] = wino_read_quad<H2IN>(lds3, r_base + (unsigned)(((2 * TH + hh) * TW + ww) * 128));
+        const f32x4 p0 = lds_read4(lds3, r_base + (unsigned)(((0 * TH + hh) * TW + ww) * 128));
+        P2[hh][ww] = lds_read4(lds3, r_base + (unsigned)(((2 * TH + hh) * TW + ww) * 128));
         x[hh] = sub4(p0, P2[hh][ww]);
       } else if constexpr (ID == 1) {
-        P1[hh][ww] = wino_read_quad<H2IN>(lds3, r_base + (unsigned)(((1 * TH + hh) * TW + ww) * 128));
+        P1[hh][ww] = lds_read4(lds3, r_base + (unsigned)(((1 * TH + hh) * TW + ww) * 128));
         x[hh] = add4(P1[hh][ww], P2[hh][ww]);
       } else if constexpr (ID == 2) {
         x[hh] = sub4(P2[hh][ww], P1[hh][ww]);
         // d2 is dead from here on: its registers take plane d3 now, in a step where this role has slack, so that the
         // last read of R happens two half-steps before the halo DMA of the next tile needs the buffer
-        P2[hh][ww] = wino_read_quad<H2IN>(lds3, r_base + (unsigned)(((3 * TH + hh) * TW + ww) * 128));
+        P2[hh][ww] = lds_read4(lds3, r_base + (unsigned)(((3 * TH + hh) * TW + ww) * 128));
       } else {
         x[hh] = sub4(P1[hh][ww], P2[hh][ww]);                 // P2 holds plane d3 (loaded by the ID 2 call)
       }
@@ -151,24 +126,12 @@ __device__ __forceinline__ void ws_transform_read(lds3_t lds3, unsigned r_base, 
   }
 }
 
-// F16 (split-fp16 Winograd, k_conv3d_wino_ws<NG, true, ..>): a transformed quad of 4 channels is stored as [4 hi halves | 4 lo halves] of value / 8 in the
-// SAME 16-byte slot -- the GEMM lane's two slots then hold hi and lo of its 8 channels, regrouped by register naming alone
-__device__ __forceinline__ f32x4 wino_split_slot(const f32x4& z) {
-  typedef _Float16 wh2 __attribute__((ext_vector_type(2)));
-  const f32x2 a = {z.x * 0.125f, z.y * 0.125f}, b = {z.z * 0.125f, z.w * 0.125f};
-  const wh2 ha = __builtin_convertvector(a, wh2), hb = __builtin_convertvector(b, wh2);
-  const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
-  const wh2 la = __builtin_convertvector(ra, wh2), lb = __builtin_convertvector(rb, wh2);
-  return f32x4{__builtin_bit_cast(float, ha), __builtin_bit_cast(float, hb), __builtin_bit_cast(float, la), __builtin_bit_cast(float, lb)};
-}
-
-template <int HH, bool F16 = false>       // w transform of rows i_h = 2 HH, 2 HH + 1 -> V[HH] (8 points)
+template <int HH>       // w transform of rows i_h = 2 HH, 2 HH + 1 -> V[HH] (8 points)
 __device__ __forceinline__ void ws_transform_write(lds3_t lds3, unsigned v_base, const f32x4 (&y)[4][4]) {
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     f32x4 z0, z1, z2, z3;
     bt4(y[2 * HH + r][0], y[2 * HH + r][1], y[2 * HH + r][2], y[2 * HH + r][3], z0, z1, z2, z3);
-    if constexpr (F16) { z0 = wino_split_slot(z0); z1 = wino_split_slot(z1); z2 = wino_split_slot(z2); z3 = wino_split_slot(z3); }
     const unsigned o = (unsigned)WINO_R_BYTES + (unsigned)HH * 32768u + v_base + (unsigned)(r * 4) * 4096u;
     lds_write4(lds3, o, z0);
     lds_write4(lds3, o + 4096u, z1);
@@ -180,12 +143,11 @@ __device__ __forceinline__ void ws_transform_write(lds3_t lds3, unsigned v_base,
 // The transform + DMA role of the wave-specialised kernels (4 waves, tw = 0..3, tt = thread 0..255 = (tile, channel
 // quad)): runs one half-step ahead of the GEMM waves, see pw_conv3d_wino.hip.  Two barriers of prologue, then 8 per
 // (work item, 32-channel chunk), one per half-step; consecutive items of a block are item, item + nslots, ... < it_end.
-template <bool F16 = false, bool H2IN = false>
 __device__ __forceinline__ void ws_transform_role(const ConvArgs& a, const PipeArgs& p, lds3_t lds3, int item, int it_end,
                                                   int nslots, int nchunk, int tw, int tt, int lane) {
   const int tile = tt >> 3, quad = tt & 7;
   const int ttd = tile >> 4, tth = (tile >> 2) & 3, ttw = tile & 3;
-  const unsigned r_base = (unsigned)((((2 * ttd) * TH + 2 * tth) * TW + 2 * ttw) * 128) + wino_quad_off<H2IN>(quad);
+  const unsigned r_base = (unsigned)((((2 * ttd) * TH + 2 * tth) * TW + 2 * ttw) * 128) + (unsigned)(quad * 16);
   const int t16 = tile & 15;
   const unsigned v_base = (unsigned)(((ttd * 16 + wino_row16(t16)) * 8 + (quad ^ (t16 & 7))) * 16);
   const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
@@ -227,35 +189,35 @@ __device__ __forceinline__ void ws_transform_role(const ConvArgs& a, const PipeA
   dma();
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                                            // barrier A: R of the first chunk
-  ws_transform_read<0, H2IN>(lds3, r_base, y, P1, P2);
-  ws_transform_write<0, F16>(lds3, v_base, y);
+  ws_transform_read<0>(lds3, r_base, y, P1, P2);
+  ws_transform_write<0>(lds3, v_base, y);
   __syncthreads();                                            // barrier B: half-step 0 in V[0]
   for (; item < it_end; item += nslots) {
     for (int ch = 0; ch < nchunk; ++ch) {
       const bool more_ch = ch + 1 < nchunk;
       const bool has_next = more_ch || item + nslots < it_end;
-      ws_transform_write<1, F16>(lds3, v_base, y); __syncthreads();                                       // step 0
-      ws_transform_read<1, H2IN>(lds3, r_base, y, P1, P2); ws_transform_write<0, F16>(lds3, v_base, y); __syncthreads();  // step 1
-      ws_transform_write<1, F16>(lds3, v_base, y); __syncthreads();                                       // step 2
-      ws_transform_read<2, H2IN>(lds3, r_base, y, P1, P2); ws_transform_write<0, F16>(lds3, v_base, y); __syncthreads();  // step 3
+      ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 0
+      ws_transform_read<1>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 1
+      ws_transform_write<1>(lds3, v_base, y); __syncthreads();                                       // step 2
+      ws_transform_read<2>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y); __syncthreads();  // step 3
       // step 4 (light): the next tile's decode is done here, off the DMA step's critical path -- a wave that shares its SIMD
       // with an MFMA stream issues roughly one instruction per 14 cycles, so WHERE its instructions sit decides who waits
-      ws_transform_write<1, F16>(lds3, v_base, y);
+      ws_transform_write<1>(lds3, v_base, y);
       if (has_next) aim(more_ch ? item : item + nslots, more_ch ? ch + 1 : 0);
       __syncthreads();
       // step 5: R was last read in step 3 (plane d3 is prefetched there), so the next chunk's / tile's halo DMA goes out
       // now and has steps 5 and 6 (~6 k cycles; it needs ~3.5 k) to land before the step-6 barrier publishes it
       if (has_next) dma();
-      ws_transform_read<3, H2IN>(lds3, r_base, y, P1, P2); ws_transform_write<0, F16>(lds3, v_base, y);
+      ws_transform_read<3>(lds3, r_base, y, P1, P2); ws_transform_write<0>(lds3, v_base, y);
       // end of step 5 WITHOUT draining the DMA: __syncthreads() would (correctly, for a release fence) wait for vmcnt
       // because the in-flight buffer_load ... lds are LDS writes; only this wave's ds_writes must have landed here
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      ws_transform_write<1, F16>(lds3, v_base, y);                                                        // step 6
+      ws_transform_write<1>(lds3, v_base, y);                                                        // step 6
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (has_next) {                                                                                // step 7
-        ws_transform_read<0, H2IN>(lds3, r_base, y, P1, P2);
-        ws_transform_write<0, F16>(lds3, v_base, y);
+        ws_transform_read<0>(lds3, r_base, y, P1, P2);
+        ws_transform_write<0>(lds3, v_base, y);
       }
       __syncthreads();
     }

@@ -317,22 +317,6 @@ def _use_wino(x_cl, cout_total, ksize, stride):
     return B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) * (cout_total // 32) >= 128
 
 
-def _wino_h2_mode():
-    """PW_CONV_WINO_H2: 0 (default) = the direct split-fp16 kernel everywhere; 1 = the 64-column full-resolution layers (conv1 +
-    downsample of a BasicBlock3D as one pass) on the split-fp16 Winograd kernel (ops.conv3d_wino_h2); 2 = the
-    32-column 3x3x3 stride-1 layers as well."""
-    import os
-    return int(os.environ.get('PW_CONV_WINO_H2', '0'))
-
-
-def _use_wino_h2(x, cout_total, stride):
-    """the Winograd kernel takes 32 or 64 output columns at stride 1 and wants a grid that fills the 256 persistent blocks"""
-    if stride != 1 or cout_total not in (32, 64) or _wino_h2_mode() < (1 if cout_total == 64 else 2):
-        return False
-    B, D, H, W, _ = x.shape
-    return B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) >= 1024
-
-
 class _PackedCache:
     """Packed/folded weights are derived data: rebuilt lazily when parameters change."""
 
@@ -410,20 +394,6 @@ class ConvModule3d(nn.Module):
             return wpk, (sc * inv).contiguous(), bi
         return self._h2cache.get(params, build)
 
-    def folded_wino_h2(self):
-        """(transform-domain split-fp16 weight, scale * 8 / pre-scale, bias) for ops.conv3d_wino_h2."""
-        params = [self.conv.weight, self.conv.bias]
-        if self.with_norm:
-            params += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
-        if not hasattr(self, '_wh2cache'):
-            self._wh2cache = _PackedCache()
-
-        def build():
-            _, sc, bi = self.folded()
-            uw, mul = ops.pack_conv_weight_wino_h2(self.conv.weight)
-            return uw, (sc * mul).contiguous(), bi
-        return self._wh2cache.get(params, build)
-
     def _check_eval(self):
         if self.training and self.with_norm:
             raise NotImplementedError('this fused HIP path folds BatchNorm (eval mode); training mode goes through '
@@ -439,10 +409,6 @@ class ConvModule3d(nn.Module):
             from . import train
             return train.conv_bias_act_forward(self, as_f32(x_cl))
         self._check_eval()
-        if precision() == 'h2' and self.kernel_size == 3 and algo == 0 and _use_wino_h2(x_cl, self.out_channels, self.stride):
-            uw, sc, bi = self.folded_wino_h2()
-            return ops.conv3d_wino_h2(as_h2(x_cl), uw, sc, bi, residual=residual, cout0=self.out_channels,
-                                      relu0=self.with_activation, out_h2=(out_h2, out_h2))
         if precision() == 'h2' and self.kernel_size in (1, 3) and self.out_channels % 32 == 0 and algo in (0, 2, 3):
             wpk, sc, bi = self.folded_h2()
             return ops.conv3d_h2(as_h2(x_cl), wpk, sc, bi, residual=residual, cout0=self.out_channels,
@@ -514,23 +480,14 @@ class BasicBlock3D(nn.Module):
             if not hasattr(self, '_h2cache'):
                 self._h2cache = _PackedCache()
 
-            wino = c1.out_channels == 32 and ds.out_channels == 32 and ds.kernel_size == 3 and _use_wino_h2(x, 64, c1.stride)
-
             def build():
-                w1, s1, b1 = c1.folded_wino_h2() if wino else c1.folded_h2()
-                wd, sd, bd = ds.folded_wino_h2() if wino else ds.folded_h2()
+                w1, s1, b1 = c1.folded_h2()
+                wd, sd, bd = ds.folded_h2()
                 return (torch.cat([w1, wd], dim=2).contiguous(), torch.cat([s1, sd]).contiguous(),
                         torch.cat([b1, bd]).contiguous())
-            if wino:
-                if not hasattr(self, '_wh2cache'):
-                    self._wh2cache = _PackedCache()
-                uw, sc, bi = self._wh2cache.get(params, build)
-                y, identity = ops.conv3d_wino_h2(x, uw, sc, bi, cout0=32, cout1=32, relu0=True, relu1=False, out1=out,
-                                                 out_h2=(True, out_h2))
-            else:
-                wpk, sc, bi = self._h2cache.get(params, build)
-                y, identity = ops.conv3d_h2(x, wpk, sc, bi, cout0=c1.out_channels, cout1=ds.out_channels, relu0=True, relu1=False,
-                                            out1=out, ksize=3, stride=c1.stride, out_h2=(True, out_h2))
+            wpk, sc, bi = self._h2cache.get(params, build)
+            y, identity = ops.conv3d_h2(x, wpk, sc, bi, cout0=c1.out_channels, cout1=ds.out_channels, relu0=True, relu1=False,
+                                        out1=out, ksize=3, stride=c1.stride, out_h2=(True, out_h2))
         else:
             w1, s1, b1 = c1.folded_h2()
             y = ops.conv3d_h2(x, w1, s1, b1, cout0=c1.out_channels, relu0=True, ksize=3, stride=c1.stride, out_h2=(True, True))
@@ -541,10 +498,6 @@ class BasicBlock3D(nn.Module):
                 identity = ops.f32_to_h2(ops.h2_to_f32(x), out=out)
             else:
                 identity = ops.h2_to_f32(x, out=out.buf if isinstance(out, ops.H2) else out)
-        if out_h2 and _use_wino_h2(y, c2.out_channels, 1):
-            u2, s2, b2 = c2.folded_wino_h2()
-            return ops.conv3d_wino_h2(y, u2, s2, b2, residual=identity, cout0=c2.out_channels, relu0=True, out0=identity,
-                                      out_h2=(True, True))
         w2, s2, b2 = c2.folded_h2()
         return ops.conv3d_h2(y, w2, s2, b2, residual=identity, cout0=c2.out_channels, relu0=True, out0=identity,
                              out_h2=(out_h2, out_h2))

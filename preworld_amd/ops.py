@@ -379,90 +379,6 @@ def pack_conv_weight_wino(w, cout_total=None):
     return Up.view(nch, 64, n16, 64, 8).float().contiguous()
 
 
-def pack_conv_weight_wino_h2(w, cout_total=None):
-    """Transform-domain weights U = G w G^T of pw_conv3d_wino_h2 as split-fp16 A operands of v_mfma_f32_32x32x16_f16 -> (uwpk, mul):
-    float32-typed [Cin/32][64 points][cout_total/32][4 pieces x 64 lanes x 4]; piece q = 2 ks + p of lane l (i = l & 31, kg = l >> 5)
-    holds the 8 halves plane p of S[n] U[n = 32 g + i][c = ch*32 + 16 kg + 8 ks + 0..7][point]; mul (cout_total,) = 8 / S[n] to fold
-    into the epilogue scale (S: per-output-channel power of two; the kernel stores the transformed input / 8)."""
-    Cout, Cin = w.shape[:2]
-    if tuple(w.shape[2:]) != (3, 3, 3) or Cin % 32:
-        raise _lib.PreworldHipError('pack_conv_weight_wino_h2 expects (Cout, 32k, 3, 3, 3)')
-    if cout_total is None:
-        cout_total = (Cout + 31) // 32 * 32
-    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
-    U = torch.einsum('ia,jb,kc,oeabc->oeijk', G, G, G, w.double()).reshape(Cout, Cin, 64)
-    S = torch.exp2(torch.floor(torch.log2(1023.0 / U.abs().amax(dim=(1, 2)).clamp_min(1e-30))))
-    Up = U.new_zeros(cout_total, Cin, 64)
-    Up[:Cout] = U * S[:, None, None]
-    hi = Up.to(torch.float16)
-    lo = (Up - hi.double()).to(torch.float16)
-    ng, nch = cout_total // 32, Cin // 32
-    t = torch.stack([hi, lo], 0).view(2, ng, 32, nch, 2, 2, 8, 64)         # (plane, g, i, ch, kg, ks, e, point)
-    t = t.permute(3, 7, 1, 5, 0, 4, 2, 6).contiguous()                     # (ch, point, g, ks, plane, kg, i, e): piece-major
-    uwpk = t.view(nch, 64, ng, 4 * 64 * 8).view(torch.float32).view(nch, 64, ng, 1024).contiguous()
-    mul = torch.zeros(cout_total, dtype=torch.float64, device=w.device)
-    mul[:Cout] = 8.0 / S
-    return uwpk, mul.float()
-
-
-def pack_conv_weights_wino_h2_concat(ws):
-    """conv1 + downsample of a BasicBlock3D over the same input: transform-domain column groups side by side (each padded to 32)."""
-    parts = [pack_conv_weight_wino_h2(w) for w in ws]
-    return torch.cat([p[0] for p in parts], dim=2).contiguous(), torch.cat([p[1] for p in parts]).contiguous()
-
-
-def conv3d_wino_h2(x, uwpk, scale, bias=None, residual=None, cout0=None, cout1=0, relu0=False, relu1=False, out0=None,
-                   out1=None, out_h2=(True, True)):
-    """3x3x3 stride-1 pad-1 conv by Winograd F(2x2x2,3x3x3) with split-fp16 operands (pw_conv3d_wino_h2; 32 or 64 output columns).
-    x: ops.H2 or fp32 (B,D,H,W,Cin); uwpk from pack_conv_weight_wino_h2 and scale (cout_total,) = (BN scale or 1) * its `mul`;
-    residual / destinations as conv3d_h2 (an ops.H2 is written under its own range slot, a raw buffer / None in h2 format gets a
-    new one; the residual has y0's format and may be out0 itself)."""
-    xh = isinstance(x, H2)
-    xb = x.buf if xh else x
-    B, D, H, W, Cin = xb.shape
-    nch, npts, ng = uwpk.shape[:3]
-    cout_total = ng * 32
-    if npts != 64 or nch * 32 != Cin or uwpk.shape[3] != 1024 or cout_total not in (32, 64):
-        raise _lib.PreworldHipError('packed Winograd weight does not match the input (pack_conv_weight_wino_h2, 32 or 64 columns)')
-    if cout0 is None:
-        cout0 = cout_total
-    fm0, fm1 = int(bool(out_h2[0])), int(bool(out_h2[1]))
-
-    def _dst(o, c, fm):
-        if o is None:
-            o = torch.empty(B, D, H, W, c, device=xb.device, dtype=_f32)
-        if not fm:
-            return (o.buf if isinstance(o, H2) else o), None
-        return _out_h2(o, xb.device)
-    y0, rng0 = _dst(out0, cout0, fm0)
-    ld0 = _row_stride(y0, (B, D, H, W, cout0), 'y0')
-    y1, ld1, rng1 = None, 0, None
-    if cout1:
-        y1, rng1 = _dst(out1, cout1, fm1)
-        ld1 = _row_stride(y1, (B, D, H, W, cout1), 'y1')
-    res, fmr = None, 0
-    if residual is not None:
-        fmr = int(isinstance(residual, H2))
-        res = residual.buf if fmr else residual
-        if fmr != fm0:
-            raise _lib.PreworldHipError('conv3d_wino_h2: the residual must be stored like y0 (both h2 or both fp32)')
-        if _row_stride(res, (B, D, H, W, cout0), 'residual') != ld0:
-            raise _lib.PreworldHipError('residual must have the same row stride as y0')
-    if scale is None or scale.numel() != cout_total:
-        raise _lib.PreworldHipError('conv3d_wino_h2 needs scale = (BN scale or 1) * mul of pack_conv_weight_wino_h2')
-    if bias is not None and bias.numel() != cout_total:
-        raise _lib.PreworldHipError('bias must have cout_total=%d entries' % cout_total)
-    if not xb.is_contiguous():
-        raise _lib.PreworldHipError('x must be dense')
-    _lib.call('pw_conv3d_wino_h2', _chk(xb, _f32, 'x'), int(xh), _chk(uwpk, _f32, 'uwpk'), _p(scale), _p(bias), _p(res), _p(y0),
-              _p(y1), B, D, H, W, Cin, cout_total, cout0, cout1, ld0, ld1, int(relu0), int(relu1), fm0, fm1, fmr,
-              _rng(x) if xh else None, _rng(residual), _p(rng0), _p(rng1), _stream())
-    r0 = H2(y0, rng0) if fm0 else y0
-    if cout1:
-        return r0, (H2(y1, rng1) if fm1 else y1)
-    return r0
-
-
 def pack_conv_weights_wino_concat(ws):
     """conv1 + downsample of a BasicBlock3D over the same input: each padded to a multiple of 32 columns."""
     return torch.cat([pack_conv_weight_wino(w) for w in ws], dim=2).contiguous()

@@ -752,97 +752,6 @@ def test_pool_h2_and_fpn_h2():
     check_close('fpn3d h2 in/out', ops.h2_to_f32(got_h2), want.cpu().numpy(), 3e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('shape,cout', [((1, 32, 6, 20, 26), 64), ((2, 64, 5, 9, 18), 64), ((1, 32, 8, 16, 16), 32), ((1, 64, 7, 13, 11), 32)])
-def test_conv3d_wino_h2_formats_and_destinations(shape, cout):
-    """pw_conv3d_wino_h2 (Winograd F(2,3)^3 with split-fp16 operands on 32x32x16 MFMA tiles; resnet.py:88-184 conv1 + downsample
-    as one pass, conv2 with the in-place residual): fp32 / h2 input x fp32 / h2 output, two destinations with ReLU on the first only, a
-    destination that is a channel slice of a wider buffer, residual + ReLU in place, edge tiles (extents that are not multiples of the
-    4x8x8 tile), against the oracle's direct convolution.  Same bound as the direct split-fp16 kernel."""
-    from _parity import check_close
-    rs = np.random.RandomState(11)
-    B, cin, D, H, W = shape
-    x = rs.standard_normal(shape).astype(np.float32)
-    w = _rand_conv(rs, cout, cin, 3)
-    scn = rs.uniform(0.5, 1.5, cout).astype(np.float32)
-    bin_ = rs.standard_normal(cout).astype(np.float32)
-    want = O.conv3d(x, w, None, 1, 1) * scn[None, :, None, None, None] + bin_[None, :, None, None, None]
-    uw, mul = ops.pack_conv_weight_wino_h2(T(w))
-    sc, bi = T(scn) * mul, T(bin_)
-    xf = cl(x)
-    xh = ops.f32_to_h2(cl(x))
-    for xin, name in ((xf, 'f32 in'), (xh, 'h2 in')):
-        got = ops.conv3d_wino_h2(xin, uw, sc, bi, out_h2=(False, False))
-        check_close('wino_h2 %s -> f32 %s' % (name, shape), ncdhw(got), want, 3e-6, atol=1e-6)
-        goth = ops.conv3d_wino_h2(xin, uw, sc, bi, out_h2=(True, True))
-        assert isinstance(goth, ops.H2)
-        check_close('wino_h2 %s -> h2 %s' % (name, shape), ncdhw(ops.h2_to_f32(goth)), want, 3e-6, atol=1e-6)
-    # residual added in place before the ReLU (BasicBlock3D's conv2): h2 residual under its own slot, and the fp32 form
-    resn = rs.standard_normal((B, cout, D, H, W)).astype(np.float32) * 2
-    wres = np.maximum(want + resn, 0)
-    rh = ops.f32_to_h2(cl(resn))
-    got = ops.conv3d_wino_h2(xh, uw, sc, bi, residual=rh, relu0=True, out0=rh, out_h2=(True, True))
-    assert got.buf.data_ptr() == rh.buf.data_ptr()
-    check_close('wino_h2 in-place h2 residual %s' % (shape,), ncdhw(ops.h2_to_f32(got)), wres, 3e-6, atol=1e-6)
-    rf = cl(resn).clone()
-    got = ops.conv3d_wino_h2(xh, uw, sc, bi, residual=rf, relu0=True, out0=rf, out_h2=(False, False))
-    check_close('wino_h2 in-place f32 residual %s' % (shape,), ncdhw(got), wres, 3e-6, atol=1e-6)
-    if cout < 64:
-        return
-    # two destinations (conv1 + ReLU | downsample), the second a channel slice of a wider h2 buffer
-    c0 = cout // 2
-    buf = ops.f32_to_h2(torch.full((B, D, H, W, 96), 7.0, device=DEV))
-    y0, y1 = ops.conv3d_wino_h2(xh, uw, sc, bi, cout0=c0, cout1=cout - c0, relu0=True, relu1=False,
-                                out1=ops.H2(buf.buf[..., 64:64 + cout - c0], buf.rng), out_h2=(True, True))
-    check_close('wino_h2 two outputs y0 %s' % (shape,), ncdhw(ops.h2_to_f32(y0)), np.maximum(want[:, :c0], 0), 3e-6, atol=1e-6)
-    check_close('wino_h2 two outputs y1 %s' % (shape,), ncdhw(ops.h2_to_f32(y1)), want[:, c0:], 3e-6, atol=1e-6)
-    assert bool((ops.h2_to_f32(ops.H2(buf.buf[..., 0:64], buf.rng)) == 7.0).all())
-
-
-@pytest.mark.parametrize('cin,cout', [(32, 32), (32, 64), (64, 64)])
-def test_conv3d_wino_h2_many_tiles_per_block(cin, cout):
-    """a grid with more 4x8x8 tiles than resident blocks (every persistent block walks several tiles: tile-end exchange, epilogue and
-    the transform role's hand-over across tiles), partial tiles on two axes, against the direct split-fp16 kernel on the same operands"""
-    from _parity import check_close
-    rs = np.random.RandomState(3)
-    B, D, H, W = 1, 14, 100, 92
-    x = T(np.maximum(rs.standard_normal((B, D, H, W, cin)), 0).astype(np.float32))
-    w = T(_rand_conv(rs, cout, cin, 3))
-    scn, bi = T(rs.uniform(0.5, 1.5, cout).astype(np.float32)), T(rs.standard_normal(cout).astype(np.float32))
-    xh = ops.f32_to_h2(x)
-    wpk, inv = ops.pack_conv_weight_h2(w)
-    uw, mul = ops.pack_conv_weight_wino_h2(w)
-    want = ops.h2_to_f32(ops.conv3d_h2(xh, wpk, scn * inv, bi, relu0=True, out_h2=(True, True)))
-    got = ops.h2_to_f32(ops.conv3d_wino_h2(xh, uw, scn * mul, bi, relu0=True, out_h2=(True, True)))
-    check_close('wino_h2 vs direct h2 %d->%d at %s' % (cin, cout, (B, D, H, W)), got, want.cpu().numpy(), 3e-6, atol=2e-6)
-
-
-def test_conv3d_wino_h2_scale_sweep():
-    """the same layer at inputs x 2^k: the h2 input's exponent is folded into the epilogue scale, the h2 output is written under
-    its own slot (calibrated by ops.ranged) -- per-element error against float64 independent of k, like the direct kernel's."""
-    rs = np.random.RandomState(5)
-    B, cin, cout, D, H, W = 1, 64, 64, 8, 16, 24
-    x = np.maximum(rs.standard_normal((B, cin, D, H, W)), 0).astype(np.float32)
-    w = _rand_conv(rs, cout, cin, 3)
-    uw, mul = ops.pack_conv_weight_wino_h2(T(w))
-    ref = torch.nn.functional.conv3d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), padding=1).numpy()
-    rms = float(np.sqrt((ref ** 2).mean()))
-    worst = []
-    for k in (-16, -7, 0, 9, 14):
-        f = float(2.0 ** k)
-        ctx = ops.RangeCtx(DEV)
-        out = {}
-
-        def run():
-            xh = ops.f32_to_h2(cl(x) * f)
-            out['y'] = ops.conv3d_wino_h2(xh, uw, mul, out_h2=(True, True))
-        ops.ranged(run, ctx)
-        got = ncdhw(ops.h2_to_f32(out['y'])).astype(np.float64) / f
-        q = float((np.abs(got - ref) / (4e-6 * np.abs(ref) + 3e-6 * rms)).max())
-        print('[parity] conv3d_wino_h2 64->64 x 2^%d: worst element %.2f of (4e-6 |ref| + 3e-6 rms)' % (k, q))
-        worst.append(q)
-    assert max(worst) <= 1.0 and max(worst) <= 1.5 * min(worst) + 0.05, worst
-
-
 def test_sustained_mfma_probe_reports_a_plausible_rate():
     """pw_probe_mfma_f16 (bench.py's roofline.sustained_mfma): a bare fp16 MFMA stream on random operands -- above the split-fp16
     conv kernels' executed rate, below the 2.5 PFLOP/s data-sheet peak."""
