@@ -222,6 +222,8 @@ def _pmc_traffic(kernel):
             if ents:
                 return int(sum(e['fetch_bytes'] + e['write_bytes'] for e in ents)), name
         ent = by.get(kernel)
+        if ent is None and kernel == 'k_render_rays':                    # template arguments vary: the forward instantiation
+            ent = next((v for k, v in sorted(by.items()) if k.startswith('k_render_rays') and ('false' in k.split(',')[1] if ',' in k else True)), None)
         if ent:
             return int(ent['fetch_bytes'] + ent['write_bytes']), name
     return None, None
@@ -263,13 +265,32 @@ def roofline_object(agg, n_probe_steps):
 
 
 # ------------------------------------------------------------------------------ CPU baseline
+def host_cpu():
+    """model string and logical CPU count of the box the baseline ran on (lscpu / nproc)"""
+    import subprocess
+    model = None
+    try:
+        for line in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.startswith('Model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except Exception:                                                     # noqa: BLE001
+        pass
+    if model is None:
+        try:
+            model = next(l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
+        except Exception:                                                 # noqa: BLE001
+            model = 'unknown'
+    return dict(model=model, nproc=os.cpu_count(), sockets_visible=len({l for l in open('/proc/cpuinfo') if l.startswith('physical id')}) or None)
+
+
 def cpu_baseline(sd, seed=100):
     """The C3 sample at FULL size (6 cameras, 200x200x16, key + adjacent frame, 7 states) on the host cores, no
     extrapolation.  Two stand-ins, because the reference has NO CPU path for its native ops:
       * torch-cpu: the reference's nn.Modules are plain torch layers, so oracle/torch_ref.py runs the same composition on
         PyTorch-CPU (oneDNN convolutions, torch.set_num_threads(all cores));
       * openmp-port: oracle/pw_oracle.c (the parity checker);
-    each leg: median of 3 runs after 1 warm-up.
+    each leg: median of 5 runs after 1 warm-up.
     `value` is the faster of the two.  The voxel pooling of both comes from the C oracle and is inside the timed region."""
     from oracle import oracle as O
     from oracle import torch_ref as TR
@@ -294,14 +315,14 @@ def cpu_baseline(sd, seed=100):
         assert len(states) == 7 and states[0].shape == (200, 200, 16)
         return time.perf_counter() - t0
 
-    RUNS = 3                                           # each leg: 1 warm-up + RUNS timed runs, median reported
+    RUNS = 5                                           # each leg: 1 warm-up + RUNS timed runs, median reported (>= 5)
     torch_run()
     tt = sorted(torch_run() for _ in range(RUNS))
     port_run()
     tp = sorted(port_run() for _ in range(RUNS))
     t_torch, t_port = tt[RUNS // 2], tp[RUNS // 2]
     best = min(t_torch, t_port)
-    return dict(value=1.0 / best, unit='samples/s', cores=threads, kind='port',
+    return dict(value=1.0 / best, unit='samples/s', cores=threads, kind='port', host=host_cpu(),
                 torch_cpu=dict(samples_per_s=round(1.0 / t_torch, 4), median_s=round(t_torch, 3), min_s=round(tt[0], 3),
                                max_s=round(tt[-1], 3), runs=RUNS, warmup=1, threads=threads),
                 openmp_port=dict(samples_per_s=round(1.0 / t_port, 4), median_s=round(t_port, 3), min_s=round(tp[0], 3),
@@ -314,6 +335,10 @@ def cpu_baseline(sd, seed=100):
 
 # ------------------------------------------------------------------------------ main
 def bench_c5(args):
+    print(json.dumps(c5_result(args)))
+
+
+def c5_result(args, quick=False):
     """Extra, non-headline line (BASELINE.json configs[4]): the volume-rendering attribute head at the literal C5 shape
     -- 6 cameras x 512 rays x 96 uniform samples through the packed (200,200,16,24) sigma / semantic / colour grid -- forward
     (pw_render_rays) and forward + backward (pw_render_rays_backward, corner scatter-add of the gradient grid), one GPU, a
@@ -364,13 +389,14 @@ def bench_c5(args):
     t_end = time.perf_counter() + args.settle_s
     while time.perf_counter() < t_end:
         fwd_bwd()
-    steps = max(args.steps, 20)
+    steps = 20 if quick else max(args.steps, 20)
     t_fb = timed(fwd_bwd, steps, args.warmup)
     t_f, t_f16 = timed(fwd, steps, args.warmup), timed(fwd16, steps, args.warmup)
     rf, rfb, _ = shape(38400, head.t_table(dev))
     t_rf, t_rfb = timed(rf, 10, 2), timed(rfb, 5, 1)
     grid_bytes = grid.numel() * 4
     pretrain = pretrain_step_ms(dev, args)
+    traffic, traffic_src = _pmc_traffic('k_render_rays')
     res = {
         'metric': 'rays/sec (render head forward + backward, 6 cams x 512 rays x 96 samples)', 'value': round(R / t_fb, 1),
         'unit': 'rays/s', 'n_gpus': 1, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': round(t_fb * 1e3, 4),
@@ -387,11 +413,55 @@ def bench_c5(args):
                         'bit-reproducible',
             'note': 'extra, non-headline entry; the headline metric is --config C3'},
         'roofline': {'bound': 'hbm', 'kernel': 'k_render_rays', 'achieved': round(grid_bytes / t_f / 1e9, 1), 'peak': PEAK_HBM_GBPS,
-                     'unit': 'GB/s', 'frac': round(grid_bytes / t_f / 1e9 / PEAK_HBM_GBPS, 4), 'traffic': None,
+                     'unit': 'GB/s', 'frac': round(grid_bytes / t_f / 1e9 / PEAK_HBM_GBPS, 4), 'traffic': traffic,
+                     'traffic_unit': 'HBM bytes per forward launch at 3072 x 96 (PMC, %s)' % traffic_src if traffic_src else None,
                      'note': 'algorithmic bytes = the 61 MB packed grid read once per forward (SURVEY 8d); the kernel is bound by the '
                              'per-ray scan and gather latency, not by HBM (profiles/r02_render_c5.txt)'},
     }
-    print(json.dumps(res))
+    return res
+
+
+def extra_figures(args, dev):
+    """compact C2 and C5 figures for the driver's record, measured AFTER the headline's timed region (BASELINE.json configs[1], [4]):
+    C2 = single frame, PreWorld detector, 1 state (captured step, two in flight, rotating inputs like the headline); C5 = the render
+    head forward / forward + backward at the literal 3 072 x 96 shape and at the reference's 38 400 x 417, and the pre-train step."""
+    ex = {}
+    try:
+        from preworld_amd.pipeline import CapturedSample
+        net2, _ = build_net(dev, 'C2')
+        caps = [CapturedSample(net2, *make_inputs(dev, seed=50 + k, n_frames=1), n_steps=0, d2h=not args.no_d2h) for k in range(2)]
+        sets = [make_inputs(dev, seed=2000 + j, n_frames=1) for j in range(3)]
+        streams = [torch.cuda.Stream() for _ in range(2)]
+
+        def run(n):
+            for i in range(n):
+                with torch.cuda.stream(streams[i % 2]):
+                    caps[i % 2].run(*sets[i % 3])
+        run(10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 60
+        run(n)
+        torch.cuda.synchronize()
+        e = time.perf_counter() - t0
+        bad = [c.bad_replays() for c in caps]
+        ex['c2'] = dict(workload='C2: single frame (with_prev=False), 6 cams, 200x200x16, PreWorld detector, 1 state; captured step, 2 in '
+                                 'flight, 3 rotating input sets', samples_per_s=round(n / e, 2), ms_per_step=round(e / n * 1e3, 4),
+                        steps=n, recalibrations=int(sum(b[0] for b in bad)))
+        del caps, net2
+    except Exception as e:                                                # noqa: BLE001
+        ex['c2'] = {'error': repr(e)[:300]}
+    try:
+        r = c5_result(args, quick=True)
+        c = r['config']
+        ex['c5'] = dict(workload='C5: NerfHead render 3072 rays x 96 samples (and the reference shape 38 400 x 417), one GPU',
+                        rays_per_s_fwd_bwd=r['value'], fwd_bwd_ms=r['ms_per_step'], forward_ms=c['forward_ms'],
+                        reference_shape_38400x417=c['reference_shape_38400x417'], pretrain_step=c['pretrain_step'],
+                        roofline=r['roofline'])
+    except Exception as e:                                                # noqa: BLE001
+        ex['c5'] = {'error': repr(e)[:300]}
+    torch.cuda.empty_cache()
+    return ex
 
 
 def pretrain_step_ms(dev, args):
@@ -454,6 +524,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-d2h', action='store_true', help='leave the occupancy grids on the device (no host payload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the compact C2 / C5 figures appended after the timed region')
     args = ap.parse_args()
     if args.config == 'C5':
         return bench_c5(args)
@@ -503,6 +574,8 @@ def main():
     net, sd = build_net(dev, args.config)
     # sharded mode: every rank works on the SAME sample; replicas: each rank has its own
     frames, ego = make_inputs(dev, seed=0 if sharded else rank, n_frames=n_frames)
+
+    phase_ms = {}
 
     def step():
         if sharded:
@@ -556,15 +629,24 @@ def main():
         streams = [torch.cuda.Stream() for _ in range(M)]
         graph = caps[0]
         out = graph.out
+        # the timed stream: N_SETS distinct samples (none of them a calibration sample), resident in HBM, rotated through the captured
+        # steps -- every step copies its sample's inputs (16 MB device-to-device) into the graph's static buffers and replays; N_SETS is
+        # odd so that every captured step sees every sample.  The activation ranges of EVERY replay are audited on the device
+        # (pw_rng_audit inside the graph), read once after the timed region.
+        N_SETS = 5
+        sets = [make_inputs(dev, seed=1000 + rank * 16 + j, n_frames=n_frames) for j in range(N_SETS)]
 
-        def run_steps(n):
+        def run_steps(n, rotate=True):
             for i in range(n):
                 with torch.cuda.stream(streams[i % M]):
-                    caps[i % M].replay()
+                    if rotate:
+                        caps[i % M].run(*sets[i % N_SETS])
+                    else:
+                        caps[i % M].replay()
     else:
         M = 1
 
-        def run_steps(n):
+        def run_steps(n, rotate=True):
             for _ in range(n):
                 step()
 
@@ -595,6 +677,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    replay_only = None
+    audit = None
+    if graph is not None:
+        bad = [c.bad_replays() for c in caps]                    # (replays outside their calibrated ranges, replays audited) per captured step
+        audit = dict(replays_audited=int(sum(b[1] for b in bad)), recalibrations=int(sum(b[0] for b in bad)))
+        if rank == 0 and world == 1:
+            # the round-3 figure beside it: the same captured steps replayed on their own calibration samples, no input copies
+            run_steps(args.warmup, rotate=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(args.steps, rotate=False)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            replay_only = dict(samples_per_s=round(args.steps / e1, 3), ms_per_step=round(e1 / args.steps * 1e3, 4))
+
     if roofline is not None and roofline.get('bound') == 'mfma':
         # what the 1400 W socket cap leaves of the matrix pipe on this box: a bare fp16 MFMA stream on random operands
         # (pw_probe_mfma_f16, ~0.5 s), run AFTER the timed region so that it cannot warm the chip for it.  `peak` / `frac` stay the
@@ -609,10 +706,21 @@ def main():
                 '0.5 s on this box right after the timed region; frac_of_it = executed_tflops / tflops '
                 '(profiles/r03_power_wall.txt: with real data the socket sits at its power cap and the clock follows)')
 
+    if sharded:
+        # per-phase times of this mode (HIP events, a few passes AFTER the timed region; rank 0's own phases), so that a multi-GPU
+        # run explains itself: which part is divided by N, which is not, what the two all_gathers cost
+        acc = {}
+        for _ in range(5):
+            t = {}
+            harness.simple_test_sharded(net, frames, ego, n_steps=n_steps_fc, gather_on_host=oversubscribed, timings=t)
+            for k, v in t.items():
+                acc[k] = acc.get(k, 0.0) + v / 5
+        phase_ms = {k: round(v, 4) for k, v in acc.items()}
+
     # every replay of the timed region stayed inside its calibrated activation ranges (pipeline.CapturedSample.ranges_ok: the
     # exponent table + recorded maxima the replays delivered to pinned host memory)
-    ranges_ok = all(c.ranges_ok() for c in caps) if graph is not None and precision() == 'h2' else None
-    assert ranges_ok is not False, 'a replay left its calibrated activation ranges: ' + str([c.rctx.check(c.host_rng) for c in caps])
+    ranges_ok = (audit['recalibrations'] == 0) if graph is not None and precision() == 'h2' else None
+    assert ranges_ok is not False, 'replays left their calibrated activation ranges: %s' % audit
 
     # sanity on the produced states (cheap, outside the timed region)
     key0 = 'semantic_occ_0s' if args.config == 'C3' else 'semantic_occ'
@@ -647,20 +755,27 @@ def main():
             'config': {
                 'workload': workload,
                 'states_per_sample': n_states,
-                'launch': ('hipGraph replay, %d independent sample(s) in flight on %d HIP stream(s)' % (M, M))
+                'launch': ('hipGraph replay, %d independent sample(s) in flight on %d HIP stream(s); %d distinct input sets rotate through '
+                           'the captured steps, each step copies its inputs (16 MB D2D) into the static buffers inside the timed region'
+                           % (M, M, N_SETS))
                 if graph is not None else 'eager',
+                'replay_same_inputs': replay_only,
+                'recalibrations': audit['recalibrations'] if audit else None,
+                'replays_audited': audit['replays_audited'] if audit else None,
                 'outputs': ('host: %d contiguous (X,Y,Z) uint8 grids per sample in pinned memory, one async D2H copy inside '
                             'the step (the reference payload, preworld_temporal_traj.py:311-366)' % (2 * n_states))
                 if graph is not None and d2h else 'device (uint8 grids stay in HBM)',
                 'single_sample_latency_ms': round(latency_ms, 4) if latency_ms else None,
+                'sharded_phase_ms_rank0': phase_ms or None,
                 'parallelism': ('frames + states sharded over %d rank(s), 2 RCCL all_gathers per sample '
                                 '(harness.simple_test_sharded)' % world) if sharded else
                 'replicas x%d (independent samples, no data-path collective)' % world,
                 'note': ' OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else None,
                 'excluded': 'image backbone + DepthNet (stay on PyTorch, SURVEY 8a)',
-                'activation_ranges': ('per-tensor power-of-two exponents calibrated on the warm-up sample (ops.RangeCtx); every '
-                                      'replay re-records each tensor\'s maximum and delivers it with the results: all inside '
-                                      '[2^6, 65504] stored units = %s' % ranges_ok) if ranges_ok is not None else None,
+                'activation_ranges': ('per-tensor power-of-two exponents calibrated on each captured step\'s warm-up sample (ops.RangeCtx); '
+                                      'every replay re-records each tensor\'s maximum and a kernel inside the graph tallies the replays '
+                                      'whose maxima left [2^6, 65504] stored units (pw_rng_audit): none of the %d replays since '
+                                      'capture did = %s' % (audit['replays_audited'], ranges_ok)) if ranges_ok is not None else None,
                 'arithmetic': ('PW_PRECISION=%s: ' % precision()) + (
                     'every value is fp32; conv / forecast products run as exact-fp32 MFMA (Winograd / direct kernels)'
                     if precision() == 'f32' else
@@ -671,6 +786,8 @@ def main():
             },
             'roofline': roofline,
         }
+        if world == 1 and not sharded and args.config == 'C3' and not args.no_extra:
+            res['extra'] = extra_figures(args, dev)
         if not args.no_cpu_baseline and world == 1 and not sharded:
             res['cpu_baseline'] = cpu_baseline(sd)
         print(json.dumps(res))

@@ -212,12 +212,17 @@ int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale, const 
  * the producing kernels raise with return-less atomics -- thousands of atomics on one address would serialise at ~100 ns each.
  * pw_rng_fold(tab, n_slots, compact): rng[1] = max(rng[1], partials), partials cleared, for n_slots consecutive slots, and (if
  * compact != NULL) the (n_slots, 2) pairs [exponent, maximum] copied there contiguously -- one small launch at the end of a pass.
+ * pw_rng_audit(compact, n_slots, sticky): the steady-state test ON THE DEVICE, for passes nobody waits for (graph replays in
+ * flight): sticky[0] += slots of this pass whose recorded maximum left [2^6, 65504] stored units (or is not finite), sticky[1] += 1
+ * if there was one, sticky[2] += 1 (passes audited).  The counters are never cleared by the library: the host reads them whenever
+ * it likes and knows whether EVERY pass since stayed inside its calibrated ranges.
  * pw_f32_to_h2: auto_exp != 0 first derives rng[0] from the largest finite |x| (three extra small launches) instead of
  * taking it as it is. */
 #define PW_RNG_ROW 1056
 #define PW_RNG_SCRATCH 32
 #define PW_RNG_WORDS 1024
 int pw_rng_fold(int32_t* tab, int n_slots, int32_t* compact, void* stream);
+int pw_rng_audit(const int32_t* compact, int n_slots, int32_t* sticky, void* stream);
 int pw_f32_to_h2(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, int32_t* rng, int auto_exp, void* stream);
 int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, const int32_t* rng, void* stream);
 

@@ -770,6 +770,31 @@ PW_API int pw_rng_fold(int32_t* tab, int n_slots, int32_t* compact, void* stream
   return PW_OK;
 }
 
+// the hard window of ops.RangeCtx.check on the device: one thread per slot of a folded (n, 2) table
+__global__ void __launch_bounds__(256) k_rng_audit(const int* __restrict__ compact, int n_slots, int* sticky) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_slots; i += 256) {
+    const unsigned bits = (unsigned)compact[2 * i + 1];
+    if (bits == 0u) continue;
+    const float stored = __builtin_ldexpf(__uint_as_float(bits), -compact[2 * i]);
+    if (!(stored >= 64.f && stored <= H2_MAX)) atomicAdd(&bad, 1);            // NaN / Inf fail the comparison
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sticky[0] += bad;
+    sticky[1] += bad ? 1 : 0;
+    sticky[2] += 1;
+  }
+}
+PW_API int pw_rng_audit(const int32_t* compact, int n_slots, int32_t* sticky, void* stream) {
+  PW_CHECK_ARG(compact && sticky && n_slots > 0, "pw_rng_audit: bad arguments");
+  hipLaunchKernelGGL(k_rng_audit, dim3(1), dim3(256), 0, pw_stream(stream), compact, n_slots, sticky);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
 __global__ void k_absmax(const float* __restrict__ x, long long n_vox, int C, int ld_x, int* rng) {
   const int groups = C >> 2;
   const long long n = n_vox * groups;

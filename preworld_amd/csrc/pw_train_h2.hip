@@ -397,11 +397,8 @@ PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const 
   const dim3 grid((unsigned)(3 * p.cog * p.cig * p.n_strips * B * D * p.oh_splits));
 #define PW_WG_LAUNCH(CO, CI)                                                                                                    \
   do {                                                                                                                          \
-    static bool attr_set = false;                                                                                               \
-    if (!attr_set) {                                                                                                            \
-      PW_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3d_wgrad_h2<CO, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
-      attr_set = true;                                                                                                          \
-    }                                                                                                                           \
+    /* per launch: the attribute is per device, and the call is cheap next to a ~100 us kernel */                  \
+    PW_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3d_wgrad_h2<CO, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
     hipLaunchKernelGGL((k_conv3d_wgrad_h2<CO, CI>), grid, dim3(WG_THREADS), p.lds, st, a);                                             \
   } while (0)
   if (p.co_t == 2 && p.ci_t == 2) PW_WG_LAUNCH(2, 2);

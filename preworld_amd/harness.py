@@ -90,7 +90,7 @@ def evaluate(net, samples, device='cuda:0', use_image_mask=True):
 
 
 @torch.no_grad()
-def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=False):
+def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=False, timings=None):
     """The latency mode of DESIGN.md section 7 wired to the real modules (one process per GPU, torch.distributed
     initialised): frame f is lifted + pre-processed on rank f % W and all ranks receive every frame's (B,Z,Y,X,32)
     feature through ONE all_gather (parallel.lift_frames_sharded), every rank runs the encoder, state k is forecast +
@@ -98,7 +98,10 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
     Returns {'semantic_occ_%ds': [(X,Y,Z) uint8]} like simple_test_from_lift.  `with_prev=False` drops the adjacent
     frames: their channel slice is zeros (bevdet_occ.py:243-258), exactly as in extract_bev_feat_cl.
     gather_on_host=True moves the 0.64 MB grids through host memory (for process groups that cannot all_gather device
-    tensors: gloo in the tests; RCCL takes device tensors)."""
+    tensors: gloo in the tests; RCCL takes device tensors).
+    timings: a dict that receives the milliseconds of the LAST pass's phases on this rank -- lift (LSS + pre_process of this rank's
+    frames), gather_frames (the 81.92 MB per frame all_gather), encoder (cat + bev_encoder + final_conv), decode (this rank's
+    share of the recursion + OccHead), gather_states (the uint8 all_gather) -- from HIP events on the current stream (synchronises)."""
     from . import ops, parallel
     from .modules import precision
     vt = net.img_view_transformer
@@ -122,16 +125,27 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
         occ = occ.permute(0, 3, 2, 1)[0].contiguous()                          # batch element 0, (X,Y,Z) (:306)
         return occ.cpu() if gather_on_host else occ
 
+    events = []
+
+    def mark(name):
+        if timings is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            events.append((name, e))
+
     def one_pass():
+        del events[:]
+        mark('start')
         lifted = parallel.lift_frames_sharded(use, lift, (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device,
-                                              group, via_host=gather_on_host)
+                                              group, via_host=gather_on_host, mark=mark)
         x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                   # [adjacent ..., key] (bevdet_occ.py:266)
         if len(lifted) < n:
             x = torch.cat([x.new_zeros(x.shape[:-1] + ((n - len(lifted)) * C,)), x], dim=-1)
         # final_conv -> forecast -> OccHead keep h2 storage like simple_test_from_lift (post-finetune decode)
         v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.f32_to_h2(x) if h2 else x, out_h2=h2), out_h2=h2)
+        mark('encoder')
         return parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k, out_h2=h2)[0][k - 1], decode,
-                                              n_steps + 1, group)
+                                              n_steps + 1, group, mark=mark)
 
     if h2:
         # ranks own different tensors, so they must agree on whether another calibration pass runs (the passes contain
@@ -142,4 +156,8 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
         grids = ops.ranged(one_pass, ctx, agree=lambda ok: parallel.all_agree(ok, f0['depth'].device, group, gather_on_host))
     else:
         grids = one_pass()
+    if timings is not None:
+        torch.cuda.synchronize()
+        for (_, a), (name, b) in zip(events[:-1], events[1:]):
+            timings[name] = a.elapsed_time(b)
     return {'semantic_occ_%ds' % k: [g] for k, g in enumerate(grids)}

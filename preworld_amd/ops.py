@@ -433,6 +433,7 @@ class RangeCtx:
         # a slot = RNG_ROW int32: [exponent, folded maximum, ..., 1 024 partial maxima] (include/preworld_hip.h "RANGE SLOTS")
         self.tab = torch.zeros(n_slots, RNG_ROW, dtype=_i32, device=device)
         self.compact = torch.zeros(n_slots, 2, dtype=_i32, device=device)      # [exponent, maximum] pairs, written by fold()
+        self.sticky = torch.zeros(4, dtype=_i32, device=device)                 # audit(): [bad slots, bad passes, passes audited, -]
         self.n = 0
         self.device = torch.device(device)
 
@@ -444,6 +445,16 @@ class RangeCtx:
     def fold(self):
         """end of a pass: fold the partial maxima the kernels raised into the slots and refresh `compact` (one small launch)"""
         _lib.call('pw_rng_fold', _p(self.tab), self.tab.shape[0], _p(self.compact), _stream())
+
+    def audit(self):
+        """after fold(): the hard-window test of check() on the device, accumulated in `sticky` (pw_rng_audit) -- capturable, so
+        every replay of a graph is tested without the host waiting for it; read the verdict with audited()"""
+        _lib.call('pw_rng_audit', _p(self.compact), self.compact.shape[0], _p(self.sticky), _stream())
+
+    def audited(self):
+        """(passes that left their calibrated ranges, passes audited) since the table was created (synchronises)"""
+        bad_slots, bad_passes, passes, _ = self.sticky.tolist()
+        return bad_passes, passes
 
     def new_slot(self):
         if self.n >= self.tab.shape[0]:
@@ -920,8 +931,7 @@ def forecast_pack_h2(fusion_w1, fusion_w2):
 def forecast_steps_h2(v0, n_samples, packed, c1p, fusion_b2, n_steps, states=None, out_h2=False):
     """forecast_steps on the fp16 matrix cores with split-fp16 operands; packed = forecast_pack_h2(...).
     v0: fp32 tensor or ops.H2; out_h2=True returns the states as ONE ops.H2 of shape (n_steps, *v0.shape).  The recursion
-    runs in the units of the states' range slot (a new one, or `states.rng`) whatever the output format; with fp32 output
-    the slot is returned as the second value only when want_slot."""
+    runs in the units of the states' range slot (a new one, or `states.rng`) whatever the output format."""
     w1p, w2p, inv1, inv2, l1 = packed
     v0_h2 = isinstance(v0, H2)
     vbuf = v0.buf if v0_h2 else v0

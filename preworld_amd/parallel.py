@@ -37,7 +37,11 @@ def owned_states(n_states, rank, world):
     return list(range(rank, n_states, world))
 
 
-def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None):
+def _no_mark(name):
+    pass
+
+
+def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark=_no_mark):
     """v0: encoder output on every rank.  forecast_fn(v0, k) -> state-k features (k >= 1 applications
     of the recursion); decode_fn(features) -> uint8 occupancy grid.  Returns the list of all
     n_states grids (identical on every rank)."""
@@ -48,6 +52,7 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None):
     for k in mine:
         feats = v0 if k == 0 else forecast_fn(v0, k)
         local[k] = decode_fn(feats)
+    mark('decode')
     if world == 1 and not ALWAYS_COLLECTIVE:
         return [local[k] for k in range(n_states)]
     # pad every rank to the same number of slots so one all_gather moves everything
@@ -58,6 +63,7 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None):
         send[i] = local[k]
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send, group=group)
+    mark('gather_states')
     out = [None] * n_states
     for r in range(world):
         for i, k in enumerate(owned_states(n_states, r, world)):
@@ -65,7 +71,7 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None):
     return out
 
 
-def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, via_host=False):
+def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, via_host=False, mark=_no_mark):
     """frames: list of per-frame inputs (present on every rank); frame f is lifted by rank f % W.  The features reach
     every rank through ONE all_gather of a (slots, *out_shape) buffer per rank (slots = ceil(F / W); 81.92 MB per frame at
     C3) -- on xGMI's point-to-point links every rank's shard travels its own link.  Returns the list of lifted features
@@ -77,6 +83,7 @@ def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, v
     if world == 1 and not ALWAYS_COLLECTIVE:
         outs = [lift_fn(fr).contiguous() for fr in frames]
         assert all(tuple(o.shape) == tuple(out_shape) for o in outs)
+        mark('lift')
         return outs
     slots = (F + world - 1) // world
     send = torch.zeros((slots,) + tuple(out_shape), dtype=dtype, device=device)
@@ -84,9 +91,11 @@ def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, v
         buf = lift_fn(frames[f])
         assert tuple(buf.shape) == tuple(out_shape)
         send[i].copy_(buf)
+    mark('lift')
     if via_host:
         send = send.cpu()
     recv = torch.empty((world * slots,) + tuple(out_shape), dtype=dtype, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.to(device).view((world, slots) + tuple(out_shape))
+    mark('gather_frames')
     return [recv[f % world, f // world] for f in range(F)]

@@ -50,6 +50,7 @@ class CapturedSample:
             self.rctx.begin()
             self.out = self._step()
             self.rctx.fold()
+            self.rctx.audit()                                   # sticky device counters: EVERY replay is range-checked (bad_replays())
             self.host_rng.copy_(self.rctx.compact, non_blocking=True)
 
     def _step(self):
@@ -82,6 +83,12 @@ class CapturedSample:
         """after the replay has completed (stream / device synchronised): did every h2 tensor of it stay inside the
         representable window under the exponents it ran with?  False -> recalibrate() and replay that sample again."""
         return not self.rctx.check(self.host_rng)
+
+    def bad_replays(self):
+        """(replays that left their calibrated activation ranges, replays audited) since capture (synchronises): the device-side
+        tally of pw_rng_audit, which every replay feeds -- unlike ranges_ok(), which only sees the LAST replay's table"""
+        torch.cuda.synchronize()
+        return self.rctx.audited()
 
     def recalibrate(self):
         """re-derive the exponents from the inputs currently in the static buffers (eager passes; the graph keeps reading

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, full=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -31,29 +31,32 @@ def _worker(rank, world, port, q):
     try:
         dev = 'cuda:0'
         torch.cuda.set_device(0)
-        net = harness.build_model(harness.model_cfg(S.GRID_CONFIG_C1), S.synth_state_dict(0), dev)
-        frames = harness.lifted_frames(5, 1, dev)
+        net = harness.build_model(harness.model_cfg(S.GRID_CONFIG_FULL if full else S.GRID_CONFIG_C1), S.synth_state_dict(0), dev)
+        frames = harness.lifted_frames(5, 6 if full else 1, dev)
         ego = torch.from_numpy(S.ego_state(5)).to(dev)
         with torch.no_grad():
             want = net.simple_test_from_lift(frames, ego, n_steps=6)
         got = harness.simple_test_sharded(net, frames, ego, n_steps=6, gather_on_host=True)
-        same = [bool(torch.equal(got['semantic_occ_%ds' % k][0].cpu(), want['semantic_occ_%ds' % k][0].cpu())) for k in range(7)]
+        same = [int((got['semantic_occ_%ds' % k][0].cpu() != want['semantic_occ_%ds' % k][0].cpu()).sum()) for k in range(7)]
         # with_prev=False (C2's frame handling): the adjacent frame is dropped, its channel slice is zeros
         net.with_prev = False
         with torch.no_grad():
             want = net.simple_test_from_lift(frames, ego, n_steps=2)
         got = harness.simple_test_sharded(net, frames, ego, n_steps=2, gather_on_host=True)
-        same += [bool(torch.equal(got['semantic_occ_%ds' % k][0].cpu(), want['semantic_occ_%ds' % k][0].cpu())) for k in range(3)]
+        same += [int((got['semantic_occ_%ds' % k][0].cpu() != want['semantic_occ_%ds' % k][0].cpu()).sum()) for k in range(3)]
         q.put((rank, same))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_lift_and_decode_two_ranks_equal_single_process():
+@pytest.mark.parametrize('full', [False, True], ids=['C1-grid', 'C4-full-size-200x200x16'])
+def test_sharded_lift_and_decode_two_ranks_equal_single_process(full):
+    """full: BASELINE.json configs[3] at its real size on what one GPU allows -- 6 cameras, 200x200x16, the 81.92 MB fp32 frame
+    exchange and its re-split under one exponent, all 7 states, with and without the adjacent frame (bevdet_occ.py:266-267)"""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, full)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -61,11 +64,18 @@ def test_sharded_lift_and_decode_two_ranks_equal_single_process():
         p.join(60)
         assert p.exitcode == 0
     assert sorted(r for r, _ in res) == [0, 1]
-    for _, same in res:
-        assert all(same), same
+    # voxels that differ from the single-process result, per state (7 with the adjacent frame, 3 without).  The sharded pass
+    # exchanges fp32 values and re-splits the concatenated buffer under ONE exponent, the single process keeps each frame under the
+    # exponent of its own slot: values can differ below 2^-38 of a tensor's maximum, i.e. a handful of exact ties among the 640 000
+    # voxels of a full-size state (the same allowance as a separately calibrated eager pass, tests/test_gpu_range.py); both ranks
+    # must hold the SAME grids
+    assert res[0][1] == res[1][1], res
+    for _, diff in res:
+        print('[sharded, 2 ranks, %s] differing voxels per state: %s' % ('200x200x16' if full else 'C1 grid', diff))
+        assert max(diff) <= (8 if full else 0), diff
 
 
-def _rccl_worker(port, q):
+def _rccl_worker(port, q, full=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -74,31 +84,36 @@ def _rccl_worker(port, q):
     dist.init_process_group('nccl', rank=0, world_size=1)            # 'nccl' == RCCL on ROCm
     try:
         dev = 'cuda:0'
-        net = harness.build_model(harness.model_cfg(S.GRID_CONFIG_C1), S.synth_state_dict(0), dev)
-        frames = harness.lifted_frames(5, 1, dev)
+        net = harness.build_model(harness.model_cfg(S.GRID_CONFIG_FULL if full else S.GRID_CONFIG_C1), S.synth_state_dict(0), dev)
+        frames = harness.lifted_frames(5, 6 if full else 1, dev)
         ego = torch.from_numpy(S.ego_state(5)).to(dev)
         with torch.no_grad():
             want = net.simple_test_from_lift(frames, ego, n_steps=6)
         parallel.ALWAYS_COLLECTIVE = True                            # run both all_gathers even with one rank
-        got = harness.simple_test_sharded(net, frames, ego, n_steps=6)
+        t = {}
+        got = harness.simple_test_sharded(net, frames, ego, n_steps=6, timings=t)
         torch.cuda.synchronize()
-        same = [bool(torch.equal(got['semantic_occ_%ds' % k][0], want['semantic_occ_%ds' % k][0])) for k in range(7)]
-        q.put((dist.get_backend(), same, bool(got['semantic_occ_0s'][0].is_cuda)))
+        same = [int((got['semantic_occ_%ds' % k][0] != want['semantic_occ_%ds' % k][0]).sum()) for k in range(7)]
+        q.put((dist.get_backend(), same, bool(got['semantic_occ_0s'][0].is_cuda), t))
     finally:
         dist.destroy_process_group()
 
 
-def test_rccl_device_tensor_all_gathers_world_size_1():
-    """RCCL really initialised (backend 'nccl') and both data-path collectives of the sharded mode -- the 10.24 MB frame
-    all_gather (C1 grid) and the uint8 state all_gather -- executed on DEVICE tensors; one rank is all a 1-GPU box allows."""
+@pytest.mark.parametrize('full', [False, True], ids=['C1-grid', 'C4-full-size-200x200x16'])
+def test_rccl_device_tensor_all_gathers_world_size_1(full):
+    """RCCL really initialised (backend 'nccl') and both data-path collectives of the sharded mode -- the frame all_gather (10.24 MB
+    on the C1 grid; full: 2 x 81.92 MB through all_gather_into_tensor, the size BASELINE.json configs[3] moves) and the uint8 state
+    all_gather -- executed on DEVICE tensors; one rank is all a 1-GPU box allows.  The per-phase timings are printed."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q, full))
     p.start()
-    backend, same, on_dev = q.get(timeout=300)
+    backend, same, on_dev, t = q.get(timeout=600)
     p.join(60)
     assert p.exitcode == 0
-    assert backend == 'nccl' and on_dev and all(same), (backend, same)
+    assert backend == 'nccl' and on_dev and max(same) <= (8 if full else 0), (backend, same)       # (ties: see the two-rank test)
+    assert set(t) == {'lift', 'gather_frames', 'encoder', 'decode', 'gather_states'}, t
+    print('[sharded, RCCL world 1, %s] phase ms: %s' % ('200x200x16' if full else 'C1 grid', {k: round(v, 3) for k, v in t.items()}))
 
 
 def _syncbn_worker(rank, world, port, q):
