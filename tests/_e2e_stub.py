@@ -15,14 +15,19 @@ N_CAMS = 2
 IN_CH = 16           # channels of the (stand-in) image-view feature map
 D, C = 88, 32
 TEST_THRESHOLD = 0.7  # density threshold of the attribute-MLP decode (8.5 in the configs; random weights never reach that)
+VARIANTS = {
+    'small': dict(grid=GRID, cams=[1, 4]),
+    # BASELINE.json configs[0]'s voxel grid with the full camera rig: 6 cameras, 100 x 100 x 8
+    'c6': dict(grid={'x': [-40, 40, 0.8], 'y': [-40, 40, 0.8], 'z': [-1, 5.4, 0.8], 'depth': [1.0, 45.0, 0.5]}, cams=[0, 1, 2, 3, 4, 5]),
+}
 RUNS = [('p4d_ft', 'PreWorld4DTraj', True, True), ('p4d_ft_noprev', 'PreWorld4DTraj', True, False),
         ('p4d_attr', 'PreWorld4DTraj', False, True), ('pw_ft', 'PreWorld', True, True), ('pw_attr', 'PreWorld', False, True)]
 
 
-def model_cfg(detector, if_post_finetune, with_prev=True):
+def model_cfg(detector, if_post_finetune, with_prev=True, variant='small'):
     """the `model = dict(...)` of configs/preworld/**.py at the reduced grid above (cf. harness.model_cfg)"""
     from preworld_amd import harness
-    cfg = harness.model_cfg(GRID, with_prev=with_prev, if_post_finetune=if_post_finetune, detector=detector)
+    cfg = harness.model_cfg(VARIANTS[variant]['grid'], with_prev=with_prev, if_post_finetune=if_post_finetune, detector=detector)
     cfg['img_view_transformer'].update(input_size=INPUT_SIZE, in_channels=IN_CH)
     cfg['use_focal_loss'] = False        # loss objects are not part of the inference path (mmdet registry, not in the tree)
     cfg['test_threshold'] = TEST_THRESHOLD
@@ -37,14 +42,15 @@ def _pose(yaw, t):
     return m
 
 
-def img_inputs(seed=0):
+def img_inputs(seed=0, variant='small'):
     """the 7-tuple `img_inputs` the dataset pipeline delivers (datasets/pipelines/loading.py:1091-1123): imgs (B, N*T, 3, H, W)
     camera-major / frame-minor, sensor2egos / ego2globals (B, T*N, 4, 4) frame-major, intrins, post_rots, post_trans, bda.
     T = 3 frames (key, adjacent, extra stereo reference) with a moving ego; per-camera image augmentation; a BEV augmentation."""
     rs = np.random.RandomState(1000 + seed)
     T = 3
     rig = S.synthetic_rig(6, dtype=np.float64)
-    cams = [1, 4][:N_CAMS]
+    cams = VARIANTS[variant]['cams']
+    N_CAMS = len(cams)
     s2e = np.stack([rig['sensor2ego'][0, cams]] * T, 0)                      # (T, N, 4, 4): same rig every frame
     e2g = np.stack([np.stack([_pose(0.10 - 0.03 * t, [10.0 - 2.4 * t, 5.0 - 0.3 * t, 0.2])] * N_CAMS, 0) for t in range(T)], 0)
     K = np.stack([rig['intrin'][0, cams]] * T, 0)
@@ -102,3 +108,37 @@ def install_image_side(model, seed=0):
     dn = SeededDepthNet(seed)
     model.img_view_transformer.depth_net = dn
     return dn
+
+
+# ---- training (tools/gen_golden.py gen_e2e_train / tests/test_gpu_e2e_reference.py): the fine-tune flags of
+# configs/preworld/preworld-7frame-finetune*.py with every voxel loss switched on
+TRAIN_CFG = dict(if_render=False, if_post_finetune=True, use_lss_depth_loss=False, use_focal_loss=False, weight_voxel_ce=1.0,
+                 weight_voxel_sem_scal=1.0, weight_voxel_geo_scal=1.0, weight_voxel_lovasz=1.0)
+
+
+TRAIN_EPOCH = 7      # PreWorld4DTraj.set_epoch: without rendering, epoch 7 supervises the current state and three forecast intervals
+
+
+def train_kwargs(seed, detector, device='cpu'):
+    """the keyword arguments forward_train reads (preworld.py:256-263, preworld_temporal_traj.py:412-524): voxel_semantics (B,X,Y,Z),
+    mask_camera, and for the temporal detector temporal_semantics[k]['voxel_semantics'], temporal_ego_states, temporal_trajs"""
+    rs = np.random.RandomState(3000 + seed)
+    X, Y, Z = 40, 40, 8
+    sem = lambda: torch.from_numpy(rs.randint(0, 18, (1, X, Y, Z))).to(device)       # noqa: E731
+    kw = dict(voxel_semantics=sem(), mask_camera=None)
+    if detector == 'PreWorld4DTraj':
+        kw['temporal_semantics'] = [dict(voxel_semantics=sem()) for _ in range(7)]
+        kw['temporal_ego_states'] = [torch.from_numpy(S.ego_state(40 + seed)).to(device)]
+        kw['temporal_trajs'] = torch.from_numpy(rs.standard_normal((1, 6, 2)).astype(np.float32)).to(device)
+    return kw
+
+
+def grad_probes(model, detector):
+    """(name, parameter) pairs whose gradients the training fixture stores"""
+    pr = [('final_conv', model.final_conv.conv.weight), ('occ_conv', model.occupancy_head.occ_convs[0][0].weight),
+          ('encoder_l0_conv1', model.img_bev_encoder_backbone.layers[0][0].conv1.conv.weight),
+          ('pre_process_conv2', model.pre_process_net.layers[0][0].conv2.conv.weight)]
+    if detector == 'PreWorld4DTraj':
+        pr += [('fusion_head0', model.fusion_head[0].weight), ('plan_head0', model.plan_head[0].weight),
+               ('traj_head2', model.traj_head[2].weight), ('downscale1', model.downscale.downscale1.weight)]
+    return pr

@@ -17,11 +17,14 @@ from preworld_amd.modules import as_f32  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'e2e_small.npz'))
+_GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+GOLD = np.load(os.path.join(_GDIR, 'e2e_small.npz'))
+GOLD_C6 = np.load(os.path.join(_GDIR, 'e2e_c6.npz'))
+GOLD_TRAIN = np.load(os.path.join(_GDIR, 'e2e_train_small.npz'))
 
 
-def _build(det, post_ft, with_prev):
-    net = harness.build_model(E.model_cfg(det, post_ft, with_prev), S.synth_state_dict(0), DEV)
+def _build(det, post_ft, with_prev, variant='small'):
+    net = harness.build_model(E.model_cfg(det, post_ft, with_prev, variant=variant), S.synth_state_dict(0), DEV)
     return net, E.install_image_side(net, seed=0)
 
 
@@ -35,6 +38,8 @@ def test_prepare_inputs_matches_reference():
 
 @pytest.mark.parametrize('tag,det,post_ft,with_prev', E.RUNS)
 def test_dropin_detectors_match_reference_detectors(tag, det, post_ft, with_prev):
+    """the drop-in's simple_test against the reference classes' own (e2e_small.npz): keys, every grid; a differing voxel of a
+    post-finetune semantic grid must be a near-tie of the REFERENCE's logits (round 4), threshold-decode grids allow exact ties"""
     net, dn = _build(det, post_ft, with_prev)
     inputs = tuple(t.to(DEV) for t in E.img_inputs(0))
     ego = [[t.to(DEV) for t in E.ego_states(0)[0]]]
@@ -48,9 +53,20 @@ def test_dropin_detectors_match_reference_detectors(tag, det, post_ft, with_prev
         want = GOLD[tag + '_' + k]
         got = res[k][0]
         assert isinstance(got, np.ndarray) and got.dtype == np.uint8 and got.shape == want.shape, (k, type(got))
-        flips = int((got != want).sum())
-        print('[e2e] %-14s %-16s flips vs the reference classes: %d / %d' % (tag, k, flips, want.size))
-        assert flips <= 3, (tag, k, flips)               # exact ties of the fp32 logits only
+        flips = np.nonzero((got != want).reshape(-1))[0]
+        print('[e2e] %-14s %-16s flips vs the reference classes: %d / %d' % (tag, k, flips.size, want.size))
+        if post_ft and k.startswith('semantic_occ'):
+            # every differing voxel must be one of the reference's OWN near-ties (the fixture lists the voxels whose top-2 logit margin
+            # is below 1e-3 of the largest logit, with margin and runner-up class): we chose the runner-up, and the margin is within
+            # twice the logit error bound of DESIGN.md section 6 (2e-5 of the largest logit)
+            ti, tm, tc = GOLD['%s_%s_tie_idx' % (tag, k)], GOLD['%s_%s_tie_margin' % (tag, k)], GOLD['%s_%s_tie_cls' % (tag, k)]
+            tol = 2 * 2e-5 * float(GOLD['%s_%s_logit_absmax' % (tag, k)])
+            for v in flips:
+                j = np.nonzero(ti == v)[0]
+                assert j.size == 1, (tag, k, int(v), 'differs at a voxel that is not a near-tie of the reference logits')
+                assert got.reshape(-1)[v] == tc[j[0]] and tm[j[0]] <= tol, (tag, k, int(v), float(tm[j[0]]), tol)
+        else:
+            assert flips.size <= 3, (tag, k, flips.size)               # threshold decode / geo grids: exact ties only
     # intermediate tensors: encoder output and voxel_feats at the sampled voxels
     dn.reset()
     with torch.no_grad():
@@ -65,3 +81,67 @@ def test_dropin_detectors_match_reference_detectors(tag, det, post_ft, with_prev
         err = float(np.abs(rows - want).max()) / float(np.abs(want).max())
         print('[e2e] %-14s %-4s rows: max|err| / max|ref| = %.2e' % (tag, name, err))
         assert err <= 1e-5, (tag, name, err)
+
+
+def test_dropin_detector_matches_reference_detector_six_cameras_100x100x8():
+    """the same comparison with the full rig on BASELINE.json configs[0]'s grid (6 cameras, 100 x 100 x 8): the reference's own
+    PreWorld4DTraj.simple_test (tests/golden/e2e_c6.npz) vs the drop-in, every flip explained by the reference's logits"""
+    net, dn = _build('PreWorld4DTraj', True, True, variant='c6')
+    inputs = tuple(t.to(DEV) for t in E.img_inputs(0, 'c6'))
+    ego = [[t.to(DEV) for t in E.ego_states(0)[0]]]
+    with torch.no_grad():
+        res = net.simple_test(None, None, img=inputs, temporal_ego_states=ego)
+    G, tag = GOLD_C6, 'p4d_ft'
+    assert dn.k == int(G[tag + '_n_depthnet_calls']) and sorted(res.keys()) == list(G[tag + '_keys'])
+    np.testing.assert_allclose(torch.stack(dn.mlp_inputs, 0).numpy(), G['mlp_input'], rtol=1e-6, atol=1e-6)
+    for k in res:
+        want, got = G[tag + '_' + k], res[k][0]
+        assert got.dtype == np.uint8 and got.shape == want.shape == (100, 100, 8)
+        flips = np.nonzero((got != want).reshape(-1))[0]
+        print('[e2e c6] %-16s flips vs the reference class: %d / %d' % (k, flips.size, want.size))
+        if k.startswith('semantic_occ'):
+            ti, tm, tc = G['%s_%s_tie_idx' % (tag, k)], G['%s_%s_tie_margin' % (tag, k)], G['%s_%s_tie_cls' % (tag, k)]
+            tol = 2 * 2e-5 * float(G['%s_%s_logit_absmax' % (tag, k)])
+            for v in flips:
+                j = np.nonzero(ti == v)[0]
+                assert j.size == 1 and got.reshape(-1)[v] == tc[j[0]] and tm[j[0]] <= tol, (k, int(v))
+        else:
+            assert flips.size <= 8, (k, flips.size)
+
+
+@pytest.mark.parametrize('tag,det', [('pw', 'PreWorld'), ('p4d', 'PreWorld4DTraj')])
+def test_dropin_forward_train_matches_reference_forward_train(tag, det):
+    """VERDICT r03 missing 3 / next 6: the training composition against the reference's OWN forward_train (preworld.py:229-309,
+    preworld_temporal_traj.py:372-530; tests/golden/e2e_train_small.npz, produced by tools/gen_golden.py gen_e2e_train running those
+    methods in train() mode): the loss dict's keys (which state gets which term, `..._{k}s`), every loss value to 1e-4, and
+    d sum(losses) / d of final_conv, OccHead, encoder, pre_process and (temporal) the forecast / trajectory heads' weights."""
+    G = GOLD_TRAIN
+    cfg = E.model_cfg(det, True, True)
+    cfg.update(E.TRAIN_CFG)
+    net = harness.build_model(cfg, S.synth_state_dict(0), DEV).train()
+    if hasattr(net, 'set_epoch'):
+        net.set_epoch(E.TRAIN_EPOCH)
+    E.install_image_side(net, seed=0)
+    inputs = tuple(t.to(DEV) for t in E.img_inputs(0))
+    losses = net(return_loss=True, img_inputs=inputs, img_metas=[dict()], **E.train_kwargs(0, det, DEV))
+    assert sorted(losses.keys()) == list(G[tag + '_keys']), sorted(losses.keys())
+    for k, v in losses.items():
+        want = float(G['%s_%s' % (tag, k)])
+        print('[e2e train] %-4s %-24s %.7f   reference forward_train %.7f' % (tag, k, float(v), want))
+        assert abs(float(v) - want) <= 1e-4 * max(abs(want), 1.0), (k, float(v), want)
+    total = sum(losses.values())
+    assert abs(float(total) - float(G[tag + '_total'])) <= 1e-4 * abs(float(G[tag + '_total']))
+    total.backward()
+    for name, p in E.grad_probes(net, det):
+        g = p.grad.detach().reshape(-1)
+        want = G['%s_grad_%s' % (tag, name)]
+        got = (g if g.numel() <= 40000 else g[::7]).cpu().numpy()
+        d = got.astype(np.float64) - want
+        l2, mx = float(np.linalg.norm(d) / np.linalg.norm(want)), float(np.abs(d).max() / np.abs(want).max())
+        nrm = float(p.grad.double().norm()) / float(G['%s_gradnorm_%s' % (tag, name)])
+        print('[e2e train] %-4s d / d %-18s l2 err / l2 %.2e   max err / max %.2e   |g| / |g_ref| %.6f' % (tag, name, l2, mx, nrm))
+        # (ReLU units whose pre-activation is within fp32 rounding of zero fall on different sides: tests/test_gpu_train.py)
+        assert l2 <= 1e-2 and mx <= 3e-2 and abs(nrm - 1.0) <= 2e-3, (name, l2, mx, nrm)
+    bn = net.occupancy_head.occ_convs[0][1]
+    assert int(bn.num_batches_tracked) == int(G[tag + '_occ_bn_batches'])
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), G[tag + '_occ_bn_running_mean'], rtol=1e-4, atol=1e-5)

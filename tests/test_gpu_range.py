@@ -123,7 +123,8 @@ def test_conv3d_h2_residual_two_outputs_sweep(k):
 
 def test_conv3d_h2_heavy_tailed_bn():
     """per-channel BN scales spread over six decades and Student-t(2) activations: one tensor-wide exponent must still leave
-    every element within the per-element bound (the bound's rms term is the tensor's, as in the sweep)"""
+    every element within the per-element bound with the TENSOR's rms, and every channel within the bound with ITS OWN rms plus the
+    format's absolute floor of 2^-36 of the tensor maximum"""
     rs = np.random.RandomState(13)
     cin, cout = 32, 64
     x = rs.standard_t(2.0, size=(1, 6, 12, 20, cin)).astype(np.float32)
@@ -140,11 +141,21 @@ def test_conv3d_h2_heavy_tailed_bn():
            + bi[None, :, None, None, None]).transpose(0, 2, 3, 4, 1)
     # (measured 1.71 in units of 4e-6 |ref| + 2e-6 rms, the fp32 oracle 3.72: a few huge products dominate each sum)
     _per_element('conv3d_h2 heavy-tailed BN (tensor rms)', got, ref, CONV_REL, 2 * CONV_ABS, o32)
-    # and channel by channel for the channels within 2^-12 of the largest: their own rms in the bound
+    # and EVERY channel by its own rms.  What one exponent per TENSOR costs a small channel is an absolute
+    # floor: the tensor's largest magnitude is stored in [2^12, 2^13), fp16 subnormals have spacing 2^-24, so hi + lo resolves
+    # 2^-25 stored units = 2^-37 of the tensor maximum; a channel at 2^-k of the maximum keeps 22-bit significands for k <= 15 and
+    # 37 - k bits below.  Per element:  |err| <= REL |ref| + 2 ABS rms(channel) + 2^-36 max|tensor|
     crms = np.sqrt((ref ** 2).mean(axis=(0, 1, 2, 3)))
-    for c in np.nonzero(crms >= crms.max() * 2.0 ** -12)[0]:
-        bound = CONV_REL * np.abs(ref[..., c]) + 2 * CONV_ABS * crms[c]
-        assert (np.abs(got[..., c] - ref[..., c]) <= bound).all(), ('channel', int(c), float(crms[c] / crms.max()))
+    floor = 2.0 ** -36 * float(np.abs(ref).max())
+    worst, worst_c = 0.0, -1
+    for c in range(cout):
+        bound = CONV_REL * np.abs(ref[..., c]) + 2 * CONV_ABS * crms[c] + floor
+        q = float((np.abs(got[..., c] - ref[..., c]) / bound).max())
+        if q > worst:
+            worst, worst_c = q, c
+        assert q <= 1.0, ('channel', int(c), 'rms / largest channel rms = 2^%.1f' % np.log2(crms[c] / crms.max()), q)
+    print('[parity] heavy-tailed BN, every channel by its own rms (channel rms spread 2^%.1f): worst %.2f of the bound at channel %d '
+          '(2^%.1f of the largest)' % (np.log2(crms.max() / crms.min()), worst, worst_c, np.log2(crms[worst_c] / crms.max())))
 
 
 @pytest.mark.parametrize('k', SWEEP)
