@@ -173,14 +173,15 @@ class KernelProbe:
                      bytes=4.0 * (vs.n_keys * C + depth.numel() + feat.numel() + (vs.n_keys + 1) + 2 * kept))
         elif name == 'lss_lift_pool':
             # one frame's whole lift (camera matrices, voxel ids, point lists, pooling: 5 launches, timed together).  Algorithmic
-            # bytes = what the stage must touch: the pooled grid written once, depth and context read once, the frustum table read
-            # once per camera; the id slots and lists are the implementation's own traffic and are not counted
+            # bytes = SURVEY 8(d)'s 90.0 MB per frame: the pooled grid written once (81.92), depth (5.95) and context (2.16) read
+            # once; the frustum table (2.97 MB, shared by the cameras and L2-resident), the id slots and the lists are the
+            # implementation's own traffic and are not counted
             fr, depth, feat = args[0], args[9], args[10]
             size = args[8]
             n_vox = int(args[1].shape[0]) * int(size[0]) * int(size[1]) * int(size[2])
             C = feat.shape[-1]
             w.update(label='lss_lift_pool (whole frame, 5 launches)', flops=2.0 * C * depth.numel(), exec_flops=0.0, mfma=None,
-                     bytes=4.0 * (n_vox * C + depth.numel() + feat.numel() + 3 * depth.numel()))
+                     bytes=4.0 * (n_vox * C + depth.numel() + feat.numel()))
         elif name == 'segment_sort':
             keys, n_keys = args[0], args[1]
             w.update(label='segment_sort', mfma=None, bytes=4.0 * (3 * keys.numel() + 2 * n_keys))

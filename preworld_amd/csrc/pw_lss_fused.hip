@@ -16,12 +16,12 @@
 // kernels; one wave per heavy voxel sorts up to 64 ids in registers, a block sorts longer ones through LDS.
 //
 //   k_lss_prologue      zero the counters; camera matrices                                                  (2.6 MB)
-//   k_lss_index_slots   geometry, run-compressed returning atomics, slot / overflow writes; ALSO zero-fills `out` -- the kernel is
-//                       bound by atomic throughput and has the memory pipe free, so the fill of the empty voxels costs no time
+//   k_lss_index_slots   geometry, run-compressed returning atomics, slot writes, arrival rank per point (4 bytes)
 //   k_lss_heavy_alloc   storage for the heavy voxels (wave scan + one atomic per wave), lists by size class
-//   k_lss_ovf_scatter   overflow entries -> tmp[start(voxel) + arrival rank]
-//   k_lss_pool_slots    light voxels: 64 counters per wave, non-empty ones compacted in the wave, eight at a time;
-//                       heavy voxels: first blocks of the launch
+//   k_lss_ovf_scatter   points of rank >= 8 (their voxel recomputed from the geometry) -> tmp[start(voxel) + arrival rank]
+//   k_lss_pool_slots    light voxels: 64 counters per wave, non-empty ones compacted in the wave, eight at a time; the EMPTY voxels
+//                       of the wave's 64 get their zero rows here, so the grid is written exactly once (round 4: the zero fill of
+//                       all 82 MB used to ride in k_lss_index_slots and 44 MB of it was overwritten); heavy voxels: first blocks
 // HBM-bound integer/byte work: no MFMA.  Compiled with -ffp-contract=off (see pw_lss_common.h).
 #include "pw_lss_common.h"
 
@@ -81,12 +81,7 @@ __global__ void __launch_bounds__(256)
 k_lss_index_slots(int N, int64_t DHW, int64_t total, const float* __restrict__ frustum, const float* __restrict__ ipr,
                   const float* __restrict__ ptr, const float* __restrict__ comb, const float* __restrict__ trn,
                   const float* __restrict__ bda, GridParams gp, int32_t* __restrict__ count,
-                  int32_t* __restrict__ slots, int2* __restrict__ kr, int4* __restrict__ zero_out, int64_t n_zero16, int dbg) {
-  if (!(dbg & 8)) {
-    const int64_t per = (n_zero16 + gridDim.x - 1) / gridDim.x;
-    const int64_t z0 = (int64_t)blockIdx.x * per, z1 = min(z0 + per, n_zero16);
-    for (int64_t j = z0 + threadIdx.x; j < z1; j += blockDim.x) zero_out[j] = make_int4(0, 0, 0, 0);
-  }
+                  int32_t* __restrict__ slots, int32_t* __restrict__ rank) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int k = i < total ? lss_voxel_of_point(i, N, DHW, frustum, ipr, ptr, comb, trn, bda, gp, nullptr) : -1;
@@ -103,8 +98,9 @@ k_lss_index_slots(int N, int64_t DHW, int64_t total, const float* __restrict__ f
   const int r = base + lane - start;                                        // arrival rank of this point in its voxel
   if (k >= 0 && r < LS) slots[(int64_t)k * LS + r] = (int32_t)i;
   // points beyond the slots are placed by k_lss_ovf_scatter once their voxel has storage.  (An overflow LIST appended to here
-  // -- one atomic per wave on a cursor -- cost 80 us: same-address atomics serialise.  8 bytes per point, coalesced, cost nothing.)
-  if (i < total) kr[i] = make_int2(k, r);
+  // -- one atomic per wave on a cursor -- cost 80 us: same-address atomics serialise.  4 bytes per point, coalesced, cost nothing;
+  // the voxel is recomputed there instead of being carried: 6 MB less written and read.)
+  if (i < total) rank[i] = k >= 0 ? r : -1;
 }
 
 // storage and size class of the heavy voxels: a sweep over the counters, 2 048 voxels per block, ONE atomic per block and cursor
@@ -148,11 +144,16 @@ k_lss_heavy_alloc(const int32_t* __restrict__ count, int64_t n_vox, int32_t* __r
 }
 
 __global__ void __launch_bounds__(256)
-k_lss_ovf_scatter(int64_t total, const int2* __restrict__ kr, const int32_t* __restrict__ hstart, int32_t* __restrict__ tmp) {
+k_lss_ovf_scatter(int N, int64_t DHW, int64_t total, const float* __restrict__ frustum, const float* __restrict__ ipr,
+                  const float* __restrict__ ptr, const float* __restrict__ comb, const float* __restrict__ trn,
+                  const float* __restrict__ bda, GridParams gp, const int32_t* __restrict__ rank, const int32_t* __restrict__ hstart,
+                  int32_t* __restrict__ tmp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int2 e = kr[i];
-  if (e.x >= 0 && e.y >= LS) tmp[hstart[e.x] + e.y] = (int32_t)i;   // positions start .. start + 7 stay unused: those ids sit in the slots
+  const int r = rank[i];
+  if (r < LS) return;                                              // outside the grid (-1) or in a slot
+  const int k = lss_voxel_of_point(i, N, DHW, frustum, ipr, ptr, comb, trn, bda, gp, nullptr);      // same code, same bits as in the index kernel
+  tmp[hstart[k] + r] = (int32_t)i;                                 // positions start .. start + 7 stay unused: those ids sit in the slots
 }
 
 namespace {
@@ -344,13 +345,22 @@ k_lss_pool_slots(const float* __restrict__ depth, const float4* __restrict__ fea
   } else {
     // ---- the light voxels (1 .. 8 points).  A wave reads the counters of 64 consecutive voxels, moves the (voxel, count) pairs
     // of the non-empty light ones to its first lanes (ds_permute over a full permutation), and its eight lane groups take eight of
-    // them at a time: the group sorts the voxel's ids (8 shuffles + one ds_permute), gathers the rows, adds them in order.  Empty
-    // voxels were zero-filled by k_lss_index_slots.
+    // them at a time: the group sorts the voxel's ids (8 shuffles + one ds_permute), gathers the rows, adds them in order.  The
+    // EMPTY voxels among the 64 get their zero row here (8 rows per store instruction, one per lane group; all-zero bytes are zero
+    // in both output formats), so every row of the grid is written by exactly one kernel, once.
     const int grp = lane / LPV, gbase = lane - sub;
     const int64_t wid = (int64_t)((int)blockIdx.x - C_BLOCKS - B_BLOCKS) * 4 + wave;
     const int64_t nw = (int64_t)((int)gridDim.x - C_BLOCKS - B_BLOCKS) * 4;
     for (int64_t v0 = wid * 64; v0 < ((dbg & 4) ? 0 : n_vox); v0 += nw * 64) {
-      const int c = v0 + lane < n_vox ? count[v0 + lane] : 0;
+      const int c = v0 + lane < n_vox ? count[v0 + lane] : -1;
+      {
+        const unsigned long long empty = __ballot(c == 0);
+        if (empty) {
+#pragma unroll
+          for (int j = 0; j < GROUPS; ++j)
+            if ((empty >> (j * GROUPS + grp)) & 1ull) out[(v0 + j * GROUPS + grp) * LPV + sub] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
       const bool light = c > 0 && c <= LS;
       const unsigned long long m = __ballot(light);
       const int nl = __builtin_popcountll(m);
@@ -404,7 +414,7 @@ struct FusedWs {
   size_t zero_bytes;
   float *ipr, *comb, *tr;
   int32_t* slots;
-  int2* kr;
+  int32_t* rank;
   int32_t* hstart;
   int4 *list_b, *list_c;
   int32_t *tmp, *sorted_pf;
@@ -422,7 +432,7 @@ FusedWs fused_ws(char* base, int64_t n, int64_t n_vox, int BN) {
   w.comb = (float*)take((size_t)BN * 9 * 4);
   w.tr = (float*)take((size_t)BN * 3 * 4);
   w.slots = (int32_t*)take((size_t)n_vox * LS * 4);
-  w.kr = (int2*)take((size_t)n * 8);
+  w.rank = (int32_t*)take((size_t)n * 4);
   w.hstart = (int32_t*)take((size_t)n_vox * 4);
   w.list_b = (int4*)take((size_t)(n / (LS + 1) + 1) * 16);
   w.list_c = (int4*)take((size_t)(n / (HEAVY_WAVE_MAX + 1) + 1) * 16);
@@ -468,10 +478,11 @@ PW_API int pw_lss_lift_pool(int B, int N, int D, int H, int W, const float* frus
                      w.ipr, w.comb, w.tr, (int4*)w.count, nz);
   int32_t* cur = w.count + n_vox;
   hipLaunchKernelGGL(k_lss_index_slots, dim3((unsigned)pw_cdiv(total, 256)), dim3(256), 0, st, N, DHW, total, frustum, w.ipr,
-                     post_trans, w.comb, w.tr, bda, gp, w.count, w.slots, w.kr, (int4*)out, n_vox * (int64_t)c * 4 / 16, dbg);
+                     post_trans, w.comb, w.tr, bda, gp, w.count, w.slots, w.rank);
   hipLaunchKernelGGL(k_lss_heavy_alloc, dim3((unsigned)pw_cdiv(n_vox, 256 * HA_ITEMS)), dim3(256), 0, st, w.count, n_vox, cur,
                      w.hstart, w.list_b, w.list_c);
-  hipLaunchKernelGGL(k_lss_ovf_scatter, dim3((unsigned)pw_cdiv(total, 256)), dim3(256), 0, st, total, w.kr, w.hstart, w.tmp);
+  hipLaunchKernelGGL(k_lss_ovf_scatter, dim3((unsigned)pw_cdiv(total, 256)), dim3(256), 0, st, N, DHW, total, frustum, w.ipr,
+                     post_trans, w.comb, w.tr, bda, gp, w.rank, w.hstart, w.tmp);
   const FeatIdx fi{(int)DHW, H * W, 1.0f / (float)DHW, 1.0f / (float)(H * W)};
   const int64_t want = pw_cdiv(pw_cdiv(n_vox, 64), 4);
   hipLaunchKernelGGL(k_lss_pool_slots, dim3((unsigned)(want < 4096 ? want : 4096) + C_BLOCKS + B_BLOCKS), dim3(256), SORT_LDS_IDS * 4,
