@@ -263,6 +263,28 @@ __device__ __forceinline__ void split8(const float* x, fh8& hi, fh8& lo) {
   lo = __builtin_bit_cast(fh8, b);
 }
 
+// split of 8 BOUNDED values (the hidden activations: at most 2^15 by construction, never Inf): hi = v_cvt_pk_f16_f32 per pair, lo =
+// fp16(x - hi) as ONE v_fma_mixlo_f16 / v_fma_mixhi_f16 per value -- hi * -1 + x is exact in fp32 and rounded once into the fp16 half
+// of the destination, the same bits as the convert-subtract-convert form of h2_split8, without its Inf guard (v_med3) and second
+// convert: 1.5 instead of 3 VALU instructions per value in a kernel that is bound by them
+__device__ __forceinline__ void split8_bounded(const float* x, fh8& hi, fh8& lo) {
+  typedef _Float16 sh2 __attribute__((ext_vector_type(2)));
+  typedef float sf2 __attribute__((ext_vector_type(2)));
+  unsigned hp[4], lp[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const sf2 v = {x[2 * p], x[2 * p + 1]};
+    hp[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, sh2));
+    unsigned l;                              // (mixlo writes the low half, mixhi then the high half: no initialisation needed)
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hp[p]), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hp[p]), "v"(v[1]));
+    lp[p] = l;
+  }
+  typedef unsigned su4 __attribute__((ext_vector_type(4)));
+  hi = __builtin_bit_cast(fh8, su4{hp[0], hp[1], hp[2], hp[3]});
+  lo = __builtin_bit_cast(fh8, su4{lp[0], lp[1], lp[2], lp[3]});
+}
+
 // softplus_t20(z) / 2^eh from zs = z / 2^eh:  max(zs, 0) + (ln2 / 2^eh) log2(1 + exp2(-|zs| 2^eh log2e)) -- the same six
 // instructions, the hidden activations come out in the units they are split in (kexp = 2^eh log2e, kln = ln2 / 2^eh)
 __device__ __forceinline__ float softplus_scaled(float zs, float kexp, float kln) {
@@ -323,111 +345,144 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
   const char* a1 = reinterpret_cast<const char*>(l_w1) + lane * 16;
   const char* a2 = reinterpret_cast<const char*>(l_w2) + lane * 16;
 
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
-    const long long m0 = tile * 32;
-    long long m = m0 + j;
-    const bool valid = m < n_total;
-    if (!valid) m = n_total - 1;
-    const int sample = (int)(m / n_vox_per_sample);
-    const float* c1s = l_c1 + (size_t)sample * HID + h * 64;
-    float v[16];
-    if (v0_h2) {
-      // h2 storage (pw_h2.h): channels 8 q + 4 h + 0..3 = the 8-byte group at slot 4 (q & 1) + 2 (q >> 1) + plane, byte 8 h
-      const char* src = reinterpret_cast<const char*>(v0 + (size_t)m * C) + 8 * h;
+  // TWO voxel tiles per wave and trip (round 4): the kernel is bound by its VALU work -- per hidden tile 16 softplus (two quarter-rate
+  // transcendentals each) + 16 splits, ~1 050 issue cycles against 384 of MFMA -- and inside ONE tile everything is a dependent
+  // chain MFMA -> softplus -> split -> MFMA.  With two independent tiles in the loop body one tile's softplus / split instructions
+  // issue while the other tile's MFMAs execute.
+  constexpr int NU = 2;
+  const long long n_pairs = (n_tiles + NU - 1) / NU;
+  for (long long pair = (long long)blockIdx.x * 4 + wave; pair < n_pairs; pair += (long long)gridDim.x * 4) {
+    long long m[NU];
+    bool valid[NU];
+    const float* c1s[NU];
+    float v[NU][16];
+    fh8 vh[NU][2], vl[NU][2];               // split of the current state: GEMM operand of this step AND the h2 output of the last
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int off = (4 * (q & 1) + 2 * (q >> 1)) * 16;
-        const fh4 hi4 = *reinterpret_cast<const fh4*>(src + off), lo4 = *reinterpret_cast<const fh4*>(src + off + 16);
+    for (int u = 0; u < NU; ++u) {
+      m[u] = (pair * NU + u) * 32 + j;
+      valid[u] = m[u] < n_total;
+      if (!valid[u]) m[u] = n_total - 1;
+      const int sample = (int)(m[u] / n_vox_per_sample);
+      c1s[u] = l_c1 + (size_t)sample * HID + h * 64;
+      if (v0_h2) {
+        // h2 storage (pw_h2.h): channels 8 q + 4 h + 0..3 = the 8-byte group at slot 4 (q & 1) + 2 (q >> 1) + plane, byte 8 h
+        const char* src = reinterpret_cast<const char*>(v0 + (size_t)m[u] * C) + 8 * h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] = ((float)hi4[e] + (float)lo4[e]) * k_in;
+        for (int q = 0; q < 4; ++q) {
+          const int off = (4 * (q & 1) + 2 * (q >> 1)) * 16;
+          const fh4 hi4 = *reinterpret_cast<const fh4*>(src + off), lo4 = *reinterpret_cast<const fh4*>(src + off + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][4 * q + e] = ((float)hi4[e] + (float)lo4[e]) * k_in;
+        }
+      } else {
+        const float* src = v0 + (size_t)m[u] * C + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 t4 = *reinterpret_cast<const float4*>(src + 8 * q);
+          v[u][4 * q + 0] = t4.x * k_in; v[u][4 * q + 1] = t4.y * k_in; v[u][4 * q + 2] = t4.z * k_in; v[u][4 * q + 3] = t4.w * k_in;
+        }
       }
-    } else {
-      const float* src = v0 + (size_t)m * C + 4 * h;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 t4 = *reinterpret_cast<const float4*>(src + 8 * q);
-        v[4 * q + 0] = t4.x * k_in; v[4 * q + 1] = t4.y * k_in; v[4 * q + 2] = t4.z * k_in; v[4 * q + 3] = t4.w * k_in;
-      }
+      split8(v[u], vh[u][0], vl[u][0]);
+      split8(v[u] + 8, vh[u][1], vl[u][1]);
     }
-    fh8 vh[2], vl[2];                        // split of the current state: GEMM operand of this step AND the h2 output of the last
-    split8(v, vh[0], vl[0]);
-    split8(v + 8, vh[1], vl[1]);
     for (int step = 0; step < n_steps; ++step) {
-      f32x16 o;
+      f32x16 o[NU];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) o[s] = 0.f;
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) o[u][s] = 0.f;
 #pragma unroll 1
       for (int t = 0; t < 4; ++t) {
-        f32x16 hid;
+        f32x16 hid[NU];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) hid[s] = 0.f;
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int s = 0; s < 16; ++s) hid[u][s] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const fh8 wh = __builtin_bit_cast(fh8, *reinterpret_cast<const fv4*>(a1 + ((t * 2 + ks) * 2 + 0) * 1024));
           const fh8 wl = __builtin_bit_cast(fh8, *reinterpret_cast<const fv4*>(a1 + ((t * 2 + ks) * 2 + 1) * 1024));
-          hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, vh[ks], hid, 0, 0, 0);
-          hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, vh[ks], hid, 0, 0, 0);
-          hid = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, vl[ks], hid, 0, 0, 0);
-        }
-        float hs[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 c4 = *reinterpret_cast<const float4*>(c1s + t * 16 + q * 4);
-          hs[4 * q + 0] = softplus_scaled(fmaf(hid[4 * q + 0], k1, c4.x), kexp, kln);
-          hs[4 * q + 1] = softplus_scaled(fmaf(hid[4 * q + 1], k1, c4.y), kexp, kln);
-          hs[4 * q + 2] = softplus_scaled(fmaf(hid[4 * q + 2], k1, c4.z), kexp, kln);
-          hs[4 * q + 3] = softplus_scaled(fmaf(hid[4 * q + 3], k1, c4.w), kexp, kln);
+          for (int u = 0; u < NU; ++u) {
+            hid[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, vh[u][ks], hid[u], 0, 0, 0);
+            hid[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, vh[u][ks], hid[u], 0, 0, 0);
+            hid[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, vl[u][ks], hid[u], 0, 0, 0);
+          }
+        }
+        fh8 hh[NU][2], hl[NU][2];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          float hs[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 c4 = *reinterpret_cast<const float4*>(c1s[u] + t * 16 + q * 4);
+            hs[4 * q + 0] = softplus_scaled(fmaf(hid[u][4 * q + 0], k1, c4.x), kexp, kln);
+            hs[4 * q + 1] = softplus_scaled(fmaf(hid[u][4 * q + 1], k1, c4.y), kexp, kln);
+            hs[4 * q + 2] = softplus_scaled(fmaf(hid[u][4 * q + 2], k1, c4.z), kexp, kln);
+            hs[4 * q + 3] = softplus_scaled(fmaf(hid[u][4 * q + 3], k1, c4.w), kexp, kln);
+          }
+#ifdef PW_X_FC_OLD_SPLIT                      // A/B builds only (tools/build_variant.py)
+          split8(hs, hh[u][0], hl[u][0]);
+          split8(hs + 8, hh[u][1], hl[u][1]);
+#else
+          split8_bounded(hs, hh[u][0], hl[u][0]);
+          split8_bounded(hs + 8, hh[u][1], hl[u][1]);
+#endif
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-          fh8 hh, hl;
-          split8(hs + 8 * kb, hh, hl);
           const fh8 wh = __builtin_bit_cast(fh8, *reinterpret_cast<const fv4*>(a2 + ((t * 2 + kb) * 2 + 0) * 1024));
           const fh8 wl = __builtin_bit_cast(fh8, *reinterpret_cast<const fv4*>(a2 + ((t * 2 + kb) * 2 + 1) * 1024));
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl, o, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            o[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh[u][kb], o[u], 0, 0, 0);
+            o[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[u][kb], o[u], 0, 0, 0);
+            o[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[u][kb], o[u], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
-      for (int s = 0; s < 16; ++s) v[s] = fmaf(o[s], k2, b2r[s]) + v[s];   // + b2, residual connection (:342)
-      split8(v, vh[0], vl[0]);
-      split8(v + 8, vh[1], vl[1]);
-      if (valid) {
+      for (int u = 0; u < NU; ++u) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) amax = fmaxf(amax, fabsf(v[s]));
-        if (out_h2) {
-          // h2 storage: a 16-byte slot holds 8 channels of one plane, but this lane has only 4 of them (8 q + 4 h + e) and its
-          // partner lane (l ^ 32, same voxel) the other 4.  One v_permlane32_swap per dword trades the pieces so that lane half
-          // h ends up with both pieces of the slots of q = 2 h, 2 h + 1: four 16-byte stores like the fp32 layout.
-          fh4 hi4[4], lo4[4];
+        for (int s = 0; s < 16; ++s) v[u][s] = fmaf(o[u][s], k2, b2r[s]) + v[u][s];   // + b2, residual connection (:342)
+        split8(v[u], vh[u][0], vl[u][0]);
+        split8(v[u] + 8, vh[u][1], vl[u][1]);
+        if (valid[u]) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+          for (int s = 0; s < 16; ++s) amax = fmaxf(amax, fabsf(v[u][s]));
+          if (out_h2) {
+            // h2 storage: a 16-byte slot holds 8 channels of one plane, but this lane has only 4 of them (8 q + 4 h + e) and its
+            // partner lane (l ^ 32, same voxel) the other 4.  One v_permlane32_swap per dword trades the pieces so that lane half
+            // h ends up with both pieces of the slots of q = 2 h, 2 h + 1: four 16-byte stores like the fp32 layout.
+            fh4 hi4[4], lo4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              hi4[q][e] = vh[q >> 1][4 * (q & 1) + e];
-              lo4[q][e] = vl[q >> 1][4 * (q & 1) + e];
-            }
-          char* dst = reinterpret_cast<char*>(states + ((size_t)step * n_total + m) * C);
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int qq = 0; qq < 2; ++qq)
+              for (int e = 0; e < 4; ++e) {
+                hi4[q][e] = vh[u][q >> 1][4 * (q & 1) + e];
+                lo4[q][e] = vl[u][q >> 1][4 * (q & 1) + e];
+              }
+            char* dst = reinterpret_cast<char*>(states + ((size_t)step * n_total + m[u]) * C);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-              typedef unsigned fu2 __attribute__((ext_vector_type(2)));
-              typedef unsigned fu4 __attribute__((ext_vector_type(4)));
-              const fu2 a = __builtin_bit_cast(fu2, p ? lo4[qq] : hi4[qq]), b = __builtin_bit_cast(fu2, p ? lo4[qq + 2] : hi4[qq + 2]);
-              const auto s0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
-              const auto s1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-              fu4 slot;
-              slot[0] = s0[0]; slot[1] = s1[0]; slot[2] = s0[1]; slot[3] = s1[1];      // channels +0..3 | +4..7
-              *reinterpret_cast<fu4*>(dst + (4 * qq + 2 * h + p) * 16) = slot;
-            }
-        } else {
-          float* dst = states + ((size_t)step * n_total + m) * C + 4 * h;
+            for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(v[4 * q + 0] * k_out, v[4 * q + 1] * k_out, v[4 * q + 2] * k_out,
-                                                                  v[4 * q + 3] * k_out);
+              for (int p = 0; p < 2; ++p) {
+                typedef unsigned fu2 __attribute__((ext_vector_type(2)));
+                typedef unsigned fu4 __attribute__((ext_vector_type(4)));
+                const fu2 a = __builtin_bit_cast(fu2, p ? lo4[qq] : hi4[qq]), b = __builtin_bit_cast(fu2, p ? lo4[qq + 2] : hi4[qq + 2]);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                fu4 slot;
+                slot[0] = s0[0]; slot[1] = s1[0]; slot[2] = s0[1]; slot[3] = s1[1];      // channels +0..3 | +4..7
+                *reinterpret_cast<fu4*>(dst + (4 * qq + 2 * h + p) * 16) = slot;
+              }
+          } else {
+            float* dst = states + ((size_t)step * n_total + m[u]) * C + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(v[u][4 * q + 0] * k_out, v[u][4 * q + 1] * k_out, v[u][4 * q + 2] * k_out,
+                                                                    v[u][4 * q + 3] * k_out);
+          }
         }
       }
     }
@@ -446,8 +501,8 @@ PW_API int pw_forecast_steps_h2(const float* v0, int64_t n_vox_per_sample, int n
                "pw_forecast_steps_h2: pointers must be 16-B aligned");
   const size_t lds_bytes = (size_t)2 * WH2 * 4 + (size_t)n_samples * HID * 4;   // 32 KB + the scaled ego terms
   long long n_tiles = (n_vox_per_sample * n_samples + 31) / 32;
-  long long want = (n_tiles + 3) / 4;
-  unsigned nb = (unsigned)(want < 1024 ? want : 1024);   // 4 blocks x 256 CUs, grid-stride
+  long long want = ((n_tiles + 1) / 2 + 3) / 4;            // a wave takes two tiles per trip
+  unsigned nb = (unsigned)(want < 512 ? want : 512);     // 2 resident blocks x 256 CUs, grid-stride: 10 000 tile pairs at C3 = 4.9 trips per wave
   hipLaunchKernelGGL(k_forecast_h2, dim3(nb), dim3(256), lds_bytes, pw_stream(stream), v0, (long long)n_vox_per_sample,
                      n_samples, w1p, w2p, inv1, inv2, c1p, fusion_b2, n_steps, states, v0_h2, out_h2, v0_rng, states_rng, w1_l1max);
   pw_note_kernel("k_forecast_h2");
