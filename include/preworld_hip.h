@@ -159,8 +159,9 @@ int pw_lss_lift_pool(int B, int N, int D, int H, int W, const float* frustum, co
  *   0 = dense (cout0 / cout1); larger when the output is a channel slice of a wider channels-last
  *   buffer (the [adjacent, key] concat of bevdet_occ.py:266 is produced in place this way).
  *   ksize in {1,2,3} (pad = (ksize-1)/2; ksize 2 needs stride 2), stride in {1,2}.
- *   algo: 0 auto, 1 LDS-tiled kernel (k3 s1), 2 gather kernel, 3 gather kernel with the input-channel
- *   chunks split over the 4 waves of a block and summed in LDS in a fixed order (small grids). */
+ *   algo: 0 auto; the others force one kernel (tests, A/B): 1 tile-per-block LDS kernel (k3 s1), 2 gather kernel, 3 gather kernel
+ *   with the input-channel chunks split over the 4 waves of a block and summed in LDS in a fixed order (small grids), 4 persistent
+ *   DMA-pipelined LDS kernel (k3 s1). */
 int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale, const float* bias,
                     const float* residual, float* y0, float* y1, int B, int D, int H, int W,
                     int Cin, int cout_total, int cout0, int cout1, int ld_y0, int ld_y1, int ksize,
@@ -227,8 +228,9 @@ int pw_f32_to_h2(const float* x, float* y, int64_t n_vox, int C, int ld_x, int l
 int pw_h2_to_f32(const float* x, float* y, int64_t n_vox, int C, int ld_x, int ld_y, const int32_t* rng, void* stream);
 
 /* Convolution with split-fp16 operands, same contract as pw_conv3d_ndhwc -- scale/bias, residual, ReLU, two destinations,
- * row strides -- for ksize 3 (stride 1: persistent LDS-tiled kernel; stride 2: gather kernel) and ksize 1 (stride 1); algo 2 / 3
- * force the gather kernel (3 = input-channel chunks split over the 4 waves, tiny grids), with
+ * row strides -- for ksize 3 (stride 1: persistent LDS-tiled kernel; stride 2: LDS-tiled k_conv3d_h2_s2 for the shapes it is built
+ * for, else the gather kernel) and ksize 1 (stride 1); algo 0 auto, algo 2 / 3 force the gather kernel (3 = input-channel chunks
+ * split over the 4 waves, tiny grids), with
  *   x        (B, D, H, W, Cin) in h2 storage;
  *   wpk      split-fp16 packed weights float[Cin/32][ksize^3][cout_total/32][4 pieces][64 lanes][4]: piece q = 2*ks + p of
  *            lane l (j = l & 31, h = l >> 5) holds the 8 halves plane p of S[n] * w[n = nt*32 + j][c = ch*32 + 16*ks + 8*h + 0..7][tap],

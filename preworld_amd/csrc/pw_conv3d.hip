@@ -65,7 +65,6 @@ __global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
   const int td = bid % a.tiles_d;
   const int b = bid / a.tiles_d;
   const int d0 = td * (BD * WD), h0 = th * BH, w0 = tw * BW;
-  const StageLane sl = stage_lane_setup(a, w0, lane);
 
   f32x16 acc[2][NT];
 #pragma unroll
@@ -83,8 +82,7 @@ __global__ void __launch_bounds__(256 * WD, 2) k_conv3d_k3s1(ConvArgs a) {
     const unsigned wsoff = (unsigned)((ch * 27 * ntiles_total + ng * NT) * 4096);
     float4 b0[NT][4], b1[NT][4];
     load_b<NT>(wr, wsoff, lane_off, b0);
-    if (WD == 1 && a.dma_stage) stage_halo_chunk_dma(a, xr, lds, b, d0, h0, w0, ch, wave, lane);
-    else stage_halo_chunk<WD, 8>(a, xr, lds, sl, b, d0, h0, w0, ch, wave, lane);
+    stage_halo_chunk_dma(a, xr, lds, b, d0, h0, w0, ch, wave, lane);
     if (a.probe && ch == 0) ts1 = __builtin_readcyclecounter();
     tap_pair<NT, 0>(lds, aaddr, wr, wsoff, lane_off, wstride, b0, b1, acc);
   }
@@ -511,25 +509,20 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
     long long nblk2 = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w * (ntiles / 2);
     if (nblk2 < 512) NT = 1;
   }
-  if (const char* e = getenv("PW_CONV_NT")) {          // experiments only
-    const int f = atoi(e);
-    if ((f == 1 || f == 2) && ntiles % f == 0) NT = f;
-  }
   const int ngroups = ntiles / NT;
   const long long n_out = (long long)B * a.Do * a.Ho * a.Wo;
-  // algo: 0 = auto, 1 = force LDS-tiled (k3 s1 only), 2 = force gather, 3 = gather with the input
-  // channels split over the 4 waves of a block (small grids, see k_conv3d_gather)
+  // algo: 0 = auto, 1 = the tile-per-block LDS kernel (k3 s1 only), 2 = the gather kernel, 3 = gather with the input channels
+  // split over the 4 waves of a block (small grids, see k_conv3d_gather), 4 = the persistent DMA-pipelined kernel (k3 s1 only)
   // auto: a grid with fewer (tile, N-group) items than CUs and >= 4 input chunks (the 4x50x50 128->128
   // stage: 196 items) runs ~5 % faster on the channel-split gather kernel (106 vs 112 us)
   if (algo == 0 && ksize == 3 && stride == 1 && NT == 1 && (Cin / KC) % 4 == 0 &&
       (long long)B * a.tiles_d * a.tiles_h * a.tiles_w * ngroups < pw_num_cus())
     algo = 3;
   const bool tiled = (ksize == 3 && stride == 1 && algo != 2 && algo != 3);
-  PW_CHECK_ARG(!(algo == 1 && !tiled), "pw_conv3d_ndhwc: algo=1 needs ksize 3 stride 1");
+  PW_CHECK_ARG(!((algo == 1 || algo == 4) && !tiled), "pw_conv3d_ndhwc: algo 1 / 4 need ksize 3 stride 1");
   a.probe = nullptr;
   if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
-  a.dma_stage = dma_stage_default();
-  if (tiled && use_pipe((long long)B * a.tiles_d * a.tiles_h * a.tiles_w * ngroups, NT)) {
+  if (tiled && use_pipe((long long)B * a.tiles_d * a.tiles_h * a.tiles_w * ngroups, NT, algo)) {
     PipeArgs p;
     p.ngroups = ngroups;
     p.n_items = (int)((long long)B * a.tiles_d * a.tiles_h * a.tiles_w * ngroups);
@@ -549,22 +542,17 @@ PW_API int pw_conv3d_ndhwc(const float* x, const float* wpk, const float* scale,
       pw_note_kernel("k_conv3d_k3s1_pipe<1>");
     }
   } else if (tiled) {
-    const int WD = choose_wd(B, a.Do, a.Ho, a.Wo, ngroups);
-    a.tiles_d = (a.Do + BD * WD - 1) / (BD * WD);
     long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
     PW_CHECK_ARG(nblk < (1ll << 31), "pw_conv3d_ndhwc: grid too large");
     dim3 grid((unsigned)nblk, (unsigned)ngroups);
-#define PW_LAUNCH_TILED(NTv, WDv)                                                              \
+#define PW_LAUNCH_TILED(NTv)                                                                   \
   do {                                                                                         \
-    static int once = set_lds_limit(k_conv3d_k3s1<NTv, WDv>, TileGeom<WDv>::LDS);               \
+    static int once = set_lds_limit(k_conv3d_k3s1<NTv, 1>, TileGeom<1>::LDS);                   \
     if (once) return once;                                                                     \
-    hipLaunchKernelGGL((k_conv3d_k3s1<NTv, WDv>), grid, dim3(256 * WDv), TileGeom<WDv>::LDS, st, a); \
-    pw_note_kernel("k_conv3d_k3s1<%d, %d>", NTv, WDv);                                          \
+    hipLaunchKernelGGL((k_conv3d_k3s1<NTv, 1>), grid, dim3(256), TileGeom<1>::LDS, st, a);      \
+    pw_note_kernel("k_conv3d_k3s1<%d, 1>", NTv);                                                \
   } while (0)
-    if (NT == 2 && WD == 2) PW_LAUNCH_TILED(2, 2);
-    else if (NT == 2) PW_LAUNCH_TILED(2, 1);
-    else if (WD == 2) PW_LAUNCH_TILED(1, 2);
-    else PW_LAUNCH_TILED(1, 1);
+    if (NT == 2) PW_LAUNCH_TILED(2); else PW_LAUNCH_TILED(1);
 #undef PW_LAUNCH_TILED
   } else {
     if (int rc = pw_launch_conv3d_gather(a, NT, ngroups, ksize, stride, algo, Cin, n_out, st)) return rc;

@@ -35,7 +35,7 @@ struct ConvArgs {
   int relu0, relu1;
   int tiles_d, tiles_h, tiles_w;
   long long* probe;       // development aid: per-wave phase timestamps (PW_CONV_PROBE) or null
-  int dma_stage;          // tile-per-block kernels: stage the halo with buffer_load ... lds
+  int dma_stage;          // pw_fpn3d.hip: input-format flag (x8 and wpk8 are split-fp16)
   int fmt_y0, fmt_y1, fmt_res;  // split-fp16 kernels (pw_h2.h): 0 = fp32, 1 = h2 storage of y0 / y1 / residual
   // range slots of the h2 operands (pw_h2.h "Range"; null = exponent 0, nothing recorded): x / residual are read under
   // x_rng[0] / res_rng[0], y0 / y1 are written under y*_rng[0] and their largest magnitude is recorded in y*_rng[1]
@@ -149,81 +149,6 @@ template <int WD> struct TileGeom {
   static constexpr int ROWS_PER_WAVE = (ROWS + NW - 1) / NW;      // 15 (WD=1) / 13 (WD=2)
   static constexpr int LDS = TDt * TH * TW * KC * 4;              // 76800 / 128000 bytes
 };
-
-// per-lane constants of the staging pattern: a halo row is 10 voxels x 8 slots = 80 float4;
-// pass 0 covers voxels 0..7 (64 lanes), pass 1 voxels 8..9 (lanes 0..15)
-struct StageLane {
-  unsigned goff[2];        // global BYTE offset inside a row: (ww*Cin + slot*4)*4
-  unsigned loff[2][2];     // LDS byte offset inside a row, [hh parity][pass], swizzle applied
-  bool wok[2];             // w0-1+ww inside [0,W)
-};
-
-__device__ __forceinline__ StageLane stage_lane_setup(const ConvArgs& a, int w0, int lane) {
-  StageLane s;
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int ww = ps * 8 + (lane >> 3), slot = lane & 7;
-    // offsets are relative to voxel max(w0-1, 0) of the row: buffer soffset/voffset are UNSIGNED,
-    // so the "-1 voxel" of the halo cannot be expressed as a negative scalar offset at w0 = 0
-    // (there lane ww = 0 is masked by wok and its wrapped offset is never used)
-    s.goff[ps] = (unsigned)((ww - (w0 == 0 ? 1 : 0)) * a.Cin + slot * 4) * 4u;      // bytes
-    s.wok[ps] = (unsigned)(w0 - 1 + ww) < (unsigned)a.W && (ps == 0 || lane < 16);
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int f = ((ww >> 1) & 3) | (par << 2);
-      s.loff[par][ps] = (unsigned)((ww * 8 + (slot ^ f)) * 16);
-    }
-  }
-  return s;
-}
-
-// stage the 6x10x10 halo tile of one 32-channel chunk: global -> registers -> swizzled LDS
-template <int WD, int KB0>
-__device__ __forceinline__ void stage_halo_chunk(const ConvArgs& a, rsrc_t xr, float* lds,
-                                                 const StageLane& sl, int b, int d0, int h0, int w0,
-                                                 int ch, int wave, int lane) {
-  using G = TileGeom<WD>;
-  char* ldsb = reinterpret_cast<char*>(lds);
-  if (ch > 0) __syncthreads();   // every wave finished reading the previous chunk
-  // KB0 rows per batch (all loads of a batch are issued before its LDS writes): 8 rows = 64 VGPRs
-  // for the NT=1 kernels, 4 rows where the 2 x 32-wide accumulators leave fewer registers
-  constexpr int NBATCH = (G::ROWS_PER_WAVE + KB0 - 1) / KB0;
-#pragma unroll
-  for (int batch = 0; batch < NBATCH; ++batch) {
-    const int k0 = batch * KB0, k1 = (batch + 1) * KB0 < G::ROWS_PER_WAVE ? (batch + 1) * KB0 : G::ROWS_PER_WAVE;
-    float4 tmp[KB0][2];
-#pragma unroll
-    for (int k = k0; k < k1; ++k) {
-      const int row = wave + G::NW * k;                 // wave-uniform (wave comes from readfirstlane)
-      const int dd = row / TH, hh = row - dd * TH;
-      const int gd = d0 + dd - 1, gh = h0 + hh - 1;
-      const bool rok = row < G::ROWS && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H;
-      // scalar byte offset of voxel max(w0-1, 0) of this row (see stage_lane_setup)
-      const unsigned soff = (unsigned)((((((long long)b * a.D + gd) * a.H + gh) * a.W + (w0 > 0 ? w0 - 1 : 0)) * a.Cin + ch * KC) * 4);
-#pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rok && sl.wok[ps]) v = buf_load4(xr, sl.goff[ps], soff);
-        tmp[k - k0][ps] = v;
-      }
-    }
-#pragma unroll
-    for (int k = k0; k < k1; ++k) {
-      const int row = wave + G::NW * k;
-      const int dd = row / TH, hh = row - dd * TH;
-      const unsigned rofs = (unsigned)row * (TW * 128);
-      if (row < G::ROWS) {
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          const unsigned lo = (hh & 1) ? sl.loff[1][ps] : sl.loff[0][ps];
-          if (ps == 0 || lane < 16)
-            *reinterpret_cast<float4*>(ldsb + rofs + lo) = tmp[k - k0][ps];
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
 
 template <int NT>
 __device__ __forceinline__ void load_b(rsrc_t wr, unsigned wsoff, unsigned lane_off, float4 (&b)[NT][4]) {
@@ -421,13 +346,6 @@ static int set_lds_limit(K kernel, int bytes) {
   return PW_OK;
 }
 
-// halo staging of the tile-per-block kernels by buffer_load ... lds: on by default (A/B on one box, C3 step:
-// 7.125 ms with the VGPR staging, 7.056 ms with DMA); PW_CONV_DMA_STAGE=0 selects the VGPR path
-static inline int dma_stage_default() {
-  const char* e = getenv("PW_CONV_DMA_STAGE");
-  return e ? (atoi(e) ? 1 : 0) : 1;
-}
-
 // exact x / d by one mulhi for x * d < 2^32 (tile counts): floor(2^32 / d) + 1
 static inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 
@@ -442,34 +360,16 @@ static inline int pw_num_cus() {
   return n;
 }
 
-// Persistent DMA-pipelined kernel: PW_CONV_PIPE=0|1 forces it off/on.  Sustained timings (1 s loops,
-// clocks settled at 2.39 GHz, tools/bench_layers.py), tile-per-block vs pipelined:
+// Persistent DMA-pipelined kernel or tile-per-block kernel (algo 4 / 1 of pw_conv3d_ndhwc force one).  Sustained timings (1 s
+// loops, clocks settled at 2.39 GHz, tools/bench_layers.py), tile-per-block vs pipelined:
 //   16x200x200 32->32  277.9 / 278.4 us    32->64  518.3 / 537.6    64->64 1002.8 / 1049.3
 //   8x100x100  64->64  180.4 / 165.6 us    64->128 308.0 / 319.5    4x50x50 128->128 110.8 / 110.4
 // Both designs sit on the same ceiling (operand loads cost matrix-pipe time, see the kernel comment);
 // the pipelined one wins where a wave owns a single N-tile and the grid gives every CU 2+ items.
-static inline bool use_pipe(long long n_items, int NT) {
-  const char* e = getenv("PW_CONV_PIPE");            // read per call: tests flip it inside one process
-  const int forced = e ? (atoi(e) ? 1 : 0) : 2;
-  if (forced != 2) return forced == 1 && n_items < (1ll << 20);
+static inline bool use_pipe(long long n_items, int NT, int algo) {
+  if (algo == 1 || algo == 4) return algo == 4 && n_items < (1ll << 20);
   return NT == 1 && n_items >= 512 && n_items < (1ll << 20);
 }
-
-// 8-wave blocks (WD=2) when the grid has enough 8x8x8 tiles to fill the 256 CUs more than once;
-// 4-wave blocks otherwise (small encoder stages).  PW_CONV_WD=1|2 forces a variant (A/B runs).
-static inline int choose_wd(int B, int Do, int Ho, int Wo, int ngroups) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("PW_CONV_WD");
-    forced = e ? atoi(e) : 0;
-  }
-  if (forced == 1 || forced == 2) return forced;
-  // measured equal within noise on the 16x200x200 grid (325 vs 326 us for 32->32); the 4-wave
-  // variant is the default because it needs less LDS per block and tiles small grids better
-  (void)B; (void)Do; (void)Ho; (void)Wo; (void)ngroups;
-  return 1;
-}
-
 
 // gather kernel launcher (pw_conv3d_gather.hip)
 int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, int stride, int algo, int Cin,

@@ -273,24 +273,18 @@ __global__ void __launch_bounds__(256) k_conv3d_gather(ConvArgs a, long long n_o
 
 int pw_launch_conv3d_gather(const ConvArgs& a, int NT, int ngroups, int ksize, int stride, int algo, int Cin,
                              long long n_out, hipStream_t st, bool f16) {
-    // M-tiles per wave: 2 halves the weight loads per MFMA but measured slower (32->128 stride 2:
-    // 199 us vs 180 us -- fewer waves to hide the L2 gather latency); PW_GATHER_MT=2 selects it
-    const char* mte = getenv("PW_GATHER_MT");
-    int MT = (!f16 && mte && atoi(mte) == 2) ? 2 : 1;
+    // M-tiles per wave: 2 halves the weight loads per MFMA but measured slower on the fp32 pipe (32->128 stride 2:
+    // 199 us vs 180 us -- fewer waves to hide the L2 gather latency)
+    int MT = 1;
     if (f16 && ksize == 3 && stride == 2) {
       // split-fp16 stride-2 layers: the 32-cycle MFMA makes the weight loads weigh 4x more; two voxel tiles per wave win once the
       // launch has few blocks anyway (8x100x100 64->2x128: 107 -> 88 us) and lose while there are enough (16x200x200 32->2x64:
       // 135 -> 152 us)
       MT = (pw_cdiv(n_out, 128) * ngroups < 512) ? 2 : 1;
-      if (mte) MT = atoi(mte) == 2 ? 2 : 1;
     }
     const int nchunk = Cin / KC;
     int ksplit = 1;
     if (algo == 3) ksplit = (nchunk % 4 == 0) ? 4 : (nchunk % 2 == 0 ? 2 : 1);
-    if (const char* e = getenv("PW_GATHER_KSPLIT")) {
-      const int f = atoi(e);
-      if ((f == 1 || f == 2 || f == 4) && nchunk % f == 0) ksplit = f;
-    }
     if (ksplit > 1 && MT != 1) ksplit = 1;              // the split variants are built for MT = 1
     const int mgroups = 4 / ksplit;                     // M-groups (32*MT voxels each) per block
     dim3 grid((unsigned)pw_cdiv(n_out, 32 * MT * mgroups), (unsigned)ngroups);

@@ -639,102 +639,6 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
 // per 64 -> 64 stage, and the SAME wall time: with real data the socket sits at its 1400 W cap and the shader clock drops to
 // match, 1.87 -> 1.69 GHz.  profiles/r03_power_wall.txt; DESIGN.md 4.13.  It was removed again.)
 
-// ------------------------------------------------------------------------------------
-// tile-per-block variant: one 4x8x8 tile x N-group per 4-wave block, single 76.8 KB halo buffer -> TWO blocks per CU.
-// Nothing is pipelined inside a block (halo DMA burst -> wait -> 27 taps -> epilogue per chunk); the two resident
-// blocks drift apart so that one block's DMA wait / epilogue overlaps the other's MFMA phase (on the fp16 matrix
-// cores the sibling wave's VALU / VMEM instructions do issue beside an MFMA stream).
-// ------------------------------------------------------------------------------------
-template <int NT, int TAP>
-__device__ __forceinline__ void h2_tile_step(lds3_t lds3, rsrc_t wr, unsigned wsoff, unsigned wstride, unsigned lane_off,
-                                             const unsigned (&aaddr)[2][3][4], v4f (&ac)[2][4], v4f (&an)[2][4],
-                                             v4f (&b0)[NT][4], v4f (&b1)[NT][4], f32x16 (&acc)[2][NT]) {
-  if constexpr (TAP + 1 < 27) {
-    h2_load_b<NT>(wr, wsoff + (unsigned)(TAP + 1) * wstride, lane_off, b1);
-    h2_read_a_tap<TAP + 1>(lds3, aaddr, an);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  h2_mfma<NT>(ac, b0, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (TAP + 1 < 27) h2_tile_step<NT, TAP + 1>(lds3, wr, wsoff, wstride, lane_off, aaddr, an, ac, b1, b0, acc);
-}
-
-template <int NT>
-__global__ void __launch_bounds__(256, 2) k_conv3d_h2_tile(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  const int half = lane >> 5, j = lane & 31;
-  const int ng = blockIdx.y;
-  const int pj = patch_of_row(j), pr = pj >> 3, pc = pj & 7;
-  const int ntiles_total = a.cout_total >> 5;
-  const int nchunk = a.Cin / KC;
-  unsigned aaddr[2][3][4];
-#pragma unroll
-  for (int khp = 0; khp < 2; ++khp)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int ww = pc + kw;
-      const int f = ((ww >> 1) & 3) | (((pr + khp) & 1) << 2);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        aaddr[khp][kw][q] = (unsigned)((((wave * TH + pr) * TW + ww) * 8 + ((half * 4 + q) ^ f)) * 16);
-    }
-  const unsigned lane_off = (unsigned)lane * 16u;
-  const unsigned wstride = (unsigned)ntiles_total * 4096u;
-  const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
-  const rsrc_t wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 27 * ntiles_total * 4096));
-  const lds3_t lds3 = (lds3_t)lds;
-
-  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-  const int tw = bid % a.tiles_w; bid /= a.tiles_w;
-  const int th = bid % a.tiles_h; bid /= a.tiles_h;
-  const int td = bid % a.tiles_d;
-  const int b = bid / a.tiles_d;
-  const int d0 = td * BD, h0 = th * BH, w0 = tw * BW;
-
-  f32x16 acc[2][NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  long long ts0 = 0, ts1 = 0, ts2 = 0;
-  if (a.probe) ts0 = __builtin_readcyclecounter();
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const unsigned wsoff = (unsigned)((ch * 27 * ntiles_total + ng * NT) * 4096);
-    v4f a0[2][4], a1[2][4], b0[NT][4], b1[NT][4];
-    h2_load_b<NT>(wr, wsoff, lane_off, b0);
-    stage_halo_chunk_dma(a, xr, lds, b, d0, h0, w0, ch, wave, lane);
-    if (a.probe && ch == 0) ts1 = __builtin_readcyclecounter();
-    h2_read_a_tap<0>(lds3, aaddr, a0);
-    h2_tile_step<NT, 0>(lds3, wr, wsoff, wstride, lane_off, aaddr, a0, a1, b0, b1, acc);
-  }
-  if (a.probe) ts2 = __builtin_readcyclecounter();
-
-  // every wave is done with the halo buffer; scale / bias go to the tail of it, the accumulators to this wave's rows
-  __syncthreads();
-  float* sb = lds + (PIPE_BUF_BYTES - 2 * H2_MAX_COUT * 4) / 4;      // rows 58, 59 (never staging rows: those end at 31)
-  const RngScale rs = rng_scales(a);
-  for (int n = tid; n < a.cout_total; n += 256) {
-    const bool to_y0 = n < a.cout0;
-    sb[n] = (a.scale ? a.scale[n] : 1.f) * (to_y0 ? rs.s0 : rs.s1);
-    sb[H2_MAX_COUT + n] = (a.bias ? a.bias[n] : 0.f) * (to_y0 ? rs.b0 : rs.b1);
-  }
-  __syncthreads();
-  float amax0 = 0.f, amax1 = 0.f;
-  h2_epilogue<NT>(a, acc, sb, reinterpret_cast<char*>(lds) + (unsigned)wave * (TW * 128), b, d0, h0, w0, ng, wave, lane, rs.res,
-                  amax0, amax1);
-  if (a.fmt_y0) rng_note(a.y0_rng, __float_as_uint(amax0), rs.e0);
-  if (a.fmt_y1 && a.y1) rng_note(a.y1_rng, __float_as_uint(amax1), rs.e1);
-  if (a.probe && lane == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
-    long long* pp = a.probe + ((size_t)blockIdx.x * 4 + wave) * 4;
-    pp[0] = ts0; pp[1] = ts1; pp[2] = ts2; pp[3] = __builtin_readcyclecounter();
-  }
-}
-
 // ------------------------------------------------------------------------------------ fp32 <-> h2
 // one thread per (voxel, 4-channel group); ld_* = floats between consecutive voxels (channel slices of wider buffers).
 // rng: the destination's / source's range slot (pw_h2.h "Range") or null.  auto_exp (host side): the slot's exponent is first
@@ -927,13 +831,10 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
   if (!(ksize == 3 && stride == 1) || algo == 2 || algo == 3) {
     // stride-2 / 1x1x1 (and, on request, tiny 3x3x3 grids): the gather kernel with split-fp16 operands
     if (ksize == 3 && stride == 2 && algo == 0) {
-      // LDS-tiled stride-2 kernel (pw_conv3d_h2_s2.hip) for the shapes it is built for; PW_H2_S2=0 keeps the gather kernel
-      const char* e = getenv("PW_H2_S2");
-      if (!(e && atoi(e) == 0)) {
-        const int rc = pw_launch_conv3d_h2_s2(a, pw_stream(stream));
-        if (rc == PW_OK) { PW_CHECK_LAUNCH(); return PW_OK; }
-        if (rc != PW_EUNSUP) return rc;
-      }
+      // LDS-tiled stride-2 kernel (pw_conv3d_h2_s2.hip) for the shapes it is built for (algo 2 keeps the gather kernel)
+      const int rc = pw_launch_conv3d_h2_s2(a, pw_stream(stream));
+      if (rc == PW_OK) { PW_CHECK_LAUNCH(); return PW_OK; }
+      if (rc != PW_EUNSUP) return rc;
     }
     const int NTg = (ntiles % 2 == 0) ? 2 : 1;
     const long long n_out = (long long)B * a.Do * a.Ho * a.Wo;
@@ -943,29 +844,6 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
   }
   // two N-tiles per wave (A fragments shared) when that still leaves every CU two or more work items
   int NT = (ntiles % 2 == 0 && nblk * (ntiles / 2) >= 2 * pw_num_cus()) ? 2 : 1;
-  if (const char* e = getenv("PW_H2_NT")) {          // experiments only
-    const int f = atoi(e);
-    if ((f == 1 || f == 2) && ntiles % f == 0) NT = f;
-  }
-  if (const char* e = getenv("PW_H2_TILE")) {
-    if (atoi(e)) {
-      hipStream_t st = pw_stream(stream);
-      dim3 grid((unsigned)nblk, (unsigned)(ntiles / NT));
-      if (NT == 2) {
-        static int once = set_lds_limit(k_conv3d_h2_tile<2>, PIPE_BUF_BYTES);
-        if (once) return once;
-        hipLaunchKernelGGL(k_conv3d_h2_tile<2>, grid, dim3(256), PIPE_BUF_BYTES, st, a);
-        pw_note_kernel("k_conv3d_h2_tile<2>");
-      } else {
-        static int once = set_lds_limit(k_conv3d_h2_tile<1>, PIPE_BUF_BYTES);
-        if (once) return once;
-        hipLaunchKernelGGL(k_conv3d_h2_tile<1>, grid, dim3(256), PIPE_BUF_BYTES, st, a);
-        pw_note_kernel("k_conv3d_h2_tile<1>");
-      }
-      PW_CHECK_LAUNCH();
-      return PW_OK;
-    }
-  }
   PipeArgs p;
   p.ngroups = ntiles / NT;
   PW_CHECK_ARG(nblk * p.ngroups < (1ll << 20), "pw_conv3d_h2: too many work items");
@@ -979,7 +857,6 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
   if (fmt_y0 == 1 && y1_h2 && !residual) epi = 1;
   else if (fmt_y0 == 1 && cout1 == 0 && residual && fmt_res == 1) epi = 2;
   else if (fmt_y0 == 0 && y1_f32 && !residual) epi = 3;
-  if (const char* e = getenv("PW_H2_EPI")) { if (atoi(e) == 0) epi = 0; }      // A/B runs and tests of the generic phase
 #define PW_H2_LAUNCH(NTv, EPIv)                                                          \
   do {                                                                                   \
     static int once = set_lds_limit(k_conv3d_h2<NTv, EPIv>, H2_LDS);                      \
@@ -987,9 +864,8 @@ PW_API int pw_conv3d_h2(const float* x, const float* wpk, const float* scale, co
     hipLaunchKernelGGL((k_conv3d_h2<NTv, EPIv>), dim3(nb), dim3(256), H2_LDS, st, a, p);  \
     pw_note_kernel("k_conv3d_h2<%d, %d, false>", NTv, EPIv);                                     \
   } while (0)
-  // resident hi planes: one chunk, one cout tile (PW_H2_WR=0 keeps the streaming variant)
-  bool wres = NT == 1 && ntiles == 1 && Cin == KC && epi > 0;
-  if (const char* e = getenv("PW_H2_WR")) { if (atoi(e) == 0) wres = false; }
+  // resident hi planes: one chunk, one cout tile
+  const bool wres = NT == 1 && ntiles == 1 && Cin == KC && epi > 0;
 #define PW_H2_LAUNCH_WR(EPIv)                                                                  \
   do {                                                                                         \
     static int once = set_lds_limit(k_conv3d_h2<1, EPIv, true>, H2_LDS);                        \

@@ -10,103 +10,14 @@
 // (cuDNN picks the same algorithm family for fp32 3x3 convolutions; rounding differs from the direct sum
 // at the 1e-6 level, far inside the stated tolerance, see tests.)
 //
-// One 256-thread block computes a 4x8x8 output tile (= 2x4x4 = 32 Winograd tiles) x 32 output channels:
-//   * the 6x10x10x32ch halo is written to LDS by buffer_load ... lds (R, 76.8 KB, unswizzled);
-//   * for each d-transform row i_d (4 chunks of 16 points): thread (tile, channel quad) combines its two
-//     d-planes, transforms along h and w in registers (48 float4 add/sub) and writes its 16 points to V
-//     (64 KB: [point][tile][32 ch], row order and 16-byte slots chosen so the MFMA A reads are
-//     bank-conflict free);
-//   * wave w owns 16 tiles (one d-pair) x 16 couts: per point 2 ds_read_b128 (A) + 2 buffer loads (U) +
-//     8 v_mfma_f32_16x16x4_f32 into a fresh accumulator, which is then added/subtracted into the (at most
-//     8) outputs it contributes to -- 8 x 4 accumulator registers per lane hold the whole output tile;
-//   * epilogue = the direct kernels' (scale/bias, residual, ReLU, two destinations, row stride).
+// Work item = a 4x8x8 output tile (= 2x4x4 = 32 Winograd tiles) x a group of 32 or 64 output channels; the 6x10x10x32ch halo lands
+// in LDS by buffer_load ... lds (R, 76.8 KB); thread (tile, channel quad) of the transform role combines its two d-planes, transforms
+// along h and w in registers and writes V ([point][tile][32 ch], slots swizzled for conflict-free A reads); a GEMM wave owns 16
+// tiles x 16 couts: per point 2 ds_read_b128 (A) + 2 buffer loads (U) + 8 v_mfma_f32_16x16x4_f32 into a fresh accumulator, which is
+// then added / subtracted into the (at most 8) outputs it contributes to; epilogue = the direct kernels' (scale / bias, residual,
+// ReLU, two destinations, row stride).  The kernel below is the wave-specialised persistent form (the first, tile-per-block form --
+// every wave doing every phase in turn, 201 vs 141 us at 32 -> 32 -- was removed in round 4; it is in the history).
 #include "pw_wino_common.h"
-
-// Points are processed a ROW (4 points = 4 independent MFMA chains, interleaved) at a time; the operands
-// of the next row are requested before this row's MFMAs, and the output transform of a row's products is
-// deferred until the next row's MFMAs have been issued (it runs in their shadow).
-template <int IH>
-__device__ __forceinline__ void wino_load_row(const WinoCtx& c, unsigned usoff, f32x4 (&aq)[4][2], f32x4 (&bq)[4][2]) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      aq[k][q] = lds_read4(c.lds3, c.a_addr[q] + (unsigned)(IH * 4 + k) * 4096u);
-      const float4 w = buf_load4(c.wr, c.lane_off + (unsigned)(q * 16), usoff + (unsigned)(IH * 4 + k) * c.ustep);
-      bq[k][q] = f32x4{w.x, w.y, w.z, w.w};
-    }
-}
-
-template <int ID, int IH>
-__device__ __forceinline__ void wino_row(const WinoCtx& c, unsigned usoff, f32x4 (&ac)[4][2], f32x4 (&bc)[4][2],
-                                         f32x4 (&an)[4][2], f32x4 (&bn)[4][2], f32x4 (&Mp)[4], f32x4 (&Y)[8]) {
-  if constexpr (IH + 1 < 4) wino_load_row<IH + 1>(c, usoff, an, bn);
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 M[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) M[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        M[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k][q][e], bc[k][q][e], M[k], 0, 0, 0);
-  if constexpr (IH >= 1) wino_scatter_row<ID, IH - 1>(Mp, Y);      // the previous row's products, under this row's MFMAs
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) Mp[k] = M[k];
-  if constexpr (IH + 1 < 4) wino_row<ID, IH + 1>(c, usoff, an, bn, ac, bc, Mp, Y);
-}
-
-// d-transform row ID of this thread's tile: 16 (h, w) positions x one channel quad, then h and w transforms, -> V
-template <int ID>
-__device__ __forceinline__ void wino_transform_chunk(lds3_t lds3, unsigned r_base, unsigned v_base) {
-  // B^T row ID: (plane A, plane B, sign of B): 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-  constexpr int pa = ID == 0 ? 0 : (ID == 2 ? 2 : 1);
-  constexpr int pb = ID == 0 ? 2 : (ID == 1 ? 2 : (ID == 2 ? 1 : 3));
-  constexpr bool plus = ID == 1;
-  // one w-column at a time (8 reads -> 4 combined values -> h-transform): keeps the live set at the 16
-  // h-transformed values + one column instead of two full 4x4 arrays
-  f32x4 y[4][4];
-#pragma unroll
-  for (int ww = 0; ww < 4; ++ww) {
-    f32x4 x[4];
-#pragma unroll
-    for (int hh = 0; hh < 4; ++hh) {
-      const f32x4 A = lds_read4(lds3, r_base + (unsigned)(((pa * TH + hh) * TW + ww) * 128));
-      const f32x4 B = lds_read4(lds3, r_base + (unsigned)(((pb * TH + hh) * TW + ww) * 128));
-      x[hh] = plus ? A + B : sub4(A, B);
-    }
-    bt4(x[0], x[1], x[2], x[3], y[0][ww], y[1][ww], y[2][ww], y[3][ww]);
-  }
-#pragma unroll
-  for (int ih = 0; ih < 4; ++ih) {
-    f32x4 z0, z1, z2, z3;
-    bt4(y[ih][0], y[ih][1], y[ih][2], y[ih][3], z0, z1, z2, z3);
-    lds_write4(lds3, (unsigned)WINO_R_BYTES + v_base + (unsigned)((ih * 4 + 0) * 4096), z0);
-    lds_write4(lds3, (unsigned)WINO_R_BYTES + v_base + (unsigned)((ih * 4 + 1) * 4096), z1);
-    lds_write4(lds3, (unsigned)WINO_R_BYTES + v_base + (unsigned)((ih * 4 + 2) * 4096), z2);
-    lds_write4(lds3, (unsigned)WINO_R_BYTES + v_base + (unsigned)((ih * 4 + 3) * 4096), z3);
-  }
-}
-
-template <int ID, int NG>
-__device__ __forceinline__ void wino_chunk(const WinoCtx& c, unsigned r_base, unsigned v_base, unsigned usoff,
-                                           f32x4 (&Y)[NG][8]) {
-  wino_transform_chunk<ID>(c.lds3, r_base, v_base);
-  __syncthreads();                                   // V of this chunk complete
-#pragma unroll
-  for (int ng = 0; ng < NG; ++ng) {                  // the transformed tile serves every 32-cout group
-    f32x4 a0[4][2], a1[4][2], b0[4][2], b1[4][2];
-    f32x4 Mp[4];
-    const unsigned us = usoff + (unsigned)ng * 4096u;            // 2 n16 blocks of 2048 B per 32-cout group
-    wino_load_row<0>(c, us, a0, b0);
-    wino_row<ID, 0>(c, us, a0, b0, a1, b1, Mp, Y[ng]);
-    wino_scatter_row<ID, 3>(Mp, Y[ng]);
-  }
-  __syncthreads();                                   // everyone done reading V before the next chunk overwrites it
-}
 
 // scale/bias, residual, ReLU and the two destinations for the wave's 16 tiles (d-pair mh) x 16 couts (half nh)
 template <int NG>
@@ -174,75 +85,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&Y
         }
     }
   }   // ng
-}
-
-// One block per output tile, all 32-cout groups of the layer inside the block (the transformed tile is
-// reused by every group).  A persistent variant with the next tile's halo DMA issued early was tried
-// (dedicated DMA wave: starved by the MFMA waves; early issue from the compute waves: needs the chunk's 16
-// weight taps preloaded past the in-order vmcnt, 128 more live registers -> spills): 195 us for 32->32 but
-// far slower for two cout groups, so the halo load stays exposed (~15 % of a tile).
-template <int NG>    // 32-cout groups (cout_total = 32 NG)
-__global__ void __launch_bounds__(256, 1) k_conv3d_wino(ConvArgs a, int n16_total) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  const int mh = wave & 1, nh = wave >> 1;            // tile half (d-pair) and cout half of this wave
-  int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-  const int tw_ = bid % a.tiles_w; bid /= a.tiles_w;
-  const int th_ = bid % a.tiles_h; bid /= a.tiles_h;
-  const int td_ = bid % a.tiles_d;
-  const int b = bid / a.tiles_d;
-  const int d0 = td_ * BD, h0 = th_ * BH, w0 = tw_ * BW;
-
-  // transform role: thread = (tile 0..31, channel quad 0..7)
-  const int tile = tid >> 3, quad = tid & 7;
-  const int ttd = tile >> 4, tth = (tile >> 2) & 3, ttw = tile & 3;
-  const unsigned r_base = (unsigned)((((2 * ttd) * TH + 2 * tth) * TW + 2 * ttw) * 128 + quad * 16);
-  const int t16 = tile & 15;
-  const unsigned v_base = (unsigned)(((ttd * 16 + wino_row16(t16)) * 8 + (quad ^ (t16 & 7))) * 16);
-
-  // GEMM role: lane = (tile l&15 of the wave's half, k-group l>>4)
-  WinoCtx c;
-  c.lds3 = (lds3_t)lds;
-  {
-    const int lt = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      c.a_addr[q] = (unsigned)WINO_R_BYTES + (unsigned)(((mh * 16 + wino_row16(lt)) * 8 + ((g * 2 + q) ^ (lt & 7))) * 16);
-  }
-  const int nchunk = a.Cin / KC;
-  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 64 * n16_total * 2048));
-  c.lane_off = (unsigned)lane * 32u;
-  c.ustep = (unsigned)n16_total * 2048u;               // bytes between the weights of consecutive points
-  const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
-  f32x4 Y[NG][8];
-#pragma unroll
-  for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-    for (int o = 0; o < 8; ++o) Y[ng][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  PipeDma dm;
-  wino_lane_offsets(a, w0, lane, dm);
-  dm.b = b; dm.d0 = d0; dm.h0 = h0; dm.wbase = w0 > 0 ? w0 - 1 : 0; dm.ldsbuf = 0; dm.live = true;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const unsigned ubase = (unsigned)(((ch * 64) * n16_total + nh) * 2048);
-    const unsigned ustep = c.ustep;
-    if (ch > 0) __syncthreads();
-    dm.ch = ch;
-    pipe_dma_row<0>(a, xr, c.lds3, dm, wave); pipe_dma_row<1>(a, xr, c.lds3, dm, wave); pipe_dma_row<2>(a, xr, c.lds3, dm, wave);
-    pipe_dma_row<3>(a, xr, c.lds3, dm, wave); pipe_dma_row<4>(a, xr, c.lds3, dm, wave); pipe_dma_row<5>(a, xr, c.lds3, dm, wave);
-    pipe_dma_row<6>(a, xr, c.lds3, dm, wave); pipe_dma_row<7>(a, xr, c.lds3, dm, wave); pipe_dma_row<8>(a, xr, c.lds3, dm, wave);
-    pipe_dma_row<9>(a, xr, c.lds3, dm, wave); pipe_dma_row<10>(a, xr, c.lds3, dm, wave); pipe_dma_row<11>(a, xr, c.lds3, dm, wave);
-    pipe_dma_row<12>(a, xr, c.lds3, dm, wave); pipe_dma_row<13>(a, xr, c.lds3, dm, wave); pipe_dma_row<14>(a, xr, c.lds3, dm, wave);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    // point index = i_d*16 + i_h*4 + i_w; weights of point p at ubase + p * n16_total * 2048
-    wino_chunk<0, NG>(c, r_base, v_base, ubase + 0u * 16u * ustep, Y);
-    wino_chunk<1, NG>(c, r_base, v_base, ubase + 16u * ustep, Y);
-    wino_chunk<2, NG>(c, r_base, v_base, ubase + 32u * ustep, Y);
-    wino_chunk<3, NG>(c, r_base, v_base, ubase + 48u * ustep, Y);
-  }
-  wino_epilogue<NG>(a, Y, b, d0, h0, w0, mh, nh, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -423,20 +265,15 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
                "pw_conv3d_wino: tensors must be < 4 GiB (32-bit buffer addressing)");
   const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
   PW_CHECK_ARG(nblk < (1ll << 20), "pw_conv3d_wino: too many tiles");
-  {
-    // wave-specialised persistent kernel (default); PW_WINO_WS=0 keeps the tile-per-block kernel (<= 64 columns).
-    // Work item = (tile, group of NG x 32 output columns).  NG = 2 halves the input-transform work per output but
-    // halves the item count: taken when that still leaves >= 2 items per CU (PW_WINO_NG overrides).
-    const char* e = getenv("PW_WINO_WS");
-    if (!e || atoi(e)) {
-      const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
-      int NG = (cout_total % 64 == 0 && nblk * (cout_total / 64) >= 2ll * nb) ? 2 : 1;
-      if (const char* g = getenv("PW_WINO_NG")) NG = (atoi(g) == 2 && cout_total % 64 == 0) ? 2 : 1;
-      PipeArgs p = {};
-      p.ngroups = cout_total / (32 * NG);
-      PW_CHECK_ARG(nblk * p.ngroups < (1ll << 20), "pw_conv3d_wino: too many work items");
-      p.n_items = (int)nblk * p.ngroups;
-      p.m_ng = magic_of(p.ngroups); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
+  // Work item = (tile, group of NG x 32 output columns).  NG = 2 halves the input-transform work per output but halves the item
+  // count: taken when that still leaves >= 2 items per CU.
+  const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
+  const int NG = (cout_total % 64 == 0 && nblk * (cout_total / 64) >= 2ll * nb) ? 2 : 1;
+  PipeArgs p = {};
+  p.ngroups = cout_total / (32 * NG);
+  PW_CHECK_ARG(nblk * p.ngroups < (1ll << 20), "pw_conv3d_wino: too many work items");
+  p.n_items = (int)nblk * p.ngroups;
+  p.m_ng = magic_of(p.ngroups); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
 #define PW_WINO_WS(NGv)                                                                                     \
   do {                                                                                                      \
     static int once = set_lds_limit(k_conv3d_wino_ws<NGv>, WINO_LDS);                                        \
@@ -445,24 +282,8 @@ PW_API int pw_conv3d_wino(const float* x, const float* uwpk, const float* scale,
                        cout_total / 16);                                                                    \
     pw_note_kernel("k_conv3d_wino_ws<%d>", NGv);                                                            \
   } while (0)
-      if (NG == 1) PW_WINO_WS(1); else PW_WINO_WS(2);
+  if (NG == 1) PW_WINO_WS(1); else PW_WINO_WS(2);
 #undef PW_WINO_WS
-      PW_CHECK_LAUNCH();
-      return PW_OK;
-    }
-  }
-  const int NG = cout_total / 32;
-  PW_CHECK_ARG(NG == 1 || NG == 2, "pw_conv3d_wino: the tile-per-block kernel takes cout_total 32 or 64 (got %d)", cout_total);
-#define PW_WINO(NGv)                                                                                      \
-  do {                                                                                                    \
-    static int once = set_lds_limit(k_conv3d_wino<NGv>, WINO_LDS);                                         \
-    if (once) return once;                                                                                \
-    hipLaunchKernelGGL(k_conv3d_wino<NGv>, dim3((unsigned)nblk), dim3(256), WINO_LDS, pw_stream(stream), a, \
-                       cout_total / 16);                                                                  \
-    pw_note_kernel("k_conv3d_wino<%d>", NGv);                                                             \
-  } while (0)
-  if (NG == 1) PW_WINO(1); else PW_WINO(2);
-#undef PW_WINO
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

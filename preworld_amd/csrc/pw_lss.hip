@@ -744,7 +744,7 @@ PW_API int pw_bev_pool_dense(const float* depth, const float* feat, const int32_
     int lpv = c / 4;
     // memory-bound: cap the grid at ~8 blocks/CU x 256 CUs and grid-stride
     int64_t want = pw_cdiv(n_voxels * lpv, 256);
-    static const int cap = [] { const char* e = getenv("PW_POOL_BLOCKS"); return e ? atoi(e) : 2048; }();
+    const int cap = 2048;
     unsigned nb = (unsigned)(want < cap ? want : cap) + (long_list ? LONG_BLOCKS : 0);
     PW_DISPATCH_LPV(lpv, hipLaunchKernelGGL((k_pool_dense<L>), dim3(nb), dim3(256), 0, st, depth,
                                             (const float4*)feat, seg_start, order, order_feat,

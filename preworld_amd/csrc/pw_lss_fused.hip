@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
 k_lss_pool_slots(const float* __restrict__ depth, const float4* __restrict__ feat, const int32_t* __restrict__ count,
                  const int32_t* __restrict__ slots, int64_t n_vox, const int32_t* __restrict__ cur, const int4* __restrict__ list_b, const int4* __restrict__ list_c,
                  const int32_t* __restrict__ tmp, int32_t* __restrict__ sorted_pf, float* __restrict__ sorted_d, FeatIdx fi,
-                 float4* __restrict__ out, int out_h2, int* __restrict__ out_rng, int dbg) {
+                 float4* __restrict__ out, int out_h2, int* __restrict__ out_rng) {
   extern __shared__ __attribute__((aligned(16))) int32_t ids[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPV;
@@ -194,7 +194,7 @@ k_lss_pool_slots(const float* __restrict__ depth, const float4* __restrict__ fea
   const float omul = rng_pow2(-e_out);
   unsigned amax = 0u;
   if ((int)blockIdx.x < C_BLOCKS) {
-    const int nc = (dbg & 1) ? 0 : cur[CUR_C];
+    const int nc = cur[CUR_C];
     for (int li = blockIdx.x; li < nc; li += C_BLOCKS) {
       const int4 e = list_c[li];
       const int64_t k = e.x;
@@ -292,7 +292,7 @@ k_lss_pool_slots(const float* __restrict__ depth, const float4* __restrict__ fea
       }
     }
   } else if ((int)blockIdx.x < C_BLOCKS + B_BLOCKS) {
-    const int nb = (dbg & 2) ? 0 : cur[CUR_B];
+    const int nb = cur[CUR_B];
     const int hb = lane & 32, c = lane & 31;
     int32_t* lpf = ids + (wave * 2 + (lane >> 5)) * 128;          // 64 pixels + 64 depths per half: 4 KB of the block's LDS
     float* ld = reinterpret_cast<float*>(lpf + 64);
@@ -351,7 +351,7 @@ k_lss_pool_slots(const float* __restrict__ depth, const float4* __restrict__ fea
     const int grp = lane / LPV, gbase = lane - sub;
     const int64_t wid = (int64_t)((int)blockIdx.x - C_BLOCKS - B_BLOCKS) * 4 + wave;
     const int64_t nw = (int64_t)((int)gridDim.x - C_BLOCKS - B_BLOCKS) * 4;
-    for (int64_t v0 = wid * 64; v0 < ((dbg & 4) ? 0 : n_vox); v0 += nw * 64) {
+    for (int64_t v0 = wid * 64; v0 < n_vox; v0 += nw * 64) {
       const int c = v0 + lane < n_vox ? count[v0 + lane] : -1;
       {
         const unsigned long long empty = __ballot(c == 0);
@@ -470,7 +470,6 @@ PW_API int pw_lss_lift_pool(int B, int N, int D, int H, int W, const float* frus
     return PW_ENOSPC;
   }
   hipStream_t st = pw_stream(stream);
-  static const int dbg = [] { const char* e = getenv("PW_LSS_DEBUG"); return e ? atoi(e) : 0; }();   // timing experiments only
   const GridParams gp{lower3_host[0], lower3_host[1], lower3_host[2], interval3_host[0], interval3_host[1], interval3_host[2],
                       gx, gy, gz};
   const int64_t nz = (int64_t)(w.zero_bytes / 16);
@@ -487,7 +486,7 @@ PW_API int pw_lss_lift_pool(int B, int N, int D, int H, int W, const float* frus
   const int64_t want = pw_cdiv(pw_cdiv(n_vox, 64), 4);
   hipLaunchKernelGGL(k_lss_pool_slots, dim3((unsigned)(want < 4096 ? want : 4096) + C_BLOCKS + B_BLOCKS), dim3(256), SORT_LDS_IDS * 4,
                      st, depth, (const float4*)feat, w.count, w.slots, n_vox, cur, w.list_b, w.list_c, w.tmp, w.sorted_pf, w.sorted_d,
-                     fi, (float4*)out, out_h2, out_rng, dbg);
+                     fi, (float4*)out, out_h2, out_rng);
   pw_note_kernel("k_lss_pool_slots");
   PW_CHECK_LAUNCH();
   return PW_OK;

@@ -91,7 +91,6 @@ __global__ void __launch_bounds__(256 * WD, 2) k_occ_head16(ConvArgs a, OccTail 
       for (int q = 0; q < 2; ++q)
         aaddr[khp][kw][q] = (unsigned)((((wave * TH + hr) * TW + ww) * 8 + ((g * 2 + q) ^ f)) * 16);
     }
-  const StageLane sl = stage_lane_setup(a, w0, lane);
   const unsigned lane_off = (unsigned)lane * 32u;
   const rsrc_t xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
   const rsrc_t wr = make_rsrc(a.wpk, (unsigned)((size_t)(a.Cin / KC) * 27 * 2048));
@@ -105,8 +104,7 @@ __global__ void __launch_bounds__(256 * WD, 2) k_occ_head16(ConvArgs a, OccTail 
     const unsigned wsoff = (unsigned)(ch * 27 * 2048);
     float4 b0[2], b1[2];
     load_b16(wr, wsoff, lane_off, b0);
-    if (WD == 1 && a.dma_stage) stage_halo_chunk_dma(a, xr, lds, b, d0, h0, w0, ch, wave, lane);
-    else stage_halo_chunk<WD, 8>(a, xr, lds, sl, b, d0, h0, w0, ch, wave, lane);
+    stage_halo_chunk_dma(a, xr, lds, b, d0, h0, w0, ch, wave, lane);
     tap_pair16<0>(lds, aaddr, wr, wsoff, lane_off, b0, b1, acc);
   }
   // ---- tail: BN+ReLU, transpose 64 voxels x 16 channels through LDS, per-voxel MLP + argmax
@@ -152,205 +150,6 @@ __global__ void __launch_bounds__(256 * WD, 2) k_occ_head16(ConvArgs a, OccTail 
     }
     tail.occ[vox] = (uint8_t)arg;
     if (tail.geo) tail.geo[vox] = arg != tail.empty_idx ? (uint8_t)0 : (uint8_t)(tail.n_cls - 1);
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// OccHead, persistent DMA-pipelined variant: the stage machinery of k_conv3d_k3s1_pipe (two halo
-// buffers, buffer_load ... lds issued by the MFMA wave, A of tap t+1 / weights of tap t+2 in
-// flight, one item = one 4x8x8 tile) around the 16x16x4 tap body and the fused 16->8->18+argmax
-// tail of k_occ_head16.  The tail transposes through the stage's own halo buffer once every wave
-// is done reading it, hence a second barrier before the next stage's DMA may overwrite it.
-// ------------------------------------------------------------------------------------
-struct OccPipeCtx {
-  lds3_t lds3;
-  rsrc_t xr, wr;
-  unsigned lane_off;
-  unsigned wsoff, wsoff_next;
-  PipeDma dm;
-  int wave;
-};
-
-template <int TAP>
-__device__ __forceinline__ void occ_read_a_tap(lds3_t lds3, const unsigned (&aaddr)[2][3][2], float4 (&aq)[4][2]) {
-  constexpr int kd = TAP / 9, kh = (TAP / 3) % 3, kw = TAP % 3;
-  typedef float v4f __attribute__((ext_vector_type(4)));
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    constexpr unsigned imm0 = (unsigned)(((kd * TH + kh) * TW) * 128);
-    const unsigned imm = imm0 + (unsigned)(mt * 2 * TW * 128);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const v4f v = *reinterpret_cast<const __attribute__((address_space(3))) v4f*>(lds3 + aaddr[kh & 1][kw][q] + imm);
-      aq[mt][q] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  }
-}
-
-__device__ __forceinline__ void occ_mfma(const float4 (&aq)[4][2], const float4 (&b)[2], f32x4 (&acc)[4]) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float bv[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const float av[4] = {aq[mt][q].x, aq[mt][q].y, aq[mt][q].z, aq[mt][q].w};
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[mt], 0, 0, 0);
-      }
-    }
-  }
-}
-
-template <int TAP>
-__device__ __forceinline__ void occ_step(const ConvArgs& a, const OccPipeCtx& c, const unsigned (&aaddr)[2][3][2],
-                                         float4 (&ac)[4][2], float4 (&an)[4][2], float4 (&b0)[2], float4 (&b1)[2],
-                                         float4 (&b2)[2], f32x4 (&acc)[4]) {
-  if constexpr (TAP + 2 < 27) load_b16(c.wr, c.wsoff + (unsigned)(TAP + 2) * 2048u, c.lane_off, b2);
-  else load_b16(c.wr, c.wsoff_next + (unsigned)(TAP + 2 - 27) * 2048u, c.lane_off, b2);
-  if constexpr (TAP >= 1 && TAP <= PIPE_ROWS_PER_WAVE) pipe_dma_row<TAP - 1>(a, c.xr, c.lds3, c.dm, c.wave);
-  if constexpr (TAP < 26) occ_read_a_tap<TAP + 1>(c.lds3, aaddr, an);
-  __builtin_amdgcn_sched_barrier(0);
-  occ_mfma(ac, b0, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (TAP < 26) occ_step<TAP + 1>(a, c, aaddr, an, ac, b1, b2, b0, acc);
-}
-
-__global__ void __launch_bounds__(256, 1) k_occ_head16_pipe(ConvArgs a, PipeArgs p, OccTail tail) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  const int g = lane >> 4, i = lane & 15;
-  const int nchunk = a.Cin / KC;
-  const int nslots = (int)gridDim.x >> 3;
-  const int per = (p.n_items + 7) >> 3;
-  const int it_end = min(((int)blockIdx.x & 7) * per + per, p.n_items);
-  int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  if (item >= it_end) return;
-
-  unsigned aaddr0[2][3][2];
-#pragma unroll
-  for (int khp = 0; khp < 2; ++khp)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int ww = (i & 7) + kw, hr = i >> 3;
-      const int f = ((ww >> 1) & 3) | (((hr + khp) & 1) << 2);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        aaddr0[khp][kw][q] = (unsigned)((((wave * TH + hr) * TW + ww) * 8 + ((g * 2 + q) ^ f)) * 16);
-    }
-  OccPipeCtx c;
-  c.lds3 = (lds3_t)lds;
-  c.xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 4));
-  c.wr = make_rsrc(a.wpk, (unsigned)((size_t)nchunk * 27 * 2048));
-  c.lane_off = (unsigned)lane * 32u;
-  c.wave = wave;
-
-  PipeTile t = pipe_decode(a, p, item);
-  int ch = 0;
-  float4 a0[4][2], a1[4][2], b0[2], b1[2], b2[2];
-  f32x4 acc[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[mt][r] = 0.f;
-  {
-    PipeDma dm;
-    pipe_lane_offsets(a, t.w0, lane, dm.voff);
-    dm.b = t.b; dm.d0 = t.d0; dm.h0 = t.h0; dm.wbase = t.w0 > 0 ? t.w0 - 1 : 0; dm.ch = 0; dm.ldsbuf = 0;
-    dm.live = true;
-    load_b16(c.wr, 0u, c.lane_off, b0);
-    load_b16(c.wr, 2048u, c.lane_off, b1);
-    pipe_dma_row<0>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<1>(a, c.xr, c.lds3, dm, wave);
-    pipe_dma_row<2>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<3>(a, c.xr, c.lds3, dm, wave);
-    pipe_dma_row<4>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<5>(a, c.xr, c.lds3, dm, wave);
-    pipe_dma_row<6>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<7>(a, c.xr, c.lds3, dm, wave);
-    pipe_dma_row<8>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<9>(a, c.xr, c.lds3, dm, wave);
-    pipe_dma_row<10>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<11>(a, c.xr, c.lds3, dm, wave);
-    pipe_dma_row<12>(a, c.xr, c.lds3, dm, wave); pipe_dma_row<13>(a, c.xr, c.lds3, dm, wave);
-    pipe_dma_row<14>(a, c.xr, c.lds3, dm, wave);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-  }
-  const float sc = a.scale ? a.scale[i] : 1.f;
-  const float bi = a.bias ? a.bias[i] : 0.f;
-
-  for (int stage = 0;; ++stage) {
-    const unsigned bufoff = (stage & 1) ? (unsigned)PIPE_BUF_BYTES : 0u;
-    unsigned aaddr[2][3][2];
-#pragma unroll
-    for (int khp = 0; khp < 2; ++khp)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          aaddr[khp][kw][q] = aaddr0[khp][kw][q] + bufoff;
-          asm volatile("" : "+v"(aaddr[khp][kw][q]));
-        }
-    occ_read_a_tap<0>(c.lds3, aaddr, a0);
-    PipeTile tn = t;
-    int chn = ch + 1, itemn = item;
-    if (chn == nchunk) { chn = 0; itemn = item + nslots; }
-    const bool has_next = itemn < it_end;
-    if (has_next && chn == 0) tn = pipe_decode(a, p, itemn);
-    if (!has_next) chn = 0;
-    c.wsoff = (unsigned)(ch * 27 * 2048);
-    c.wsoff_next = (unsigned)(chn * 27 * 2048);
-    pipe_lane_offsets(a, tn.w0, lane, c.dm.voff);
-    c.dm.b = tn.b; c.dm.d0 = tn.d0; c.dm.h0 = tn.h0; c.dm.wbase = tn.w0 > 0 ? tn.w0 - 1 : 0;
-    c.dm.ch = chn; c.dm.ldsbuf = (unsigned)PIPE_BUF_BYTES - bufoff; c.dm.live = has_next;
-
-    occ_step<0>(a, c, aaddr, a0, a1, b0, b1, b2, acc);
-
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();                   // next stage's halo landed; this stage's buffer is free
-
-    if (ch == nchunk - 1) {
-      // ---- tail (see k_occ_head16): BN+ReLU, 64x16 transpose through this stage's halo buffer,
-      // per-voxel 16->8->18 + argmax
-      constexpr int MS = 17;
-      float* sm = lds + (bufoff >> 2) + wave * (64 * MS);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sm[(mt * 16 + g * 4 + r) * MS + i] = fmaxf(acc[mt][r] * sc + bi, 0.f);
-      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes are done (wave-private tile)
-      const int od = t.d0 + wave;
-      const int mt = lane >> 4, row = lane & 15;
-      const int oh = t.h0 + mt * 2 + (row >> 3), ow = t.w0 + (row & 7);
-      if (od < a.Do && oh < a.Ho && ow < a.Wo) {
-        const size_t vox = (((size_t)t.b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-        float mid[16], hid[8];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mid[k] = sm[lane * MS + k];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          float s_ = 0.f;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) s_ += mid[k] * tail.w1[o * 16 + k];
-          hid[o] = fmaxf(s_ * tail.s1[o] + tail.b1[o], 0.f);
-        }
-        float best = 0.f;
-        int arg = 0;
-#pragma unroll
-        for (int cc = 0; cc < 18; ++cc) {
-          float s_ = 0.f;
-#pragma unroll
-          for (int o = 0; o < 8; ++o) s_ += hid[o] * tail.w2[cc * 8 + o];
-          if (tail.logits) tail.logits[vox * 18 + cc] = s_;
-          if (cc == 0 || s_ > best) { best = s_; arg = cc; }
-        }
-        tail.occ[vox] = (uint8_t)arg;
-        if (tail.geo) tail.geo[vox] = arg != tail.empty_idx ? (uint8_t)0 : (uint8_t)(tail.n_cls - 1);
-      }
-#pragma unroll
-      for (int m4 = 0; m4 < 4; ++m4)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m4][r] = 0.f;
-      __syncthreads();                 // transposes done before the next stage's DMA reuses this buffer
-    }
-    if (!has_next) break;
-    t = tn; ch = chn; item = itemn;
   }
 }
 
@@ -557,7 +356,6 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
   a.cout_total = 32; a.cout0 = n_mid; a.relu0 = 1;
   a.tiles_d = (D + BD - 1) / BD; a.tiles_h = (H + BH - 1) / BH; a.tiles_w = (W + BW - 1) / BW;
   OccTail t = {w1, s1, b1, w2, occ, logits, geo, empty_idx, n_mid, n_hid, n_cls};
-  a.dma_stage = dma_stage_default();
   long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
   if (wpk_layout == 64) {
     // Winograd-domain weights (pack_conv_weight_wino with 16 columns): the wave-specialised persistent kernel
@@ -575,37 +373,7 @@ PW_API int pw_occ_head_fused(const float* x, const float* wpk, const float* scal
     return PW_OK;
   }
   PW_CHECK_ARG(wpk_layout == 16, "pw_occ_head_fused: wpk_layout must be 16 (direct 16x16x4 MFMA packing) or 64 (Winograd)");
-  // persistent DMA-pipelined variant: opt-in with PW_OCC_PIPE=1.  Measured at 16x200x200: 176 us vs
-  // 160 us for the tile-per-block kernel -- with one block per CU nothing overlaps the fused tail
-  // (two LDS transposes, ~330 VALU, the 16->8->18 weights) that the second resident block hides there.
   {
-    const char* e = getenv("PW_OCC_PIPE");
-    const int forced = e ? (atoi(e) ? 1 : 0) : 2;
-    const bool pipe = forced == 1;
-    if (pipe && nblk < (1ll << 20)) {
-      PipeArgs p;
-      p.ngroups = 1; p.n_items = (int)nblk;
-      p.m_ng = magic_of(1); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);
-      const unsigned nb = (unsigned)(pw_num_cus() / 8 * 8);
-      constexpr int PLDS = 2 * PIPE_BUF_BYTES;
-      static int once = set_lds_limit(k_occ_head16_pipe, PLDS);
-      if (once) return once;
-      hipLaunchKernelGGL(k_occ_head16_pipe, dim3(nb), dim3(256), PLDS, pw_stream(stream), a, p, t);
-      pw_note_kernel("k_occ_head16_pipe");
-      PW_CHECK_LAUNCH();
-      return PW_OK;
-    }
-  }
-  const int WD = choose_wd(B, D, H, W, 1);
-  a.tiles_d = (D + BD * WD - 1) / (BD * WD);
-  nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
-  if (WD == 2) {
-    static int once = set_lds_limit(k_occ_head16<2>, TileGeom<2>::LDS);
-    if (once) return once;
-    hipLaunchKernelGGL(k_occ_head16<2>, dim3((unsigned)nblk, 1), dim3(512), TileGeom<2>::LDS,
-                       pw_stream(stream), a, t);
-    pw_note_kernel("k_occ_head16<2>");
-  } else {
     static int once = set_lds_limit(k_occ_head16<1>, TileGeom<1>::LDS);
     if (once) return once;
     hipLaunchKernelGGL(k_occ_head16<1>, dim3((unsigned)nblk, 1), dim3(256), TileGeom<1>::LDS,

@@ -429,11 +429,6 @@ __global__ void __launch_bounds__(ST_THREADS, 4) k_stereo_cost_volume_tile(Stere
   }
 }
 
-static int stereo_env(const char* name, int dflt) {     // read per call: tests flip the knob inside one process
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 PW_API int pw_stereo_cost_volume(const float* prev, const float* curr, int BN, int C, int H, int W,
                                  int64_t s_bn, int64_t s_c, int64_t s_y, int64_t s_x, const float* ds, int D,
                                  const float* xs, const float* ys, const float* inv_post_rot,
@@ -457,7 +452,7 @@ PW_API int pw_stereo_cost_volume(const float* prev, const float* curr, int BN, i
                   (((uintptr_t)curr & 15) == 0);
   const bool fits32 = (long long)BN * D * H * W * 4 < (1ll << 32) &&            // the tiled kernel addresses through buffer descriptors
                       ((long long)(H - 1) * s_y + (long long)(W - 1) * s_x + C) * 4 < (1ll << 32);
-  if (cl && fits32 && C <= 128 && stereo_env("PW_STEREO_TILE", 1) != 0) {
+  if (cl && fits32 && C <= 128) {
     const size_t lds = (size_t)(ST_CAP + 1) * C * 4 + 8 * 64 * sizeof(StereoGeo) + 64 * sizeof(StereoBox) + 64 * 4;
     constexpr int lds_max = (ST_CAP + 1) * 128 * 4 + 8 * 64 * 32 + 64 * 16 + 64 * 4;
     static int once = [] {

@@ -309,9 +309,8 @@ def as_f32(x):
 def _use_wino(x_cl, cout_total, ksize, stride):
     """3x3x3 stride-1 convs whose (4x8x8 tile, 32-column group) work items number >= 128 run on the Winograd
     F(2x2x2,3x3x3) kernel (pw_conv3d_wino: 3.4x fewer multiplies, 1.7-2.2x faster than the direct MFMA
-    kernels at the C3 shapes); PW_CONV_WINO=0 keeps everything on the direct kernels."""
-    import os
-    if ksize != 3 or stride != 1 or cout_total % 32 or os.environ.get('PW_CONV_WINO', '1') == '0':
+    kernels at the C3 shapes); smaller grids and everything else: the direct kernels (ops.conv3d_ndhwc)."""
+    if ksize != 3 or stride != 1 or cout_total % 32:
         return False
     B, D, H, W, _ = x_cl.shape
     return B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) * (cout_total // 32) >= 128
@@ -753,7 +752,7 @@ class OccHead(nn.Module):
         import os
         B, D, H, W, C = x_cl.shape
         is_h2 = isinstance(x_cl, ops.H2)
-        if C == 32 and (is_h2 or precision() == 'h2') and os.environ.get('PW_OCC_H2', '1') != '0':
+        if C == 32 and (is_h2 or precision() == 'h2'):
             # split-fp16 kernel (k_occ_head_h2); an fp32 input is converted first (30 us at 16x200x200, still ahead)
             wpk, s0, b0, tailpk, inv2, bounds = self._folded_h2(transposed)
             return ops.occ_head_h2(x_cl if is_h2 else ops.f32_to_h2(x_cl.contiguous()), wpk, s0, b0, tailpk, inv2, bounds,
@@ -761,9 +760,8 @@ class OccHead(nn.Module):
         if is_h2:
             x_cl = ops.h2_to_f32(x_cl)
         # fp32: the 32->16 conv runs as Winograd F(2x2x2,3x3x3) (k_occ_head_wino) on grids with enough 4x8x8 tiles to
-        # keep the persistent blocks busy; PW_OCC_WINO=0 keeps the direct 16x16x4 MFMA kernel
-        wino = (C == 32 and B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) >= 256
-                and os.environ.get('PW_OCC_WINO', '1') != '0')
+        # keep the persistent blocks busy, the direct 16x16x4 MFMA kernel on smaller ones
+        wino = C == 32 and B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) >= 256
         wpk, s0, b0, w1, s1, b1, w2 = self._folded(transposed, wino)
         return ops.occ_head_fused(x_cl, wpk, s0, b0, w1, s1, b1, w2, want_logits=want_logits,
                                   want_geo=want_geo, empty_idx=self.empty_idx)

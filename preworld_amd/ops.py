@@ -1243,7 +1243,7 @@ def render_rays_backward(rays_o, rays_d, t, grid, consts, g_depth, g_sem, g_rgb,
                          n_sem=17, c_rgb=19, grad_grid=None, algo=None):
     """Backward of render_rays: gradient of the packed (Z,Y,X,GC) grid given the gradients of depth (R), semantic (R,17),
     color (R,3), alphainv_last (R) [and of the dense weights (R,S)].
-    algo 'sorted' (default; PW_RENDER_BWD=atomics selects the other): pw_render_rays_backward_sorted -- entries sorted by voxel,
+    algo 'sorted' (default): pw_render_rays_backward_sorted -- entries sorted by voxel,
     fixed-point segmented sums, no float atomics, bit-reproducible; 'atomics': pw_render_rays_backward (168 float atomics per
     kept sample, arrival order decides the last bits; kept for A/B)."""
     import os
@@ -1253,7 +1253,7 @@ def render_rays_backward(rays_o, rays_d, t, grid, consts, g_depth, g_sem, g_rgb,
         grad_grid = torch.zeros_like(grid)
     if R == 0:
         return grad_grid
-    algo = algo or os.environ.get('PW_RENDER_BWD', 'sorted')
+    algo = algo or 'sorted'
     ch = (ctypes.c_float * 27)(*[float(v) for v in consts])
     gw = _chk(g_weights.contiguous(), _f32, 'g_weights') if g_weights is not None else None
     args = (_chk(rays_o.contiguous(), _f32, 'rays_o'), _chk(rays_d.contiguous(), _f32, 'rays_d'), R,

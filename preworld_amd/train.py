@@ -24,10 +24,12 @@ import torch
 from . import _lib, ops
 
 _f32 = torch.float32
-# PW_WGRAD=f32 keeps the exact-fp32 MFMA weight-gradient kernel for the 3x3x3 stride-1 layers too (default: split-fp16, pw_train_h2.hip)
-_WGRAD = __import__('os').environ.get('PW_WGRAD', 'h2')
-# PW_DGRAD_S2=valu keeps the plain-FMA stride-2 data-gradient kernel (pw_conv3d_dgrad_s2); default: zero insertion + the stride-1 MFMA kernels
-_DGRAD_S2 = __import__('os').environ.get('PW_DGRAD_S2', 'mfma')
+# module-level settings (tests set them; no environment switches):
+# _WGRAD 'f32' keeps the exact-fp32 MFMA weight-gradient kernel for the 3x3x3 stride-1 layers too (default: split-fp16, pw_train_h2.hip)
+_WGRAD = 'h2'
+# _DGRAD_S2 'valu' keeps the plain-FMA stride-2 data-gradient kernel (pw_conv3d_dgrad_s2), which also serves channel counts that are
+# not multiples of 32; default: zero insertion + the stride-1 MFMA kernels
+_DGRAD_S2 = 'mfma'
 
 
 def _cl(t, name):
@@ -55,13 +57,12 @@ def pack_weight(w, wino, flip_t=False):
 
 def _conv_fwd(x, w, stride, flip_t=False):
     """bias-free conv of channels-last x with torch-layout w (or, flip_t, with w.flip(2,3,4).transpose(0,1): the stride-1 data
-    gradient) on the fp32 inference kernels: Winograd F(2x2x2,3x3x3) where the module stack uses it (3x3x3 stride 1, enough tiles;
-    PW_CONV_WINO=0 / PW_TRAIN_WINO=0 keep the direct MFMA kernel), else direct"""
-    import os
+    gradient) on the fp32 inference kernels: Winograd F(2x2x2,3x3x3) where the module stack uses it (3x3x3 stride 1, enough tiles),
+    else direct"""
     from .modules import _use_wino
     k, cout = w.shape[2], (w.shape[1] if flip_t else w.shape[0])
     cout_total = (cout + 31) // 32 * 32
-    if os.environ.get('PW_TRAIN_WINO', '1') != '0' and _use_wino(x, cout_total, k, stride):
+    if _use_wino(x, cout_total, k, stride):
         return ops.conv3d_wino(x, pack_weight(w, True, flip_t), cout0=cout)
     return ops.conv3d_ndhwc(x, pack_weight(w, False, flip_t), cout0=cout, ksize=k, stride=stride)
 

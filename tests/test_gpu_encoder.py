@@ -92,9 +92,8 @@ def test_conv3d_outputs_into_channel_slices(shape):
     wpk2 = ops.pack_conv_weights_concat(w)
     sc = T(rs.uniform(0.5, 1.5, 64).astype(np.float32)); bi = T(rs.standard_normal(64).astype(np.float32))
     res = T(rs.standard_normal((B, D, H, W, 32)).astype(np.float32))
-    for algo, pipe in ((1, '0'), (1, '1'), (2, '0')):
-        os.environ['PW_CONV_PIPE'] = pipe
-        try:
+    for algo in (1, 4, 2):                  # tile-per-block, persistent DMA-pipelined, gather
+        if True:
             d0, d1 = ops.conv3d_ndhwc(x, wpk2, sc, bi, cout0=32, cout1=32, ksize=3, relu0=True, algo=algo)
             buf = torch.full((B, D, H, W, 96), 7.0, device=DEV)
             s0, s1 = ops.conv3d_ndhwc(x, wpk2, sc, bi, cout0=32, cout1=32, ksize=3, relu0=True, algo=algo,
@@ -113,8 +112,6 @@ def test_conv3d_outputs_into_channel_slices(shape):
                              relu0=True, algo=algo, out0=buf2[..., 32:64])
             np.testing.assert_array_equal(buf2[..., 32:64].cpu().numpy(), dense.cpu().numpy())
             assert bool((buf2[..., 0:32] == -3.0).all())
-        finally:
-            os.environ.pop('PW_CONV_PIPE', None)
     with pytest.raises(Exception):
         ops.conv3d_ndhwc(x, wp1, residual=res, ksize=3, out0=buf2[..., 32:64])      # residual stride != y0 stride
 
@@ -143,12 +140,9 @@ WINO_TOL = dict(rtol=3e-4, atol=3e-4)      # transform-domain products: |err| ~ 
 @pytest.mark.parametrize('shape', [(1, 32, 4, 8, 8), (2, 32, 5, 11, 13), (1, 64, 3, 9, 17), (1, 32, 16, 40, 48),
                                    (1, 64, 1, 1, 1), (1, 32, 2, 7, 3)])
 @pytest.mark.parametrize('cout', [32, 64, 16])
-@pytest.mark.parametrize('ws', ['1', '0'])
-def test_conv3d_wino_vs_oracle(shape, cout, ws, monkeypatch):
-    """pw_conv3d_wino (Winograd F(2x2x2,3x3x3)) against the direct-form oracle conv + folded BN + residual +
-    ReLU, on whole tiles, ragged edges in every axis and grids smaller than one tile; both kernels: the
-    wave-specialised persistent one (default) and the tile-per-block one (PW_WINO_WS=0)."""
-    monkeypatch.setenv('PW_WINO_WS', ws)
+def test_conv3d_wino_vs_oracle(shape, cout):
+    """pw_conv3d_wino (Winograd F(2x2x2,3x3x3), wave-specialised persistent kernel) against the direct-form oracle conv + folded
+    BN + residual + ReLU, on whole tiles, ragged edges in every axis and grids smaller than one tile."""
     rs = np.random.RandomState(hash((shape, cout)) % 2 ** 31)
     x = rs.standard_normal(shape).astype(np.float32)
     w = _rand_conv(rs, cout, shape[1], 3)
@@ -167,28 +161,21 @@ def test_conv3d_wino_vs_oracle(shape, cout, ws, monkeypatch):
 
 def test_conv3d_wino_persistent_many_tiles_per_block():
     """More tiles than CUs x 1: every block of the persistent kernel walks several tiles (halo DMA of the next tile
-    issued under the current tile's MFMAs) and two 32-channel chunks; must equal the tile-per-block kernel bit for bit
-    (same arithmetic, same order)."""
-    import os
+    issued under the current tile's MFMAs) and two 32-channel chunks; against the direct MFMA kernel on the same operands."""
     rs = np.random.RandomState(11)
     x = T(rs.standard_normal((2, 16, 88, 104, 64)).astype(np.float32))           # 2*4*11*13 = 1144 tiles
-    uw = ops.pack_conv_weight_wino(T(_rand_conv(rs, 64, 64, 3)))
+    w = T(_rand_conv(rs, 64, 64, 3))
     sc = T(rs.uniform(0.5, 1.5, 64).astype(np.float32)); bi = T(rs.standard_normal(64).astype(np.float32))
-    a = ops.conv3d_wino(x, uw, sc, bi, relu0=True)
-    os.environ['PW_WINO_WS'] = '0'
-    try:
-        b = ops.conv3d_wino(x, uw, sc, bi, relu0=True)
-    finally:
-        os.environ.pop('PW_WINO_WS', None)
-    assert torch.equal(a, b)
+    a = ops.conv3d_wino(x, ops.pack_conv_weight_wino(w), sc, bi, relu0=True)
+    b = ops.conv3d_ndhwc(x, ops.pack_conv_weight(w), sc, bi, ksize=3, relu0=True)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), **WINO_TOL)
+    assert torch.equal(a, ops.conv3d_wino(x, ops.pack_conv_weight_wino(w), sc, bi, relu0=True))
 
 
 @pytest.mark.parametrize('shape', [(1, 4, 50, 50, 128, 128), (1, 8, 20, 28, 64, 96), (2, 5, 9, 11, 32, 160)])
-@pytest.mark.parametrize('ng', ['1', '2'])
-def test_conv3d_wino_cout_groups(shape, ng, monkeypatch):
+def test_conv3d_wino_cout_groups(shape):
     """More than 64 output columns: work items = (tile, group of 32 or 64 columns) of the persistent kernel, residual
     and ReLU on every group, against the direct gather kernel."""
-    monkeypatch.setenv('PW_WINO_NG', ng)
     B, D, H, W, ci, co = shape
     rs = np.random.RandomState(13)
     x = T(rs.standard_normal((B, D, H, W, ci)).astype(np.float32))
@@ -200,7 +187,7 @@ def test_conv3d_wino_cout_groups(shape, ng, monkeypatch):
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), **WINO_TOL)
 
 
-def test_conv3d_wino_two_outputs_and_channel_slices(monkeypatch):
+def test_conv3d_wino_two_outputs_and_channel_slices():
     """The BasicBlock3D forms: conv1+downsample in one launch (y0 ReLU, y1 not), outputs written into
     channel slices of wider buffers, residual added in place -- same contract as conv3d_ndhwc."""
     rs = np.random.RandomState(5)
@@ -231,17 +218,13 @@ def test_conv3d_wino_two_outputs_and_channel_slices(monkeypatch):
     assert bool((buf2[..., 0:32] == -3.0).all())
     with pytest.raises(Exception):
         ops.conv3d_wino(x, uw1, residual=res, out0=buf2[..., 32:64])           # residual stride != y0 stride
-    monkeypatch.setenv('PW_WINO_WS', '0')
-    with pytest.raises(Exception):
-        ops.conv3d_wino(x, ops.pack_conv_weight_wino(T(_rand_conv(rs, 128, 32, 3))))   # > 64 columns: persistent kernel only
-    monkeypatch.delenv('PW_WINO_WS')
     with pytest.raises(Exception):
         ops.conv3d_wino(x[..., :24].contiguous(), uw1)
 
 
 def test_module_dispatch_wino_matches_direct():
-    """modules._use_wino: the module stack on the Winograd kernel (default) and with PW_CONV_WINO=0 agree to
-    the conv tolerance, and the dispatch really changes the kernel (results differ in the last bits)."""
+    """modules._use_wino: under PW_PRECISION=f32 the module stack runs large 3x3x3 stride-1 layers on the Winograd kernel; the same
+    block composed from the direct kernel (ops.conv3d_ndhwc) agrees to the conv tolerance and differs in the last bits."""
     import os
     rs = np.random.RandomState(9)
     blk = M.BasicBlock3D(32, 32, stride=1, downsample=M.ConvModule3d(32, 32, 3, stride=1, padding=1, bias=False, norm_cfg=dict(type='BN3d'), act_cfg=None)).to(DEV).eval()
@@ -251,16 +234,18 @@ def test_module_dispatch_wino_matches_direct():
     x = T(rs.standard_normal((1, 16, 48, 56, 32)).astype(np.float32))
     assert M._use_wino(x, 64, 3, 1) and not M._use_wino(x[:, :2, :8, :8], 64, 3, 1) and M._use_wino(x, 128, 3, 1) and not M._use_wino(x, 48, 3, 1)
     with torch.no_grad():
-        h = blk.forward_cl(x)                               # default precision: split-fp16 kernels
+        blk.forward_cl(x)                                   # default precision: split-fp16 kernels
         os.environ['PW_PRECISION'] = 'f32'
         try:
             a = blk.forward_cl(x)
-            os.environ['PW_CONV_WINO'] = '0'
-            assert not M._use_wino(x, 64, 3, 1)
-            b = blk.forward_cl(x)
         finally:
-            os.environ.pop('PW_CONV_WINO', None)
             os.environ.pop('PW_PRECISION', None)
+        w1, s1, b1 = blk.conv1.folded()
+        wd, sd, bd = blk.downsample.folded()
+        w2, s2, b2 = blk.conv2.folded()
+        y = ops.conv3d_ndhwc(x, w1, s1, b1, cout0=32, ksize=3, relu0=True)
+        idt = ops.conv3d_ndhwc(x, wd, sd, bd, cout0=32, ksize=3)
+        b = ops.conv3d_ndhwc(y, w2, s2, b2, residual=idt, cout0=32, ksize=3, relu0=True)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), **WINO_TOL)
     assert not torch.equal(a, b)
     # the three implementations (h2 on the fp16 cores, Winograd fp32, direct fp32) agree; h2 sits with the direct sum
@@ -668,10 +653,10 @@ def test_conv3d_h2_stride2_and_1x1(shape, cout):
 
 
 @pytest.mark.parametrize('shape,cout', [((1, 32, 7, 11, 13), 64), ((2, 64, 5, 9, 18), 64), ((1, 64, 8, 20, 20), 128), ((1, 32, 16, 40, 40), 64)])
-def test_conv3d_h2_stride2_tiled(shape, cout, monkeypatch):
+def test_conv3d_h2_stride2_tiled(shape, cout):
     """LDS-tiled split-fp16 stride-2 kernel (pw_conv3d_h2_s2.hip) in the form the encoder uses it -- conv1 (BN + ReLU) and the
     downsample conv (BN) of a stage's first block as one pass over 2 x Cout columns, two h2 destinations -- against the oracle
-    and against the gather kernel (PW_H2_S2=0); ragged grids (tiles cut in every axis), batch 2, a strided destination."""
+    and against the gather kernel (algo=2); ragged grids (tiles cut in every axis), batch 2, a strided destination."""
     from _parity import check_close
     from preworld_amd import _lib
     rs = np.random.RandomState(11)
@@ -688,10 +673,8 @@ def test_conv3d_h2_stride2_tiled(shape, cout, monkeypatch):
     want1 = O.conv3d(x, w2, None, 2, 1) * scn[cout:, None, None, None] + bin_[cout:, None, None, None]
     check_close('s2 tiled conv1 %s' % (shape,), ncdhw(ops.h2_to_f32(y0)), want0, 3e-6, atol=2e-6)
     check_close('s2 tiled downsample %s' % (shape,), ncdhw(ops.h2_to_f32(y1)), want1, 3e-6, atol=2e-6)
-    monkeypatch.setenv('PW_H2_S2', '0')
-    g0, g1 = ops.conv3d_h2(xh, wpk, sc * inv, bi, cout0=cout, cout1=cout, relu0=True, ksize=3, stride=2)
+    g0, g1 = ops.conv3d_h2(xh, wpk, sc * inv, bi, cout0=cout, cout1=cout, relu0=True, ksize=3, stride=2, algo=2)
     assert _lib.lib().pw_last_kernel().decode().startswith('k_conv3d_gather')
-    monkeypatch.delenv('PW_H2_S2')
     # (the two kernels add the 27 x Cin products in different orders: same bound as against the oracle)
     check_close('s2 tiled vs gather conv1 %s' % (shape,), ops.h2_to_f32(y0).cpu().numpy(), ops.h2_to_f32(g0).cpu().numpy(), 3e-6, atol=2e-6)
     check_close('s2 tiled vs gather downsample %s' % (shape,), ops.h2_to_f32(y1).cpu().numpy(), ops.h2_to_f32(g1).cpu().numpy(), 3e-6, atol=2e-6)

@@ -351,8 +351,9 @@ def test_stereo_cost_volume(golden, channels_last):
 
 
 @pytest.mark.parametrize('shape', [dict(C=128, H=19, W=45, D=88, n_cams=2), dict(C=16, H=9, W=21, D=33, n_cams=1)])
-def test_stereo_cost_volume_tile_kernel(monkeypatch, shape):
-    """The LDS-tiled channels-last kernel (default) against the point-per-lane kernel (itself pinned on the reference fixture):
+def test_stereo_cost_volume_tile_kernel(shape):
+    """The LDS-tiled channels-last kernel (default) against the point-per-lane kernel on the NCHW copy of the same features (itself
+    pinned on the reference fixture):
     same taps, the group costs summed by a lane tree instead of serially -> 1e-5-level agreement; ragged tile edges, bins
     beyond the last chunk, bias rule; plus a strong-parallax pose that pushes near bins onto the direct-gather branch."""
     from preworld_amd import _lib
@@ -364,10 +365,8 @@ def test_stereo_cost_volume_tile_kernel(monkeypatch, shape):
         if variant == 1:
             k2[0, :, :3, 3] = (1.9, 0.4, -2.5)            # large footprints for the near bins
         args = (T(fr), T(k2), T(K), T(pr), T(pt))
-        monkeypatch.setenv('PW_STEREO_TILE', '0')
-        want = ops.stereo_cost_volume(tp, tc, *args, bias=5.0)
-        assert _lib.lib().pw_last_kernel().decode() == 'k_stereo_cost_volume<true>'
-        monkeypatch.delenv('PW_STEREO_TILE')
+        want = ops.stereo_cost_volume(T(prev), T(curr), *args, bias=5.0)
+        assert _lib.lib().pw_last_kernel().decode() == 'k_stereo_cost_volume<false>'
         got = ops.stereo_cost_volume(tp, tc, *args, bias=5.0)
         assert _lib.lib().pw_last_kernel().decode() == 'k_stereo_cost_volume_tile'
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=1e-7)

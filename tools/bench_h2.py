@@ -48,14 +48,6 @@ def main():
           print('%dx%dx%dx%d %d->%d %6.1f GF  %s' % (B, D, H, W, cin, cout, gf, kern),
                 '  '.join('%s %.1f us (%.0f TF direct)' % (k, v, gf / v * 1e3) for k, v in res.items()), flush=True)
           continue
-      os.environ['PW_H2_TILE'] = '1'
-      res['tile h2->h2'] = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(True, True)))
-      for nt in ('1', '2'):
-          if cout >= 64:
-              os.environ['PW_H2_NT'] = nt
-              res['tile NT=%s' % nt] = timeit(lambda: ops.conv3d_h2(xh, wpk, sc * inv, bi, relu0=True, out0=y, out_h2=(True, True)))
-      os.environ.pop('PW_H2_NT', None)
-      os.environ.pop('PW_H2_TILE')
       t = timeit(lambda: ops.conv3d_wino(x, uw, sc, bi, relu0=True, out0=y))
       res['wino f32'] = t
       print('%dx%dx%dx%d %d->%d %6.1f GF  %s' % (B, D, H, W, cin, cout, gf, kern),

@@ -184,15 +184,12 @@ def bench_stereo():
     res['stereo_cv_hbm_alg_GBps'] = (2 * prev.numel() * 4 + npts * 4) / t / 1e3
     t2 = timeit(lambda: ops.stereo_cost_volume(prev.contiguous(), curr.contiguous(), *args, bias=5.0), iters=2)
     res['stereo_cv_nchw_us'] = t2
-    # the point-per-lane kernel on the same channels-last features (PW_STEREO_TILE=0)
+    # the point-per-lane kernel (NCHW copy of the same features) next to the tiled one
     import os
     ref = fn()
-    os.environ['PW_STEREO_TILE'] = '0'
-    old = fn()
-    res['stereo_cv_point_kernel_us'] = timeit(fn, iters=5)
+    old = ops.stereo_cost_volume(prev.contiguous(), curr.contiguous(), *args, bias=5.0)
     res['stereo_cv_max_abs_diff_to_point_kernel'] = float((ref - old).abs().max())
     res['stereo_cv_max_rel_diff_to_point_kernel'] = float(((ref - old).abs() / old.clamp_min(1e-30)).max())
-    del os.environ['PW_STEREO_TILE']
     probe = torch.zeros(48, dtype=torch.int64, device=dev)
     os.environ['PW_STEREO_PROBE'] = str(probe.data_ptr())
     fn()

@@ -1,5 +1,5 @@
 """Sustained timing of every conv layer shape of the C3 encoder (one line per shape).
-Environment knobs of the library (PW_CONV_PIPE, PW_CONV_WD) apply; LOOP_S seconds per shape.
+LOOP_S seconds per shape.
 ALGO=<0..3> picks the direct kernel (pw_conv3d_ndhwc's algo); EPI=1 adds scale/bias + in-place residual + ReLU to the Winograd runs.  ALGO=wino runs the Winograd kernel on the
 shapes it supports (k3 s1, <= 64 output columns) and skips the others.  TFLOP/s are direct-form FLOPs / time."""
 import json

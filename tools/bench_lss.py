@@ -1,5 +1,5 @@
 """LSS stage of one frame at the C3 shape (6 cams, 88x32x88 frustum, 200x200x16 grid): voxel index, sort, pooling (fp32 and h2
-output).  Development aid; env knobs of the library (PW_POOL_BLOCKS, ...) are read once per process."""
+output).  Development aid; """
 import os
 import sys
 

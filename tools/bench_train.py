@@ -37,7 +37,8 @@ def fwd():
         enc.forward_cl(x)
 
 
-for fn, name in ((fwd, 'forward (train-mode BN)'), (step, 'forward + backward')):
+ONLY_STEP = os.environ.get('ONLY_STEP', '0') == '1'       # rocprofv3 runs: just the whole training step
+for fn, name in (() if ONLY_STEP else ((fwd, 'forward (train-mode BN)'), (step, 'forward + backward'))):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -49,8 +50,8 @@ for fn, name in ((fwd, 'forward (train-mode BN)'), (step, 'forward + backward'))
     print('%-28s %.2f ms' % (name, (time.perf_counter() - t0) / n * 1e3), flush=True)
 
 # single layers
-for (D, H, W), cin, cout, s in (((16, 200, 200), 32, 32, 1), ((16, 200, 200), 64, 32, 1), ((16, 200, 200), 32, 64, 2),
-                                 ((8, 100, 100), 64, 64, 1), ((8, 100, 100), 64, 128, 2), ((4, 50, 50), 128, 128, 1)):
+for (D, H, W), cin, cout, s in (() if ONLY_STEP else (((16, 200, 200), 32, 32, 1), ((16, 200, 200), 64, 32, 1), ((16, 200, 200), 32, 64, 2),
+                                 ((8, 100, 100), 64, 64, 1), ((8, 100, 100), 64, 128, 2), ((4, 50, 50), 128, 128, 1))):
     xx = torch.randn(1, D, H, W, cin, device=dev)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
     y = train.conv3d_raw(xx, w, s)
@@ -107,7 +108,7 @@ for _ in range(2):
     out = train_step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 5
+n = int(os.environ.get('N_STEPS', '5'))
 for _ in range(n):
     train_step()
 torch.cuda.synchronize()

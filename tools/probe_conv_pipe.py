@@ -15,7 +15,6 @@ x = torch.randn(1, 16, 200, 200, cin, device=dev)
 nblk = 256
 buf = torch.zeros(nblk * 8 * 16 * 4 + 8 * 27, dtype=torch.int64, device=dev)
 os.environ['PW_CONV_PROBE'] = str(buf.data_ptr())
-os.environ['PW_CONV_PIPE'] = '1'
 from preworld_amd import ops  # noqa: E402
 if os.environ.get('OCC', '0') == '1':         # k_occ_head_h2 (same probe layout; no per-tap table)
     import numpy as _np
@@ -40,7 +39,7 @@ else:
     w = ops.pack_conv_weight(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
     for _ in range(3):
         buf.zero_()
-        ops.conv3d_ndhwc(x, w, ksize=3, algo=1)
+        ops.conv3d_ndhwc(x, w, ksize=3, algo=4)
 torch.cuda.synchronize()
 raw = buf.cpu().numpy()
 t = raw[:nblk * 8 * 16 * 4].reshape(nblk, 8, 16, 4).astype(np.float64)

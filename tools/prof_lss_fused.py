@@ -1,4 +1,4 @@
-"""Loop ops.lss_lift_pool at the C3 frame shape (for rocprofv3 --kernel-trace --stats; PW_LSS_DEBUG selects timing experiments)."""
+"""Loop ops.lss_lift_pool at the C3 frame shape (for rocprofv3 --kernel-trace --stats)."""
 import os
 import sys
 
