@@ -234,7 +234,7 @@ def test_module_dispatch_wino_matches_direct():
     x = T(rs.standard_normal((1, 16, 48, 56, 32)).astype(np.float32))
     assert M._use_wino(x, 64, 3, 1) and not M._use_wino(x[:, :2, :8, :8], 64, 3, 1) and M._use_wino(x, 128, 3, 1) and not M._use_wino(x, 48, 3, 1)
     with torch.no_grad():
-        blk.forward_cl(x)                                   # default precision: split-fp16 kernels
+        h = blk.forward_cl(x)                               # default precision: split-fp16 kernels
         os.environ['PW_PRECISION'] = 'f32'
         try:
             a = blk.forward_cl(x)
