@@ -223,8 +223,8 @@ def _pmc_traffic(kernel):
             if ents:
                 return int(sum(e['fetch_bytes'] + e['write_bytes'] for e in ents)), name
         ent = by.get(kernel)
-        if ent is None and kernel == 'k_render_rays':                    # template arguments vary: the forward instantiation
-            ent = next((v for k, v in sorted(by.items()) if k.startswith('k_render_rays') and ('false' in k.split(',')[1] if ',' in k else True)), None)
+        if ent is None and kernel == 'k_render_rays':                    # the forward instantiation of the literal 3 072 x 96 shape
+            ent = by.get('k_render_rays<2, 0, false>')
         if ent:
             return int(ent['fetch_bytes'] + ent['write_bytes']), name
     return None, None

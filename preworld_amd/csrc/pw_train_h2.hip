@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
     if (ksub > 0) return;
   }
   // partial tiles of this (chunk, K-subset): D row (co) = (r & 3) + 8 (r >> 2) + 4 h, column (ci) = lane & 31
-  const float unscale = rng_pow2(ex + ey);
+  const float unx = rng_pow2(ex), uny = rng_pow2(ey);      // applied one after the other: 2^(ex + ey) alone can leave fp32's range
   const int chunk = zi * a.n_strips + strip;
   const int cob = cg * CO_T + ct, cib = ig * CI_T + it;
   const int i = lane & 31, hh = lane >> 5;
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
     const int tap = kd * 9 + kh * 3 + t;
     float* dst = a.partial + ((((size_t)chunk * 27 + tap) * a.co_blocks + cob) * a.ci_blocks + cib) * 1024;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + i] = acc[t][r] * unscale;
+    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + i] = acc[t][r] * unx * uny;
   }
 }
 

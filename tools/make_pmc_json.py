@@ -23,8 +23,8 @@ def main(vdir, dst):
     import os
     f, w = table(vdir + '/pmc_FETCH_SIZE.md'), table(vdir + '/pmc_WRITE_SIZE.md')
     if os.path.exists(vdir + '/pmc_C5_FETCH_SIZE.md'):        # the render head's own passes (bench.py --config C5): k_render_* only
-        for dst, src in ((f, table(vdir + '/pmc_C5_FETCH_SIZE.md')), (w, table(vdir + '/pmc_C5_WRITE_SIZE.md'))):
-            dst.update({k: v for k, v in src.items() if k.startswith(('k_render', 'k_rb_', 'k_attr'))})
+        for into, extra in ((f, table(vdir + '/pmc_C5_FETCH_SIZE.md')), (w, table(vdir + '/pmc_C5_WRITE_SIZE.md'))):
+            into.update({k: v for k, v in extra.items() if k.startswith(('k_render', 'k_rb_', 'k_attr'))})
     by = {}
     for k in sorted(set(f) | set(w)):
         if not k.startswith('k_'):
