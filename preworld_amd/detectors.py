@@ -390,6 +390,14 @@ class BEVStereo4DOCC(nn.Module):
         return [r.cpu().numpy().astype(np.uint8) for r in res]
 
 
+def _zero_weight_of(mlp):
+    """the zero-weight `loss_sup_*` term of an attribute MLP that nothing else consumes (fine-tune configs: if_render=False): the
+    reference evaluates the MLP on all 640 000 voxels, a soft-target cross entropy, multiplies by 0. and back-propagates zeros through
+    both; value and gradients are known without any of it (round 4: -3 ms of the voxel-side training step)."""
+    ps = [p for p in mlp.parameters() if p.requires_grad]
+    return sum((p.sum() for p in ps), torch.zeros((), device=ps[0].device)) * 0.
+
+
 def _zero_weight(pred):
     """`CrossEntropyLoss()(pred, ones) * 0.` of preworld.py:120-127 / :305-307 -- a zero-weight term whose only job is to keep the
     attribute MLPs in the autograd graph (their parameters get zero-valued gradients).  Its value is 0 and its gradient is 0 for any
@@ -466,9 +474,13 @@ class _PreWorldCommon(BEVStereo4DOCC):
         # the attribute MLPs act per voxel: applied to the (Z,Y,X) buffer as 1x1x1 convs on the MFMA kernels (train.mlp_cl), their
         # outputs viewed as the reference's (B,X,Y,Z,.) (:238)
         xyz = lambda t: t.permute(0, 3, 2, 1, 4)
-        density_prob = xyz(train.mlp_cl(self.density_mlp, voxel_feats_cl))
-        density, semantic = density_prob[..., 0], xyz(train.mlp_cl(self.semantic_mlp, voxel_feats_cl))
-        color = xyz(train.mlp_cl(self.color_mlp, voxel_feats_cl))
+        need_sem = self.if_render or (self.if_pretrain and interval is None)
+        density = semantic = color = None
+        if self.if_render:
+            density_prob = xyz(train.mlp_cl(self.density_mlp, voxel_feats_cl))
+            density, color = density_prob[..., 0], xyz(train.mlp_cl(self.color_mlp, voxel_feats_cl))
+        if need_sem:
+            semantic = xyz(train.mlp_cl(self.semantic_mlp, voxel_feats_cl))
         out = {}
         cw17 = torch.from_numpy(1.0 / np.log(NUSC_CLASS_FREQUENCIES[:17] + 0.001)).float()
         if self.if_post_finetune:
@@ -485,8 +497,8 @@ class _PreWorldCommon(BEVStereo4DOCC):
             out.update(self.nerf_head(density, semantic, color, if_pretrain=self.if_pretrain, dataset_type=self.dataset_type,
                                       rays=kwargs['rays'] if rays is None else rays, bda=kwargs.get('bda'), **extra))
         else:                                                         # loss_sup (:120-127): zero weight, keeps the MLPs in the graph
-            for pred, tag, n in ((semantic, 'semantic', self.num_classes - 1), (color, 'color', 3), (density, 'density', 1)):
-                out['loss_sup_%s%s' % (tag, sfx)] = _zero_weight(pred)
+            for mlp, pred, tag in ((self.semantic_mlp, semantic, 'semantic'), (self.color_mlp, color, 'color'), (self.density_mlp, density, 'density')):
+                out['loss_sup_%s%s' % (tag, sfx)] = _zero_weight(pred) if pred is not None else _zero_weight_of(mlp)
         if self.if_pretrain and interval is None:                      # preworld.py:305-307 (the temporal detector has no such term)
             n = self.num_classes - 1
             out['loss_sup_semantic'] = _zero_weight(semantic)
