@@ -553,6 +553,14 @@ int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const float* 
  * weight.permute(2,3,4,0,1)), dx (B,D,H,W,Cin), Cin % 4 == 0.  (Stride-1 and 1x1x1 data gradients are forward convolutions
  * with flipped / transposed weights: pw_conv3d_ndhwc.) */
 int pw_conv3d_dgrad_s2(const float* dy, const float* wt, float* dx, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+/* The same data gradient on the fp16 matrix cores with split-fp16 operands (see pw_conv3d_h2; 22-bit products, fp32 accumulation),
+ * as the 8 parity classes of the fine grid: dX[2j+p] is a dense 1-, 2-, 4- or 8-tap convolution over dY -- 27 tap products per 8 fine
+ * voxels, every dX row written once (no zero fill).  dy (B,Do,Ho,Wo,Cout) in h2 storage under range slot dy_rng (pw_f32_to_h2 with
+ * auto_exp), w = torch's (Cout,Cin,3,3,3) weight as it is (transposed, pre-scaled and split on the device into the workspace),
+ * dx (B,D,H,W,Cin) fp32; Cin % 32 == 0, Cout % 32 == 0.  Kernel k_conv3d_dgrad_s2_h2<NT>.  Deterministic. */
+size_t pw_conv3d_dgrad_s2_h2_workspace_bytes(int Cin, int Cout);
+int pw_conv3d_dgrad_s2_h2(const float* dy, const int32_t* dy_rng, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                          int B, int D, int H, int W, int Cin, int Cout, void* stream);
 /* dX of the unpadded Conv3d(k=2, stride=2) of the trajectory branch (heads/occupancy_head.py:180-200): dy (B,D/2,H/2,W/2,Cout),
  * wt float[2][2][2][Cout][Cin], dx (B,D,H,W,Cin).  pw_conv3d_wgrad takes ksize 2 / stride 2 for the matching dW. */
 int pw_conv3d_dgrad_k2s2(const float* dy, const float* wt, float* dx, int B, int D, int H, int W, int Cin, int Cout, void* stream);
@@ -575,11 +583,13 @@ int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t N, 
 
 /* Trilinear up-sampling with align_corners=True (torch's upsample_trilinear3d index / weight rule) of a channels-last map
  * lo (B,Dl,Hl,Wl,C) to hi (B,Dh,Hh,Wh,C), C % 4 == 0: hi = up(lo) or hi += up(lo) (accumulate != 0); and its adjoint
- * dlo = up^T(dhi), computed as a gather (deterministic).  Training side of LSSFPN3D (necks/lss_fpn.py:132-148). */
+ * dlo = up^T(dhi), one axis at a time (W, H, D: the operator is a tensor product) through two intermediates in the workspace, each pass a
+ * gather (deterministic).  Training side of LSSFPN3D (necks/lss_fpn.py:132-148). */
 int pw_upsample_trilinear_add(const float* lo, float* hi, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C,
                               int accumulate, void* stream);
-int pw_upsample_trilinear_adjoint(const float* dhi, float* dlo, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C,
-                                  void* stream);
+size_t pw_upsample_trilinear_adjoint_workspace_bytes(int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C);
+int pw_upsample_trilinear_adjoint(const float* dhi, float* dlo, void* workspace, size_t workspace_bytes, int B, int Dl, int Hl, int Wl,
+                                  int Dh, int Hh, int Wh, int C, void* stream);
 
 #ifdef __cplusplus
 }

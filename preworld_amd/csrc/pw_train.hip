@@ -501,8 +501,7 @@ PW_API int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int6
 // mmdet3d/models/necks/lss_fpn.py:132-148 in training: with the 1x1x1 conv commuted below the up-sampling only the
 // 32-channel maps are interpolated.  Source index / weights exactly as torch's upsample_trilinear3d: src = dst (in-1)/(out-1).
 //   pw_upsample_trilinear_add      hi (+)= up(lo)                        one thread per (hi voxel, 4 channels)
-//   pw_upsample_trilinear_adjoint  dlo = up^T(dhi)                        one thread per (lo voxel, 4 channels) GATHERS the hi
-//                                  voxels whose two corners along each axis include it (deterministic, no atomics)
+//   pw_upsample_trilinear_adjoint  dlo = up^T(dhi)                        one axis at a time (k_upsample_axis_adjoint)
 // ------------------------------------------------------------------------------------
 struct UpArgs {
   const float* src;
@@ -565,38 +564,29 @@ __device__ __forceinline__ float adj_weight(int d, int j, float s, int n_in) {
   return (i0 == j ? l0 : 0.f) + (i1 == j ? l1 : 0.f);
 }
 
-__global__ void __launch_bounds__(256) k_upsample_adjoint(UpArgs a) {      // src = d hi, dst = d lo
-  const int cq = a.C / 4;
+// one axis of the adjoint: src (outer, n_hi, inner) -> dst (outer, n_lo, inner), inner = float4s per index along the axis.  The
+// interpolation is a tensor product of three 1-D operators, so is its adjoint: W, then H, then D, each thread gathering the <= 2/s + 3
+// fine indices whose corners include its coarse index (deterministic, no atomics).  (The 3-D gather of round 3 looped over up to 11^3
+// fine voxels from 80 000 threads: 354 us for the 4x level at 200x200x16; the three passes move 82 + 20 + 5 MB.)
+__global__ void __launch_bounds__(256) k_upsample_axis_adjoint(const float4* __restrict__ src, float4* __restrict__ dst, size_t outer,
+                                                               int n_hi, int n_lo, int inner, float s) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)a.B * a.Dl * a.Hl * a.Wl * cq;
-  if (idx >= total) return;
-  const int c4 = (int)(idx % cq);
-  size_t v = idx / cq;
-  const int xl = (int)(v % a.Wl); v /= a.Wl;
-  const int yl = (int)(v % a.Hl); v /= a.Hl;
-  const int zl = (int)(v % a.Dl);
-  const int b = (int)(v / a.Dl);
-  int zlo, zhi, ylo, yhi, xlo, xhi;
-  adj_range(zl, a.sd, a.Dh, zlo, zhi);
-  adj_range(yl, a.sh, a.Hh, ylo, yhi);
-  adj_range(xl, a.sw, a.Wh, xlo, xhi);
-  const float4* hi = reinterpret_cast<const float4*>(a.src) + (size_t)b * a.Dh * a.Hh * a.Wh * cq + c4;
+  if (idx >= outer * n_lo * inner) return;
+  const int i4 = (int)(idx % inner);
+  size_t v = idx / inner;
+  const int j = (int)(v % n_lo);
+  const size_t o = v / n_lo;
+  int lo, hi;
+  adj_range(j, s, n_hi, lo, hi);
+  const float4* p = src + o * n_hi * inner + i4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int z = zlo; z <= zhi; ++z) {
-    const float wz = adj_weight(z, zl, a.sd, a.Dl);
-    if (wz == 0.f) continue;
-    for (int y = ylo; y <= yhi; ++y) {
-      const float wy = adj_weight(y, yl, a.sh, a.Hl) * wz;
-      if (wy == 0.f) continue;
-      for (int x = xlo; x <= xhi; ++x) {
-        const float w = adj_weight(x, xl, a.sw, a.Wl) * wy;
-        if (w == 0.f) continue;
-        const float4 g = hi[(((size_t)z * a.Hh + y) * a.Wh + x) * cq];
-        acc.x = fmaf(w, g.x, acc.x); acc.y = fmaf(w, g.y, acc.y); acc.z = fmaf(w, g.z, acc.z); acc.w = fmaf(w, g.w, acc.w);
-      }
-    }
+  for (int d = lo; d <= hi; ++d) {
+    const float w = adj_weight(d, j, s, n_lo);
+    if (w == 0.f) continue;
+    const float4 g = p[(size_t)d * inner];
+    acc.x = fmaf(w, g.x, acc.x); acc.y = fmaf(w, g.y, acc.y); acc.z = fmaf(w, g.z, acc.z); acc.w = fmaf(w, g.w, acc.w);
   }
-  reinterpret_cast<float4*>(a.dst)[idx] = acc;
+  dst[idx] = acc;
 }
 
 static int up_args(UpArgs& a, const float* src, float* dst, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C,
@@ -629,13 +619,29 @@ PW_API int pw_upsample_trilinear_add(const float* lo, float* hi, int B, int Dl, 
   return PW_OK;
 }
 
-PW_API int pw_upsample_trilinear_adjoint(const float* dhi, float* dlo, int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh,
-                                         int C, void* stream) {
+PW_API size_t pw_upsample_trilinear_adjoint_workspace_bytes(int B, int Dl, int Hl, int Wl, int Dh, int Hh, int Wh, int C) {
+  return ((size_t)B * Dh * Hh * Wl + (size_t)B * Dh * Hl * Wl) * C * sizeof(float) + 256;
+}
+
+PW_API int pw_upsample_trilinear_adjoint(const float* dhi, float* dlo, void* workspace, size_t workspace_bytes, int B, int Dl, int Hl,
+                                         int Wl, int Dh, int Hh, int Wh, int C, void* stream) {
   UpArgs a;
   if (int rc = up_args(a, dhi, dlo, B, Dl, Hl, Wl, Dh, Hh, Wh, C, "pw_upsample_trilinear_adjoint")) return rc;
-  const size_t total = (size_t)B * Dl * Hl * Wl * (C / 4);
-  hipLaunchKernelGGL(k_upsample_adjoint, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, pw_stream(stream), a);
-  pw_note_kernel("k_upsample_adjoint");
+  PW_CHECK_ARG(workspace && workspace_bytes >= pw_upsample_trilinear_adjoint_workspace_bytes(B, Dl, Hl, Wl, Dh, Hh, Wh, C) &&
+               ((uintptr_t)workspace & 15) == 0, "pw_upsample_trilinear_adjoint: workspace missing, misaligned or too small");
+  float4* t1 = static_cast<float4*>(workspace);                                    // (B, Dh, Hh, Wl, C)
+  float4* t2 = t1 + (size_t)B * Dh * Hh * Wl * (C / 4);                            // (B, Dh, Hl, Wl, C)
+  hipStream_t st = pw_stream(stream);
+  const int cq = C / 4;
+  auto pass = [&](const float4* src, float4* dst, size_t outer, int n_hi, int n_lo, int inner, float s) {
+    const size_t total = outer * n_lo * inner;
+    hipLaunchKernelGGL(k_upsample_axis_adjoint, dim3((unsigned)pw_cdiv((int64_t)total, 256)), dim3(256), 0, st, src, dst, outer, n_hi,
+                       n_lo, inner, s);
+  };
+  pass(reinterpret_cast<const float4*>(dhi), t1, (size_t)B * Dh * Hh, Wh, Wl, cq, a.sw);
+  pass(t1, t2, (size_t)B * Dh, Hh, Hl, Wl * cq, a.sh);
+  pass(t2, reinterpret_cast<float4*>(dlo), (size_t)B, Dh, Dl, Hl * Wl * cq, a.sd);
+  pw_note_kernel("k_upsample_axis_adjoint");
   PW_CHECK_LAUNCH();
   return PW_OK;
 }

@@ -468,8 +468,8 @@ class _PreWorldCommon(BEVStereo4DOCC):
         sfx = '' if interval is None else '_%ds' % interval
         voxel_semantics = kwargs['voxel_semantics'] if voxel_semantics is None else voxel_semantics
         head = self.occupancy_head
-        logits = torch.cat([train.occ_head_forward(head, voxel_feats_cl[b:b + 1], transposed=True)
-                            for b in range(voxel_feats_cl.shape[0])], 0)           # (B,Z,Y,X,18)
+        parts = [train.occ_head_forward(head, voxel_feats_cl[b:b + 1], transposed=True) for b in range(voxel_feats_cl.shape[0])]
+        logits = parts[0] if len(parts) == 1 else torch.cat(parts, 0)               # (B,Z,Y,X,18); per batch element as :240-247
         occ_preds = logits.permute(0, 4, 3, 2, 1)                                   # (B,18,X,Y,Z) view, as :240-247 stacks them
         # the attribute MLPs act per voxel: applied to the (Z,Y,X) buffer as 1x1x1 convs on the MFMA kernels (train.mlp_cl), their
         # outputs viewed as the reference's (B,X,Y,Z,.) (:238)

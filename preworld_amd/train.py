@@ -27,9 +27,9 @@ _f32 = torch.float32
 # module-level settings (tests set them; no environment switches):
 # _WGRAD 'f32' keeps the exact-fp32 MFMA weight-gradient kernel for the 3x3x3 stride-1 layers too (default: split-fp16, pw_train_h2.hip)
 _WGRAD = 'h2'
-# _DGRAD_S2 'valu' keeps the plain-FMA stride-2 data-gradient kernel (pw_conv3d_dgrad_s2), which also serves channel counts that are
-# not multiples of 32; default: zero insertion + the stride-1 MFMA kernels
-_DGRAD_S2 = 'mfma'
+# _DGRAD_S2 'valu' keeps the plain-FMA stride-2 data-gradient kernel (pw_conv3d_dgrad_s2, exact fp32 order), which also serves channel
+# counts that are not multiples of 32 (default: split-fp16 parity-class kernel, pw_dgrad_s2_h2.hip)
+_DGRAD_S2 = 'h2'
 
 
 def _cl(t, name):
@@ -88,12 +88,15 @@ def conv3d_dgrad(dy, w, x_shape, stride=1):
     if stride != 2 or k not in (2, 3):
         raise _lib.PreworldHipError('conv3d_dgrad: only stride 1 (k 1 | 3), 3x3x3 stride 2 and 2x2x2 stride 2 are built')
     if k == 3 and Cout % 32 == 0 and Cin % 32 == 0 and _DGRAD_S2 != 'valu':
-        # stride-2 data gradient = the stride-1 data gradient of dY with zeros inserted between its voxels: dX[i] = sum_k W[k]^T
-        # dYd[i + 1 - k] with dYd[2 j] = dY[j].  Seven eighths of the products are with zeros, and the MFMA forward kernels still run
-        # it in half the time of the plain-VALU kernel below (12 TFLOP/s): 748 -> ~400 us at the encoder's first down-sampling stage.
-        dyd = torch.zeros(B, D, H, W, Cout, device=dy.device, dtype=_f32)
-        dyd[:, ::2, ::2, ::2] = dy
-        return _conv_fwd(dyd, w, 1, flip_t=True)
+        # the 8 parity classes of the fine grid as dense 1- to 8-tap convolutions over dY, split-fp16 operands: 27 tap products per
+        # 8 fine voxels and no zero fill (round 3 inserted zeros into dY and ran the stride-1 Winograd kernel: 27 per voxel)
+        dyh = ops.f32_to_h2(_cl(dy, 'dy'))
+        nbytes = _lib.call_size('pw_conv3d_dgrad_s2_h2_workspace_bytes', Cin, Cout)
+        ws = ops._workspace(nbytes, dy.device)
+        dx = torch.empty(B, D, H, W, Cin, device=dy.device, dtype=_f32)
+        _lib.call('pw_conv3d_dgrad_s2_h2', ops._p(dyh.buf), ops._p(dyh.rng), ops._p(_cl(w.detach(), 'w')), ops._p(dx), ops._p(ws), nbytes,
+                  B, D, H, W, Cin, Cout, ops._stream())
+        return dx
     dx = torch.empty(B, D, H, W, Cin, device=dy.device, dtype=_f32)
     _lib.call('pw_conv3d_dgrad_s2' if k == 3 else 'pw_conv3d_dgrad_k2s2', ops._p(_cl(dy, 'dy')),
               ops._p(_cl(w.detach().permute(2, 3, 4, 0, 1).contiguous(), 'w')), ops._p(dx), B, D, H, W, Cin, Cout, ops._stream())
@@ -174,6 +177,16 @@ class Conv3dCL(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
+        pad = (-w.shape[0]) % 32
+        if pad and ctx.stride == 1:
+            # a narrow layer (OccHead's 32 -> 16 conv, the attribute MLPs' last Linear): the gradient kernels take multiples of 32
+            # output channels, so dY and W get zero columns HERE -- one pad kernel, instead of a padded weight in the forward graph
+            # whose output slice autograd turns into a strided copy forward and a zero fill + strided copy backward
+            dy = torch.nn.functional.pad(dy, (0, pad))
+            wp = torch.cat([w.detach(), w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
+            dx = conv3d_dgrad(dy, wp, x.shape, 1) if ctx.needs_input_grad[0] else None
+            dw = conv3d_wgrad(x, dy, wp.shape, 1)[:w.shape[0]] if ctx.needs_input_grad[1] else None
+            return dx, dw, None
         dx = conv3d_dgrad(dy, w, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
         dw = conv3d_wgrad(x, dy, w.shape, ctx.stride) if ctx.needs_input_grad[1] else None
         return dx, dw, None
@@ -301,8 +314,10 @@ def upsample_add(lo, hi, accumulate):
 def upsample_adjoint(dhi, lo_shape):
     B, Dl, Hl, Wl, C = lo_shape
     dlo = torch.empty(tuple(lo_shape), device=dhi.device, dtype=_f32)
-    _lib.call('pw_upsample_trilinear_adjoint', ops._p(_cl(dhi, 'dhi')), ops._p(dlo), B, Dl, Hl, Wl, dhi.shape[1], dhi.shape[2],
-              dhi.shape[3], C, ops._stream())
+    dims = (B, Dl, Hl, Wl, dhi.shape[1], dhi.shape[2], dhi.shape[3], C)
+    nbytes = _lib.call_size('pw_upsample_trilinear_adjoint_workspace_bytes', *dims)
+    ws = ops._workspace(nbytes, dhi.device)
+    _lib.call('pw_upsample_trilinear_adjoint', ops._p(_cl(dhi, 'dhi')), ops._p(dlo), ops._p(ws), nbytes, *dims, ops._stream())
     return dlo
 
 
@@ -422,9 +437,7 @@ def linear_cl(x_cl, lin):
     N, K = lin.weight.shape
     if x_cl.dim() != 5 or K % 32 or not x_cl.is_cuda:
         return torch.nn.functional.linear(x_cl, lin.weight, lin.bias)
-    pad = (-N) % 32
-    w = torch.cat([lin.weight, lin.weight.new_zeros(pad, K)], 0) if pad else lin.weight
-    y = Conv3dCL.apply(x_cl.contiguous(), w.reshape(N + pad, K, 1, 1, 1), 1)[..., :N]
+    y = Conv3dCL.apply(x_cl.contiguous(), lin.weight.reshape(N, K, 1, 1, 1), 1)      # narrow N: padded inside Conv3dCL.backward
     return y + lin.bias if lin.bias is not None else y
 
 
@@ -438,16 +451,13 @@ def mlp_cl(seq, x_cl):
 def occ_head_forward(head, x_cl, transposed=True):
     """OccHead.forward_coarse_voxel (occupancy_head.py:124-161) in training mode on channels-last x (B,Z,Y,X,32) -> logits
     (B,Z,Y,X,18).  transposed: x is the encoder's native (Z,Y,X) buffer while the reference convolves (X,Y,Z): the taps are
-    permuted instead of the activation.  3x3x3 conv 32 -> 16 on the MFMA kernels (output columns zero-padded to 32 so that
-    dgrad runs on them too), batch-statistics BatchNorm on the HIP kernels; the per-voxel 16 -> 8 -> 18 layers (and the soft-weight
+    permuted instead of the activation.  3x3x3 conv 32 -> 16 on the MFMA kernels (Conv3dCL pads dY / W to 32 columns for the
+    gradient kernels), batch-statistics BatchNorm on the HIP kernels; the per-voxel 16 -> 8 -> 18 layers (and the soft-weight
     branch) on pw_linear_rows (LinearRowsCL)."""
     c0, bn0 = head.occ_convs[0][0], head.occ_convs[0][1]
     c1, bn1, c2 = head.occ_pred_conv[0], head.occ_pred_conv[1], head.occ_pred_conv[3]
     w0 = c0.weight.permute(0, 1, 4, 3, 2) if transposed else c0.weight
-    pad = 32 - w0.shape[0]
-    w0p = torch.cat([w0, w0.new_zeros((pad,) + tuple(w0.shape[1:]))], 0) if pad else w0
-    mid = Conv3dCL.apply(x_cl.contiguous(), w0p.contiguous(), 1)[..., :w0.shape[0]]
-    mid = _bn_cl(bn0, mid, True)
+    mid = _bn_cl(bn0, Conv3dCL.apply(x_cl.contiguous(), w0.contiguous(), 1), True)
     if head.soft_weights:
         # occupancy_head.py:141-151 with num_level = 1: softmax over ONE channel == 1, so the features are unchanged and the branch
         # receives exactly zero gradients -- but its BatchNorm sees the batch (running statistics move) and its parameters get

@@ -8,6 +8,7 @@ import sys
 
 
 def short(name):
+    name = name.replace('(anonymous namespace)::', '')
     name = re.sub(r'\(.*$', '', name)
     name = name.replace('void ', '')
     return name[:90]
