@@ -580,6 +580,11 @@ int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t N,
 int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean, const float* rstd,
                     const float* gamma, const float* sum_dz, const float* sum_dz_xhat, int relu, float* dx, float* dres,
                     void* stream);
+/* nn.BatchNorm3d's running-statistics update after a training-mode forward, one launch: running_mean = (1 - momentum) running_mean
+ * + momentum mean; running_var likewise with the UNBIASED batch variance var * n / max(n - 1, 1); num_batches_tracked (int64, may be
+ * NULL) += 1.  n = n_rows_dev[0] (device float: the SyncBN row count over all ranks) when n_rows_dev != NULL, else n_rows. */
+int pw_bn_update_running(const float* mean, const float* var, int C, double n_rows, const float* n_rows_dev, float momentum,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream);
 
 /* Trilinear up-sampling with align_corners=True (torch's upsample_trilinear3d index / weight rule) of a channels-last map
  * lo (B,Dl,Hl,Wl,C) to hi (B,Dh,Hh,Wh,C), C % 4 == 0: hi = up(lo) or hi += up(lo) (accumulate != 0); and its adjoint

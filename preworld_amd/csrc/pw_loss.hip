@@ -8,6 +8,7 @@
 // scalar loss algebra runs on those sums; the backward is a second pass that recomputes the softmax
 // and writes d(loss)/d(logits) directly (per-class coefficient vectors come from the sums).
 #include "pw_common.h"
+#include "pw_vox.h"
 
 namespace {
 constexpr int MAXC = 32;
@@ -21,15 +22,8 @@ struct LossArgs {
   int B, C, X, Y, Z;
   long long sb, sc, sx, sy, sz;
   int ignore, empty;
+  VoxWalk walk;
 };
-
-__device__ __forceinline__ long long vox_offset(const LossArgs& a, long long v, int& b) {
-  const int z = (int)(v % a.Z); long long t = v / a.Z;
-  const int y = (int)(t % a.Y); t /= a.Y;
-  const int x = (int)(t % a.X);
-  b = (int)(t / a.X);
-  return b * a.sb + x * a.sx + y * a.sy + z * a.sz;
-}
 
 template <int C>
 __device__ __forceinline__ void softmax_c(const LossArgs& a, long long off, int ncls, float (&p)[C], float& lse) {
@@ -61,9 +55,10 @@ __global__ void __launch_bounds__(256) k_voxel_loss_stats(LossArgs a, long long 
   float sp[C], st[C], spt[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) { sp[c] = 0.f; st[c] = 0.f; spt[c] = 0.f; }
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n_vox; v += (long long)gridDim.x * blockDim.x) {
-    int b;
-    const long long off = vox_offset(a, v, b);
+  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < n_vox; u += (long long)gridDim.x * blockDim.x) {
+    int b, x, y, z;
+    long long v;
+    const long long off = vox_walk(a, u, b, x, y, z, v);
     float p[C], lse;
     softmax_c<C>(a, off, a.C, p, lse);
     const int t = a.target[v];
@@ -118,10 +113,11 @@ __global__ void __launch_bounds__(256) k_voxel_loss_stats(LossArgs a, long long 
 template <int C>
 __global__ void __launch_bounds__(256) k_voxel_loss_grad(LossArgs a, long long n_vox, const float* __restrict__ coef,
                                                         float* __restrict__ grad) {
-  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n_vox) return;
-  int b;
-  const long long off = vox_offset(a, v, b);
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_vox) return;
+  int b, x, y, z;
+  long long v;
+  const long long off = vox_walk(a, u, b, x, y, z, v);
   float p[C], lse;
   softmax_c<C>(a, off, a.C, p, lse);
   const int t = a.target[v];
@@ -157,6 +153,7 @@ static int fill_args(LossArgs& a, const float* logits, const uint8_t* target, co
   a.B = B; a.C = n_cls; a.X = X; a.Y = Y; a.Z = Z;
   a.sb = sb; a.sc = sc; a.sx = sx; a.sy = sy; a.sz = sz;
   a.ignore = ignore_index; a.empty = empty_idx;
+  a.walk = vox_walk_order(sx, sy, sz);
   return PW_OK;
 }
 

@@ -19,6 +19,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "pw_common.h"
+#include "pw_vox.h"
 
 namespace {
 struct VoxArgs {
@@ -29,6 +30,7 @@ struct VoxArgs {
   int B, C, X, Y, Z;
   long long sb, sc, sx, sy, sz;
   int ignore;
+  VoxWalk walk;
 };
 
 __device__ __forceinline__ long long vox_decode(const VoxArgs& a, long long v, int& xh, int& yw) {
@@ -65,11 +67,12 @@ __device__ __forceinline__ float powg(float b, float gamma) { return gamma == 2.
 __global__ void __launch_bounds__(256) k_focal_stats(VoxArgs a, FocalPar f, long long n_vox, double* __restrict__ stats) {
   __shared__ float red[4];
   float sum = 0.f, cnt = 0.f;
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n_vox; v += (long long)gridDim.x * blockDim.x) {
+  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < n_vox; u += (long long)gridDim.x * blockDim.x) {
+    int b, xh, yw, z;
+    long long v;
+    const long long off = vox_walk(a, u, b, xh, yw, z, v);
     const int t = a.target[v];
     if (t == a.ignore || (a.cam && !a.cam[v])) continue;
-    int xh, yw;
-    const long long off = vox_decode(a, v, xh, yw);
     float s = 0.f;
     for (int c = 0; c < a.C; ++c) {
       const float p = 1.f / (1.f + __expf(-a.x[off + c * a.sc]));
@@ -91,10 +94,11 @@ __global__ void k_focal_finish(const double* __restrict__ stats, float loss_weig
 __global__ void __launch_bounds__(256) k_focal_grad(VoxArgs a, FocalPar f, long long n_vox, const double* __restrict__ stats,
                                                     float loss_weight, const float* __restrict__ gout, float* __restrict__ grad) {
   const float coef = gout[0] * loss_weight / (float)stats[1];
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n_vox; v += (long long)gridDim.x * blockDim.x) {
+  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < n_vox; u += (long long)gridDim.x * blockDim.x) {
+    int b, xh, yw, z;
+    long long v;
+    const long long off = vox_walk(a, u, b, xh, yw, z, v);
     const int t = a.target[v];
-    int xh, yw;
-    const long long off = vox_decode(a, v, xh, yw);
     const bool valid = t != a.ignore && !(a.cam && !a.cam[v]);
     const float wv = valid ? coef * radial(f, xh, yw) : 0.f;
     for (int c = 0; c < a.C; ++c) {
@@ -130,11 +134,12 @@ __global__ void __launch_bounds__(256) k_lovasz_keys(VoxArgs a, long long n_vox,
   if (threadIdx.x < 33) scnt[threadIdx.x] = 0;
   __syncthreads();
   const bool ign_in = a.ignore >= 0 && a.ignore < a.C;
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n_vox; v += (long long)gridDim.x * blockDim.x) {
+  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < n_vox; u += (long long)gridDim.x * blockDim.x) {
+    int b, xh, yw, z;
+    long long v;
+    const long long off = vox_walk(a, u, b, xh, yw, z, v);
     const int t = a.target[v];
     const bool valid = t != a.ignore && !(a.cam && !a.cam[v]);
-    int xh, yw;
-    const long long off = vox_decode(a, v, xh, yw);
     if (valid) {
       atomicAdd(&scnt[32], 1u);
       if (t < a.C) atomicAdd(&scnt[t], 1u);
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(256) k_lovasz_keys(VoxArgs a, long long n_vox,
         const float err = fabsf((c == t ? 1.f : 0.f) - a.x[off + c * a.sc]);
         k = min(~__float_as_uint(err), 0xFFFFFFFEu);        // ascending key = descending error; valid < invalid
       }
-      const size_t pos = (size_t)seg_of(c, a.ignore, a.C) * (size_t)n_vox + (size_t)v;
+      const size_t pos = (size_t)seg_of(c, a.ignore, a.C) * (size_t)n_vox + (size_t)u;      // walk order: coalesced (ties sort in it)
       w.keys_in[pos] = ((unsigned long long)c << 32) | k;
       w.vals_in[pos] = (unsigned)v;
     }
@@ -206,15 +211,18 @@ __global__ void __launch_bounds__(256) k_lovasz_dot(VoxArgs a, long long n_vox, 
   const unsigned i0 = blockIdx.x * LV_BLOCK + threadIdx.x * 4;
   unsigned fg[4], vv[4];
   float err[4];
+  bool nz[4];                                    // error > 0 (key below the clamp of k_lovasz_keys)
   unsigned local = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const unsigned i = i0 + j;
-    fg[j] = 0; vv[j] = 0; err[j] = 0.f;
+    fg[j] = 0; vv[j] = 0; err[j] = 0.f; nz[j] = false;
     if (i < nvalid) {
       vv[j] = w.vals_out[base + i];
       fg[j] = a.target[vv[j]] == c ? 1u : 0u;
-      err[j] = __uint_as_float(~(unsigned)(w.keys_out[base + i] & 0xFFFFFFFFull));
+      const unsigned kb = (unsigned)(w.keys_out[base + i] & 0xFFFFFFFFull);
+      err[j] = __uint_as_float(~kb);
+      nz[j] = kb != 0xFFFFFFFEu;
     }
     local += fg[j];
   }
@@ -247,9 +255,9 @@ __global__ void __launch_bounds__(256) k_lovasz_dot(VoxArgs a, long long n_vox, 
       if (dprob) {
         int xh, yw;
         const long long off = vox_decode(a, (long long)vv[j], xh, yw);
-        const float p = a.x[off + c * a.sc];
-        const float d = (fg[j] ? 1.f : 0.f) - p;
-        dprob[off + c * a.sc] = d > 0.f ? -g : (d < 0.f ? g : 0.f);      // d|fg - p|/dp = -sign(fg - p)
+        // d|fg - p|/dp = -sign(fg - p), and p in [0, 1]: the sign is that of fg - 1/2 unless the error is zero -- no second
+        // (random) read of the probability
+        dprob[off + c * a.sc] = nz[j] ? (fg[j] ? -g : g) : 0.f;
       }
     }
   }
@@ -303,7 +311,7 @@ int lovasz_layout(long long n_vox, int C, int ignore, char* base, size_t have, L
 }  // namespace
 
 #define PW_VOX_ARGS(a, ptr)                                                                                          \
-  VoxArgs a = {ptr, target, cam_mask, class_weights, B, C, X, Y, Z, sb, sc, sx, sy, sz, ignore_index};               \
+  VoxArgs a = {ptr, target, cam_mask, class_weights, B, C, X, Y, Z, sb, sc, sx, sy, sz, ignore_index, vox_walk_order(sx, sy, sz)}; \
   const long long n_vox = (long long)B * X * Y * Z;                                                                  \
   PW_CHECK_ARG(ptr && target && B > 0 && C > 0 && X > 0 && Y > 0 && Z > 0, "voxel loss: bad arguments");            \
   const unsigned grid = (unsigned)((n_vox + 255) / 256 < 2048 ? (n_vox + 255) / 256 : 2048)

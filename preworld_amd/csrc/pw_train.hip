@@ -404,6 +404,30 @@ PW_API int pw_bn_stats(const float* x, int64_t N, int C, float eps, void* worksp
   return PW_OK;
 }
 
+// nn.BatchNorm3d's running-statistics bookkeeping (torch/nn/modules/batchnorm.py) in one launch: exponential average with the
+// UNBIASED batch variance, num_batches_tracked += 1.  (As torch ops it is ten tiny kernels per BatchNorm -- 270 launches per step.)
+__global__ void __launch_bounds__(256) k_bn_update_running(const float* __restrict__ mean, const float* __restrict__ var, int C,
+                                                           double n_host, const float* __restrict__ n_dev, float momentum,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           int64_t* __restrict__ num_batches_tracked) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+  if (c >= C) return;
+  const float n = n_dev ? n_dev[0] : (float)n_host;
+  const float unbias = n / fmaxf(n - 1.f, 1.f);
+  running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mean[c];
+  running_var[c] = running_var[c] * (1.f - momentum) + momentum * (var[c] * unbias);
+}
+
+PW_API int pw_bn_update_running(const float* mean, const float* var, int C, double n_rows, const float* n_rows_dev, float momentum,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
+  PW_CHECK_ARG(mean && var && running_mean && running_var && C > 0 && (n_rows_dev || n_rows > 0), "pw_bn_update_running: bad arguments");
+  hipLaunchKernelGGL(k_bn_update_running, dim3((unsigned)pw_cdiv(C, 256)), dim3(256), 0, pw_stream(stream), mean, var, C, n_rows,
+                     n_rows_dev, momentum, running_mean, running_var, num_batches_tracked);
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}
+
 __global__ void __launch_bounds__(256) k_bn_apply(const float4* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const float4* __restrict__ residual,

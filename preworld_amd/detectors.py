@@ -395,7 +395,20 @@ def _zero_weight_of(mlp):
     reference evaluates the MLP on all 640 000 voxels, a soft-target cross entropy, multiplies by 0. and back-propagates zeros through
     both; value and gradients are known without any of it (round 4: -3 ms of the voxel-side training step)."""
     ps = [p for p in mlp.parameters() if p.requires_grad]
-    return sum((p.sum() for p in ps), torch.zeros((), device=ps[0].device)) * 0.
+    return _ZeroTerm.apply(*ps)
+
+
+class _ZeroTerm(torch.autograd.Function):
+    """0. * (anything finite computed from the parameters): value 0, zero-valued gradients for every parameter"""
+
+    @staticmethod
+    def forward(ctx, *ps):
+        ctx.meta = [(p.shape, p.dtype, p.device) for p in ps]
+        return torch.zeros((), device=ps[0].device)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(torch.zeros(s, dtype=d, device=dev) for s, d, dev in ctx.meta)
 
 
 def _zero_weight(pred):
@@ -468,7 +481,8 @@ class _PreWorldCommon(BEVStereo4DOCC):
         sfx = '' if interval is None else '_%ds' % interval
         voxel_semantics = kwargs['voxel_semantics'] if voxel_semantics is None else voxel_semantics
         head = self.occupancy_head
-        parts = [train.occ_head_forward(head, voxel_feats_cl[b:b + 1], transposed=True) for b in range(voxel_feats_cl.shape[0])]
+        nb = voxel_feats_cl.shape[0]                 # (a batch slice of an autograd tensor costs a zero fill + copy of it backward)
+        parts = [train.occ_head_forward(head, voxel_feats_cl if nb == 1 else voxel_feats_cl[b:b + 1], transposed=True) for b in range(nb)]
         logits = parts[0] if len(parts) == 1 else torch.cat(parts, 0)               # (B,Z,Y,X,18); per batch element as :240-247
         occ_preds = logits.permute(0, 4, 3, 2, 1)                                   # (B,18,X,Y,Z) view, as :240-247 stacks them
         # the attribute MLPs act per voxel: applied to the (Z,Y,X) buffer as 1x1x1 convs on the MFMA kernels (train.mlp_cl), their

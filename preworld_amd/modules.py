@@ -72,8 +72,11 @@ class LSSViewTransformer(nn.Module):
         return fr
 
     def _grid(self):
-        return ([float(v) for v in self.grid_lower_bound], [float(v) for v in self.grid_interval],
-                [int(v) for v in self.grid_size])
+        key = (id(self.grid_lower_bound), id(self.grid_interval), id(self.grid_size))
+        if getattr(self, '_grid_host', (None,))[0] != key:                 # host copies of the three 3-vectors, made once
+            self._grid_host = (key, ([float(v) for v in self.grid_lower_bound], [float(v) for v in self.grid_interval],
+                                     [int(v) for v in self.grid_size]))
+        return self._grid_host[1]
 
     def _frustum_on(self, ref):
         if self.frustum.device != ref.device:

@@ -55,7 +55,7 @@ def pack_weight(w, wino, flip_t=False):
     return out
 
 
-def _conv_fwd(x, w, stride, flip_t=False):
+def _conv_fwd(x, w, stride, flip_t=False, residual=None):
     """bias-free conv of channels-last x with torch-layout w (or, flip_t, with w.flip(2,3,4).transpose(0,1): the stride-1 data
     gradient) on the fp32 inference kernels: Winograd F(2x2x2,3x3x3) where the module stack uses it (3x3x3 stride 1, enough tiles),
     else direct"""
@@ -63,8 +63,19 @@ def _conv_fwd(x, w, stride, flip_t=False):
     k, cout = w.shape[2], (w.shape[1] if flip_t else w.shape[0])
     cout_total = (cout + 31) // 32 * 32
     if _use_wino(x, cout_total, k, stride):
-        return ops.conv3d_wino(x, pack_weight(w, True, flip_t), cout0=cout)
-    return ops.conv3d_ndhwc(x, pack_weight(w, False, flip_t), cout0=cout, ksize=k, stride=stride)
+        return ops.conv3d_wino(x, pack_weight(w, True, flip_t), cout0=cout, residual=residual)
+    return ops.conv3d_ndhwc(x, pack_weight(w, False, flip_t), cout0=cout, ksize=k, stride=stride, residual=residual)
+
+
+def _conv_fwd_pair(x, w1, w2, stride):
+    """(conv(x, w1), conv(x, w2)) from ONE pass over x: the packed columns of both weights side by side, two destinations
+    (pw_conv3d_ndhwc / pw_conv3d_wino cout0 / cout1) -- conv1 and downsample of a BasicBlock3D read the same input."""
+    from .modules import _use_wino
+    k, c1, c2 = w1.shape[2], w1.shape[0], w2.shape[0]
+    w = torch.cat([w1, w2], 0)
+    if _use_wino(x, c1 + c2, k, stride):
+        return ops.conv3d_wino(x, pack_weight(w, True), cout0=c1, cout1=c2)
+    return ops.conv3d_ndhwc(x, pack_weight(w, False), cout0=c1, cout1=c2, ksize=k, stride=stride)
 
 
 def conv3d_raw(x, w, stride=1):
@@ -76,15 +87,18 @@ def conv3d_raw(x, w, stride=1):
     return _conv_fwd(_cl(x, 'x'), w.detach(), stride)
 
 
-def conv3d_dgrad(dy, w, x_shape, stride=1):
-    """d loss / d x of conv3d_raw: dy (B,Do,Ho,Wo,Cout) -> (B,D,H,W,Cin)."""
+def conv3d_dgrad(dy, w, x_shape, stride=1, accumulate=None):
+    """d loss / d x of conv3d_raw: dy (B,Do,Ho,Wo,Cout) -> (B,D,H,W,Cin).  accumulate (stride 1): a (B,D,H,W,Cin) tensor the result
+    is added to in the kernel's epilogue (returned; the gradient of an input that two convolutions read)."""
     k = w.shape[2]
     Cout, Cin = w.shape[:2]
     B, D, H, W, _ = x_shape
     if stride == 1:
         if Cout % 32:
             raise _lib.PreworldHipError('conv3d_dgrad: Cout %% 32 == 0 expected (encoder layers)')
-        return _conv_fwd(_cl(dy, 'dy'), w, 1, flip_t=True)
+        return _conv_fwd(_cl(dy, 'dy'), w, 1, flip_t=True, residual=accumulate)
+    if accumulate is not None:
+        raise _lib.PreworldHipError('conv3d_dgrad: accumulate is built for stride 1')
     if stride != 2 or k not in (2, 3):
         raise _lib.PreworldHipError('conv3d_dgrad: only stride 1 (k 1 | 3), 3x3x3 stride 2 and 2x2x2 stride 2 are built')
     if k == 3 and Cout % 32 == 0 and Cin % 32 == 0 and _DGRAD_S2 != 'valu':
@@ -218,6 +232,7 @@ class BatchNormCL(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, eps, relu, sync=False):
+        ctx.set_materialize_grads(False)          # the statistics outputs never carry gradients: no zero tensors made for them
         mean, var, rstd = bn_stats(x, eps)
         n_local = float(x.numel() // x.shape[-1])
         n_total = n_local
@@ -235,13 +250,14 @@ class BatchNormCL(torch.autograd.Function):
         y = bn_apply(x, mean, rstd, g, b, residual, relu)
         ctx.save_for_backward(x, y, mean, rstd, g)
         ctx.relu, ctx.has_res, ctx.sync, ctx.n_ratio = bool(relu), residual is not None, bool(sync), n_local / n_total
-        cnt = torch.full((1,), n_total, dtype=torch.float32, device=x.device)
-        ctx.mark_non_differentiable(mean, var, cnt)
-        return y, mean, var, cnt
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var, n_total                                  # the row count goes out as a plain number
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv, _dc):
         x, y, mean, rstd, g = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None, None, None, None
         if _sync_world(ctx.sync) > 1:
             return BatchNormCL._backward_sync(ctx, x, dy.contiguous(), y, mean, rstd, g)
         dx, dgamma, dbeta, dres = bn_backward(x, dy.contiguous(), y, mean, rstd, g, ctx.relu, ctx.has_res and ctx.needs_input_grad[3])
@@ -274,6 +290,12 @@ def _update_running(bn, mean, var, n):
     n: (1,) device tensor (or a plain number), the number of rows the statistics were taken over (all ranks for a SyncBN) -- no host sync"""
     if not bn.track_running_stats or bn.running_mean is None:
         return
+    if bn.momentum is not None and bn.running_mean.is_cuda and bn.running_mean.dtype == _f32 and bn.running_var.dtype == _f32:
+        on_dev = torch.is_tensor(n)
+        _lib.call('pw_bn_update_running', ops._p(mean), ops._p(var), mean.numel(), 0.0 if on_dev else float(n),
+                  ops._p(n.float().contiguous()) if on_dev else None, float(bn.momentum), ops._p(bn.running_mean), ops._p(bn.running_var),
+                  ops._p(bn.num_batches_tracked) if bn.num_batches_tracked is not None else None, ops._stream())
+        return
     with torch.no_grad():
         bn.num_batches_tracked += 1
         m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
@@ -282,23 +304,68 @@ def _update_running(bn, mean, var, n):
         bn.running_var.mul_(1.0 - m).add_(var * unbias, alpha=m)
 
 
+class ConvPairCL(torch.autograd.Function):
+    """(conv3d(x, w1), conv3d(x, w2)), same kernel size and stride: conv1 and downsample of a BasicBlock3D (resnet.py:108-123) read
+    the same input.  Forward: one kernel pass over x with two destinations.  Backward: the two data gradients meet in ONE tensor --
+    stride 1: the second convolution adds the first one's result in its epilogue; stride 2: one parity-class kernel over the
+    channel-concatenated dY (the pair is a convolution with Cout1 + Cout2 output channels) -- where autograd would launch two
+    convolutions and an add over the input-sized gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, stride):
+        ctx.save_for_backward(x, w1, w2)
+        ctx.stride = stride
+        return _conv_fwd_pair(_cl(x, 'x'), w1.detach(), w2.detach(), stride)
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x, w1, w2 = ctx.saved_tensors
+        dy1, dy2 = dy1.contiguous(), dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.stride == 1:
+                dx = conv3d_dgrad(dy2, w2, x.shape, 1, accumulate=conv3d_dgrad(dy1, w1, x.shape, 1))
+            else:
+                dx = conv3d_dgrad(torch.cat([dy1, dy2], -1), torch.cat([w1.detach(), w2.detach()], 0), x.shape, ctx.stride)
+        dw1 = conv3d_wgrad(x, dy1, w1.shape, ctx.stride) if ctx.needs_input_grad[1] else None
+        dw2 = conv3d_wgrad(x, dy2, w2.shape, ctx.stride) if ctx.needs_input_grad[2] else None
+        return dx, dw1, dw2, None
+
+
 # ------------------------------------------------------------------------------ module-level training forwards
 def conv_module_forward(m, x, residual=None, relu=None):
     """ConvModule3d (conv -> BN -> ReLU) in training mode; `relu` overrides the module's own activation flag and, with
     `residual`, gives BasicBlock3D's relu(bn(conv(x)) + identity)."""
     if m.conv.bias is not None or not m.with_norm:
         raise NotImplementedError('training path: bias-free conv + BatchNorm3d modules only (the encoder blocks)')
-    y = Conv3dCL.apply(x.contiguous(), m.conv.weight, m.stride)
+    return _norm_act(m, Conv3dCL.apply(x.contiguous(), m.conv.weight, m.stride), residual, relu)
+
+
+def _norm_act(m, y, residual=None, relu=None):
+    """the BatchNorm (batch statistics) + activation half of a ConvModule3d on its conv output y"""
     relu = m.with_activation if relu is None else relu
     out, mean, var, cnt = BatchNormCL.apply(y, m.bn.weight, m.bn.bias, residual, m.bn.eps, relu, getattr(m.bn, 'pw_sync', False))
     _update_running(m.bn, mean, var, cnt)
     return out
 
 
+def _pairable(a, b):
+    """two ConvModule3d over the same input that one kernel pass can serve: bias-free, normed, same kernel size / stride, output
+    channels in whole 32-column tiles"""
+    return (a.conv.bias is None and b.conv.bias is None and a.with_norm and b.with_norm and a.stride == b.stride and
+            a.conv.weight.shape[1:] == b.conv.weight.shape[1:] and a.conv.weight.shape[2] == 3 and
+            a.conv.weight.shape[0] % 32 == 0 and b.conv.weight.shape[0] % 32 == 0 and a.conv.weight.shape[1] % 32 == 0)
+
+
 def basic_block_forward(blk, x):
     """resnet.py:108-123 in training mode: relu(conv2(conv1(x)) + downsample(x)), every conv followed by batch-stat BN"""
-    identity = conv_module_forward(blk.downsample, x) if blk.downsample is not None else x
-    y = conv_module_forward(blk.conv1, x)
+    if blk.downsample is not None and _pairable(blk.conv1, blk.downsample):
+        y1, yd = ConvPairCL.apply(x.contiguous(), blk.conv1.conv.weight, blk.downsample.conv.weight, blk.conv1.stride)
+        identity = _norm_act(blk.downsample, yd)          # the reference normalises the identity branch first (BN bookkeeping order)
+        y = _norm_act(blk.conv1, y1)
+    else:
+        identity = conv_module_forward(blk.downsample, x) if blk.downsample is not None else x
+        y = conv_module_forward(blk.conv1, x)
     return conv_module_forward(blk.conv2, y, residual=identity.contiguous(), relu=True)
 
 

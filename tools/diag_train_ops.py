@@ -15,6 +15,7 @@ from torch.utils._python_dispatch import TorchDispatchMode
 g = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bench_train.py'), run_name='__main__')
 step = g['train_step']
 log = collections.defaultdict(lambda: [0, 0])
+MIN_ELEMS = int(os.environ.get('MIN_ELEMS', '200000'))          # MIN_ELEMS=0 BY_COUNT=1: every launch, busiest source lines first
 SKIP = ('aten.view', 'aten.permute', 'aten.slice.', 'aten.select', 'aten.detach', 'aten.alias', 'aten.t.', 'aten.reshape', 'aten._unsafe_view',
         'aten.unsqueeze', 'aten.squeeze', 'aten.expand', 'aten.as_strided', 'aten.transpose', 'aten.empty', 'aten.is_', 'aten.sym_', 'aten.stride')
 
@@ -30,7 +31,7 @@ class Log(TorchDispatchMode):
                     n = max(n, a.numel())
                 elif isinstance(a, (list, tuple)):
                     n = max([n] + [t.numel() for t in a if isinstance(t, torch.Tensor)])
-            if n >= 200000:
+            if n >= MIN_ELEMS:
                 where = 'autograd engine'
                 for f in reversed(traceback.extract_stack()[:-1]):
                     if 'preworld_amd' in f.filename or 'bench_train' in f.filename:
@@ -45,7 +46,7 @@ class Log(TorchDispatchMode):
 with Log():
     step()
 torch.cuda.synchronize()
-rows = sorted(log.items(), key=lambda kv: -kv[1][0])
-print('aten ops on tensors of >= 200 000 elements in ONE training step, by total elements touched (x4 bytes, x2-3 for read+write):')
-for (name, where), (n, c) in rows[:60]:
+rows = sorted(log.items(), key=lambda kv: -kv[1][1 if os.environ.get('BY_COUNT') else 0])
+print('aten ops on tensors of >= %d elements in ONE training step (x4 bytes, x2-3 for read+write):' % MIN_ELEMS)
+for (name, where), (n, c) in rows[:int(os.environ.get('ROWS', '60'))]:
     print('%8.1f M elems  x%-3d %-32s %s' % (n / 1e6, c, name, where))
