@@ -311,38 +311,73 @@ PW_API int pw_conv3d_dgrad_k2s2(const float* dy, const float* wt, float* dx, int
 //   bwd_reduce: dz = dy (y > 0 if ReLU);  sum_dz[c], sum_dz_xhat[c]
 //   bwd_apply:  dx = gamma rstd (dz - sum_dz / N - x_hat sum_dz_xhat / N);  dres = dz (optional)
 // ------------------------------------------------------------------------------------
-constexpr int BN_BLOCKS = 512;
+constexpr int BN_BLOCKS = 1024;
 
+// one row of the reduction: 4 channels of a lane.  BWD: dz = dy (masked by y > 0), sums of dz and dz * x_hat; else sums of x and x^2
 template <bool BWD>
-__global__ void __launch_bounds__(256) k_bn_reduce(const float* __restrict__ x, const float* __restrict__ dy,
-                                                   const float* __restrict__ y, const float* __restrict__ mean,
+__device__ __forceinline__ void bn_acc4(const float4& xv, const float4& gv, const float4& yv, bool relu, const float (&m)[4],
+                                        const float (&rs)[4], double (&s0)[4], double (&s1)[4]) {
+  const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+  if (BWD) {
+    float dz[4] = {gv.x, gv.y, gv.z, gv.w};
+    if (relu) {
+      const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(ye[e] > 0.f)) dz[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s0[e] += (double)dz[e]; s1[e] += (double)dz[e] * (double)((xe[e] - m[e]) * rs[e]); }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s0[e] += (double)xe[e]; s1[e] += (double)xe[e] * (double)xe[e]; }
+  }
+}
+
+// A lane owns 4 channels (16-byte loads) and every (256 / (C/4))-th row of its block's row range, four rows in flight.  (The first
+// version loaded 4 bytes per lane with one load in flight: 1.7-2.6 TB/s, 1.8 ms of the training step in these two reductions.)
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bn_reduce(const float4* __restrict__ x, const float4* __restrict__ dy,
+                                                   const float4* __restrict__ y, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, int64_t N, int C, int relu,
                                                    double* __restrict__ partial /* [blocks][2][C] */) {
-  __shared__ double red[2][256];
-  const int c = threadIdx.x % C, rsub = threadIdx.x / C, rstep = 256 / C;
+  __shared__ double red[2][4][256];
+  const int cq = C >> 2;
+  const int q = threadIdx.x % cq, rsub = threadIdx.x / cq, rstep = 256 / cq;
   const int64_t per = (N + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < N ? r0 + per : N;
-  double s0 = 0.0, s1 = 0.0;
-  float m = 0.f, rs = 0.f;
-  if (BWD) { m = mean[c]; rs = rstd[c]; }
-  for (int64_t r = r0 + rsub; r < r1; r += rstep) {
-    const float xv = x[r * C + c];
-    if (BWD) {
-      float dz = dy[r * C + c];
-      if (relu && !(y[r * C + c] > 0.f)) dz = 0.f;
-      s0 += (double)dz;
-      s1 += (double)dz * (double)((xv - m) * rs);
-    } else {
-      s0 += (double)xv;
-      s1 += (double)xv * (double)xv;
-    }
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  float m[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (BWD) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m[e] = mean[4 * q + e]; rs[e] = rstd[4 * q + e]; }
   }
-  red[0][threadIdx.x] = s0;
-  red[1][threadIdx.x] = s1;
+  const bool mask = BWD && relu;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t r = r0 + rsub;
+  for (; r + 3 * rstep < r1; r += 4 * rstep) {
+    float4 xv[4], gv[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = (r + u * rstep) * cq + q;
+      xv[u] = x[i];
+      gv[u] = BWD ? dy[i] : zero;
+      yv[u] = mask ? y[i] : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bn_acc4<BWD>(xv[u], gv[u], yv[u], mask, m, rs, s0, s1);
+  }
+  for (; r < r1; r += rstep) {
+    const int64_t i = r * cq + q;
+    bn_acc4<BWD>(x[i], BWD ? dy[i] : zero, mask ? y[i] : zero, mask, m, rs, s0, s1);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][e][threadIdx.x] = s0[e]; red[1][e][threadIdx.x] = s1[e]; }
   __syncthreads();
   if (threadIdx.x < C) {
+    const int qq = threadIdx.x >> 2, e = threadIdx.x & 3;
     double a0 = 0.0, a1 = 0.0;
-    for (int q = 0; q < rstep; ++q) { a0 += red[0][q * C + threadIdx.x]; a1 += red[1][q * C + threadIdx.x]; }
+    for (int g = 0; g < rstep; ++g) { a0 += red[0][e][g * cq + qq]; a1 += red[1][e][g * cq + qq]; }
     partial[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a0;
     partial[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = a1;
   }
@@ -378,6 +413,13 @@ __global__ void __launch_bounds__(64) k_bn_finish(const double* __restrict__ par
 
 PW_API size_t pw_bn_workspace_bytes(int C) { return (size_t)BN_BLOCKS * 2 * C * sizeof(double); }
 
+// blocks of a reduction: at least 4 rows per lane (the finishing kernel walks the block partials), at most BN_BLOCKS
+static int bn_blocks(int64_t N, int C) {
+  const int64_t rows_per_pass = 256 / (C / 4);
+  const int64_t want = pw_cdiv(N, rows_per_pass * 4);
+  return (int)(want < 1 ? 1 : (want > BN_BLOCKS ? BN_BLOCKS : want));
+}
+
 static int bn_check(int64_t N, int C, const void* ws, size_t ws_bytes, const char* who) {
   if (!(N > 0 && C > 0 && C <= 256 && 256 % C == 0 && C % 4 == 0)) {
     pw_set_error("%s: C must divide 256 and be a multiple of 4 (got N=%lld C=%d)", who, (long long)N, C);
@@ -392,11 +434,11 @@ static int bn_check(int64_t N, int C, const void* ws, size_t ws_bytes, const cha
 
 PW_API int pw_bn_stats(const float* x, int64_t N, int C, float eps, void* workspace, size_t workspace_bytes, float* mean,
                        float* var, float* rstd, void* stream) {
-  PW_CHECK_ARG(x && mean && var && rstd, "pw_bn_stats: null pointer");
+  PW_CHECK_ARG(x && mean && var && rstd && ((uintptr_t)x & 15) == 0, "pw_bn_stats: null or misaligned pointer");
   if (int rc = bn_check(N, C, workspace, workspace_bytes, "pw_bn_stats")) return rc;
-  const int blocks = (int)(N < BN_BLOCKS ? N : BN_BLOCKS);
+  const int blocks = bn_blocks(N, C);
   hipStream_t st = pw_stream(stream);
-  hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+  hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, st, (const float4*)x, (const float4*)nullptr, (const float4*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, N, C, 0, (double*)workspace);
   hipLaunchKernelGGL(k_bn_finish, dim3(C), dim3(64), 0, st, (const double*)workspace, blocks, C, N, eps, 1, mean, var, rstd);
   pw_note_kernel("k_bn_reduce<false>");
@@ -465,11 +507,13 @@ PW_API int pw_bn_apply(const float* x, int64_t N, int C, const float* mean, cons
 PW_API int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean,
                             const float* rstd, int relu, void* workspace, size_t workspace_bytes, float* sum_dz,
                             float* sum_dz_xhat, void* stream) {
-  PW_CHECK_ARG(x && dy && mean && rstd && sum_dz && sum_dz_xhat && (!relu || y), "pw_bn_bwd_reduce: null pointer");
+  PW_CHECK_ARG(x && dy && mean && rstd && sum_dz && sum_dz_xhat && (!relu || y) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y) & 15) == 0,
+               "pw_bn_bwd_reduce: null or misaligned pointer");
   if (int rc = bn_check(N, C, workspace, workspace_bytes, "pw_bn_bwd_reduce")) return rc;
-  const int blocks = (int)(N < BN_BLOCKS ? N : BN_BLOCKS);
+  const int blocks = bn_blocks(N, C);
   hipStream_t st = pw_stream(stream);
-  hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, st, x, dy, y, mean, rstd, N, C, relu, (double*)workspace);
+  hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, st, (const float4*)x, (const float4*)dy, (const float4*)y, mean, rstd, N, C,
+                     relu, (double*)workspace);
   hipLaunchKernelGGL(k_bn_finish, dim3(C), dim3(64), 0, st, (const double*)workspace, blocks, C, N, 0.f, 0, sum_dz, sum_dz_xhat,
                      (float*)nullptr);
   pw_note_kernel("k_bn_reduce<true>");

@@ -169,6 +169,21 @@ def lovasz_softmax(probas, labels, classes='present', per_image=False, ignore=No
     return _Lovasz.apply(probas, labels, camera_mask, ignore)
 
 
+class _Sanitise(torch.autograd.Function):
+    """NaN / +-Inf -> 0, the gradient passing where the value was finite (what the reference's two masked assignments do)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        return g * (x == y)                      # NaN != 0 and Inf != 0: exactly the replaced elements drop out
+
+
 def _softmax_classes(x):
     """torch.softmax(x, dim=1) of (B,C,X,Y,Z) logits.  The OccHead's logits are a permuted view of a channels-last buffer (class axis
     innermost in memory); torch.softmax would first copy them into (B,C,X,Y,Z) order -- a 46 MB transpose forward and another for the
@@ -191,7 +206,7 @@ def loss_voxel(output_voxels, target_voxels, class_weights, camera_mask=None, em
     # :137-138 zero NaN / Inf logits with two in-place masked assignments.  Same values from ONE elementwise pass in the tensor's
     # own memory layout: in place on the permuted view of an autograd tensor the assignments cost ~9 transposing copies of the
     # 46 MB logits per step (CopySlices forward and backward, 0.2 ms each); the caller's tensor is left as it was
-    output_voxels = torch.nan_to_num(output_voxels, nan=0.0, posinf=0.0, neginf=0.0)
+    output_voxels = _Sanitise.apply(output_voxels)
     cw = torch.cat([class_weights.to(output_voxels.device), torch.zeros(1, device=output_voxels.device)]).type_as(output_voxels)
     ce, sem, geo = voxel_losses(output_voxels, target_voxels, cw, 255, empty_idx, camera_mask)
     if use_focal_loss:

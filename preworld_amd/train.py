@@ -394,9 +394,12 @@ class UpsampleSumCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, base, a, b):
         ctx.shapes = (tuple(a.shape), tuple(b.shape))
-        out = base.clone()
+        # in place on `base` (a conv output nothing else reads or saved): no 82 MB clone
+        out = base if base.is_contiguous() else base.contiguous()
         upsample_add(a.contiguous(), out, True)
         upsample_add(b.contiguous(), out, True)
+        if out is base:
+            ctx.mark_dirty(base)
         return out
 
     @staticmethod
