@@ -541,14 +541,15 @@ int pw_linear_rows(const float* x, const float* w, float* y, int64_t n, int K, i
 
 /* the same gradient for 3x3x3 stride-1 layers with Cin, Cout multiples of 32 on the fp16 matrix cores with split-fp16 operands
  * (22-bit products, fp32 accumulation; operands transposed through LDS, three input rows resident): 3-4x pw_conv3d_wgrad.
- * amax2: pw_absmax2(x, dy)'s 512 partial maxima (per-tensor power-of-two pre-scales; NULL = none).  Deterministic. */
+ * amax_x / amax_y: 256 partial maxima of |x| / |dy| each -- the two halves of pw_absmax2's output, or what pw_bn_apply / pw_bn_bwd_apply
+ * recorded when they wrote the tensor -- for the per-tensor power-of-two pre-scales; both NULL = none.  Deterministic. */
 /* largest magnitudes of two fp32 tensors in one launch, as 2 x 256 partial maxima (no atomics): out (device float[512]) [0..255]
- * over x, [256..511] over y; the maximum of a half is max |.|.  Element counts multiples of 4, 16-byte aligned.  Feeds
- * pw_conv3d_wgrad_h2's amax2, which reduces the partials itself. */
+ * over x, [256..511] over y; the maximum of a half is max |.|.  Element counts multiples of 4 (0 = skip that tensor: zeros), 16-byte
+ * aligned.  Feeds pw_conv3d_wgrad_h2's amax_x / amax_y, which reduces the partials itself. */
 int pw_absmax2(const float* x, int64_t nx, const float* y, int64_t ny, float* out, void* stream);
 size_t pw_conv3d_wgrad_h2_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
-int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const float* amax2, void* workspace, size_t workspace_bytes,
-                       int B, int D, int H, int W, int Cin, int Cout, void* stream);
+int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const float* amax_x, const float* amax_y, void* workspace,
+                       size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout, void* stream);
 /* dX of Conv3d(k=3, stride=2, padding=1): dy (B,Do,Ho,Wo,Cout) with Do = (D-1)/2+1 .., wt float[3][3][3][Cout][Cin] (torch's
  * weight.permute(2,3,4,0,1)), dx (B,D,H,W,Cin), Cin % 4 == 0.  (Stride-1 and 1x1x1 data gradients are forward convolutions
  * with flipped / transposed weights: pw_conv3d_ndhwc.) */
@@ -569,17 +570,22 @@ int pw_conv3d_dgrad_k2s2(const float* dy, const float* wt, float* dx, int B, int
  *   pw_bn_apply       y = (x - mean) rstd gamma + beta (+ residual) (ReLU if relu)
  *   pw_bn_bwd_reduce  dz = dy (masked by y > 0 if relu);  sum_dz[c] = sum dz,  sum_dz_xhat[c] = sum dz x_hat
  *   pw_bn_bwd_apply   dx = gamma rstd (dz - sum_dz / N - x_hat sum_dz_xhat / N);  dres = dz (or NULL)
- * d gamma = sum_dz_xhat, d beta = sum_dz.  workspace: pw_bn_workspace_bytes(C). */
+ * d gamma = sum_dz_xhat, d beta = sum_dz.  workspace: pw_bn_workspace_bytes(C).
+ * Recorded maxima (all four pointers may be NULL): y_amax / dx_amax = float[256] partial maxima of |y| / |dx| in pw_absmax2's format, what
+ * pw_conv3d_wgrad_h2 takes as amax_x / amax_y -- the layer that consumes y (or dx) then needs no absmax pass over it.  The buffer is
+ * cleared by the reduction that precedes the apply on the same stream: hand the SAME pointer to pw_bn_stats (amax_clear) and
+ * pw_bn_apply (y_amax), or to pw_bn_bwd_reduce and pw_bn_bwd_apply. */
 size_t pw_bn_workspace_bytes(int C);
 int pw_bn_stats(const float* x, int64_t N, int C, float eps, void* workspace, size_t workspace_bytes, float* mean, float* var,
-                float* rstd, void* stream);
+                float* rstd, float* amax_clear, void* stream);
 int pw_bn_apply(const float* x, int64_t N, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                const float* residual, int relu, float* y, void* stream);
+                const float* residual, int relu, float* y, float* y_amax, void* stream);
 int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean, const float* rstd,
-                     int relu, void* workspace, size_t workspace_bytes, float* sum_dz, float* sum_dz_xhat, void* stream);
+                     int relu, void* workspace, size_t workspace_bytes, float* sum_dz, float* sum_dz_xhat, float* amax_clear,
+                     void* stream);
 int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean, const float* rstd,
                     const float* gamma, const float* sum_dz, const float* sum_dz_xhat, int relu, float* dx, float* dres,
-                    void* stream);
+                    float* dx_amax, void* stream);
 /* nn.BatchNorm3d's running-statistics update after a training-mode forward, one launch: running_mean = (1 - momentum) running_mean
  * + momentum mean; running_var likewise with the UNBIASED batch variance var * n / max(n - 1, 1); num_batches_tracked (int64, may be
  * NULL) += 1.  n = n_rows_dev[0] (device float: the SyncBN row count over all ranks) when n_rows_dev != NULL, else n_rows. */

@@ -312,6 +312,21 @@ PW_API int pw_conv3d_dgrad_k2s2(const float* dy, const float* wt, float* dx, int
 //   bwd_apply:  dx = gamma rstd (dz - sum_dz / N - x_hat sum_dz_xhat / N);  dres = dz (optional)
 // ------------------------------------------------------------------------------------
 constexpr int BN_BLOCKS = 1024;
+// Largest magnitude of a tensor, recorded by the kernel that writes it: BN_AMAX_PARTS partial maxima (bit patterns of non-negative
+// floats) in the format of pw_absmax2 -- pw_conv3d_wgrad_h2 derives its per-tensor power-of-two pre-scales from them, and the
+// separate 25-50 us absmax pass over both operands of every weight gradient goes away.  One return-less atomic per block.
+constexpr int BN_AMAX_PARTS = 256;
+__device__ __forceinline__ void bn_note_amax(unsigned* __restrict__ amax, const float (&o)[4]) {
+  __shared__ unsigned wm[4];
+  unsigned m = max(max(__float_as_uint(fabsf(o[0])), __float_as_uint(fabsf(o[1]))), max(__float_as_uint(fabsf(o[2])), __float_as_uint(fabsf(o[3]))));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    (void)__hip_atomic_fetch_max(amax + (blockIdx.x & (BN_AMAX_PARTS - 1)), max(max(wm[0], wm[1]), max(wm[2], wm[3])), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // one row of the reduction: 4 channels of a lane.  BWD: dz = dy (masked by y > 0), sums of dz and dz * x_hat; else sums of x and x^2
 template <bool BWD>
@@ -388,8 +403,11 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float4* __restrict__ x,
 // version walked all 512 partials with one thread per channel: 129 us per call, 16 % of a training step)
 __global__ void __launch_bounds__(64) k_bn_finish(const double* __restrict__ partial, int blocks, int C, int64_t N, float eps,
                                                   int fwd, float* __restrict__ out0, float* __restrict__ out1,
-                                                  float* __restrict__ rstd) {
+                                                  float* __restrict__ rstd, unsigned* __restrict__ amax_clear) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  // the BN_AMAX_PARTS partial maxima the apply kernel that follows on this stream raises (bn_note_amax) start from zero
+  if (amax_clear)
+    for (int i = c * 64 + lane; i < BN_AMAX_PARTS; i += gridDim.x * 64) amax_clear[i] = 0u;
   double a0 = 0.0, a1 = 0.0;
   for (int b = lane; b < blocks; b += 64) { a0 += partial[((size_t)b * 2 + 0) * C + c]; a1 += partial[((size_t)b * 2 + 1) * C + c]; }
 #pragma unroll
@@ -433,14 +451,15 @@ static int bn_check(int64_t N, int C, const void* ws, size_t ws_bytes, const cha
 }
 
 PW_API int pw_bn_stats(const float* x, int64_t N, int C, float eps, void* workspace, size_t workspace_bytes, float* mean,
-                       float* var, float* rstd, void* stream) {
+                       float* var, float* rstd, float* amax_clear, void* stream) {
   PW_CHECK_ARG(x && mean && var && rstd && ((uintptr_t)x & 15) == 0, "pw_bn_stats: null or misaligned pointer");
   if (int rc = bn_check(N, C, workspace, workspace_bytes, "pw_bn_stats")) return rc;
   const int blocks = bn_blocks(N, C);
   hipStream_t st = pw_stream(stream);
   hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, st, (const float4*)x, (const float4*)nullptr, (const float4*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, N, C, 0, (double*)workspace);
-  hipLaunchKernelGGL(k_bn_finish, dim3(C), dim3(64), 0, st, (const double*)workspace, blocks, C, N, eps, 1, mean, var, rstd);
+  hipLaunchKernelGGL(k_bn_finish, dim3(C), dim3(64), 0, st, (const double*)workspace, blocks, C, N, eps, 1, mean, var, rstd,
+                     (unsigned*)amax_clear);
   pw_note_kernel("k_bn_reduce<false>");
   PW_CHECK_LAUNCH();
   return PW_OK;
@@ -473,32 +492,36 @@ PW_API int pw_bn_update_running(const float* mean, const float* var, int C, doub
 __global__ void __launch_bounds__(256) k_bn_apply(const float4* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const float4* __restrict__ residual,
-                                                  int64_t n4, int C, int relu, float4* __restrict__ y) {
+                                                  int64_t n4, int C, int relu, float4* __restrict__ y,
+                                                  unsigned* __restrict__ amax) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  const int c = (int)((i * 4) % C);
-  const float4 v = x[i];
-  float o[4] = {v.x, v.y, v.z, v.w};
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+    const int c = (int)((i * 4) % C);
+    const float4 v = x[i];
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (o[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e];
-  if (residual) {
-    const float4 r = residual[i];
-    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-  }
-  if (relu) {
+    for (int e = 0; e < 4; ++e) o[e] = (o[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e];
+    if (residual) {
+      const float4 r = residual[i];
+      o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+    }
+    if (relu) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
+    y[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
-  y[i] = make_float4(o[0], o[1], o[2], o[3]);
+  if (amax) bn_note_amax(amax, o);
 }
 
 PW_API int pw_bn_apply(const float* x, int64_t N, int C, const float* mean, const float* rstd, const float* gamma,
-                       const float* beta, const float* residual, int relu, float* y, void* stream) {
+                       const float* beta, const float* residual, int relu, float* y, float* y_amax, void* stream) {
   PW_CHECK_ARG(x && mean && rstd && gamma && beta && y && N > 0 && C > 0 && C % 4 == 0, "pw_bn_apply: bad arguments");
   PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, "pw_bn_apply: tensors must be 16-byte aligned");
   const int64_t n4 = N * C / 4;
   hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)pw_cdiv(n4, 256)), dim3(256), 0, pw_stream(stream), (const float4*)x, mean, rstd,
-                     gamma, beta, (const float4*)residual, n4, C, relu, (float4*)y);
+                     gamma, beta, (const float4*)residual, n4, C, relu, (float4*)y, (unsigned*)y_amax);
   pw_note_kernel("k_bn_apply");
   PW_CHECK_LAUNCH();
   return PW_OK;
@@ -506,7 +529,7 @@ PW_API int pw_bn_apply(const float* x, int64_t N, int C, const float* mean, cons
 
 PW_API int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean,
                             const float* rstd, int relu, void* workspace, size_t workspace_bytes, float* sum_dz,
-                            float* sum_dz_xhat, void* stream) {
+                            float* sum_dz_xhat, float* amax_clear, void* stream) {
   PW_CHECK_ARG(x && dy && mean && rstd && sum_dz && sum_dz_xhat && (!relu || y) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y) & 15) == 0,
                "pw_bn_bwd_reduce: null or misaligned pointer");
   if (int rc = bn_check(N, C, workspace, workspace_bytes, "pw_bn_bwd_reduce")) return rc;
@@ -515,7 +538,7 @@ PW_API int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, st, (const float4*)x, (const float4*)dy, (const float4*)y, mean, rstd, N, C,
                      relu, (double*)workspace);
   hipLaunchKernelGGL(k_bn_finish, dim3(C), dim3(64), 0, st, (const double*)workspace, blocks, C, N, 0.f, 0, sum_dz, sum_dz_xhat,
-                     (float*)nullptr);
+                     (float*)nullptr, (unsigned*)amax_clear);
   pw_note_kernel("k_bn_reduce<true>");
   PW_CHECK_LAUNCH();
   return PW_OK;
@@ -526,31 +549,34 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4* __restrict__
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ sum_dz, const float* __restrict__ sum_dz_xhat,
                                                       int64_t n4, int C, float inv_n, int relu, float4* __restrict__ dx,
-                                                      float4* __restrict__ dres) {
+                                                      float4* __restrict__ dres, unsigned* __restrict__ amax) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  const int c = (int)((i * 4) % C);
-  const float4 xv = x[i], gv = dy[i];
-  float xe[4] = {xv.x, xv.y, xv.z, xv.w}, dz[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
-  if (relu) {
-    const float4 yv = y[i];
-    const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+    const int c = (int)((i * 4) % C);
+    const float4 xv = x[i], gv = dy[i];
+    float xe[4] = {xv.x, xv.y, xv.z, xv.w}, dz[4] = {gv.x, gv.y, gv.z, gv.w};
+    if (relu) {
+      const float4 yv = y[i];
+      const float ye[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (!(ye[e] > 0.f)) dz[e] = 0.f;
-  }
+      for (int e = 0; e < 4; ++e)
+        if (!(ye[e] > 0.f)) dz[e] = 0.f;
+    }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float xh = (xe[e] - mean[c + e]) * rstd[c + e];
-    o[e] = gamma[c + e] * rstd[c + e] * (dz[e] - sum_dz[c + e] * inv_n - xh * sum_dz_xhat[c + e] * inv_n);
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xe[e] - mean[c + e]) * rstd[c + e];
+      o[e] = gamma[c + e] * rstd[c + e] * (dz[e] - sum_dz[c + e] * inv_n - xh * sum_dz_xhat[c + e] * inv_n);
+    }
+    dx[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (dres) dres[i] = make_float4(dz[0], dz[1], dz[2], dz[3]);
   }
-  dx[i] = make_float4(o[0], o[1], o[2], o[3]);
-  if (dres) dres[i] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+  if (amax) bn_note_amax(amax, o);
 }
 
 PW_API int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean,
                            const float* rstd, const float* gamma, const float* sum_dz, const float* sum_dz_xhat, int relu,
-                           float* dx, float* dres, void* stream) {
+                           float* dx, float* dres, float* dx_amax, void* stream) {
   PW_CHECK_ARG(x && dy && mean && rstd && gamma && sum_dz && sum_dz_xhat && dx && (!relu || y) && N > 0 && C > 0 && C % 4 == 0,
                "pw_bn_bwd_apply: bad arguments");
   PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0,
@@ -558,7 +584,7 @@ PW_API int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int6
   const int64_t n4 = N * C / 4;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)pw_cdiv(n4, 256)), dim3(256), 0, pw_stream(stream), (const float4*)x,
                      (const float4*)dy, (const float4*)y, mean, rstd, gamma, sum_dz, sum_dz_xhat, n4, C, 1.f / (float)N, relu,
-                     (float4*)dx, (float4*)dres);
+                     (float4*)dx, (float4*)dres, (unsigned*)dx_amax);
   pw_note_kernel("k_bn_bwd_apply");
   PW_CHECK_LAUNCH();
   return PW_OK;

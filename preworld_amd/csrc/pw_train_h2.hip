@@ -44,7 +44,8 @@ struct WgH2Args {
   const float* x;
   const float* dy;
   float* partial;            // [chunk][27][co_blocks][ci_blocks][32 * 32]
-  const float* amax2;        // pw_absmax2's partial maxima [2][WG_AMAX_PARTS] (x, dy) or null
+  const float* amax_x;       // WG_AMAX_PARTS partial maxima of |x| / |dy| (pw_absmax2, or recorded by the kernel that wrote the
+  const float* amax_y;       // tensor: pw_bn_apply / pw_bn_bwd_apply), or null = no pre-scale
   int B, D, H, W, Cin, Cout;
   int co_t, ci_t;            // 32-channel tiles per block along co / ci (1 or 2)
   int cog, cig;              // tile groups along co / ci
@@ -97,10 +98,11 @@ __global__ void __launch_bounds__(WG_THREADS) k_conv3d_wgrad_h2(WgH2Args a) {
   const int oh0 = split * a.rows_per_split, oh1 = min(a.H, oh0 + a.rows_per_split);
   // exponents e such that amax * 2^-e lies in [2^12, 2^13) (0 for zero / non-finite / absent): the block reduces pw_absmax2's partials
   int ex = 0, ey = 0;
-  if (a.amax2) {
+  if (a.amax_x && a.amax_y) {
     __shared__ unsigned amx[2][WG_THREADS / 64];
-    const unsigned* part = reinterpret_cast<const unsigned*>(a.amax2);
-    unsigned m0 = threadIdx.x < WG_AMAX_PARTS ? part[threadIdx.x] : 0u, m1 = threadIdx.x < WG_AMAX_PARTS ? part[WG_AMAX_PARTS + threadIdx.x] : 0u;
+    const unsigned* px = reinterpret_cast<const unsigned*>(a.amax_x);
+    const unsigned* py = reinterpret_cast<const unsigned*>(a.amax_y);
+    unsigned m0 = threadIdx.x < WG_AMAX_PARTS ? px[threadIdx.x] : 0u, m1 = threadIdx.x < WG_AMAX_PARTS ? py[threadIdx.x] : 0u;
     m0 = wave_umax(m0); m1 = wave_umax(m1);
     if (lane == 0) { amx[0][wave] = m0; amx[1][wave] = m1; }
     __syncthreads();
@@ -379,7 +381,7 @@ PW_API size_t pw_conv3d_wgrad_h2_workspace_bytes(int B, int D, int H, int W, int
   return (size_t)p.n_chunks * 27 * (Cout / 32) * (Cin / 32) * 1024 * 4;
 }
 
-PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const float* amax2, void* workspace,
+PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const float* amax_x, const float* amax_y, void* workspace,
                               size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
   PW_CHECK_ARG(x && dy && dw && workspace, "pw_conv3d_wgrad_h2: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0,
@@ -388,7 +390,7 @@ PW_API int pw_conv3d_wgrad_h2(const float* x, const float* dy, float* dw, const 
   PW_CHECK_ARG(workspace_bytes >= pw_conv3d_wgrad_h2_workspace_bytes(B, D, H, W, Cin, Cout), "pw_conv3d_wgrad_h2: workspace too small");
   const WgPlan p = wg_plan(B, D, H, W, Cin, Cout);
   WgH2Args a;
-  a.x = x; a.dy = dy; a.partial = (float*)workspace; a.amax2 = amax2;
+  a.x = x; a.dy = dy; a.partial = (float*)workspace; a.amax_x = amax_x; a.amax_y = amax_y;
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.co_t = p.co_t; a.ci_t = p.ci_t; a.cog = p.cog; a.cig = p.cig;
   a.n_strips = p.n_strips; a.oh_splits = p.oh_splits; a.rows_per_split = p.rows_per_split;
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(256) k_absmax2(const float4* __restrict__ x, i
 }
 
 PW_API int pw_absmax2(const float* x, int64_t nx, const float* y, int64_t ny, float* out, void* stream) {
-  PW_CHECK_ARG(x && y && out && nx > 0 && ny > 0 && nx % 4 == 0 && ny % 4 == 0, "pw_absmax2: bad arguments (element counts must be multiples of 4)");
+  PW_CHECK_ARG(x && y && out && nx >= 0 && ny >= 0 && nx % 4 == 0 && ny % 4 == 0, "pw_absmax2: bad arguments (element counts must be multiples of 4)");
   PW_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "pw_absmax2: x / y must be 16-byte aligned");
   hipLaunchKernelGGL(k_absmax2, dim3(WG_AMAX_PARTS, 2), dim3(256), 0, pw_stream(stream), (const float4*)x, nx / 4, (const float4*)y, ny / 4,
                      (unsigned*)out);

@@ -117,19 +117,31 @@ def conv3d_dgrad(dy, w, x_shape, stride=1, accumulate=None):
     return dx
 
 
-def conv3d_wgrad(x, dy, w_shape, stride=1):
-    """d loss / d w of conv3d_raw, torch layout (Cout,Cin,k,k,k)."""
+def _amax_of(t):
+    """the 256 partial maxima a BatchNorm kernel recorded when it wrote this tensor (BatchNormCL: y forward, dx backward), or None.
+    They ride on the tensor object: autograd hands the same object to the consuming Function; a tensor that was summed, padded or
+    copied on the way simply arrives without them and gets an absmax pass."""
+    return getattr(t, '_pw_amax', None)
+
+
+def conv3d_wgrad(x, dy, w_shape, stride=1, x_amax=None):
+    """d loss / d w of conv3d_raw, torch layout (Cout,Cin,k,k,k).  x_amax: recorded maxima of x (see _amax_of) when the caller kept them."""
     Cout, Cin, k = w_shape[0], w_shape[1], w_shape[2]
     B, D, H, W, _ = x.shape
     if k == 3 and stride == 1 and Cin % 32 == 0 and Cout % 32 == 0 and _WGRAD != 'f32':
         # split-fp16 operands on the fp16 matrix cores (pw_conv3d_wgrad_h2): 22-bit products, fp32 accumulation; the two maxima
         # (device side, no sync) give the per-tensor power-of-two pre-scales
-        amax2 = torch.empty(512, device=x.device, dtype=_f32)
-        _lib.call('pw_absmax2', ops._p(_cl(x, 'x')), x.numel(), ops._p(_cl(dy, 'dy')), dy.numel(), ops._p(amax2), ops._stream())
+        ax, ay = _amax_of(x) if x_amax is None else x_amax, _amax_of(dy)
+        if ax is None or ay is None:
+            # one pass over whichever operand did not come with its maximum recorded by the kernel that wrote it
+            amax2 = torch.empty(512, device=x.device, dtype=_f32)
+            _lib.call('pw_absmax2', ops._p(_cl(x, 'x')), x.numel() if ax is None else 0, ops._p(_cl(dy, 'dy')), dy.numel() if ay is None else 0,
+                      ops._p(amax2), ops._stream())
+            ax, ay = amax2[:256] if ax is None else ax, amax2[256:] if ay is None else ay
         nbytes = _lib.call_size('pw_conv3d_wgrad_h2_workspace_bytes', B, D, H, W, Cin, Cout)
         ws = ops._workspace(nbytes, x.device)
         dw = torch.empty(tuple(w_shape), device=x.device, dtype=_f32)
-        _lib.call('pw_conv3d_wgrad_h2', ops._p(_cl(x, 'x')), ops._p(_cl(dy, 'dy')), ops._p(dw), ops._p(amax2), ops._p(ws), nbytes,
+        _lib.call('pw_conv3d_wgrad_h2', ops._p(_cl(x, 'x')), ops._p(_cl(dy, 'dy')), ops._p(dw), ops._p(ax), ops._p(ay), ops._p(ws), nbytes,
                   B, D, H, W, Cin, Cout, ops._stream())
         return dw
     nbytes = _lib.call_size('pw_conv3d_wgrad_workspace_bytes', B, D, H, W, Cin, Cout, k, stride)
@@ -140,28 +152,32 @@ def conv3d_wgrad(x, dy, w_shape, stride=1):
     return dw
 
 
-def bn_stats(x, eps):
+def bn_stats(x, eps, amax=None):
+    """amax: float32[256] buffer that bn_apply(..., amax=) will record max |y| into (cleared here)"""
     C = x.shape[-1]
     N = x.numel() // C
     nbytes = _lib.call_size('pw_bn_workspace_bytes', C)
     ws = ops._workspace(nbytes, x.device)
     mean, var, rstd = (torch.empty(C, device=x.device, dtype=_f32) for _ in range(3))
     _lib.call('pw_bn_stats', ops._p(_cl(x, 'x')), N, C, float(eps), ops._p(ws), nbytes, ops._p(mean), ops._p(var), ops._p(rstd),
-              ops._stream())
+              ops._p(amax), ops._stream())
     return mean, var, rstd
 
 
-def bn_apply(x, mean, rstd, gamma, beta, residual=None, relu=False):
+def bn_apply(x, mean, rstd, gamma, beta, residual=None, relu=False, amax=None):
     C = x.shape[-1]
     y = torch.empty_like(x)
     _lib.call('pw_bn_apply', ops._p(_cl(x, 'x')), x.numel() // C, C, ops._p(mean), ops._p(rstd), ops._p(_cl(gamma, 'gamma')),
               ops._p(_cl(beta, 'beta')), ops._p(_cl(residual, 'residual') if residual is not None else None), int(relu), ops._p(y),
-              ops._stream())
+              ops._p(amax), ops._stream())
+    if amax is not None:
+        y._pw_amax = amax
     return y
 
 
-def bn_backward(x, dy, y, mean, rstd, gamma, relu, want_dres):
-    """-> (dx, dgamma, dbeta, dres or None)"""
+def bn_backward(x, dy, y, mean, rstd, gamma, relu, want_dres, record_amax=False):
+    """-> (dx, dgamma, dbeta, dres or None); record_amax: dx carries its recorded maxima (_amax_of)"""
+    amax = torch.empty(256, device=x.device, dtype=_f32) if record_amax else None
     C = x.shape[-1]
     N = x.numel() // C
     nbytes = _lib.call_size('pw_bn_workspace_bytes', C)
@@ -169,11 +185,13 @@ def bn_backward(x, dy, y, mean, rstd, gamma, relu, want_dres):
     s0, s1 = torch.empty(C, device=x.device, dtype=_f32), torch.empty(C, device=x.device, dtype=_f32)
     yp = ops._p(_cl(y, 'y')) if relu else None
     _lib.call('pw_bn_bwd_reduce', ops._p(_cl(x, 'x')), ops._p(_cl(dy, 'dy')), yp, N, C, ops._p(mean), ops._p(rstd), int(relu),
-              ops._p(ws), nbytes, ops._p(s0), ops._p(s1), ops._stream())
+              ops._p(ws), nbytes, ops._p(s0), ops._p(s1), ops._p(amax), ops._stream())
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     _lib.call('pw_bn_bwd_apply', ops._p(x), ops._p(dy), yp, N, C, ops._p(mean), ops._p(rstd), ops._p(_cl(gamma, 'gamma')),
-              ops._p(s0), ops._p(s1), int(relu), ops._p(dx), ops._p(dres), ops._stream())
+              ops._p(s0), ops._p(s1), int(relu), ops._p(dx), ops._p(dres), ops._p(amax), ops._stream())
+    if amax is not None:
+        dx._pw_amax = amax
     return dx, s1, s0, dres
 
 
@@ -184,7 +202,7 @@ class Conv3dCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride):
         ctx.save_for_backward(x, w)
-        ctx.stride = stride
+        ctx.stride, ctx.x_amax = stride, _amax_of(x)
         return conv3d_raw(x, w, stride)
 
     @staticmethod
@@ -199,10 +217,10 @@ class Conv3dCL(torch.autograd.Function):
             dy = torch.nn.functional.pad(dy, (0, pad))
             wp = torch.cat([w.detach(), w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
             dx = conv3d_dgrad(dy, wp, x.shape, 1) if ctx.needs_input_grad[0] else None
-            dw = conv3d_wgrad(x, dy, wp.shape, 1)[:w.shape[0]] if ctx.needs_input_grad[1] else None
+            dw = conv3d_wgrad(x, dy, wp.shape, 1, ctx.x_amax)[:w.shape[0]] if ctx.needs_input_grad[1] else None
             return dx, dw, None
         dx = conv3d_dgrad(dy, w, x.shape, ctx.stride) if ctx.needs_input_grad[0] else None
-        dw = conv3d_wgrad(x, dy, w.shape, ctx.stride) if ctx.needs_input_grad[1] else None
+        dw = conv3d_wgrad(x, dy, w.shape, ctx.stride, ctx.x_amax) if ctx.needs_input_grad[1] else None
         return dx, dw, None
 
 
@@ -233,7 +251,8 @@ class BatchNormCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, eps, relu, sync=False):
         ctx.set_materialize_grads(False)          # the statistics outputs never carry gradients: no zero tensors made for them
-        mean, var, rstd = bn_stats(x, eps)
+        amax = torch.empty(256, device=x.device, dtype=_f32)
+        mean, var, rstd = bn_stats(x, eps, amax)
         n_local = float(x.numel() // x.shape[-1])
         n_total = n_local
         if _sync_world(sync) > 1:
@@ -247,7 +266,7 @@ class BatchNormCL(torch.autograd.Function):
             mean, var = m64.float(), v64.float()
             rstd = torch.rsqrt(v64 + eps).float()
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        y = bn_apply(x, mean, rstd, g, b, residual, relu)
+        y = bn_apply(x, mean, rstd, g, b, residual, relu, amax)
         ctx.save_for_backward(x, y, mean, rstd, g)
         ctx.relu, ctx.has_res, ctx.sync, ctx.n_ratio = bool(relu), residual is not None, bool(sync), n_local / n_total
         ctx.mark_non_differentiable(mean, var)
@@ -260,7 +279,7 @@ class BatchNormCL(torch.autograd.Function):
             return None, None, None, None, None, None, None
         if _sync_world(ctx.sync) > 1:
             return BatchNormCL._backward_sync(ctx, x, dy.contiguous(), y, mean, rstd, g)
-        dx, dgamma, dbeta, dres = bn_backward(x, dy.contiguous(), y, mean, rstd, g, ctx.relu, ctx.has_res and ctx.needs_input_grad[3])
+        dx, dgamma, dbeta, dres = bn_backward(x, dy.contiguous(), y, mean, rstd, g, ctx.relu, ctx.has_res and ctx.needs_input_grad[3], True)
         return dx, dgamma, dbeta, dres, None, None, None
 
     @staticmethod
@@ -274,14 +293,14 @@ class BatchNormCL(torch.autograd.Function):
         s0, s1 = torch.empty(C, device=x.device, dtype=_f32), torch.empty(C, device=x.device, dtype=_f32)
         yp = ops._p(_cl(y, 'y')) if ctx.relu else None
         _lib.call('pw_bn_bwd_reduce', ops._p(_cl(x, 'x')), ops._p(_cl(dy, 'dy')), yp, N, C, ops._p(mean), ops._p(rstd), int(ctx.relu),
-                  ops._p(ws), nbytes, ops._p(s0), ops._p(s1), ops._stream())
+                  ops._p(ws), nbytes, ops._p(s0), ops._p(s1), None, ops._stream())
         tot = _all_reduce_sum(torch.cat([s0, s1]).double()) * ctx.n_ratio
         g0, g1 = tot[:C].float().contiguous(), tot[C:].float().contiguous()
         dx = torch.empty_like(x)
         want_dres = ctx.has_res and ctx.needs_input_grad[3]
         dres = torch.empty_like(x) if want_dres else None
         _lib.call('pw_bn_bwd_apply', ops._p(x), ops._p(dy), yp, N, C, ops._p(mean), ops._p(rstd), ops._p(_cl(g, 'gamma')),
-                  ops._p(g0), ops._p(g1), int(ctx.relu), ops._p(dx), ops._p(dres), ops._stream())
+                  ops._p(g0), ops._p(g1), int(ctx.relu), ops._p(dx), ops._p(dres), None, ops._stream())
         return dx, s1, s0, dres, None, None, None
 
 
@@ -314,7 +333,7 @@ class ConvPairCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, w2, stride):
         ctx.save_for_backward(x, w1, w2)
-        ctx.stride = stride
+        ctx.stride, ctx.x_amax = stride, _amax_of(x)
         return _conv_fwd_pair(_cl(x, 'x'), w1.detach(), w2.detach(), stride)
 
     @staticmethod
@@ -327,8 +346,13 @@ class ConvPairCL(torch.autograd.Function):
                 dx = conv3d_dgrad(dy2, w2, x.shape, 1, accumulate=conv3d_dgrad(dy1, w1, x.shape, 1))
             else:
                 dx = conv3d_dgrad(torch.cat([dy1, dy2], -1), torch.cat([w1.detach(), w2.detach()], 0), x.shape, ctx.stride)
-        dw1 = conv3d_wgrad(x, dy1, w1.shape, ctx.stride) if ctx.needs_input_grad[1] else None
-        dw2 = conv3d_wgrad(x, dy2, w2.shape, ctx.stride) if ctx.needs_input_grad[2] else None
+        xa = ctx.x_amax
+        if xa is None and ctx.stride == 1 and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            xa = torch.empty(512, device=x.device, dtype=_f32)           # one pass over x serves both weight gradients
+            _lib.call('pw_absmax2', ops._p(x), x.numel(), ops._p(x), 0, ops._p(xa), ops._stream())
+            xa = xa[:256]
+        dw1 = conv3d_wgrad(x, dy1, w1.shape, ctx.stride, xa) if ctx.needs_input_grad[1] else None
+        dw2 = conv3d_wgrad(x, dy2, w2.shape, ctx.stride, xa) if ctx.needs_input_grad[2] else None
         return dx, dw1, dw2, None
 
 

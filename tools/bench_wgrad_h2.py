@@ -18,7 +18,7 @@ for (B, D, H, W), cin, cout in (((1, 16, 200, 200), 32, 32), ((1, 16, 200, 200),
     dw = torch.empty(cout, cin, 3, 3, 3, device=dev)
     nbytes = _lib.call_size('pw_conv3d_wgrad_h2_workspace_bytes', B, D, H, W, cin, cout)
     ws = ops._workspace(nbytes, dev)
-    fn = lambda: _lib.call('pw_conv3d_wgrad_h2', ops._p(x), ops._p(dy), ops._p(dw), None, ops._p(ws), nbytes, B, D, H, W, cin, cout,
+    fn = lambda: _lib.call('pw_conv3d_wgrad_h2', ops._p(x), ops._p(dy), ops._p(dw), None, None, ops._p(ws), nbytes, B, D, H, W, cin, cout,
                            ops._stream())
     t = timeit(fn)
     gf = 2.0 * B * D * H * W * 27 * cin * cout / 1e9
