@@ -423,7 +423,7 @@ def c5_result(args, quick=False):
 
 
 def extra_figures(args, dev):
-    """compact C2 and C5 figures for the driver's record, measured AFTER the headline's timed region (BASELINE.json configs[1], [4]):
+    """compact C2, C5 and training-step figures for the driver's record, measured AFTER the headline's timed region (BASELINE.json configs[1], [4]):
     C2 = single frame, PreWorld detector, 1 state (captured step, two in flight, rotating inputs like the headline); C5 = the render
     head forward / forward + backward at the literal 3 072 x 96 shape and at the reference's 38 400 x 417, and the pre-train step."""
     ex = {}
@@ -461,8 +461,54 @@ def extra_figures(args, dev):
                         roofline=r['roofline'])
     except Exception as e:                                                # noqa: BLE001
         ex['c5'] = {'error': repr(e)[:300]}
+    try:
+        ex['train'] = finetune_step(dev)
+    except Exception as e:                                                # noqa: BLE001
+        ex['train'] = {'error': repr(e)[:300]}
     torch.cuda.empty_cache()
     return ex
+
+
+def finetune_step(dev, n=6):
+    """The voxel side of PreWorld.forward_train for the fine-tune configs at the C3 shape (preworld.py:229-309; the composition of
+    tools/bench_train.py): pooling of the key frame under autograd and of the adjacent frame without, pre_process, CustomResNet3D,
+    LSSFPN3D, final_conv, OccHead with batch-statistics BatchNorm, loss_voxel (CE + sem_scal + geo_scal + focal + Lovasz), backward
+    through all of it on the HIP training kernels (preworld_amd/train.py).  Image side excluded."""
+    from preworld_amd.modules import to_channels_last_3d
+    cfg = harness.model_cfg(S.GRID_CONFIG_FULL, detector='PreWorld')
+    cfg.update(if_render=False, if_post_finetune=True, use_lss_depth_loss=False, weight_voxel_ce=1.0, weight_voxel_sem_scal=1.0,
+               weight_voxel_geo_scal=1.0, weight_voxel_lovasz=1.0)
+    net = harness.build_model(cfg, S.synth_state_dict(0), dev).train()
+    frames = harness.lifted_frames(0, 6, dev, n_frames=2)
+    sem = torch.randint(0, 18, (1, 200, 200, 16), device=dev)
+    vt = net.img_view_transformer
+
+    def lift(fr, grad):
+        d, f = fr['depth'].detach().requires_grad_(grad), fr['tran_feat'].detach().requires_grad_(grad)
+        B, N = fr['sensor2keyego'].shape[:2]
+        inp = [d.new_empty(B, N, 1, d.shape[-2], d.shape[-1]), fr['sensor2keyego'], None, fr['intrin'], fr['post_rot'], fr['post_tran'],
+               fr['bda']]
+        return net.pre_process_net.forward_cl(to_channels_last_3d(vt.view_transform(inp, d, f)[0]).float())[0]
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        key = lift(frames[0], True)
+        with torch.no_grad():
+            adj = lift(frames[1], False)
+        losses = net.forward_train_from_feats(net.bev_encoder_cl(torch.cat([adj, key], -1)), voxel_semantics=sem)
+        sum(losses.values()).backward()
+        return losses
+    for _ in range(2):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return dict(workload='voxel side of PreWorld.forward_train, fine-tune config, C3 shape (6 cams, key + adjacent, 200x200x16), forward + '
+                         'backward, eager (no graph capture)', ms_per_step=round(ms, 2), steps=n,
+                losses={k: round(float(v), 4) for k, v in out.items() if 'sup' not in k})
 
 
 def pretrain_step_ms(dev, args):
