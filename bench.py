@@ -540,6 +540,8 @@ def pretrain_step_ms(dev, args):
             losses = net.forward_train_from_feats(f, voxel_semantics=sem, rays=rays_t.clone(), bda=bda)
             sum(losses.values()).backward()
             return losses
+        if args == 'step':                                            # tools/diag_train_ops.py: just the closure
+            return step
         for _ in range(2):
             losses = step()
         torch.cuda.synchronize()

@@ -511,6 +511,18 @@ int pw_focal_loss_grad(const float* logits, const uint8_t* target, const uint8_t
                        int64_t sc, int64_t sx, int64_t sy, int64_t sz, int ignore_index, float gamma,
                        float alpha, const double* stats, float loss_weight, const float* grad_loss,
                        float* grad_logits, void* stream);
+/* Distortion loss of the render head (mmdet3d/models/nerf/nerf_head.py:316-327 -> flatten_eff_distloss of torch_efficient_distloss,
+ * third-party; mip-NeRF 360 eq. 15 as DVGOv2 evaluates it) on the dense per-sample weights of pw_render_rays:
+ *   weights (n_rays, n_samples), 0 where a sample was culled; s (n_samples) the normalised sample positions;
+ *   loss[0] = sum_rays [ (1/3) sum_i w_i^2 / n_kept + 2 sum_i w_i (s_i sum_{j<i} w_j - sum_{j<i} w_j s_j) ] / n_rays_used
+ *   (n_kept = samples with w > 0 in the batch, at least 1; n_rays_used = 1 + index of the last ray that kept one, at least 1);
+ *   scal[0..1] = the two coefficients pw_distortion_loss_backward needs; grad_weights = grad_loss[0] * d loss / d weights.
+ * One pass over the weights each way (a wave per ray, wave scans with a carry); block partials folded in double: deterministic. */
+size_t pw_distortion_workspace_bytes(int n_rays);
+int pw_distortion_loss(const float* weights, const float* s, int n_rays, int n_samples, void* workspace, size_t workspace_bytes,
+                       float* loss, float* scal, void* stream);
+int pw_distortion_loss_backward(const float* weights, const float* s, int n_rays, int n_samples, const float* scal,
+                                const float* grad_loss, float* grad_weights, void* stream);
 size_t pw_lovasz_workspace_bytes(int64_t n_vox, int n_cls, int ignore_index);
 int pw_lovasz_softmax(const float* probas, const uint8_t* target, const uint8_t* cam_mask, int B, int n_cls,
                       int X, int Y, int Z, int64_t sb, int64_t sc, int64_t sx, int64_t sy, int64_t sz,
@@ -591,6 +603,15 @@ int pw_bn_bwd_apply(const float* x, const float* dy, const float* y, int64_t N, 
  * NULL) += 1.  n = n_rows_dev[0] (device float: the SyncBN row count over all ranks) when n_rows_dev != NULL, else n_rows. */
 int pw_bn_update_running(const float* mean, const float* var, int C, double n_rows, const float* n_rows_dev, float momentum,
                          float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream);
+
+/* y = act(x + bias[c]) on channels-last rows x (N, C), C <= 256, and its backward in one pass each: dx = dy act'(x + bias),
+ * dbias[c] = sum over rows of dx (double accumulation, deterministic; NULL = not wanted).  act: 0 none, 1 ReLU, 2 Softplus (beta 1,
+ * threshold 20: torch.nn.Softplus()).  bias may be NULL (zeros).  Training side of the attribute MLPs' Linear -> Softplus
+ * (detectors/preworld.py:101-110), final_conv's bias + ReLU (:72-79) and the trajectory branch's biased convs. */
+size_t pw_bias_act_workspace_bytes(int C);
+int pw_bias_act(const float* x, const float* bias, int64_t N, int C, int act, float* y, void* stream);
+int pw_bias_act_backward(const float* x, const float* bias, const float* dy, int64_t N, int C, int act, float* dx, float* dbias,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Trilinear up-sampling with align_corners=True (torch's upsample_trilinear3d index / weight rule) of a channels-last map
  * lo (B,Dl,Hl,Wl,C) to hi (B,Dh,Hh,Wh,C), C % 4 == 0: hi = up(lo) or hi += up(lo) (accumulate != 0); and its adjoint

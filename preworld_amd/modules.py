@@ -932,16 +932,7 @@ class NerfHead(nn.Module):
         if self.weight_distortion > 0 and 'weights' in out:
             w = out['weights']                                   # (R,S) dense, 0 where culled
             t = self.t_table(w.device)
-            s = (1 - 1 / (1 + t))[None]
-            kept = w > 0
-            n_max = kept.sum().clamp_min(1)
-            rays_with = kept.any(1).nonzero()
-            n_rays = (rays_with.max() + 1) if rays_with.numel() else torch.ones((), device=w.device)
-            wm = w * s
-            w_pre = torch.cumsum(w, 1) - w
-            wm_pre = torch.cumsum(wm, 1) - wm
-            loss = ((1 / 3) * (1.0 / n_max) * w.pow(2)).sum() + (2 * w * (s * w_pre - wm_pre)).sum()
-            losses['loss_sdf_distortion' + suffix] = self.weight_distortion * loss / n_rays
+            losses['loss_sdf_distortion' + suffix] = self.weight_distortion * ops.distortion_loss(w, 1 - 1 / (1 + t))
         return losses
 
     def forward(self, density, semantic, color, if_pretrain=False, if_temporal=False,

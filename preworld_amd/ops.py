@@ -1294,6 +1294,40 @@ class RenderRays(torch.autograd.Function):
         return gg, None, None, None, None
 
 
+class _Distortion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, s):
+        R, S_ = w.shape
+        nbytes = _lib.call_size('pw_distortion_workspace_bytes', R)
+        ws = _workspace(nbytes, w.device)
+        out = torch.empty(3, device=w.device, dtype=_f32)
+        _lib.call('pw_distortion_loss', _p(w), _p(s), R, S_, _p(ws), nbytes, _p(out[0:1]), _p(out[1:3]), _stream())
+        ctx.save_for_backward(w, s, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        w, s, out = ctx.saved_tensors
+        gw = torch.empty_like(w)
+        _lib.call('pw_distortion_loss_backward', _p(w), _p(s), w.shape[0], w.shape[1], _p(out[1:3]), _p(g.reshape(1).float().contiguous()),
+                  _p(gw), _stream())
+        return gw, None
+
+
+def distortion_loss(weights, s):
+    """flatten_eff_distloss (torch_efficient_distloss, called at nerf_head.py:316-327) on the dense (R, S) render weights (0 where a
+    sample was culled) and the normalised sample positions s (S,): sum over rays of (1/3) sum w_i^2 / n_kept + 2 sum_i w_i (s_i
+    sum_{j<i} w_j - sum_{j<i} w_j s_j), divided by 1 + the index of the last ray that kept a sample (pw_distortion_loss); autograd
+    through pw_distortion_loss_backward."""
+    if weights.dim() != 2 or s.numel() != weights.shape[1]:
+        raise _lib.PreworldHipError('distortion_loss: weights (R, S), s (S,)')
+    return _Distortion.apply(_chk_t(weights), _chk_t(s.reshape(-1)))
+
+
+def _chk_t(t):
+    return t if (t.dtype == _f32 and t.is_contiguous()) else t.float().contiguous()
+
+
 def confusion_hist(pred, gt, mask, n_cl, hist):
     """hist (n_cl,n_cl) int64 += bincount(n_cl*gt + pred) over (masked) voxels -- occ_metrics.py:82-105."""
     p = pred.contiguous().view(-1)

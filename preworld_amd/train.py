@@ -434,23 +434,35 @@ class UpsampleSumCL(torch.autograd.Function):
                 upsample_adjoint(dy, sb) if ctx.needs_input_grad[2] else None)
 
 
-class BiasReLUCL(torch.autograd.Function):
-    """relu(x + bias) on channels-last rows, through the BatchNorm kernels with mean 0 / rstd 1 / gamma 1"""
+_ACT = {None: 0, 'none': 0, 'relu': 1, 'softplus': 2}
+
+
+class BiasActCL(torch.autograd.Function):
+    """act(x + bias) on channels-last rows, one kernel each way (pw_bias_act / pw_bias_act_backward: d x and the column sums for
+    d bias from the same pass).  act: None | 'relu' | 'softplus' (torch.nn.Softplus defaults)."""
 
     @staticmethod
-    def forward(ctx, x, bias, relu):
+    def forward(ctx, x, bias, act):
         C = x.shape[-1]
-        zero, one = torch.zeros(C, device=x.device, dtype=_f32), torch.ones(C, device=x.device, dtype=_f32)
-        y = bn_apply(x, zero, one, one, bias.detach().float().contiguous(), None, relu)
-        ctx.save_for_backward(x, y, zero, one)
-        ctx.relu = bool(relu)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        _lib.call('pw_bias_act', ops._p(_cl(x, 'x')), ops._p(b), x.numel() // C, C, _ACT[act], ops._p(y), ops._stream())
+        ctx.save_for_backward(x, b if b is not None else torch.empty(0))
+        ctx.act, ctx.has_bias = _ACT[act], b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, zero, one = ctx.saved_tensors
-        _, _, dbias, dz = bn_backward(x, dy.contiguous(), y, zero, one, one, ctx.relu, True)
-        return dz, dbias, None
+        x, b = ctx.saved_tensors
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        want_db = ctx.has_bias and ctx.needs_input_grad[1]
+        db = torch.empty(C, device=x.device, dtype=_f32) if want_db else None
+        nbytes = _lib.call_size('pw_bias_act_workspace_bytes', C)
+        ws = ops._workspace(nbytes, x.device)
+        _lib.call('pw_bias_act_backward', ops._p(x), ops._p(b) if ctx.has_bias else None, ops._p(_cl(dy.contiguous(), 'dy')), x.numel() // C, C,
+                  ctx.act, ops._p(dx), ops._p(db), ops._p(ws), nbytes, ops._stream())
+        return dx, db, None
 
 
 def fpn_forward(neck, feats):
@@ -475,8 +487,7 @@ def conv_bias_act_forward(m, x):
     y = Conv3dCL.apply(x.contiguous(), m.conv.weight, m.stride)
     if m.conv.bias is None and not m.with_activation:
         return y
-    bias = m.conv.bias if m.conv.bias is not None else torch.zeros(y.shape[-1], device=y.device, dtype=_f32)
-    return BiasReLUCL.apply(y, bias, m.with_activation)
+    return BiasActCL.apply(y, m.conv.bias, 'relu' if m.with_activation else None)
 
 
 def _bn_cl(bn, x, relu):
@@ -523,22 +534,39 @@ def _conv1x1_cl(x, conv):
     return torch.matmul(x, w.t())
 
 
-def linear_cl(x_cl, lin):
-    """nn.Linear applied per voxel to a channels-last (B,Z,Y,X,K) tensor as a 1x1x1 convolution on the MFMA conv kernels (forward,
-    data and weight gradients: Conv3dCL), output columns zero-padded to a multiple of 32 and sliced back.  For K % 32 == 0 (the
-    attribute MLPs 32 -> 64 -> {2, 17, 3} of preworld.py:101-110, which the library GEMM ran at 1.0-1.5 ms per call on 640 000
-    voxels); anything else goes to F.linear."""
+def linear_cl(x_cl, lin, act=None):
+    """act(nn.Linear(x)) per voxel of a channels-last (B,Z,Y,X,K) tensor: the product as a 1x1x1 convolution on the MFMA conv kernels
+    (forward, data and weight gradients: Conv3dCL; narrow outputs are padded to 32 columns inside its backward), bias and activation
+    in one more pass (BiasActCL).  For K % 32 == 0 (the attribute MLPs 32 -> 64 -> {2, 17, 3} of preworld.py:101-110, which the
+    library GEMM ran at 1.0-1.5 ms per call on 640 000 voxels); anything else goes to F.linear."""
     N, K = lin.weight.shape
     if x_cl.dim() != 5 or K % 32 or not x_cl.is_cuda:
-        return torch.nn.functional.linear(x_cl, lin.weight, lin.bias)
-    y = Conv3dCL.apply(x_cl.contiguous(), lin.weight.reshape(N, K, 1, 1, 1), 1)      # narrow N: padded inside Conv3dCL.backward
-    return y + lin.bias if lin.bias is not None else y
+        y = torch.nn.functional.linear(x_cl, lin.weight, lin.bias)
+        return torch.nn.functional.softplus(y) if act == 'softplus' else (torch.relu(y) if act == 'relu' else y)
+    y = Conv3dCL.apply(x_cl.contiguous(), lin.weight.reshape(N, K, 1, 1, 1), 1)
+    return BiasActCL.apply(y, lin.bias, act) if (lin.bias is not None or act is not None) else y
+
+
+def _plain_act(m):
+    """'softplus' / 'relu' for an activation module BiasActCL reproduces exactly, else None"""
+    if isinstance(m, torch.nn.Softplus) and m.beta == 1 and m.threshold == 20:
+        return 'softplus'
+    return 'relu' if isinstance(m, torch.nn.ReLU) else None
 
 
 def mlp_cl(seq, x_cl):
-    """an nn.Sequential of Linear / activation modules per voxel of a channels-last tensor (Linear layers through linear_cl)"""
-    for m in seq:
-        x_cl = linear_cl(x_cl, m) if isinstance(m, torch.nn.Linear) else m(x_cl)
+    """an nn.Sequential of Linear / activation modules per voxel of a channels-last tensor: every Linear through linear_cl, a Softplus /
+    ReLU that follows one is fused into its bias pass"""
+    mods, i = list(seq), 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Linear):
+            act = _plain_act(mods[i + 1]) if i + 1 < len(mods) else None
+            x_cl = linear_cl(x_cl, m, act)
+            i += 2 if act is not None else 1
+        else:
+            x_cl = m(x_cl)
+            i += 1
     return x_cl
 
 
@@ -570,7 +598,7 @@ def downscale_forward(mod, v_cl):
     x = v_cl.contiguous()
     for conv in (mod.downscale1, mod.downscale2, mod.downscale3):
         y = Conv3dCL.apply(x, conv.weight.permute(0, 1, 4, 3, 2).contiguous(), 2)
-        x = BiasReLUCL.apply(y, conv.bias, False)
+        x = BiasActCL.apply(y, conv.bias, None)
     return x.mean(dim=(1, 2, 3))
 
 

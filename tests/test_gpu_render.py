@@ -194,6 +194,36 @@ def test_nerf_head_losses_vs_oracle():
         assert abs(float(losses[k]) - ol[k]) <= 2e-3 * abs(ol[k]) + 1e-6, (k, float(losses[k]), ol[k])
 
 
+@pytest.mark.parametrize('R,S_', [(37, 417), (5, 64), (130, 96), (4, 1)])
+def test_distortion_loss_and_gradient_vs_torch_float64(R, S_):
+    """ops.distortion_loss (pw_distortion_loss / _backward: one pass each way) against the plain torch composition of
+    flatten_eff_distloss' formula in float64 under autograd: culled samples (w = 0), empty trailing rays (they do not count in
+    n_rays), ragged sample counts (417 = 6 x 64 + 33), one sample."""
+    rs = np.random.RandomState(R * 1000 + S_)
+    w = (rs.uniform(0, 1, (R, S_)) ** 4).astype(np.float32)
+    w[rs.uniform(size=(R, S_)) < 0.6] = 0.0
+    w[R - max(1, R // 5):] = 0.0                                  # the last rays kept nothing
+    t = np.sort(rs.uniform(0.05, 60, S_)).astype(np.float32)
+    s = 1 - 1 / (1 + t)
+    wt = T(w).requires_grad_(True)
+    loss = ops.distortion_loss(wt, T(s))
+    loss.backward(torch.tensor(1.7, device=DEV))
+    wd = torch.from_numpy(w).double().requires_grad_(True)
+    sd = torch.from_numpy(s).double()[None]
+    kept = wd > 0
+    n_max = kept.sum().clamp_min(1)
+    rays_with = kept.any(1).nonzero()
+    n_rays = (rays_with.max() + 1) if rays_with.numel() else 1
+    wm = wd * sd
+    w_pre, wm_pre = torch.cumsum(wd, 1) - wd, torch.cumsum(wm, 1) - wm
+    ref = (((1 / 3) * (1.0 / n_max) * wd.pow(2)).sum() + (2 * wd * (sd * w_pre - wm_pre)).sum()) / n_rays
+    ref.backward(torch.tensor(1.7, dtype=torch.float64))
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-9, (float(loss), float(ref))
+    g, gr = wt.grad.cpu().double().numpy(), wd.grad.numpy()
+    assert np.abs(g - gr).max() <= 3e-6 * np.abs(gr).max() + 1e-9, (np.abs(g - gr).max(), np.abs(gr).max())
+    assert torch.equal(ops.distortion_loss(wt.detach(), T(s)), loss.detach())          # deterministic
+
+
 def test_metric_miou_golden_and_oracle(golden):
     """A22: GPU confusion matrix is bit-identical to the reference's Metric_mIoU histogram."""
     from preworld_amd.metrics import Metric_mIoU, Metric_mIoU_Temporal

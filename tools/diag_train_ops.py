@@ -12,8 +12,14 @@ os.environ['N_STEPS'] = '1'
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
-g = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bench_train.py'), run_name='__main__')
-step = g['train_step']
+if os.environ.get('WHICH', 'finetune') == 'pretrain':              # the pre-train (render) step of bench.py's extra.c5
+    import bench
+    step = bench.pretrain_step_ms('cuda:0', 'step')
+    for _ in range(2):
+        step()
+else:
+    g = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bench_train.py'), run_name='__main__')
+    step = g['train_step']
 log = collections.defaultdict(lambda: [0, 0])
 MIN_ELEMS = int(os.environ.get('MIN_ELEMS', '200000'))          # MIN_ELEMS=0 BY_COUNT=1: every launch, busiest source lines first
 SKIP = ('aten.view', 'aten.permute', 'aten.slice.', 'aten.select', 'aten.detach', 'aten.alias', 'aten.t.', 'aten.reshape', 'aten._unsafe_view',
