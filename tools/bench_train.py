@@ -113,7 +113,7 @@ for _ in range(n):
     train_step()
 torch.cuda.synchronize()
 print('PreWorld.forward_train voxel side, C3 shape (6 cams, 2 frames, 200x200x16), forward + backward: %.1f ms per step   losses: %s' % (
-    (time.perf_counter() - t0) / n * 1e3, ', '.join('%s %.3f' % (k, float(v)) for k, v in out.items() if 'sup' not in k)), flush=True)
+    (time.perf_counter() - t0) / n * 1e3, ', '.join('%s %.3f' % (k, float(v.detach())) for k, v in out.items() if 'sup' not in k)), flush=True)
 
 if os.environ.get('PW_TORCH_PROFILE'):           # which torch ops (glue around the HIP kernels) the step spends device time in
     from torch.profiler import ProfilerActivity, profile
