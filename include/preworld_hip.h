@@ -365,15 +365,21 @@ int pw_render_rays_backward(const float* rays_o, const float* rays_d, int n_rays
  * under torch, is deterministic given sorted ray_id): the march emits one (voxel, ray, w*corner weight, d sigma*corner weight)
  * entry per visited sample and in-bounds corner, a counting sort groups the entries by voxel, and one wave per voxel sums
  * [d sigma | w g_sem[ray] | w g_rgb[ray]] in 64-bit fixed point (exact integer sums: order-free), written by a single writer.
- * g_semrgb: (R, 20) rows [g_sem | g_rgb]; g_absmax: device scalar max |g_semrgb|; workspace: pw_render_backward_workspace_bytes
- * (40 bytes per possible entry, n_rays*n_samples*8 of them -- 5.1 GB at 38 400 x 417), 256-byte aligned. */
-size_t pw_render_backward_workspace_bytes(int n_rays, int n_samples, int X, int Y, int Z);
+ * g_semrgb: (R, 20) rows [g_sem | g_rgb]; g_absmax: device scalar max |g_semrgb|; workspace: pw_render_backward_workspace_bytes,
+ * 256-byte aligned, 40 bytes per entry the arrays are laid out for.  max_entries: an upper bound of the entries the march will emit
+ * -- 8 x the number of samples above the alpha threshold, i.e. 8 x the sum of pw_render_rays' out_counts[:, 1], is one -- or 0 for
+ * the worst case n_rays*n_samples*8 (5.1 GB at 38 400 x 417; the forward's count brings it to a few hundred MB).  A bound that turns
+ * out too small is a caller bug: nothing is written out of range, grad_grid[0] becomes NaN.
+ * Exactness: the fixed-point units leave room for 2^22 largest-magnitude terms per voxel and channel group (a voxel near the cameras
+ * sees 10^4..10^5); non-finite upstream gradients are not representable in them and count as 0 (the float-atomics entry point
+ * propagates them). */
+size_t pw_render_backward_workspace_bytes(int n_rays, int n_samples, int X, int Y, int Z, int64_t max_entries);
 int pw_render_rays_backward_sorted(const float* rays_o, const float* rays_d, int n_rays, const float* t, int n_samples,
                                    const float* grid, int X, int Y, int Z, int grid_channels, int c_sigma, int c_sem,
                                    int n_sem, int c_rgb, const float* consts_host, const float* g_depth, const float* g_sem,
                                    const float* g_rgb, const float* g_last, const float* g_weights,
                                    const float* g_semrgb, const float* g_absmax, void* workspace, size_t workspace_bytes,
-                                   float* grad_grid, void* stream);
+                                   int64_t max_entries, float* grad_grid, void* stream);
 
 /* A12  attribute projection (preworld_temporal_traj.py:81-104): density/semantic/color MLPs
  * (each 32 -> 64 Softplus -> {2,17,3}) fused; v0 (n_vox,32) channels-last; out (n_vox,24) packed

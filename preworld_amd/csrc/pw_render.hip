@@ -222,7 +222,8 @@ struct RenderArgs {
   // sample, in-bounds trilinear corner) -- see "sorted backward" below
   int2* e_kr;              // (voxel (z*Y + y)*X + x, arrival rank inside the voxel's segment = the returning histogram atomic)
   float4* e_pay;           // (ray as int bits, a = w_i * corner weight (0 for culled samples), b = d loss / d sigma_i * corner weight, 0)
-  int* e_head;             // [0] number of entries, [1] bits of max |e_b|
+  int* e_head;             // [0] number of entries, [1] bits of max |e_b|, [4] set when a reservation passed e_cap (see below)
+  int e_cap;               // entries the arrays hold
   int* e_count;            // per-voxel histogram (zeroed by the host side)
 };
 
@@ -515,6 +516,10 @@ __global__ void __launch_bounds__(256) k_render_rays(RenderArgs a) {
       int base = 0;
       if (lane == 0) base = atomicAdd(a.e_head, total);
       base = __builtin_amdgcn_readfirstlane(base);
+      if (base + total > a.e_cap) {            // cannot happen with the caller's bound (8 corners x samples above the alpha threshold);
+        if (lane == 0) a.e_head[4] = 1;        // if it does: nothing is written, the later kernels stand down and the result is poisoned
+        continue;
+      }
       int pos = base + incl - cnt;
       PW_FOR_CORNERS(t3, {
         // histogram atomic, one per RUN of lanes (consecutive samples of the ray, half a voxel apart) whose corner is the same
@@ -727,6 +732,7 @@ __device__ __forceinline__ double rb_scale(float m) {
 }  // namespace
 
 __global__ void __launch_bounds__(256) k_rb_scatter(RbArgs a) {
+  if (a.head[4]) return;                                       // entry arrays overflowed: stand down (k_rb_finish_long poisons the result)
   const int n = a.head[0];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int2 kr = a.kr[i];
@@ -817,14 +823,22 @@ __global__ void __launch_bounds__(256) k_rb_gather_long(RbArgs a) {
 __global__ void __launch_bounds__(256) k_rb_finish_long(RbArgs a) {
   const int nl = min(a.head[2], a.max_long);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // the caller's entry bound was too small (a bug, not a data condition): no partial gradient passes for a result
+  if (i == 0 && a.head[4]) a.grad_grid[0] = __uint_as_float(0x7fc00000u);
   if (i >= nl * RB_CH) return;
   const int li = i / RB_CH, ch = i - li * RB_CH;
   const double sc = ch == 0 ? rb_scale(__uint_as_float((unsigned)a.head[1])) : rb_scale(*a.gmax);
   a.grad_grid[(size_t)a.long_list[li] * a.GC + rb_channel_index(a, ch)] += (float)((double)a.long_acc[i] / sc);
 }
 
-PW_API size_t pw_render_backward_workspace_bytes(int n_rays, int n_samples, int X, int Y, int Z) {
-  const size_t cap = (size_t)n_rays * n_samples * 8, nv = (size_t)X * Y * Z;
+// entries the arrays are laid out for: the caller's bound when it gives one, else every sample of every ray with 8 in-bounds corners
+static size_t rb_capacity(int n_rays, int n_samples, int64_t max_entries) {
+  const size_t worst = (size_t)n_rays * n_samples * 8;
+  return max_entries > 0 && (size_t)max_entries < worst ? (size_t)max_entries : worst;
+}
+
+PW_API size_t pw_render_backward_workspace_bytes(int n_rays, int n_samples, int X, int Y, int Z, int64_t max_entries) {
+  const size_t cap = rb_capacity(n_rays, n_samples, max_entries), nv = (size_t)X * Y * Z;
   const size_t max_long = cap / RB_LONG + 1;
   return 256 + 3 * pw_align_up((nv + 1) * 4, 256) + pw_scan_ws_bytes((int64_t)nv + 1) + 10 * pw_align_up(cap * 4, 256) +
          pw_align_up(max_long * 4, 256) + pw_align_up(max_long * RB_CH * 8, 256);
@@ -838,7 +852,7 @@ PW_API int pw_render_rays_backward_sorted(const float* rays_o, const float* rays
                                           int n_sem, int c_rgb, const float* consts_host, const float* g_depth, const float* g_sem,
                                           const float* g_rgb, const float* g_last, const float* g_weights,
                                           const float* g_semrgb, const float* g_absmax, void* workspace, size_t workspace_bytes,
-                                          float* grad_grid, void* stream) {
+                                          int64_t max_entries, float* grad_grid, void* stream) {
   if (n_rays == 0) return PW_OK;
   PW_CHECK_ARG(rays_o && rays_d && t && grid && consts_host && g_depth && g_sem && g_rgb && g_last && grad_grid && g_semrgb &&
                    g_absmax && workspace, "pw_render_rays_backward_sorted: null pointer");
@@ -847,10 +861,10 @@ PW_API int pw_render_rays_backward_sorted(const float* rays_o, const float* rays
   PW_CHECK_ARG(c_sigma >= 0 && c_sigma < grid_channels && c_sem >= 0 && c_sem + n_sem <= grid_channels && c_rgb >= 0 &&
                    c_rgb + 3 <= grid_channels, "pw_render_rays_backward_sorted: channel offsets outside the packed grid");
   PW_CHECK_ARG((size_t)n_rays * n_samples * 8 < (1ull << 31) && (size_t)X * Y * Z < (1ull << 31), "pw_render_rays_backward_sorted: too many entries for int32 indices");
-  PW_CHECK_ARG(workspace_bytes >= pw_render_backward_workspace_bytes(n_rays, n_samples, X, Y, Z) && ((uintptr_t)workspace & 255) == 0,
+  PW_CHECK_ARG(workspace_bytes >= pw_render_backward_workspace_bytes(n_rays, n_samples, X, Y, Z, max_entries) && ((uintptr_t)workspace & 255) == 0,
                "pw_render_rays_backward_sorted: workspace too small or not 256-byte aligned");
   hipStream_t st = pw_stream(stream);
-  const size_t cap = (size_t)n_rays * n_samples * 8, nv = (size_t)X * Y * Z;
+  const size_t cap = rb_capacity(n_rays, n_samples, max_entries), nv = (size_t)X * Y * Z;
   const size_t max_long = cap / RB_LONG + 1;
   char* ws = (char*)workspace;
   int* head = (int*)ws; ws += 256;
@@ -879,7 +893,7 @@ PW_API int pw_render_rays_backward_sorted(const float* rays_o, const float* rays
   a.c_sigma = c_sigma; a.c_sem = c_sem; a.n_sem = n_sem; a.c_rgb = c_rgb;
   a.g_depth = g_depth; a.g_sem = g_sem; a.g_rgb = g_rgb; a.g_last = g_last; a.g_w = g_weights; a.grad_grid = grad_grid;
   a.e_kr = e_kr; a.e_pay = e_pay;
-  a.e_head = head; a.e_count = count;
+  a.e_head = head; a.e_count = count; a.e_cap = (int)cap;
   const dim3 grid_dim((unsigned)pw_cdiv(n_rays, 4));
   if (n_samples <= 128) hipLaunchKernelGGL((k_render_rays<2, 2>), grid_dim, dim3(256), 0, st, a);
   else if (n_samples <= 256) hipLaunchKernelGGL((k_render_rays<4, 2>), grid_dim, dim3(256), 0, st, a);

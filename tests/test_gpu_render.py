@@ -218,7 +218,8 @@ def test_distortion_loss_and_gradient_vs_torch_float64(R, S_):
     w_pre, wm_pre = torch.cumsum(wd, 1) - wd, torch.cumsum(wm, 1) - wm
     ref = (((1 / 3) * (1.0 / n_max) * wd.pow(2)).sum() + (2 * wd * (sd * w_pre - wm_pre)).sum()) / n_rays
     ref.backward(torch.tensor(1.7, dtype=torch.float64))
-    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-9, (float(loss), float(ref))
+    lv, rv = float(loss.detach()), float(ref.detach())
+    assert abs(lv - rv) <= 2e-6 * abs(rv) + 1e-9, (lv, rv)
     g, gr = wt.grad.cpu().double().numpy(), wd.grad.numpy()
     assert np.abs(g - gr).max() <= 3e-6 * np.abs(gr).max() + 1e-9, (np.abs(g - gr).max(), np.abs(gr).max())
     assert torch.equal(ops.distortion_loss(wt.detach(), T(s)), loss.detach())          # deterministic
@@ -421,3 +422,20 @@ def test_render_backward_sorted_is_deterministic_and_equals_the_atomic_form(R):
     base = torch.full_like(grid, 0.5)
     acc = ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, gw, grad_grid=base.clone(), algo='sorted')
     check_close('accumulates into grad_grid', acc - 0.5, a, 1e-6, atol=1e-6)
+    # workspace sized from the forward pass's count of samples above the alpha threshold (x 8 corners) instead of R x S x 8: same bits,
+    # a fraction of the memory; a bound that is too small poisons the result instead of writing out of range
+    kept = int(ops.render_rays(ro, rd, t, grid, consts, want_debug=True)['counts'][:, 1].sum())
+    Z, Y, X, _ = grid.shape
+    worst = ops._lib.call_size('pw_render_backward_workspace_bytes', R, t.numel(), X, Y, Z, 0)
+    tight = ops._lib.call_size('pw_render_backward_workspace_bytes', R, t.numel(), X, Y, Z, 8 * kept)
+    print('render backward workspace R=%d: worst case %.1f MB, from the forward count %.1f MB' % (R, worst / 1e6, tight / 1e6))
+    assert tight < 0.6 * worst
+    assert torch.equal(ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, gw, algo='sorted', max_entries=8 * kept), a)
+    bad = ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, gw, algo='sorted', max_entries=max(kept // 4, 1))
+    assert bool(torch.isnan(bad.reshape(-1)[0]))
+    # the autograd Function picks the count up without waiting for it
+    gridr = grid.clone().requires_grad_(True)
+    outs = ops.RenderRays.apply(gridr, ro, rd, t, consts)
+    torch.cuda.synchronize()                                   # (a real step has the loss kernels between forward and backward)
+    torch.autograd.backward(outs, [gd, gs, gc, gl, gw])
+    assert torch.equal(gridr.grad, a)
