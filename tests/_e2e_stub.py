@@ -19,6 +19,8 @@ VARIANTS = {
     'small': dict(grid=GRID, cams=[1, 4]),
     # BASELINE.json configs[0]'s voxel grid with the full camera rig: 6 cameras, 100 x 100 x 8
     'c6': dict(grid={'x': [-40, 40, 0.8], 'y': [-40, 40, 0.8], 'z': [-1, 5.4, 0.8], 'depth': [1.0, 45.0, 0.5]}, cams=[0, 1, 2, 3, 4, 5]),
+    # BASELINE.json's headline grid (C3: 200 x 200 x 16) with the full camera rig; the image stays 128 x 352 (8 x 22 x 88 frustum per camera)
+    'full': dict(grid={'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 0.4], 'depth': [1.0, 45.0, 0.5]}, cams=[0, 1, 2, 3, 4, 5]),
 }
 RUNS = [('p4d_ft', 'PreWorld4DTraj', True, True), ('p4d_ft_noprev', 'PreWorld4DTraj', True, False),
         ('p4d_attr', 'PreWorld4DTraj', False, True), ('pw_ft', 'PreWorld', True, True), ('pw_attr', 'PreWorld', False, True)]

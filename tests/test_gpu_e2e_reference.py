@@ -20,6 +20,7 @@ DEV = 'cuda:0'
 _GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 GOLD = np.load(os.path.join(_GDIR, 'e2e_small.npz'))
 GOLD_C6 = np.load(os.path.join(_GDIR, 'e2e_c6.npz'))
+GOLD_FULL = np.load(os.path.join(_GDIR, 'e2e_full.npz'))
 GOLD_TRAIN = np.load(os.path.join(_GDIR, 'e2e_train_small.npz'))
 
 
@@ -83,22 +84,31 @@ def test_dropin_detectors_match_reference_detectors(tag, det, post_ft, with_prev
         assert err <= 1e-5, (tag, name, err)
 
 
-def test_dropin_detector_matches_reference_detector_six_cameras_100x100x8():
-    """the same comparison with the full rig on BASELINE.json configs[0]'s grid (6 cameras, 100 x 100 x 8): the reference's own
-    PreWorld4DTraj.simple_test (tests/golden/e2e_c6.npz) vs the drop-in, every flip explained by the reference's logits"""
-    net, dn = _build('PreWorld4DTraj', True, True, variant='c6')
-    inputs = tuple(t.to(DEV) for t in E.img_inputs(0, 'c6'))
+@pytest.mark.parametrize('variant,shape', [('c6', (100, 100, 8)), ('full', (200, 200, 16))])
+def test_dropin_detector_matches_reference_detector_six_cameras(variant, shape):
+    """the same comparison with the full rig: on BASELINE.json configs[0]'s grid (6 cameras, 100 x 100 x 8; tests/golden/e2e_c6.npz)
+    and on the HEADLINE grid itself (200 x 200 x 16, 7 states; e2e_full.npz, round 4) -- the reference's own
+    PreWorld4DTraj.simple_test vs the drop-in, every differing voxel explained by the reference's logits; encoder output and
+    voxel_feats rows at 1 024 sampled voxels to 1e-5 of the largest value."""
+    G, tag = (GOLD_C6 if variant == 'c6' else GOLD_FULL), 'p4d_ft'
+    net, dn = _build('PreWorld4DTraj', True, True, variant=variant)
+    inputs = tuple(t.to(DEV) for t in E.img_inputs(0, variant))
     ego = [[t.to(DEV) for t in E.ego_states(0)[0]]]
     with torch.no_grad():
         res = net.simple_test(None, None, img=inputs, temporal_ego_states=ego)
-    G, tag = GOLD_C6, 'p4d_ft'
     assert dn.k == int(G[tag + '_n_depthnet_calls']) and sorted(res.keys()) == list(G[tag + '_keys'])
     np.testing.assert_allclose(torch.stack(dn.mlp_inputs, 0).numpy(), G['mlp_input'], rtol=1e-6, atol=1e-6)
+    n_flips = 0
     for k in res:
-        want, got = G[tag + '_' + k], res[k][0]
-        assert got.dtype == np.uint8 and got.shape == want.shape == (100, 100, 8)
+        got = res[k][0]
+        if tag + '_' + k in G.files:
+            want = G[tag + '_' + k]
+        else:                                                   # geo grids of the full-size fixture: {0, 17}-valued, stored as bits
+            want = (np.unpackbits(G[tag + '_' + k + '_is17_bits'])[:got.size].reshape(got.shape) * 17).astype(np.uint8)
+        assert got.dtype == np.uint8 and got.shape == want.shape == shape
         flips = np.nonzero((got != want).reshape(-1))[0]
-        print('[e2e c6] %-16s flips vs the reference class: %d / %d' % (k, flips.size, want.size))
+        n_flips += flips.size
+        print('[e2e %s] %-16s flips vs the reference class: %d / %d' % (variant, k, flips.size, want.size))
         if k.startswith('semantic_occ'):
             ti, tm, tc = G['%s_%s_tie_idx' % (tag, k)], G['%s_%s_tie_margin' % (tag, k)], G['%s_%s_tie_cls' % (tag, k)]
             tol = 2 * 2e-5 * float(G['%s_%s_logit_absmax' % (tag, k)])
@@ -106,7 +116,20 @@ def test_dropin_detector_matches_reference_detector_six_cameras_100x100x8():
                 j = np.nonzero(ti == v)[0]
                 assert j.size == 1 and got.reshape(-1)[v] == tc[j[0]] and tm[j[0]] <= tol, (k, int(v))
         else:
-            assert flips.size <= 8, (k, flips.size)
+            assert flips.size <= (8 if variant == 'c6' else 64), (k, flips.size)      # geo grids: ties with the free class only
+    assert n_flips <= 2e-5 * 14 * np.prod(shape), n_flips
+    dn.reset()
+    with torch.no_grad():
+        frames = net.lift_inputs_from_images(net.prepare_inputs(inputs, stereo=True))
+        bev = net._ranged(lambda: as_f32(net.extract_bev_feat_cl(frames)))
+        dn.reset()
+        vf = net._ranged(lambda: as_f32(net.extract_voxel_feat_cl(frames)))
+    idx = torch.from_numpy(G['sample_idx']).to(DEV)
+    for name, t in (('bev', bev), ('vf', vf)):
+        rows, want = t[0].reshape(-1, 32)[idx].cpu().numpy(), G['%s_%s_rows' % (tag, name)]
+        err = float(np.abs(rows - want).max()) / float(np.abs(want).max())
+        print('[e2e %s] %-4s rows: max|err| / max|ref| = %.2e' % (variant, name, err))
+        assert err <= 1e-5, (variant, name, err)
 
 
 @pytest.mark.parametrize('tag,det', [('pw', 'PreWorld'), ('p4d', 'PreWorld4DTraj')])

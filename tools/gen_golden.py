@@ -1014,7 +1014,8 @@ def gen_e2e(vtm, occ):
     tests/_e2e_stub.py, native ops bound to the oracle.  Records prepare_inputs' pose algebra, the mlp_input handed to the
     DepthNet, sampled rows of the encoder output and of voxel_feats, every uint8 grid, and (post-finetune decode) the near-tie
     voxels of the OccHead logits.  e2e_small.npz: 2 cameras, 40 x 40 x 8, all five detector / decode combinations;
-    e2e_c6.npz: 6 cameras, 100 x 100 x 8 (BASELINE.json configs[0]'s grid with the full rig), PreWorld4DTraj post-finetune."""
+    e2e_c6.npz: 6 cameras, 100 x 100 x 8 (BASELINE.json configs[0]'s grid with the full rig), PreWorld4DTraj post-finetune;
+    e2e_full.npz: 6 cameras, 200 x 200 x 16 -- the headline grid -- same detector."""
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     import _e2e_stub as E
     vtm.BasicBlock = _RefBasicBlock
@@ -1030,6 +1031,17 @@ def gen_e2e(vtm, occ):
     _run_reference_detector(E, 'p4d_ft', 'PreWorld4DTraj', True, True, sd, E.img_inputs(0, 'c6'), 'c6', out6, np.random.RandomState(78),
                             (100, 100, 8))
     save('e2e_c6.npz', **out6)
+    if os.environ.get('PW_GEN_E2E_FULL', '1') == '1':
+        # the headline grid itself (200 x 200 x 16, 6 cameras, 7 states) through the reference's PreWorld4DTraj.simple_test: ~1 min of CPU.
+        # geo grids are {0, 17}-valued: stored as bit masks
+        outf = {}
+        _run_reference_detector(E, 'p4d_ft', 'PreWorld4DTraj', True, True, sd, E.img_inputs(0, 'full'), 'full', outf,
+                                np.random.RandomState(79), (200, 200, 16))
+        for k in [k for k in outf if k.startswith('p4d_ft_geo_occ')]:
+            g = outf.pop(k)
+            assert set(np.unique(g).tolist()) <= {0, 17}
+            outf[k + '_is17_bits'] = np.packbits(g.reshape(-1) == 17)
+        save('e2e_full.npz', **outf)
 
 
 def gen_e2e_train(vtm, occ):
