@@ -121,11 +121,16 @@ TRAIN_CFG = dict(if_render=False, if_post_finetune=True, use_lss_depth_loss=Fals
 TRAIN_EPOCH = 7      # PreWorld4DTraj.set_epoch: without rendering, epoch 7 supervises the current state and three forecast intervals
 
 
-def train_kwargs(seed, detector, device='cpu'):
+def grid_shape(variant='small'):
+    g = VARIANTS[variant]['grid']
+    return tuple(int(round((g[a][1] - g[a][0]) / g[a][2])) for a in 'xyz')
+
+
+def train_kwargs(seed, detector, device='cpu', variant='small'):
     """the keyword arguments forward_train reads (preworld.py:256-263, preworld_temporal_traj.py:412-524): voxel_semantics (B,X,Y,Z),
     mask_camera, and for the temporal detector temporal_semantics[k]['voxel_semantics'], temporal_ego_states, temporal_trajs"""
     rs = np.random.RandomState(3000 + seed)
-    X, Y, Z = 40, 40, 8
+    X, Y, Z = grid_shape(variant)
     sem = lambda: torch.from_numpy(rs.randint(0, 18, (1, X, Y, Z))).to(device)       # noqa: E731
     kw = dict(voxel_semantics=sem(), mask_camera=None)
     if detector == 'PreWorld4DTraj':

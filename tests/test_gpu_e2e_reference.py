@@ -22,6 +22,7 @@ GOLD = np.load(os.path.join(_GDIR, 'e2e_small.npz'))
 GOLD_C6 = np.load(os.path.join(_GDIR, 'e2e_c6.npz'))
 GOLD_FULL = np.load(os.path.join(_GDIR, 'e2e_full.npz'))
 GOLD_TRAIN = np.load(os.path.join(_GDIR, 'e2e_train_small.npz'))
+GOLD_TRAIN_FULL = np.load(os.path.join(_GDIR, 'e2e_train_full.npz'))
 
 
 def _build(det, post_ft, with_prev, variant='small'):
@@ -132,21 +133,22 @@ def test_dropin_detector_matches_reference_detector_six_cameras(variant, shape):
         assert err <= 1e-5, (variant, name, err)
 
 
-@pytest.mark.parametrize('tag,det', [('pw', 'PreWorld'), ('p4d', 'PreWorld4DTraj')])
-def test_dropin_forward_train_matches_reference_forward_train(tag, det):
+@pytest.mark.parametrize('tag,det,variant', [('pw', 'PreWorld', 'small'), ('p4d', 'PreWorld4DTraj', 'small'), ('pw', 'PreWorld', 'full')])
+def test_dropin_forward_train_matches_reference_forward_train(tag, det, variant):
     """VERDICT r03 missing 3 / next 6: the training composition against the reference's OWN forward_train (preworld.py:229-309,
     preworld_temporal_traj.py:372-530; tests/golden/e2e_train_small.npz, produced by tools/gen_golden.py gen_e2e_train running those
     methods in train() mode): the loss dict's keys (which state gets which term, `..._{k}s`), every loss value to 1e-4, and
-    d sum(losses) / d of final_conv, OccHead, encoder, pre_process and (temporal) the forecast / trajectory heads' weights."""
-    G = GOLD_TRAIN
-    cfg = E.model_cfg(det, True, True)
+    d sum(losses) / d of final_conv, OccHead, encoder, pre_process and (temporal) the forecast / trajectory heads' weights.
+    variant 'full' (round 4): PreWorld.forward_train at the HEADLINE grid, 6 cameras, 200 x 200 x 16 (e2e_train_full.npz)."""
+    G = GOLD_TRAIN if variant == 'small' else GOLD_TRAIN_FULL
+    cfg = E.model_cfg(det, True, True, variant=variant)
     cfg.update(E.TRAIN_CFG)
     net = harness.build_model(cfg, S.synth_state_dict(0), DEV).train()
     if hasattr(net, 'set_epoch'):
         net.set_epoch(E.TRAIN_EPOCH)
     E.install_image_side(net, seed=0)
-    inputs = tuple(t.to(DEV) for t in E.img_inputs(0))
-    losses = net(return_loss=True, img_inputs=inputs, img_metas=[dict()], **E.train_kwargs(0, det, DEV))
+    inputs = tuple(t.to(DEV) for t in E.img_inputs(0, variant))
+    losses = net(return_loss=True, img_inputs=inputs, img_metas=[dict()], **E.train_kwargs(0, det, DEV, variant))
     assert sorted(losses.keys()) == list(G[tag + '_keys']), sorted(losses.keys())
     for k, v in losses.items():
         want = float(G['%s_%s' % (tag, k)])

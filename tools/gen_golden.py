@@ -1058,10 +1058,20 @@ def gen_e2e_train(vtm, occ):
     vtm.BasicBlock = _RefBasicBlock
     load_detectors(occ)
     sd = S.synth_state_dict(0)
-    inputs = E.img_inputs(0)
+    for variant, runs, fname in (('small', (('pw', 'PreWorld'), ('p4d', 'PreWorld4DTraj')), 'e2e_train_small.npz'),
+                                 ('full', (('pw', 'PreWorld'),), 'e2e_train_full.npz')):
+        if variant == 'full' and os.environ.get('PW_GEN_E2E_FULL', '1') != '1':
+            continue
+        _gen_e2e_train_variant(E, sd, variant, runs, fname)
+
+
+def _gen_e2e_train_variant(E, sd, variant, runs, fname):
+    """one fixture of gen_e2e_train: `small` (2 cameras, 40 x 40 x 8, both detectors) or `full` (6 cameras, the headline 200 x 200 x 16 grid,
+    PreWorld: a few minutes of the reference on this container's CPUs)"""
+    inputs = E.img_inputs(0, variant)
     out = {}
-    for tag, det in (('pw', 'PreWorld'), ('p4d', 'PreWorld4DTraj')):
-        cfg = E.model_cfg(det, True, True)
+    for tag, det in runs:
+        cfg = E.model_cfg(det, True, True, variant=variant)
         cfg.update(E.TRAIN_CFG)
         model = _build_from_cfg(cfg)
         own = set(model.state_dict().keys())
@@ -1071,7 +1081,7 @@ def gen_e2e_train(vtm, occ):
         if hasattr(model, 'set_epoch'):
             model.set_epoch(E.TRAIN_EPOCH)                      # the epoch hook's call (:156-157): epoch 7 -> future intervals 0, 1, 2
         E.install_image_side(model, seed=0)
-        kw = E.train_kwargs(0, det)
+        kw = E.train_kwargs(0, det, variant=variant)
         losses = model.forward_train(None, [dict()], img_inputs=inputs, **kw)
         total = sum(losses.values())
         total.backward()
@@ -1088,7 +1098,7 @@ def gen_e2e_train(vtm, occ):
         bn = model.occupancy_head.occ_convs[0][1]
         out[tag + '_occ_bn_running_mean'] = bn.running_mean.numpy().copy()
         out[tag + '_occ_bn_batches'] = np.int64(bn.num_batches_tracked)
-    save('e2e_train_small.npz', **out)
+    save(fname, **out)
 
 
 def main():
