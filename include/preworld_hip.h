@@ -592,10 +592,12 @@ int pw_conv3d_dgrad_k2s2(const float* dy, const float* wt, float* dx, int B, int
  * Recorded maxima (all four pointers may be NULL): y_amax / dx_amax = float[256] partial maxima of |y| / |dx| in pw_absmax2's format, what
  * pw_conv3d_wgrad_h2 takes as amax_x / amax_y -- the layer that consumes y (or dx) then needs no absmax pass over it.  The buffer is
  * cleared by the reduction that precedes the apply on the same stream: hand the SAME pointer to pw_bn_stats (amax_clear) and
- * pw_bn_apply (y_amax), or to pw_bn_bwd_reduce and pw_bn_bwd_apply. */
+ * pw_bn_apply (y_amax), or to pw_bn_bwd_reduce and pw_bn_bwd_apply.
+ * pw_bn_stats with running_mean / running_var != NULL also does pw_bn_update_running's bookkeeping (n = N) in the same launch. */
 size_t pw_bn_workspace_bytes(int C);
 int pw_bn_stats(const float* x, int64_t N, int C, float eps, void* workspace, size_t workspace_bytes, float* mean, float* var,
-                float* rstd, float* amax_clear, void* stream);
+                float* rstd, float* amax_clear, float* running_mean, float* running_var, float momentum,
+                int64_t* num_batches_tracked, void* stream);
 int pw_bn_apply(const float* x, int64_t N, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                 const float* residual, int relu, float* y, float* y_amax, void* stream);
 int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int64_t N, int C, const float* mean, const float* rstd,

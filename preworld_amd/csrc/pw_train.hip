@@ -403,7 +403,9 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float4* __restrict__ x,
 // version walked all 512 partials with one thread per channel: 129 us per call, 16 % of a training step)
 __global__ void __launch_bounds__(64) k_bn_finish(const double* __restrict__ partial, int blocks, int C, int64_t N, float eps,
                                                   int fwd, float* __restrict__ out0, float* __restrict__ out1,
-                                                  float* __restrict__ rstd, unsigned* __restrict__ amax_clear) {
+                                                  float* __restrict__ rstd, unsigned* __restrict__ amax_clear,
+                                                  float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                                  int64_t* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x, lane = threadIdx.x;
   // the BN_AMAX_PARTS partial maxima the apply kernel that follows on this stream raises (bn_note_amax) start from zero
   if (amax_clear)
@@ -423,6 +425,12 @@ __global__ void __launch_bounds__(64) k_bn_finish(const double* __restrict__ par
     out0[c] = (float)mu;
     out1[c] = (float)var;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {                          // nn.BatchNorm3d's bookkeeping, as k_bn_update_running does it
+      const float n = (float)N, unbias = n / fmaxf(n - 1.f, 1.f);
+      running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * (float)mu;
+      running_var[c] = running_var[c] * (1.f - momentum) + momentum * ((float)var * unbias);
+      if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+    }
   } else {
     out0[c] = (float)a0;
     out1[c] = (float)a1;
@@ -451,15 +459,17 @@ static int bn_check(int64_t N, int C, const void* ws, size_t ws_bytes, const cha
 }
 
 PW_API int pw_bn_stats(const float* x, int64_t N, int C, float eps, void* workspace, size_t workspace_bytes, float* mean,
-                       float* var, float* rstd, float* amax_clear, void* stream) {
+                       float* var, float* rstd, float* amax_clear, float* running_mean, float* running_var, float momentum,
+                       int64_t* num_batches_tracked, void* stream) {
   PW_CHECK_ARG(x && mean && var && rstd && ((uintptr_t)x & 15) == 0, "pw_bn_stats: null or misaligned pointer");
+  PW_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "pw_bn_stats: running_mean and running_var come together");
   if (int rc = bn_check(N, C, workspace, workspace_bytes, "pw_bn_stats")) return rc;
   const int blocks = bn_blocks(N, C);
   hipStream_t st = pw_stream(stream);
   hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, st, (const float4*)x, (const float4*)nullptr, (const float4*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, N, C, 0, (double*)workspace);
   hipLaunchKernelGGL(k_bn_finish, dim3(C), dim3(64), 0, st, (const double*)workspace, blocks, C, N, eps, 1, mean, var, rstd,
-                     (unsigned*)amax_clear);
+                     (unsigned*)amax_clear, running_mean, running_var, momentum, num_batches_tracked);
   pw_note_kernel("k_bn_reduce<false>");
   PW_CHECK_LAUNCH();
   return PW_OK;
@@ -538,7 +548,7 @@ PW_API int pw_bn_bwd_reduce(const float* x, const float* dy, const float* y, int
   hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, st, (const float4*)x, (const float4*)dy, (const float4*)y, mean, rstd, N, C,
                      relu, (double*)workspace);
   hipLaunchKernelGGL(k_bn_finish, dim3(C), dim3(64), 0, st, (const double*)workspace, blocks, C, N, 0.f, 0, sum_dz, sum_dz_xhat,
-                     (float*)nullptr, (unsigned*)amax_clear);
+                     (float*)nullptr, (unsigned*)amax_clear, (float*)nullptr, (float*)nullptr, 0.f, (int64_t*)nullptr);
   pw_note_kernel("k_bn_reduce<true>");
   PW_CHECK_LAUNCH();
   return PW_OK;

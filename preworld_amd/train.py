@@ -152,15 +152,17 @@ def conv3d_wgrad(x, dy, w_shape, stride=1, x_amax=None):
     return dw
 
 
-def bn_stats(x, eps, amax=None):
-    """amax: float32[256] buffer that bn_apply(..., amax=) will record max |y| into (cleared here)"""
+def bn_stats(x, eps, amax=None, running=None):
+    """amax: float32[256] buffer that bn_apply(..., amax=) will record max |y| into (cleared here); running: (running_mean, running_var,
+    momentum, num_batches_tracked or None) to update like nn.BatchNorm3d in the same launch"""
     C = x.shape[-1]
     N = x.numel() // C
     nbytes = _lib.call_size('pw_bn_workspace_bytes', C)
     ws = ops._workspace(nbytes, x.device)
     mean, var, rstd = (torch.empty(C, device=x.device, dtype=_f32) for _ in range(3))
     _lib.call('pw_bn_stats', ops._p(_cl(x, 'x')), N, C, float(eps), ops._p(ws), nbytes, ops._p(mean), ops._p(var), ops._p(rstd),
-              ops._p(amax), ops._stream())
+              ops._p(amax), ops._p(running[0]) if running else None, ops._p(running[1]) if running else None,
+              float(running[2]) if running else 0.0, ops._p(running[3]) if running and running[3] is not None else None, ops._stream())
     return mean, var, rstd
 
 
@@ -249,10 +251,12 @@ class BatchNormCL(torch.autograd.Function):
     one of [sum dz, sum dz x_hat] in the backward pass; d gamma / d beta stay per rank (DDP averages parameter gradients)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, eps, relu, sync=False):
+    def forward(ctx, x, gamma, beta, residual, eps, relu, sync=False, running=None):
         ctx.set_materialize_grads(False)          # the statistics outputs never carry gradients: no zero tensors made for them
         amax = torch.empty(256, device=x.device, dtype=_f32)
-        mean, var, rstd = bn_stats(x, eps, amax)
+        # running: (running_mean, running_var, momentum, num_batches_tracked) updated inside the statistics launch -- local statistics
+        # only (a SyncBN over several ranks updates them from the all-reduced ones: _update_running)
+        mean, var, rstd = bn_stats(x, eps, amax, running if _sync_world(sync) == 1 else None)
         n_local = float(x.numel() // x.shape[-1])
         n_total = n_local
         if _sync_world(sync) > 1:
@@ -276,11 +280,11 @@ class BatchNormCL(torch.autograd.Function):
     def backward(ctx, dy, _dm, _dv, _dc):
         x, y, mean, rstd, g = ctx.saved_tensors
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         if _sync_world(ctx.sync) > 1:
             return BatchNormCL._backward_sync(ctx, x, dy.contiguous(), y, mean, rstd, g)
         dx, dgamma, dbeta, dres = bn_backward(x, dy.contiguous(), y, mean, rstd, g, ctx.relu, ctx.has_res and ctx.needs_input_grad[3], True)
-        return dx, dgamma, dbeta, dres, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None
 
     @staticmethod
     def _backward_sync(ctx, x, dy, y, mean, rstd, g):
@@ -301,7 +305,7 @@ class BatchNormCL(torch.autograd.Function):
         dres = torch.empty_like(x) if want_dres else None
         _lib.call('pw_bn_bwd_apply', ops._p(x), ops._p(dy), yp, N, C, ops._p(mean), ops._p(rstd), ops._p(_cl(g, 'gamma')),
                   ops._p(g0), ops._p(g1), int(ctx.relu), ops._p(dx), ops._p(dres), None, ops._stream())
-        return dx, s1, s0, dres, None, None, None
+        return dx, s1, s0, dres, None, None, None, None
 
 
 def _update_running(bn, mean, var, n):
@@ -367,9 +371,19 @@ def conv_module_forward(m, x, residual=None, relu=None):
 
 def _norm_act(m, y, residual=None, relu=None):
     """the BatchNorm (batch statistics) + activation half of a ConvModule3d on its conv output y"""
-    relu = m.with_activation if relu is None else relu
-    out, mean, var, cnt = BatchNormCL.apply(y, m.bn.weight, m.bn.bias, residual, m.bn.eps, relu, getattr(m.bn, 'pw_sync', False))
-    _update_running(m.bn, mean, var, cnt)
+    return _bn_train(m.bn, y, residual, m.with_activation if relu is None else relu)
+
+
+def _bn_train(bn, x, residual=None, relu=False):
+    """training-mode BatchNorm3d of a channels-last tensor (+ residual, + ReLU) with nn.BatchNorm3d's running-statistics bookkeeping --
+    inside the statistics launch when the statistics are local and the momentum fixed, else by _update_running"""
+    sync = getattr(bn, 'pw_sync', False)
+    fuse = (bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None and bn.running_mean.is_cuda and
+            bn.running_mean.dtype == _f32 and bn.running_var.dtype == _f32 and _sync_world(sync) == 1)
+    running = (bn.running_mean, bn.running_var, bn.momentum, bn.num_batches_tracked) if fuse else None
+    out, mean, var, cnt = BatchNormCL.apply(x, bn.weight, bn.bias, residual, bn.eps, relu, sync, running)
+    if not fuse:
+        _update_running(bn, mean, var, cnt)
     return out
 
 
@@ -477,9 +491,7 @@ def fpn_forward(neck, feats):
     y16 = Conv3dCL.apply(x16, w[:, c8:c8 + c16], 1)
     y32 = Conv3dCL.apply(x32, w[:, c8 + c16:], 1)
     pre = UpsampleSumCL.apply(y8, y16, y32)
-    out, mean, var, cnt = BatchNormCL.apply(pre, cm.bn.weight, cm.bn.bias, None, cm.bn.eps, cm.with_activation, getattr(cm.bn, 'pw_sync', False))
-    _update_running(cm.bn, mean, var, cnt)
-    return out
+    return _bn_train(cm.bn, pre, None, cm.with_activation)
 
 
 def conv_bias_act_forward(m, x):
@@ -491,9 +503,7 @@ def conv_bias_act_forward(m, x):
 
 
 def _bn_cl(bn, x, relu):
-    out, mean, var, cnt = BatchNormCL.apply(x.contiguous(), bn.weight, bn.bias, None, bn.eps, relu, getattr(bn, 'pw_sync', False))
-    _update_running(bn, mean, var, cnt)
-    return out
+    return _bn_train(bn, x.contiguous(), None, relu)
 
 
 _LINEAR_ROWS = {(16, 8), (8, 18), (8, 1), (8, 16), (18, 8), (1, 8), (32, 16), (16, 32)}
