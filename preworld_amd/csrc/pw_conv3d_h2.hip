@@ -465,6 +465,12 @@ __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x16 (&ac
 // tap fetches only its two lo pieces -- 8 LDS + 2 global operand loads per 12 MFMAs instead of 8 + 4 (profiles/r02_hw_probes.md).
 template <int NT, int EPI, bool WR = false>
 __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
+#ifdef PW_X_SKIP_SMALLCONV      // ablation builds only (tools/ablate_step.sh): what would the step gain if the small-grid layers were free?
+  if ((long long)a.D * a.H * a.W <= 80000) return;
+#endif
+#ifdef PW_X_SKIP_BIGCONV
+  if ((long long)a.D * a.H * a.W > 80000) return;
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);                  // = d-slice of the tile
@@ -637,7 +643,10 @@ __global__ void __launch_bounds__(256, 1) k_conv3d_h2(ConvArgs a, PipeArgs p) {
 // (A paired-wave variant of this kernel -- 8 waves per block, two per SIMD, wave pairs splitting the two k-steps of a chunk and
 // meeting in LDS when the tile is parked -- was built and measured in round 3, commit 578d615: 29.4 k instead of 35.4 k cycles
 // per 64 -> 64 stage, and the SAME wall time: with real data the socket sits at its 1400 W cap and the shader clock drops to
-// match, 1.87 -> 1.69 GHz.  profiles/r03_power_wall.txt; DESIGN.md 4.13.  It was removed again.)
+// match, 1.87 -> 1.69 GHz.  profiles/r03_power_wall.txt; DESIGN.md 4.13.  It was removed again.  Round 4 put it back for the SMALL
+// grids, which run far below the cap: 8x100x100 64->64 58.0 -> 56.2 us, 4x50x50 128->128 37.2 -> 35.3 us, no difference in the step
+// (389.6 vs 389.0 samples/s over three alternating runs on one box) -- removed again; profiles/r04_small_grid.txt has the table
+// and the ablation that shows why: no single piece of a tap's side work costs more than 10 % there.)
 
 // ------------------------------------------------------------------------------------ fp32 <-> h2
 // one thread per (voxel, 4-channel group); ld_* = floats between consecutive voxels (channel slices of wider buffers).

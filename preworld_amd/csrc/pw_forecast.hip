@@ -297,6 +297,9 @@ k_forecast_h2(const float* __restrict__ v0, long long n_vox_per_sample, int n_sa
               const float* __restrict__ w2p, float inv1, float inv2, const float* __restrict__ c1p,
               const float* __restrict__ fb2, int n_steps, float* __restrict__ states, int v0_h2, int out_h2,
               const int* __restrict__ v0_rng, int* __restrict__ st_rng, float w1_l1max) {
+#ifdef PW_X_SKIP_FC             // ablation builds only
+  return;
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* l_w1 = lds;
   float* l_w2 = lds + WH2;

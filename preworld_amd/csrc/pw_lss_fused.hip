@@ -187,6 +187,9 @@ k_lss_pool_slots(const float* __restrict__ depth, const float4* __restrict__ fea
                  const int32_t* __restrict__ slots, int64_t n_vox, const int32_t* __restrict__ cur, const int4* __restrict__ list_b, const int4* __restrict__ list_c,
                  const int32_t* __restrict__ tmp, int32_t* __restrict__ sorted_pf, float* __restrict__ sorted_d, FeatIdx fi,
                  float4* __restrict__ out, int out_h2, int* __restrict__ out_rng) {
+#ifdef PW_X_SKIP_LSS            // ablation builds only
+  return;
+#endif
   extern __shared__ __attribute__((aligned(16))) int32_t ids[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPV;

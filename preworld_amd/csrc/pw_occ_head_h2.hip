@@ -221,6 +221,9 @@ struct OhBounds { float mid_a, mid_b, hid_a, hid_b; };
 template <bool LOGITS>
 __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, OccTail tail, const float* tailpk, float inv2,
                                                         OhBounds bd) {
+#ifdef PW_X_SKIP_OCC            // ablation builds only
+  return;
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
