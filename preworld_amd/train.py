@@ -120,8 +120,16 @@ def conv3d_dgrad(dy, w, x_shape, stride=1, accumulate=None):
 def _amax_of(t):
     """the 256 partial maxima a BatchNorm kernel recorded when it wrote this tensor (BatchNormCL: y forward, dx backward), or None.
     They ride on the tensor object: autograd hands the same object to the consuming Function; a tensor that was summed, padded or
-    copied on the way simply arrives without them and gets an absmax pass."""
-    return getattr(t, '_pw_amax', None)
+    copied on the way simply arrives without them and gets an absmax pass, and so does one that was modified in place afterwards (the
+    tensor's version counter is recorded with the maxima)."""
+    rec = getattr(t, '_pw_amax', None)
+    if rec is None or rec[1] != t._version:           # written to in place since the maxima were recorded: they no longer describe it
+        return None
+    return rec[0]
+
+
+def _set_amax(t, amax):
+    t._pw_amax = (amax, t._version)
 
 
 def conv3d_wgrad(x, dy, w_shape, stride=1, x_amax=None):
@@ -173,7 +181,7 @@ def bn_apply(x, mean, rstd, gamma, beta, residual=None, relu=False, amax=None):
               ops._p(_cl(beta, 'beta')), ops._p(_cl(residual, 'residual') if residual is not None else None), int(relu), ops._p(y),
               ops._p(amax), ops._stream())
     if amax is not None:
-        y._pw_amax = amax
+        _set_amax(y, amax)
     return y
 
 
@@ -193,7 +201,7 @@ def bn_backward(x, dy, y, mean, rstd, gamma, relu, want_dres, record_amax=False)
     _lib.call('pw_bn_bwd_apply', ops._p(x), ops._p(dy), yp, N, C, ops._p(mean), ops._p(rstd), ops._p(_cl(gamma, 'gamma')),
               ops._p(s0), ops._p(s1), int(relu), ops._p(dx), ops._p(dres), ops._p(amax), ops._stream())
     if amax is not None:
-        dx._pw_amax = amax
+        _set_amax(dx, amax)
     return dx, s1, s0, dres
 
 
