@@ -631,6 +631,10 @@ size_t pw_upsample_trilinear_adjoint_workspace_bytes(int B, int Dl, int Hl, int 
 int pw_upsample_trilinear_adjoint(const float* dhi, float* dlo, void* workspace, size_t workspace_bytes, int B, int Dl, int Hl, int Wl,
                                   int Dh, int Hh, int Wh, int C, void* stream);
 
+/* n device-to-device copies (src[i] -> dst[i], bytes[i] bytes; host arrays of device pointers) in one launch per 32 segments: a
+ * sample's lifted inputs going into the static buffers of a captured step (preworld_amd.pipeline.CapturedSample.run). */
+int pw_copy_many(const void* const* src, void* const* dst, const size_t* bytes, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,3 +116,44 @@ PW_API int pw_probe_mfma_f16(double seconds, double* tflops) {
   free(hsrc);
   return rc;
 }
+
+// ------------------------------------------------------------------------------------
+// Many small device-to-device copies in ONE launch: a sample's lifted inputs (per frame: depth, context features, five small camera
+// tensors; the ego state) go into the static buffers of a captured step as 15 separate copy kernels otherwise -- most of them launch
+// latency.  The segment table travels by value in the kernel arguments.
+// ------------------------------------------------------------------------------------
+namespace {
+constexpr int CM_MAX = 32;
+struct CopyMany { const char* src[CM_MAX]; char* dst[CM_MAX]; unsigned long long bytes[CM_MAX]; };
+
+__global__ void __launch_bounds__(256) k_copy_many(CopyMany t) {
+  const int seg = blockIdx.y;
+  const char* s = t.src[seg];
+  char* d = t.dst[seg];
+  const unsigned long long n = t.bytes[seg];
+  const unsigned long long n16 = ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) ? n / 16 : 0;     // 16-byte body when both are aligned
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * blockDim.x)
+    reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  for (unsigned long long i = n16 * 16 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+    d[i] = s[i];
+}
+}  // namespace
+
+PW_API int pw_copy_many(const void* const* src, void* const* dst, const size_t* bytes, int n, void* stream) {
+  PW_CHECK_ARG(src && dst && bytes && n >= 0, "pw_copy_many: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += CM_MAX) {
+    CopyMany t = {};
+    const int m = n - i0 < CM_MAX ? n - i0 : CM_MAX;
+    size_t biggest = 0;
+    for (int i = 0; i < m; ++i) {
+      PW_CHECK_ARG(bytes[i0 + i] == 0 || (src[i0 + i] && dst[i0 + i]), "pw_copy_many: null pointer");
+      t.src[i] = (const char*)src[i0 + i]; t.dst[i] = (char*)dst[i0 + i]; t.bytes[i] = bytes[i0 + i];
+      biggest = bytes[i0 + i] > biggest ? bytes[i0 + i] : biggest;
+    }
+    if (biggest == 0) continue;
+    const int64_t want = pw_cdiv((int64_t)biggest, 256 * 16 * 4);                 // ~4 x 16 bytes per thread of the largest segment
+    hipLaunchKernelGGL(k_copy_many, dim3((unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want)), (unsigned)m), dim3(256), 0, pw_stream(stream), t);
+  }
+  PW_CHECK_LAUNCH();
+  return PW_OK;
+}

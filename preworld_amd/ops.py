@@ -42,6 +42,23 @@ def _workspace(nbytes, device):
     return torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
 
 
+def copy_many(dsts, srcs):
+    """dst[i].copy_(src[i]) for lists of same-shaped contiguous device tensors in ONE launch (pw_copy_many) -- a sample's inputs going
+    into the static buffers of a captured step are 15 small copies, mostly launch latency as separate kernels"""
+    n = len(dsts)
+    if n != len(srcs):
+        raise _lib.PreworldHipError('copy_many: %d destinations, %d sources' % (n, len(srcs)))
+    for d, s_ in zip(dsts, srcs):
+        if d.shape != s_.shape or d.dtype != s_.dtype or not (d.is_contiguous() and s_.is_contiguous() and d.is_cuda and s_.is_cuda):
+            raise _lib.PreworldHipError('copy_many: tensors must be contiguous device tensors of equal shape and dtype')
+    if n == 0:
+        return
+    S = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_ in srcs])
+    D = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    B = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d in dsts])
+    _lib.call('pw_copy_many', S, D, B, n, _stream())
+
+
 def device_info():
     cu = ctypes.c_int(0)
     lds = ctypes.c_int(0)

@@ -22,6 +22,8 @@ class CapturedSample:
     the static buffers, replays the graph and returns the (static) result dict: consume or clone the
     outputs before the next run()."""
 
+    fused_input_copy = True          # run(): one pw_copy_many launch for the inputs (False: one torch copy per tensor; A/B)
+
     def __init__(self, net, frames, ego, n_steps=6, d2h=False):
         """d2h=True: the replay also delivers the reference's host payload (preworld_temporal_traj.py:311-366: every
         semantic_occ / geo_occ grid as a contiguous uint8 (X,Y,Z) host array) -- one device-side gather of the (X,Y,Z)
@@ -112,8 +114,14 @@ class CapturedSample:
         return out
 
     def run(self, frames, ego):
+        dsts, srcs = [self.ego], [ego]
         for dst, src in zip(self.frames, frames):
             for k, v in src.items():
-                dst[k].copy_(v, non_blocking=True)
-        self.ego.copy_(ego, non_blocking=True)
+                dsts.append(dst[k])
+                srcs.append(v)
+        if self.fused_input_copy and all(s.is_cuda and s.is_contiguous() and s.dtype == d.dtype and s.shape == d.shape for d, s in zip(dsts, srcs)):
+            ops.copy_many(dsts, srcs)                      # one launch for the ~15 input tensors
+        else:
+            for d, s in zip(dsts, srcs):
+                d.copy_(s, non_blocking=True)
         return self.replay()

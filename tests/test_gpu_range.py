@@ -387,3 +387,20 @@ def test_stream_of_distinct_samples_through_one_captured_step():
           % (np.log2(min(scales)), np.log2(max(scales)), recal, bad, audited, flips_own))
     assert recal == bad, 'every replay the device audit flagged was repaired by run_checked, and no other'
     assert recal <= 4, 'a 16x spread of the input scale sits inside the 2^6 .. 2^16 window of a calibrated table: recalibration is the exception'
+
+
+def test_copy_many_equals_separate_copies():
+    """ops.copy_many (pw_copy_many: one launch for the ~15 input tensors of a sample): odd byte counts, unaligned views, uint8 / int64 /
+    float32, more than 32 segments (two launches), an empty tensor."""
+    from preworld_amd import ops
+    g = torch.Generator().manual_seed(9)
+    srcs = [torch.randn(6, 118, 16, 44, generator=g).to(DEV), torch.randn(3, 3, generator=g).to(DEV), torch.randint(0, 255, (1237,), generator=g, dtype=torch.uint8).to(DEV),
+            torch.arange(17, dtype=torch.int64, device=DEV), torch.randn(1, 1, 21, generator=g).to(DEV), torch.empty(0, device=DEV)]
+    base = torch.randint(0, 255, (4099,), generator=g, dtype=torch.uint8).to(DEV)
+    srcs.append(base[3:])                                        # contiguous, but starting 3 bytes off alignment
+    srcs += [torch.randn(5 + k, generator=g).to(DEV) for k in range(40)]
+    dsts = [torch.zeros_like(s) if s.data_ptr() % 16 == 0 or s.numel() == 0 else torch.zeros(s.numel() + 5, dtype=s.dtype, device=DEV)[5:] for s in srcs]
+    ops.copy_many(dsts, srcs)
+    torch.cuda.synchronize()
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
