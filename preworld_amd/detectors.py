@@ -496,7 +496,9 @@ class _PreWorldCommon(BEVStereo4DOCC):
         if need_sem:
             semantic = xyz(train.mlp_cl(self.semantic_mlp, voxel_feats_cl))
         out = {}
-        cw17 = torch.from_numpy(1.0 / np.log(NUSC_CLASS_FREQUENCIES[:17] + 0.001)).float()
+        cw17 = getattr(self, '_cw17', None)                           # the 17 class weights, made once per device (no per-call H2D copy)
+        if cw17 is None or cw17.device != occ_preds.device:
+            cw17 = self._cw17 = torch.from_numpy(1.0 / np.log(NUSC_CLASS_FREQUENCIES[:17] + 0.001)).float().to(occ_preds.device)
         if self.if_post_finetune:
             lv = L.loss_voxel(occ_preds, voxel_semantics, cw17, camera_mask=None, empty_idx=self.empty_idx,
                               use_focal_loss=self.use_focal_loss, weight_voxel_ce=self.weight_voxel_ce,
@@ -504,7 +506,7 @@ class _PreWorldCommon(BEVStereo4DOCC):
                               weight_voxel_lovasz=self.weight_voxel_lovasz, focal_loss=getattr(self, 'focal_loss', None))
             out.update({k + sfx: v for k, v in lv.items()})
         else:
-            cw = torch.cat([cw17, torch.zeros(1)]).to(occ_preds)
+            cw = torch.cat([cw17, torch.zeros(1, device=cw17.device)]).to(occ_preds)
             out['loss_sup_voxel' + sfx] = L.CE_ssc_loss(occ_preds, voxel_semantics, cw, 255) * 0.
         if self.if_render:
             extra = {} if interval is None else dict(if_temporal=True, interval=interval)
