@@ -29,6 +29,8 @@ The JSON line also carries
                   kernel under `also`): algorithmic work / HIP-event duration measured live on the launch stream
   cpu_baseline -- the same C3 sample at FULL size on the host cores (no extrapolation): the PyTorch-CPU composition
                   (median of 5 after a warm-up) and the OpenMP port (the reference has no CPU path for its native ops).
+  extra        -- measured after the timed region: c2 (single frame, 1 state), c5 (render head forward / forward + backward, the
+                  pre-train step), train (the voxel-side fine-tune step, forward + backward); --no-extra skips them.
 """
 import argparse
 import json
