@@ -344,36 +344,21 @@ def bench_c5(args):
 def c5_result(args, quick=False):
     """Extra, non-headline line (BASELINE.json configs[4]): the volume-rendering attribute head at the literal C5 shape
     -- 6 cameras x 512 rays x 96 uniform samples through the packed (200,200,16,24) sigma / semantic / colour grid -- forward
-    (pw_render_rays) and forward + backward (pw_render_rays_backward, corner scatter-add of the gradient grid), one GPU, a
-    scene-like grid (ground slab + a ring of occupied blocks, rays terminate after a few occupied samples).  `value` = rays/s
-    of forward + backward; the fp32-grid forward, the bf16-grid forward and the reference's own 38 400 x 417 shape are in config."""
+    (pw_render_rays) and forward + backward (pw_render_rays_backward_sorted), one GPU, on TWO scenes:
+      'mixed'       S.render_grids_mixed / S.rays_mixed: ground slab + boxes with density ~U(10,22) (occupied <=> density > 8.5,
+                    detectors/preworld.py:32,180) -- the rays that meet them TERMINATE at T < 1e-3 (render_utils_kernel.cu:591-603);
+                    the fraction that does is measured on the device and reported (`terminated_frac`);
+      'transparent' density 4.0 in a ground slab and a ring of blocks, -8 elsewhere: alpha ~3e-5 per sample, NO ray terminates
+                    (every round-2..4 figure was of this kind).
+    `value` = rays/s of forward + backward on the mixed scene; the reference's own 38 400 x 417 shape is in config for both."""
     from preworld_amd import modules as M
     dev = 'cuda:0'
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                                   # noqa: E731
     head = M.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4, scene_center=[0, 0, 2.2], radius=39).to(dev)
-    _, semantic, color = S.render_grids(41)
-    xs, ys, zs = np.meshgrid(np.arange(200), np.arange(200), np.arange(16), indexing='ij')
-    rr = np.hypot(xs - 100, ys - 100)
-    dens = np.where((zs < 2) | ((rr > 40) & (rr < 60) & ((xs // 8 + ys // 8) % 2 == 0)), 4.0, -8.0).astype(np.float32)
-    grid = M.pack_attribute_grid(T(dens), T(semantic), T(color))
-    g16 = grid.to(torch.bfloat16)
     consts = head.consts(torch.eye(3))
-
-    def shape(R, t):
-        o, d = S.rays(7, R)
-        ro, rd = T(o), T(d)
-        gd, gs, gc, gl = (torch.randn(R, device=dev), torch.randn(R, 17, device=dev), torch.randn(R, 3, device=dev),
-                          torch.randn(R, device=dev))
-        gg = torch.zeros_like(grid)
-
-        def fwd():
-            ops.render_rays(ro, rd, t, grid, consts)
-
-        def fwd_bwd():
-            ops.render_rays(ro, rd, t, grid, consts)
-            gg.zero_()
-            ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, grad_grid=gg)
-        return fwd, fwd_bwd, (lambda: ops.render_rays(ro, rd, t, g16, consts))
+    b = torch.linspace(0, 2, 97)
+    t96 = ((b[1:] + b[:-1]) * 0.5).to(dev).contiguous()
+    steps = 20 if quick else max(args.steps, 20)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -385,32 +370,64 @@ def c5_result(args, quick=False):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
-    b = torch.linspace(0, 2, 97)
-    t96 = ((b[1:] + b[:-1]) * 0.5).to(dev).contiguous()
-    R = 3072
-    fwd, fwd_bwd, fwd16 = shape(R, t96)
-    t_end = time.perf_counter() + args.settle_s
-    while time.perf_counter() < t_end:
-        fwd_bwd()
-    steps = 20 if quick else max(args.steps, 20)
-    t_fb = timed(fwd_bwd, steps, args.warmup)
-    t_f, t_f16 = timed(fwd, steps, args.warmup), timed(fwd16, steps, args.warmup)
-    rf, rfb, _ = shape(38400, head.t_table(dev))
-    t_rf, t_rfb = timed(rf, 10, 2), timed(rfb, 5, 1)
-    grid_bytes = grid.numel() * 4
+    def scene(name):
+        if name == 'mixed':
+            dens, semantic, color = S.render_grids_mixed(41)
+            ray_fn = S.rays_mixed
+        else:
+            _, semantic, color = S.render_grids(41)
+            xs, ys, zs = np.meshgrid(np.arange(200), np.arange(200), np.arange(16), indexing='ij')
+            rr = np.hypot(xs - 100, ys - 100)
+            dens = np.where((zs < 2) | ((rr > 40) & (rr < 60) & ((xs // 8 + ys // 8) % 2 == 0)), 4.0, -8.0).astype(np.float32)
+            ray_fn = S.rays
+        grid = M.pack_attribute_grid(T(dens), T(semantic), T(color))
+        g16 = grid.to(torch.bfloat16)
+
+        def shape(R, t):
+            o, d = ray_fn(7, R)
+            ro, rd = T(o), T(d)
+            gd, gs, gc, gl = (torch.randn(R, device=dev), torch.randn(R, 17, device=dev), torch.randn(R, 3, device=dev),
+                              torch.randn(R, device=dev))
+            gg = torch.zeros_like(grid)
+            dbg = ops.render_rays(ro, rd, t, grid, consts, want_debug=True)
+            stats = dict(terminated_frac=round(float((dbg['alphainv_last'] < 1e-3).float().mean()), 4),
+                         kept_samples_per_ray=round(float(dbg['counts'][:, 2].float().mean()), 1))
+
+            def fwd():
+                ops.render_rays(ro, rd, t, grid, consts)
+
+            def fwd_bwd():
+                ops.render_rays(ro, rd, t, grid, consts)
+                gg.zero_()
+                ops.render_rays_backward(ro, rd, t, grid, consts, gd, gs, gc, gl, grad_grid=gg)
+            return fwd, fwd_bwd, (lambda: ops.render_rays(ro, rd, t, g16, consts)), stats
+        fwd, fwd_bwd, fwd16, st = shape(3072, t96)
+        t_end = time.perf_counter() + args.settle_s / 2
+        while time.perf_counter() < t_end:
+            fwd_bwd()
+        t_fb = timed(fwd_bwd, steps, args.warmup)
+        t_f, t_f16 = timed(fwd, steps, args.warmup), timed(fwd16, steps, args.warmup)
+        rf, rfb, _, st_ref = shape(38400, head.t_table(dev))
+        t_rf, t_rfb = timed(rf, 10, 2), timed(rfb, 5, 1)
+        return dict(st, forward_ms=round(t_f * 1e3, 4), forward_bf16_grid_ms=round(t_f16 * 1e3, 4), fwd_bwd_ms=round(t_fb * 1e3, 4),
+                    rays_per_s_fwd_bwd=round(3072 / t_fb, 1), forward_samples_per_s=round(3072 * 96 / t_f, 0),
+                    fwd_bwd_samples_per_s=round(3072 * 96 / t_fb, 0),
+                    reference_shape_38400x417=dict(st_ref, forward_ms=round(t_rf * 1e3, 3), fwd_bwd_ms=round(t_rfb * 1e3, 3),
+                                                   forward_samples_per_s=round(38400 * 417 / t_rf, 0))), grid.numel() * 4, t_f
+    mixed, grid_bytes, t_f = scene('mixed')
+    transparent, _, _ = scene('transparent')
     pretrain = pretrain_step_ms(dev, args)
     traffic, traffic_src = _pmc_traffic('k_render_rays')
     res = {
-        'metric': 'rays/sec (render head forward + backward, 6 cams x 512 rays x 96 samples)', 'value': round(R / t_fb, 1),
-        'unit': 'rays/s', 'n_gpus': 1, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': round(t_fb * 1e3, 4),
+        'metric': 'rays/sec (render head forward + backward, 6 cams x 512 rays x 96 samples)', 'value': mixed['rays_per_s_fwd_bwd'],
+        'unit': 'rays/s', 'n_gpus': 1, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': mixed['fwd_bwd_ms'],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {
-            'workload': 'C5: NerfHead render, 3072 rays x 96 uniform samples, packed (200,200,16,24) fp32 grid, scene-like occupancy; '
-                        'a step = forward + zero-fill of the gradient grid + backward',
-            'forward_ms': round(t_f * 1e3, 4), 'forward_bf16_grid_ms': round(t_f16 * 1e3, 4),
-            'forward_samples_per_s': round(R * 96 / t_f, 0), 'fwd_bwd_samples_per_s': round(R * 96 / t_fb, 0),
-            'reference_shape_38400x417': {'forward_ms': round(t_rf * 1e3, 3), 'fwd_bwd_ms': round(t_rfb * 1e3, 3),
-                                          'forward_samples_per_s': round(38400 * 417 / t_rf, 0)},
+            'workload': 'C5: NerfHead render, 3072 rays x 96 uniform samples, packed (200,200,16,24) fp32 grid, mixed-opacity scene '
+                        '(%.0f %% of the rays terminate at T < 1e-3); a step = forward + zero-fill of the gradient grid + backward'
+                        % (100 * mixed['terminated_frac']),
+            'terminated_frac': mixed['terminated_frac'], 'mixed': mixed, 'transparent': transparent,
+            'forward_ms': mixed['forward_ms'], 'reference_shape_38400x417': mixed['reference_shape_38400x417'],
             'pretrain_step': pretrain,
             'backward': 'pw_render_rays_backward_sorted: entries sorted by voxel, 64-bit fixed-point segmented sums, no float atomics, '
                         'bit-reproducible',
@@ -459,6 +476,7 @@ def extra_figures(args, dev):
         c = r['config']
         ex['c5'] = dict(workload='C5: NerfHead render 3072 rays x 96 samples (and the reference shape 38 400 x 417), one GPU',
                         rays_per_s_fwd_bwd=r['value'], fwd_bwd_ms=r['ms_per_step'], forward_ms=c['forward_ms'],
+                        terminated_frac=c['terminated_frac'], mixed=c['mixed'], transparent=c['transparent'],
                         reference_shape_38400x417=c['reference_shape_38400x417'], pretrain_step=c['pretrain_step'],
                         roofline=r['roofline'])
     except Exception as e:                                                # noqa: BLE001

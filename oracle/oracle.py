@@ -646,13 +646,32 @@ def render_one_scene(rays_o, rays_d, bda, density, semantic, color, consts):
     col = grid_sample_xyz(np.ascontiguousarray(color.transpose(3, 0, 1, 2)), xyz, consts)
     _, alpha = raw2alpha(dens, consts.act_shift, 0.5)
     m1 = alpha > consts.fast_color_thres
+    _alpha_all, _rid_all = alpha, ray_id
     ray_id, step_id, tt, dens, alpha, sem, col = [a[m1] for a in (ray_id, step_id, tt, dens, alpha, sem, col)]
     weights, T, last, i_s, i_e = alpha2weight(alpha, ray_id, R)
     m2 = weights > consts.fast_color_thres
+    trace = dict(ray_id=ray_id, alpha=alpha, T=T, weights=weights, alpha_all=_alpha_all, ray_id_all=_rid_all)
     ray_id, step_id, tt, alpha, sem, col, weights = [a[m2] for a in (ray_id, step_id, tt, alpha, sem, col, weights)]
     s = (1 - 1 / (1 + tt)).astype(np.float32)
     return dict(alphainv_last=last, weights=weights, ray_id=ray_id, step_id=step_id, s=s, t=tt,
-                N_ray=R, semantic=sem, color=col, mask1=m1, mask2=m2, sample_mask=mask)
+                N_ray=R, semantic=sem, color=col, mask1=m1, mask2=m2, sample_mask=mask, trace=trace)
+
+
+def render_near_tie_rays(res, rel=2e-3):
+    """Rays of a render_one_scene result on which one of the three data-dependent decisions of the reference sits within `rel` of
+    its threshold: alpha > 1e-7 (nerf_head.py:229), weight > 1e-7 (:244), T_cum < 1e-3 (render_utils_kernel.cu:597).  A correct
+    fp32 implementation with another evaluation order may decide such a sample the other way; on every other ray the kept
+    sample set must be identical.  Returns a bool (N_ray,) array."""
+    tr, R = res['trace'], res['N_ray']
+    tie = np.zeros(R, bool)
+    a = tr['alpha_all']
+    tie[tr['ray_id_all'][np.abs(a - 1e-7) <= rel * 1e-7]] = True
+    w = tr['weights']
+    visited = (tr['T'] != 1) | (w != 0) | (np.r_[True, tr['ray_id'][1:] != tr['ray_id'][:-1]] if len(w) else np.zeros(0, bool))
+    tie[tr['ray_id'][visited & (np.abs(w - 1e-7) <= rel * 1e-7)]] = True
+    t_next = tr['T'].astype(np.float64) * (1.0 - tr['alpha'].astype(np.float64))
+    tie[tr['ray_id'][visited & (np.abs(t_next - 1e-3) <= rel * 1e-3)]] = True
+    return tie
 
 
 def render_outputs(res, consts):

@@ -160,6 +160,67 @@ def rays(seed, R, n_cams=6):
     return o, d
 
 
+HARD_BLOCK = (150, 150)        # (x, y) voxel of the density-30 block of render_grids_mixed
+
+
+def render_grids_mixed(seed, X=200, Y=200, Z=16, n_sem=17, n_blocks=120):
+    """A scene in the regime released checkpoints sit in (occupied <=> density > 8.5, detectors/preworld.py:32,180): free space
+    = softplus of a negative number (~2e-3), a ground slab (two layers) and n_blocks boxes with density ~ U(10, 22) -- a ray that
+    meets them loses its transmittance within a few samples and stops at T < 1e-3 (render_utils_kernel.cu:591-603) -- plus one
+    box of density 30 around HARD_BLOCK (alpha > 0.999 per sample: a ray starting inside it keeps exactly one sample).  The
+    cameras' neighbourhood stays free.  Returns density (X,Y,Z), semantic (X,Y,Z,17), color (X,Y,Z,3)."""
+    rs = np.random.RandomState(seed)
+    raw = rs.standard_normal((X, Y, Z)).astype(np.float32) * 2 - 6
+    density = np.log1p(np.exp(raw)).astype(np.float32)
+    occ = np.zeros((X, Y, Z), bool)
+    occ[:, :, :2] = True
+    for _ in range(n_blocks):
+        x0, y0 = rs.randint(0, X - 12), rs.randint(0, Y - 12)
+        sx, sy = rs.randint(2, 12, 2)
+        occ[x0:x0 + sx, y0:y0 + sy, 2:rs.randint(3, 14)] = True
+    occ[X // 2 - 8:X // 2 + 8, Y // 2 - 8:Y // 2 + 8, 2:] = False
+    density = np.where(occ, rs.uniform(10, 22, (X, Y, Z)).astype(np.float32), density)
+    hx, hy = HARD_BLOCK
+    if hx + 4 <= X and hy + 4 <= Y:
+        density[hx - 4:hx + 4, hy - 4:hy + 4, :] = 30.0
+    semantic = rs.standard_normal((X, Y, Z, n_sem)).astype(np.float32)
+    color = rs.standard_normal((X, Y, Z, 3)).astype(np.float32)
+    return density, semantic, color
+
+
+def rays_mixed(seed, R, n_cams=6, n_special=8):
+    """rays for render_grids_mixed: R - n_special from the camera centres with a wide, downward-biased pitch spread (most meet the
+    ground slab or a box), then n_special rays starting INSIDE the density-30 block (one kept sample each)."""
+    rs = np.random.RandomState(seed)
+    rig = synthetic_rig(n_cams)
+    cam = rs.randint(0, n_cams, R)
+    o = rig['sensor2ego'][0, :, :3, 3][cam].astype(np.float32)
+    d = rs.standard_normal((R, 3)).astype(np.float32)
+    d[:, 2] = d[:, 2] * 0.5 - 0.2
+    n_special = min(n_special, R)
+    if n_special:
+        hx, hy = HARD_BLOCK
+        o[R - n_special:] = np.array([-40 + 0.4 * hx, -40 + 0.4 * hy, 1.0], np.float32) + \
+            rs.uniform(-0.5, 0.5, (n_special, 3)).astype(np.float32)
+    return o, d
+
+
+def render_grids_void(seed, X=200, Y=200, Z=16, n_sem=17):
+    """density -5 everywhere: alpha = 1 - (1 + e^(-5 - 13.8))^-0.5 ~ 3e-9 is below fast_color_thres = 1e-7, so every sample INSIDE
+    the grid goes in the first compaction (nerf_head.py:229-238); out-of-grid samples read 0 and stay.  A horizontal ray
+    (rays_void) never leaves the grid and keeps nothing."""
+    rs = np.random.RandomState(seed)
+    return (np.full((X, Y, Z), -5.0, np.float32), rs.standard_normal((X, Y, Z, n_sem)).astype(np.float32),
+            rs.standard_normal((X, Y, Z, 3)).astype(np.float32))
+
+
+def rays_void(seed, R, n_cams=6):
+    """every second ray exactly horizontal (d_z = 0: all of its samples are inside the grid's z range)"""
+    o, d = rays(seed, R, n_cams)
+    d[::2, 2] = 0.0
+    return o, d
+
+
 def ray_label_inputs(seed, n_cams=4, n_pts=(300, 257, 64, 1)):
     """Seeded labelled pixels per camera for the ray-table rows (mmdet3d/datasets/ray.py):
     lists of coor (n,2) pixel xy, depth (n), seg (n) class ids as float, rgb (n,3), c2w (4,4), K (3,3)."""

@@ -392,6 +392,161 @@ def test_render_bf16_grid_storage():
         check_close('bf16-stored grid vs fp32 grid: %s' % k, out16[k], out32[k].cpu().numpy(), tol)
 
 
+# ----------------------------------------------------------------------------- rays that terminate
+_BDA_MIXED = np.array([[0.98, 0.05, 0.0], [-0.05, 0.98, 0.0], [0.0, 0.0, 1.0]], np.float32)
+# Tolerance of the opaque regime (derivation in tools/gen_golden.py:gen_render_mixed): at a free / occupied face sigma changes
+# by ~20 per voxel, fp32 places a sample to ~6e-6 voxels, every opaque sample multiplies T by (1 + e^(sigma - 13.8))^-0.5 --
+# two correct fp32 evaluation orders differ by ~5e-5 relative per opaque sample.  The imported reference and the C oracle differ by
+# 2.1e-5 absolute / 2.1e-4 relative on the 'mixed' scene; the bounds below are 1e-3 relative + 5e-5 absolute on weights in [0, 1].
+_W_RTOL, _W_ATOL = 1e-3, 5e-5
+
+
+def _scene(tag, seeds):
+    if tag == 'mixed':
+        return S.render_grids_mixed(int(seeds[0])), S.rays_mixed(int(seeds[1]), 256)
+    return S.render_grids_void(int(seeds[0])), S.rays_void(int(seeds[1]), 16)
+
+
+def _check_terminating_forward(name, out, want_dense, want_last, want_depth, want_sem, want_col, want_kept, tie):
+    """fused-kernel outputs against dense (R,S) weights, alphainv_last, depth / semantic / colour and per-ray kept counts; `tie` marks
+    the rays on which a threshold decision is a near-tie (oracle.render_near_tie_rays): everywhere else the kept sample SET is equal."""
+    from _parity import check_close
+    w = out['weights'].cpu().numpy()
+    kept = out['counts'][:, 2].cpu().numpy()
+    same_set = ((w > 0) == (want_dense > 0)).all(1)
+    bad = ~same_set & ~tie
+    print('[parity] %s: %d rays, %d terminated, kept per ray %d..%d; kept sets differ on %d rays (%d near-ties allowed, %d others)'
+          % (name, len(kept), int((want_last < 1e-3).sum()), want_kept.min(), want_kept.max(), int((~same_set).sum()), int(tie.sum()),
+             int(bad.sum())))
+    assert not bad.any(), np.nonzero(bad)[0]
+    np.testing.assert_array_equal(kept[~tie], want_kept[~tie])
+    np.testing.assert_array_equal((w > 0).sum(1), kept)                     # the count the kernel reports is the count it wrote
+    ok = ~tie
+    err = np.abs(w[ok] - want_dense[ok])
+    print('[parity] %s weights: max abs err %.2e, max rel err (w > 1e-3) %.2e' % (
+        name, err.max() if err.size else 0, (err / np.maximum(want_dense[ok], 1e-3)).max() if err.size else 0))
+    assert (err <= _W_ATOL + _W_RTOL * want_dense[ok]).all()
+    # a near-tie ray gains / loses one sample of weight <= 1e-3 (termination) or ~1e-7 (culling)
+    assert np.abs(w[tie] - want_dense[tie]).max(initial=0) <= 1.1e-3
+    np.testing.assert_allclose(out['alphainv_last'].cpu().numpy()[ok], want_last[ok], rtol=2e-3, atol=1e-7)
+    assert ((out['alphainv_last'].cpu().numpy() < 1e-3) == (want_last < 1e-3))[ok].all()      # the same rays terminate
+    check_close(name + ' depth', out['depth'], want_depth, 2e-4, atol=1.1e-3 * 39 * float(tie.any()))
+    check_close(name + ' semantic', out['semantic'], want_sem, 2e-4, atol=5e-3 * float(tie.any()))
+    check_close(name + ' color', out['color'], want_col, 2e-4, atol=5e-3 * float(tie.any()))
+
+
+@pytest.mark.parametrize('tag', ['mixed', 'void'])
+def test_fused_render_terminating_rays_golden_and_oracle(golden, tag):
+    """k_render_rays where rays TERMINATE (T < 1e-3, render_utils_kernel.cu:591-603) against the imported reference NerfHead
+    (tests/golden/render_mixed.npz) and the C oracle: dense weights, alphainv_last, depth / semantic / colour, and per-ray kept
+    sample counts EQUAL (1 .. 209 on 'mixed', incl. the rays starting in the density-30 box that keep exactly one sample; 0 on
+    the horizontal rays of 'void')."""
+    g = golden('render_mixed.npz')
+    grids, (o, d) = _scene(tag, g[tag + '_seeds'])
+    R = int(g[tag + '_R'])
+    head = _head()
+    grid = M.pack_attribute_grid(*[T(a) for a in grids])
+    out = head.render(grid, T(o), T(d), torch.from_numpy(_BDA_MIXED), want_debug=True)
+    res, depth, sem, col = _oracle_render(o, d, _BDA_MIXED, *grids)
+    tie = O.render_near_tie_rays(res)
+    kept_o = np.bincount(res['ray_id'], minlength=R)
+    if tag == 'mixed':
+        assert (res['alphainv_last'] < 1e-3).sum() > 100 and (kept_o == 1).any() and kept_o.max() > 200      # the regime is the claimed one
+    else:
+        assert (kept_o == 0).sum() >= 8
+    dense = np.zeros((R, 417), np.float32)
+    dense[res['ray_id'], res['step_id']] = res['weights']
+    _check_terminating_forward(tag + ' vs oracle', out, dense, res['alphainv_last'], depth, sem, col, kept_o, tie)
+    dense_g = np.zeros((R, 417), np.float32)
+    dense_g[g[tag + '_ray_id'], g[tag + '_step_id']] = g[tag + '_weights']
+    _check_terminating_forward(tag + ' vs reference', out, dense_g, g[tag + '_alphainv_last'], g[tag + '_depth'], g[tag + '_semantic'],
+                               g[tag + '_color'], g[tag + '_kept'], tie)
+
+
+@pytest.mark.parametrize('algo', ['sorted', 'atomics'])
+@pytest.mark.parametrize('tag', ['mixed', 'void'])
+def test_render_backward_terminating_rays_golden(golden, tag, algo):
+    """both backward forms (pw_render_rays_backward_sorted, pw_render_rays_backward) on truncated rays -- the reverse scan starts at
+    the sample the forward stopped at, seeded with grad_last * alphainv_last (render_utils_kernel.cu:654-677) -- against the imported
+    reference's autograd gradients at 4096 sampled voxels + the gradient sums."""
+    from oracle import torch_render as TR
+    from _parity import check_close
+    g = golden('render_mixed.npz')
+    seeds = g[tag + '_seeds']
+    grids, (o, d) = _scene(tag, seeds)
+    R = int(g[tag + '_R'])
+    head = _head()
+    grid = M.pack_attribute_grid(*[T(a) for a in grids])
+    coef = {k: v.to(DEV) for k, v in TR.objective_coefficients(int(seeds[2]), R, 417).items()}
+    gg = ops.render_rays_backward(T(o), T(d), head.t_table(DEV), grid, head.consts(torch.from_numpy(_BDA_MIXED)), coef['depth'],
+                                  coef['semantic'], coef['color'], coef['alphainv_last'], coef['weights'], algo=algo)
+    gd, gs, gc = gg[..., 0].permute(2, 1, 0), gg[..., 2:19].permute(2, 1, 0, 3), gg[..., 19:22].permute(2, 1, 0, 3)
+    ix = tuple(torch.from_numpy(g[tag + '_voxels'][:, i].astype(np.int64)).to(DEV) for i in range(3))
+    # gradient tolerance: the weights' 1e-3 / 5e-5 (above) times the coefficients ~N(0,1), relative to the largest gradient
+    check_close('%s/%s d loss / d density (sampled voxels)' % (tag, algo), gd[ix], g[tag + '_g_density'], 5e-4)
+    check_close('%s/%s d loss / d semantic (sampled voxels)' % (tag, algo), gs[ix], g[tag + '_g_semantic'], 5e-4)
+    check_close('%s/%s d loss / d color (sampled voxels)' % (tag, algo), gc[ix], g[tag + '_g_color'], 5e-4)
+    assert abs(float(gd.double().sum()) - float(g[tag + '_sum_density'])) <= 5e-4 * float(g[tag + '_abs_density'])
+    assert (np.abs(gs.double().sum((0, 1, 2)).cpu().numpy() - g[tag + '_sum_semantic']) <= 5e-4 * g[tag + '_abs_semantic'] + 1e-6).all()
+    assert (np.abs(gc.double().sum((0, 1, 2)).cpu().numpy() - g[tag + '_sum_color']) <= 5e-4 * g[tag + '_abs_color'] + 1e-6).all()
+    assert abs(int((gd != 0).sum()) - int(g[tag + '_n_nonzero'])) <= 8 + int(g[tag + '_n_nonzero']) // 1000
+    # and through autograd (the path NerfHead.forward takes): same bits as the direct call of the default form
+    if algo == 'sorted':
+        gr = grid.clone().requires_grad_(True)
+        outs = ops.RenderRays.apply(gr, T(o), T(d), head.t_table(DEV), head.consts(torch.from_numpy(_BDA_MIXED)))
+        TR.scalar_objective(dict(zip(('depth', 'semantic', 'color', 'alphainv_last', 'weights'), outs)), coef).backward()
+        assert torch.equal(gr.grad, gg)
+
+
+def test_render_backward_terminating_rays_whole_tensor_vs_checker():
+    """another seed of the mixed scene, ragged ray count: WHOLE gradient tensors of both backward forms against the differentiable
+    CPU checker (oracle/torch_render.py, pinned to the reference on this regime by render_mixed.npz)"""
+    from oracle import torch_render as TR
+    from _parity import check_close
+    R = 333
+    grids = S.render_grids_mixed(71)
+    o, d = S.rays_mixed(72, R)
+    head = _head()
+    grid = M.pack_attribute_grid(*[T(a) for a in grids])
+    coef = TR.objective_coefficients(73, R, 417)
+    cg = [torch.from_numpy(a).requires_grad_() for a in grids]
+    cout = TR.render(o, d, _BDA_MIXED, *cg)
+    TR.scalar_objective(cout, coef).backward()
+    assert int((cout['alphainv_last'] < 1e-3).sum()) > R // 3
+    cd = {k: v.to(DEV) for k, v in coef.items()}
+    for algo in ('sorted', 'atomics'):
+        gg = ops.render_rays_backward(T(o), T(d), head.t_table(DEV), grid, head.consts(torch.from_numpy(_BDA_MIXED)), cd['depth'],
+                                      cd['semantic'], cd['color'], cd['alphainv_last'], cd['weights'], algo=algo)
+        check_close(algo + ': d loss / d density', gg[..., 0].permute(2, 1, 0), cg[0].grad.numpy(), 5e-4)
+        check_close(algo + ': d loss / d semantic', gg[..., 2:19].permute(2, 1, 0, 3), cg[1].grad.numpy(), 5e-4)
+        check_close(algo + ': d loss / d color', gg[..., 19:22].permute(2, 1, 0, 3), cg[2].grad.numpy(), 5e-4)
+
+
+def test_c5_literal_shape_mixed_scene_vs_oracle():
+    """BASELINE configs[4] literal shape (6 x 512 rays x 96 uniform samples in t in (0, 2)) on the mixed scene: ~12 % of the rays
+    terminate (96 coarse steps of 0.81 m put one or two samples into the 0.8 m ground slab; at the reference's 417 samples 49 % do)"""
+    from _parity import check_close
+    head = _head()
+    grids = S.render_grids_mixed(81)
+    o, d = S.rays_mixed(82, 3072)
+    t = ((np.arange(96, dtype=np.float32) + 0.5) * np.float32(2 / 96)).astype(np.float32)
+    grid = M.pack_attribute_grid(*[T(a) for a in grids])
+    consts = head.consts(torch.eye(3))
+    out = ops.render_rays(T(o), T(d), T(t), grid, consts, want_debug=True)
+    c = O.NerfConsts()
+    c.t_table = lambda: t
+    res = O.render_one_scene(o, d, np.eye(3, dtype=np.float32), *grids, c)
+    depth, sem, col = O.render_outputs(res, c)
+    tie = O.render_near_tie_rays(res)
+    kept_o = np.bincount(res['ray_id'], minlength=3072)
+    frac = float((res['alphainv_last'] < 1e-3).mean())
+    print('[parity] C5 literal, mixed scene: %.1f %% of the rays terminate' % (100 * frac))
+    assert frac > 0.08
+    dense = np.zeros((3072, 96), np.float32)
+    dense[res['ray_id'], res['step_id']] = res['weights']
+    _check_terminating_forward('C5 3072x96 mixed', out, dense, res['alphainv_last'], depth, sem, col, kept_o, tie)
+
+
 @pytest.mark.parametrize('R', [3072, 24000])
 def test_render_backward_sorted_is_deterministic_and_equals_the_atomic_form(R):
     """pw_render_rays_backward_sorted (entries sorted by voxel, 64-bit fixed-point segmented sums, no float atomics; VERDICT r02

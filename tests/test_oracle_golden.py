@@ -279,6 +279,34 @@ def test_render_small(golden):
     np.testing.assert_allclose(col, g['render_color'], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize('tag', ['mixed', 'void'])
+def test_render_terminating_rays(golden, tag):
+    """the C restatement against the imported reference NerfHead where rays terminate (render_mixed.npz): the same kept samples,
+    weights within the conditioning of the opaque regime (tools/gen_golden.py:gen_render_mixed)"""
+    g = golden('render_mixed.npz')
+    seeds = g[tag + '_seeds']
+    if tag == 'mixed':
+        grids, (o, d) = S.render_grids_mixed(int(seeds[0])), S.rays_mixed(int(seeds[1]), 256)
+    else:
+        grids, (o, d) = S.render_grids_void(int(seeds[0])), S.rays_void(int(seeds[1]), 16)
+    consts = O.NerfConsts()
+    res = O.render_one_scene(o, d, g['bda'], *grids, consts)
+    depth, sem, col = O.render_outputs(res, consts)
+    np.testing.assert_array_equal(res['ray_id'], g[tag + '_ray_id'])
+    np.testing.assert_array_equal(res['step_id'], g[tag + '_step_id'])
+    np.testing.assert_array_equal(np.bincount(res['ray_id'], minlength=len(o)), g[tag + '_kept'])
+    np.testing.assert_allclose(res['weights'], g[tag + '_weights'], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(res['alphainv_last'], g[tag + '_alphainv_last'], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(depth, g[tag + '_depth'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sem, g[tag + '_semantic'], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(col, g[tag + '_color'], rtol=1e-4, atol=5e-5)
+    if tag == 'mixed':
+        assert (g[tag + '_alphainv_last'] < 1e-3).sum() == 116 and g[tag + '_kept'].min() == 1 and g[tag + '_kept'].max() == 209
+        assert O.render_near_tie_rays(res).sum() <= 2
+    else:
+        assert (g[tag + '_kept'] == 0).sum() == 9
+
+
 def test_alpha2weight_backward_matches_finite_difference():
     rs = np.random.RandomState(0)
     n_rays, per = 5, 12

@@ -709,6 +709,87 @@ def gen_render_grad(nh):
          n_nonzero=np.int64(len(nz)), depth=out['depth'].detach().numpy(), alphainv_last=out['alphainv_last'].detach().numpy())
 
 
+def _ref_head(nh):
+    return nh.NerfHead(point_cloud_range=[-40, -40, -1, 40, 40, 5.4], voxel_size=0.4, scene_center=[0, 0, 2.2], radius=39,
+                       use_depth_sup=True, weight_depth=1.0, weight_semantic=1.0, weight_color=1.0)
+
+
+def gen_render_mixed(nh):
+    """the reference NerfHead on scenes whose rays TERMINATE.  'mixed' = S.render_grids_mixed (ground slab +
+    boxes with density ~U(10,22), one density-30 box; of 256 rays ~116 end at T < 1e-3 (render_utils_kernel.cu:591-603 through
+    the bound C restatement), ~53 end partly opaque, the rest stay transparent; kept samples per ray 1 .. 209); 'void' =
+    density -5 everywhere (every in-grid sample culled by the first compaction, horizontal rays keep NOTHING).  Forward:
+    compacted weights with (ray, step) ids, alphainv_last, rendered depth / semantic / colour, kept counts.  Backward: the
+    reference's autograd gradients of a seeded scalar objective at sampled voxels + sums, cross-checked here against
+    oracle/torch_render.py."""
+    from oracle import torch_render as TR
+    head = _ref_head(nh)
+    bda_np = np.array([[0.98, 0.05, 0.0], [-0.05, 0.98, 0.0], [0.0, 0.0, 1.0]], np.float32)
+    t_tab = torch.from_numpy(O.NerfConsts().t_table())
+    S_ = int(t_tab.numel())
+    out = dict(bda=bda_np)
+    for tag, grids_np, (o_np, d_np), seeds in (
+            ('mixed', S.render_grids_mixed(61), S.rays_mixed(62, 256), (61, 62, 65)),
+            ('void', S.render_grids_void(63), S.rays_void(64, 16), (63, 64, 66))):
+        R = len(o_np)
+        density, semantic, color = [torch.from_numpy(a).requires_grad_() for a in grids_np]
+        res = head.render_one_scene(torch.from_numpy(o_np), torch.from_numpy(d_np), torch.from_numpy(bda_np), density, semantic,
+                                    color, mask=None)
+        res['N_ray'] = R
+        step_id = torch.searchsorted(t_tab, res['t'])
+        assert torch.equal(t_tab[step_id], res['t'])
+        fw = dict(depth=head.render_depth(res), semantic=head.render_semantic(res), color=head.render_color(res),
+                  alphainv_last=res['alphainv_last'],
+                  weights=torch.zeros(R, S_).index_put((res['ray_id'], step_id), res['weights']))
+        coef = TR.objective_coefficients(seeds[2], R, S_)
+        TR.scalar_objective(fw, coef).backward()
+        ref = [density.grad.clone(), semantic.grad.clone(), color.grad.clone()]
+        # the oracle (C restatement) and the differentiable checker on the same scene
+        ores = O.render_one_scene(o_np, d_np, bda_np, *grids_np, O.NerfConsts())
+        od, osem, ocol = O.render_outputs(ores, O.NerfConsts())
+        np.testing.assert_array_equal(ores['ray_id'], res['ray_id'].numpy())
+        np.testing.assert_array_equal(ores['step_id'], step_id.numpy())
+        # Conditioning of the opaque regime: at a free / occupied face the density changes by ~20 per voxel, a sample position is
+        # known to ~6e-6 voxels in fp32 (|ind_norm| ~ 1 over 100 voxels), so sigma moves by ~1e-4 between two fp32 evaluation
+        # orders and every opaque sample multiplies T by (1 + e^(sigma - 13.8))^-0.5: ~5e-5 relative per sample.  Two correct fp32
+        # implementations (torch grid_sample vs the C restatement) differ by that much; the GPU tests use the same bound.
+        wdiff = np.abs(ores['weights'] - res['weights'].detach().numpy())
+        print('  render_%s: oracle vs reference weights: max abs %.2e, max rel (w > 1e-3) %.2e' % (
+            tag, wdiff.max() if len(wdiff) else 0, (wdiff / np.maximum(ores['weights'], 1e-3)).max() if len(wdiff) else 0))
+        np.testing.assert_allclose(ores['weights'], res['weights'].detach().numpy(), rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(ores['alphainv_last'], res['alphainv_last'].detach().numpy(), rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(od, fw['depth'].detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(osem, fw['semantic'].detach().numpy(), rtol=1e-4, atol=5e-5)
+        np.testing.assert_allclose(ocol, fw['color'].detach().numpy(), rtol=1e-4, atol=5e-5)
+        g2 = [torch.from_numpy(a).requires_grad_() for a in grids_np]
+        out2 = TR.render(o_np, d_np, bda_np, *g2)
+        for k in fw:
+            np.testing.assert_allclose(out2[k].detach().numpy(), fw[k].detach().numpy(), rtol=1e-3, atol=5e-5, err_msg=tag + k)
+        TR.scalar_objective(out2, coef).backward()
+        for a, b, name in zip(ref, g2, ('density', 'semantic', 'color')):
+            np.testing.assert_allclose(b.grad.numpy(), a.numpy(), rtol=1e-3, atol=2e-6 * float(a.abs().max()) + 1e-12,
+                                       err_msg=tag + name)
+        last = res['alphainv_last'].detach().numpy()
+        kept = np.bincount(res['ray_id'].numpy(), minlength=R)
+        print('  render_%s: %d rays, %d terminated (T < 1e-3), %d partly opaque, %d transparent; kept samples per ray %d .. %d'
+              % (tag, R, int((last < 1e-3).sum()), int(((last >= 1e-3) & (last < 0.99)).sum()), int((last >= 0.99).sum()),
+                 kept.min(), kept.max()))
+        rng = np.random.RandomState(seeds[2] + 100)
+        nz = torch.nonzero(ref[0].abs() > 0).numpy()
+        pick = nz[rng.choice(len(nz), min(4096, len(nz)), replace=False)]
+        ix = tuple(torch.from_numpy(pick[:, i]) for i in range(3))
+        out.update({tag + '_' + k: v for k, v in dict(
+            seeds=np.array(seeds, np.int64), R=np.int64(R), weights=res['weights'].detach().numpy(),
+            ray_id=res['ray_id'].numpy().astype(np.int32), step_id=step_id.numpy().astype(np.int16), alphainv_last=last,
+            kept=kept.astype(np.int32), depth=fw['depth'].detach().numpy(), semantic=fw['semantic'].detach().numpy(),
+            color=fw['color'].detach().numpy(), voxels=pick.astype(np.int16), g_density=ref[0][ix].numpy(),
+            g_semantic=ref[1][ix].numpy(), g_color=ref[2][ix].numpy(), sum_density=np.float64(ref[0].double().sum()),
+            abs_density=np.float64(ref[0].double().abs().sum()), sum_semantic=ref[1].double().sum((0, 1, 2)).numpy(),
+            sum_color=ref[2].double().sum((0, 1, 2)).numpy(), abs_semantic=ref[1].double().abs().sum((0, 1, 2)).numpy(),
+            abs_color=ref[2].double().abs().sum((0, 1, 2)).numpy(), n_nonzero=np.int64(len(nz))).items()})
+    save('render_mixed.npz', **out)
+
+
 def gen_metric(om):
     """G8: Metric_mIoU on seeded random labels."""
     rng = np.random.RandomState(4)
@@ -1136,6 +1217,8 @@ def main():
         gen_metric_temporal(om)
     if want('render_grad'):
         gen_render_grad(nh)
+    if want('render_mixed'):
+        gen_render_mixed(nh)
     if want('encoder_train'):
         gen_encoder_train(res)
     if want('neck_head_train'):
