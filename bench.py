@@ -644,7 +644,7 @@ def main():
     # sharded mode: every rank works on the SAME sample; replicas: each rank has its own
     frames, ego = make_inputs(dev, seed=0 if sharded else rank, n_frames=n_frames)
 
-    phase_ms = {}
+    phase_ms, phase_bytes = {}, {}
 
     def step():
         if sharded:
@@ -784,7 +784,8 @@ def main():
             harness.simple_test_sharded(net, frames, ego, n_steps=n_steps_fc, gather_on_host=oversubscribed, timings=t)
             for k, v in t.items():
                 acc[k] = acc.get(k, 0.0) + v / 5
-        phase_ms = {k: round(v, 4) for k, v in acc.items()}
+        phase_ms = {k: round(v, 4) for k, v in acc.items() if 'bytes' not in k}
+        phase_bytes = {k: int(round(v)) for k, v in acc.items() if 'bytes' in k}
 
     # every replay of the timed region stayed inside its calibrated activation ranges (pipeline.CapturedSample.ranges_ok: the
     # exponent table + recorded maxima the replays delivered to pinned host memory)
@@ -836,8 +837,10 @@ def main():
                 if graph is not None and d2h else 'device (uint8 grids stay in HBM)',
                 'single_sample_latency_ms': round(latency_ms, 4) if latency_ms else None,
                 'sharded_phase_ms_rank0': phase_ms or None,
-                'parallelism': ('frames + states sharded over %d rank(s), 2 RCCL all_gathers per sample '
-                                '(harness.simple_test_sharded)' % world) if sharded else
+                'sharded_payload_bytes_rank0': phase_bytes or None,
+                'parallelism': ('frames + states sharded over %d rank(s): per-frame features by all_gather (full rounds) / broadcast from '
+                                'the owners (2 frames on 8 ranks), uint8 states by one all_gather (harness.simple_test_sharded)' % world)
+                if sharded else
                 'replicas x%d (independent samples, no data-path collective)' % world,
                 'note': ' OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else None,
                 'excluded': 'image backbone + DepthNet (stay on PyTorch, SURVEY 8a)',

@@ -101,7 +101,8 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
     tensors: gloo in the tests; RCCL takes device tensors).
     timings: a dict that receives the milliseconds of the LAST pass's phases on this rank -- lift (LSS + pre_process of this rank's
     frames), gather_frames (the 81.92 MB per frame all_gather), encoder (cat + bev_encoder + final_conv), decode (this rank's
-    share of the recursion + OccHead), gather_states (the uint8 all_gather) -- from HIP events on the current stream (synchronises)."""
+    share of the recursion + OccHead), gather_states (the uint8 all_gather) -- from HIP events on the current stream (synchronises) --
+    and the payload bytes of the two exchanges on this rank (frames_bytes_received / _sent, states_bytes_received)."""
     from . import ops, parallel
     from .modules import precision
     vt = net.img_view_transformer
@@ -137,7 +138,7 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
         del events[:]
         mark('start')
         lifted = parallel.lift_frames_sharded(use, lift, (B, size[2], size[1], size[0], C), torch.float32, f0['depth'].device,
-                                              group, via_host=gather_on_host, mark=mark)
+                                              group, via_host=gather_on_host, mark=mark, stats=timings)
         x = torch.cat(lifted[1:][::-1] + lifted[:1], dim=-1)                   # [adjacent ..., key] (bevdet_occ.py:266)
         if len(lifted) < n:
             x = torch.cat([x.new_zeros(x.shape[:-1] + ((n - len(lifted)) * C,)), x], dim=-1)
@@ -145,7 +146,9 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
         v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.f32_to_h2(x) if h2 else x, out_h2=h2), out_h2=h2)
         mark('encoder')
         return parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k, out_h2=h2)[0][k - 1], decode,
-                                              n_steps + 1, group, mark=mark)
+                                              n_steps + 1, group, mark=mark, stats=timings,
+                                              grid_like=((int(size[0]), int(size[1]), int(size[2])), torch.uint8,
+                                                         'cpu' if gather_on_host else f0['depth'].device))
 
     if h2:
         # ranks own different tensors, so they must agree on whether another calibration pass runs (the passes contain

@@ -10,11 +10,12 @@ RCCL over xGMI on ROCm, 'gloo' in the CPU tests).
   rank recomputes the cheap recursion locally up to its largest owned state and decodes only its
   own states; ONE all_gather of uint8 grids (0.64 MB each) assembles the 7 states everywhere.
 * frame-sharded lift (the literal north_star wording): input frame f (key / adjacent) is lifted,
-  pooled and pre-processed on rank f % W and the (B,Z,Y,X,32) fp32 features (81.92 MB each) are
-  exchanged with ONE all_gather before cat + bev_encoder (bevdet_occ.py:266-267).  xGMI is point-to-point
-  (7 links x ~153 GB/s per GPU): an all-gather of one 81.92 MB shard costs ~0.5 ms
-  direct vs ~3.7 ms around a ring, i.e. comparable to the ~1 ms of lift+pre_process it saves --
-  which is why replicas, not this mode, is the throughput mode.
+  pooled and pre-processed on rank f % W and the (B,Z,Y,X,32) fp32 features (81.92 MB each) reach
+  every rank before cat + bev_encoder (bevdet_occ.py:266-267): full rounds of W frames through one
+  all_gather, the F % W frames of a partial round by broadcasts from their owners -- 2 frames on
+  8 ranks = two broadcasts, 164 MB arriving per rank.  xGMI is point-to-point (7 links x ~153 GB/s
+  per GPU): one 81.92 MB frame costs ~0.5 ms per link, i.e. comparable to the ~1 ms of
+  lift + pre_process it saves -- which is why replicas, not this mode, is the throughput mode.
 """
 import torch
 import torch.distributed as dist
@@ -41,10 +42,16 @@ def _no_mark(name):
     pass
 
 
-def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark=_no_mark):
+def _global_rank(group, r):
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
+def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark=_no_mark, grid_like=None, stats=None):
     """v0: encoder output on every rank.  forecast_fn(v0, k) -> state-k features (k >= 1 applications
     of the recursion); decode_fn(features) -> uint8 occupancy grid.  Returns the list of all
-    n_states grids (identical on every rank)."""
+    n_states grids (identical on every rank).  grid_like = (shape, dtype, device) of a decoded grid: a rank that owns no
+    state (world > n_states: rank 7 of 8 with 7 states) sizes its empty slot from it and decodes NOTHING.
+    stats (dict): receives 'states_bytes_received' = bytes of other ranks' slots that reach this rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = owned_states(n_states, rank, world)
@@ -55,15 +62,23 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark
     mark('decode')
     if world == 1 and not ALWAYS_COLLECTIVE:
         return [local[k] for k in range(n_states)]
-    # pad every rank to the same number of slots so one all_gather moves everything
+    # pad every rank to the same number of slots so one all_gather moves everything (0.64 MB per slot at 200 x 200 x 16)
     slots = (n_states + world - 1) // world
-    ref = next(iter(local.values())) if local else decode_fn(v0)
-    send = torch.zeros((slots,) + tuple(ref.shape), dtype=ref.dtype, device=ref.device)
+    if local:
+        ref = next(iter(local.values()))
+        shape, dtype, device = tuple(ref.shape), ref.dtype, ref.device
+    elif grid_like is not None:
+        shape, dtype, device = tuple(grid_like[0]), grid_like[1], torch.device(grid_like[2])
+    else:
+        raise ValueError('decode_states_sharded: rank %d of %d owns none of the %d states and was given no grid_like' % (rank, world, n_states))
+    send = torch.zeros((slots,) + shape, dtype=dtype, device=device)
     for i, k in enumerate(mine):
         send[i] = local[k]
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send, group=group)
     mark('gather_states')
+    if stats is not None:
+        stats['states_bytes_received'] = (world - 1) * send.numel() * send.element_size()
     out = [None] * n_states
     for r in range(world):
         for i, k in enumerate(owned_states(n_states, r, world)):
@@ -71,12 +86,16 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark
     return out
 
 
-def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, via_host=False, mark=_no_mark):
-    """frames: list of per-frame inputs (present on every rank); frame f is lifted by rank f % W.  The features reach
-    every rank through ONE all_gather of a (slots, *out_shape) buffer per rank (slots = ceil(F / W); 81.92 MB per frame at
-    C3) -- on xGMI's point-to-point links every rank's shard travels its own link.  Returns the list of lifted features
-    on every rank, in frame order.  via_host=True stages the buffers through host memory (gloo cannot all_gather device
-    tensors; RCCL takes them as they are)."""
+def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, via_host=False, mark=_no_mark, stats=None):
+    """frames: list of per-frame inputs (present on every rank); frame f is lifted by rank f % W.  Returns the list of lifted
+    features on every rank, in frame order.  The exchange moves every frame to every rank exactly once and nothing else:
+      * the F // W full rounds (every rank owns one frame of the round) go through ONE all_gather_into_tensor;
+      * the F % W frames of the last, partial round are BROADCAST by their owners -- with F = 2 frames on W = 8 ranks (BASELINE.json
+        configs[3]) that is two broadcasts and 2 x 81.92 = 164 MB arriving per rank (82 MB on the two owners); round 4 padded the
+        round to W slots and all-gathered 8 x 81.92 MB, six of them zeros.  On xGMI (point-to-point, 7 links x ~153 GB/s) an owner
+        feeds its 7 peers over 7 different links, ~0.54 ms per frame if the links run concurrently.
+    via_host=True stages the buffers through host memory (gloo cannot move device tensors; RCCL takes them as they are).
+    stats (dict): receives 'frames_bytes_received' / 'frames_bytes_sent' of this rank (payload, excluding its own frames)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     F = len(frames)
@@ -85,17 +104,44 @@ def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, v
         assert all(tuple(o.shape) == tuple(out_shape) for o in outs)
         mark('lift')
         return outs
-    slots = (F + world - 1) // world
-    send = torch.zeros((slots,) + tuple(out_shape), dtype=dtype, device=device)
-    for i, f in enumerate(range(rank, F, world)):
+    out_shape = tuple(out_shape)
+    n_full, tail = F // world, F % world
+    mine = list(range(rank, F, world))
+    lifted = {}
+    for f in mine:
         buf = lift_fn(frames[f])
-        assert tuple(buf.shape) == tuple(out_shape)
-        send[i].copy_(buf)
+        assert tuple(buf.shape) == out_shape
+        lifted[f] = buf.contiguous()
     mark('lift')
-    if via_host:
-        send = send.cpu()
-    recv = torch.empty((world * slots,) + tuple(out_shape), dtype=dtype, device=send.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.to(device).view((world, slots) + tuple(out_shape))
+    xdev = 'cpu' if via_host else device
+    outs = [None] * F
+    frame_bytes = dtype.itemsize
+    for d in out_shape:
+        frame_bytes *= d
+    received = sent = 0
+    if n_full:
+        send = (lifted[rank][None] if n_full == 1 else torch.stack([lifted[j * world + rank] for j in range(n_full)], 0)).to(xdev)
+        recv = torch.empty((world * n_full,) + out_shape, dtype=dtype, device=xdev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        recv = recv.view((world, n_full) + out_shape)
+        for j in range(n_full):
+            for r in range(world):
+                outs[j * world + r] = lifted[j * world + r] if r == rank else recv[r, j].to(device)
+        received += (world - 1) * n_full * frame_bytes
+        sent += (world - 1) * n_full * frame_bytes
+    works = []
+    for f in range(n_full * world, F):
+        owner = f % world
+        buf = lifted[f].to(xdev) if owner == rank else torch.empty(out_shape, dtype=dtype, device=xdev)
+        works.append((f, owner, buf, dist.broadcast(buf, src=_global_rank(group, owner), group=group, async_op=True)))
+    for f, owner, buf, w in works:
+        w.wait()
+        outs[f] = lifted[f] if owner == rank else buf.to(device)
+        if owner == rank:
+            sent += (world - 1) * frame_bytes
+        else:
+            received += frame_bytes
     mark('gather_frames')
-    return [recv[f % world, f // world] for f in range(F)]
+    if stats is not None:
+        stats['frames_bytes_received'], stats['frames_bytes_sent'] = received, sent
+    return outs

@@ -19,9 +19,16 @@ VARIANTS = {
     'small': dict(grid=GRID, cams=[1, 4]),
     # BASELINE.json configs[0]'s voxel grid with the full camera rig: 6 cameras, 100 x 100 x 8
     'c6': dict(grid={'x': [-40, 40, 0.8], 'y': [-40, 40, 0.8], 'z': [-1, 5.4, 0.8], 'depth': [1.0, 45.0, 0.5]}, cams=[0, 1, 2, 3, 4, 5]),
-    # BASELINE.json's headline grid (C3: 200 x 200 x 16) with the full camera rig; the image stays 128 x 352 (8 x 22 x 88 frustum per camera)
-    'full': dict(grid={'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 0.4], 'depth': [1.0, 45.0, 0.5]}, cams=[0, 1, 2, 3, 4, 5]),
+    # BASELINE.json's headline config as it is (C3, round 5 / VERDICT r04 item 2): 200 x 200 x 16 grid, the full camera rig AND the
+    # 512 x 1408 image -- a 32 x 88 feature map, 88 x 32 x 88 x 6 = 1 486 848 frustum points per frame
+    # (necks/view_transformer.py:84-112), intrinsics unscaled, the test-time resize 0.88 / crop -280 of loading.py:988-1000
+    'full': dict(grid={'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 0.4], 'depth': [1.0, 45.0, 0.5]}, cams=[0, 1, 2, 3, 4, 5],
+                 input_size=(512, 1408), k_scale=1.0, post_rot=(0.88, 0.004), post_tran=(3.0, -280.0, 2.0)),
 }
+
+
+def input_size(variant='small'):
+    return VARIANTS[variant].get('input_size', INPUT_SIZE)
 RUNS = [('p4d_ft', 'PreWorld4DTraj', True, True), ('p4d_ft_noprev', 'PreWorld4DTraj', True, False),
         ('p4d_attr', 'PreWorld4DTraj', False, True), ('pw_ft', 'PreWorld', True, True), ('pw_attr', 'PreWorld', False, True)]
 
@@ -30,7 +37,7 @@ def model_cfg(detector, if_post_finetune, with_prev=True, variant='small'):
     """the `model = dict(...)` of configs/preworld/**.py at the reduced grid above (cf. harness.model_cfg)"""
     from preworld_amd import harness
     cfg = harness.model_cfg(VARIANTS[variant]['grid'], with_prev=with_prev, if_post_finetune=if_post_finetune, detector=detector)
-    cfg['img_view_transformer'].update(input_size=INPUT_SIZE, in_channels=IN_CH)
+    cfg['img_view_transformer'].update(input_size=input_size(variant), in_channels=IN_CH)
     cfg['use_focal_loss'] = False        # loss objects are not part of the inference path (mmdet registry, not in the tree)
     cfg['test_threshold'] = TEST_THRESHOLD
     return cfg
@@ -56,13 +63,20 @@ def img_inputs(seed=0, variant='small'):
     s2e = np.stack([rig['sensor2ego'][0, cams]] * T, 0)                      # (T, N, 4, 4): same rig every frame
     e2g = np.stack([np.stack([_pose(0.10 - 0.03 * t, [10.0 - 2.4 * t, 5.0 - 0.3 * t, 0.2])] * N_CAMS, 0) for t in range(T)], 0)
     K = np.stack([rig['intrin'][0, cams]] * T, 0)
-    K[..., 0, 0] *= 0.25; K[..., 1, 1] *= 0.25; K[..., 0, 2] *= 0.25; K[..., 1, 2] *= 0.25     # a 128 x 352 image
-    pr = np.stack([np.stack([np.diag([0.9 + 0.05 * n, 0.9 + 0.05 * n, 1.0]) for n in range(N_CAMS)], 0)] * T, 0)
-    pt = np.stack([np.stack([np.array([3.0 * n, -20.0 + 2.0 * n, 0.0]) for n in range(N_CAMS)], 0)] * T, 0)
+    v = VARIANTS[variant]
+    ks = v.get('k_scale', 0.25)                                                                 # 0.25: a 128 x 352 image
+    K[..., 0, 0] *= ks; K[..., 1, 1] *= ks; K[..., 0, 2] *= ks; K[..., 1, 2] *= ks
+    r0, dr = v.get('post_rot', (0.9, 0.05))
+    tx, ty, dty = v.get('post_tran', (3.0, -20.0, 2.0))
+    pr = np.stack([np.stack([np.diag([r0 + dr * n, r0 + dr * n, 1.0]) for n in range(N_CAMS)], 0)] * T, 0)
+    pt = np.stack([np.stack([np.array([tx * n, ty + dty * n, 0.0]) for n in range(N_CAMS)], 0)] * T, 0)
     a = 0.05
     bda = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]) * np.array([1.02, 1.02, 1.0])[None, :]
     f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))       # noqa: E731
-    imgs = torch.from_numpy(rs.standard_normal((1, N_CAMS * T, 3) + INPUT_SIZE).astype(np.float32))
+    if v.get('input_size') is None:
+        imgs = torch.from_numpy(rs.standard_normal((1, N_CAMS * T, 3) + INPUT_SIZE).astype(np.float32))
+    else:                       # the stand-in image side reads only the shape (155 MB at 512 x 1408): no random fill
+        imgs = torch.zeros((1, N_CAMS * T, 3) + tuple(v['input_size']))
     return (imgs, f32(s2e.reshape(1, T * N_CAMS, 4, 4)), f32(e2g.reshape(1, T * N_CAMS, 4, 4)),
             f32(K.reshape(1, T * N_CAMS, 3, 3)), f32(pr.reshape(1, T * N_CAMS, 3, 3)), f32(pt.reshape(1, T * N_CAMS, 3)),
             f32(bda[None]))
@@ -77,9 +91,9 @@ class SeededDepthNet(nn.Module):
     """stands in for view_transformer.DepthNet: call k returns a seeded (B*N, D + C, H, W) tensor (depth logits + context) and
     records the `mlp_input` it was handed"""
 
-    def __init__(self, seed=0):
+    def __init__(self, seed=0, variant='small'):
         super().__init__()
-        self.seed, self.k, self.mlp_inputs = seed, 0, []
+        self.seed, self.k, self.mlp_inputs, self.size = seed, 0, [], input_size(variant)
 
     def reset(self):
         self.k, self.mlp_inputs = 0, []
@@ -88,15 +102,15 @@ class SeededDepthNet(nn.Module):
         rs = np.random.RandomState(2000 + 10 * self.seed + self.k)
         self.k += 1
         self.mlp_inputs.append(mlp_input.detach().cpu().clone())
-        H, W = INPUT_SIZE[0] // 16, INPUT_SIZE[1] // 16
+        H, W = self.size[0] // 16, self.size[1] // 16
         out = rs.standard_normal((x.shape[0], D + C, H, W)).astype(np.float32)
         out[:, :D] *= 2.0
         return torch.from_numpy(out).to(x.device)
 
 
-def install_image_side(model, seed=0):
+def install_image_side(model, seed=0, variant='small'):
     """replace the image side of a detector (reference class or drop-in) by the stand-ins; returns the SeededDepthNet"""
-    H, W = INPUT_SIZE[0] // 16, INPUT_SIZE[1] // 16
+    H, W = input_size(variant)[0] // 16, input_size(variant)[1] // 16
 
     def image_encoder(img, stereo=False):
         B, N = img.shape[:2]
@@ -107,7 +121,7 @@ def install_image_side(model, seed=0):
         return x.new_zeros(B * N, 8, 4 * H, 4 * W)
     model.image_encoder = image_encoder
     model.extract_stereo_ref_feat = extract_stereo_ref_feat
-    dn = SeededDepthNet(seed)
+    dn = SeededDepthNet(seed, variant)
     model.img_view_transformer.depth_net = dn
     return dn
 

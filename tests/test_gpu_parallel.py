@@ -36,7 +36,8 @@ def _worker(rank, world, port, q, full=False):
         ego = torch.from_numpy(S.ego_state(5)).to(dev)
         with torch.no_grad():
             want = net.simple_test_from_lift(frames, ego, n_steps=6)
-        got = harness.simple_test_sharded(net, frames, ego, n_steps=6, gather_on_host=True)
+        st = {}
+        got = harness.simple_test_sharded(net, frames, ego, n_steps=6, gather_on_host=True, timings=st)
         same = [int((got['semantic_occ_%ds' % k][0].cpu() != want['semantic_occ_%ds' % k][0].cpu()).sum()) for k in range(7)]
         # with_prev=False (C2's frame handling): the adjacent frame is dropped, its channel slice is zeros
         net.with_prev = False
@@ -44,7 +45,7 @@ def _worker(rank, world, port, q, full=False):
             want = net.simple_test_from_lift(frames, ego, n_steps=2)
         got = harness.simple_test_sharded(net, frames, ego, n_steps=2, gather_on_host=True)
         same += [int((got['semantic_occ_%ds' % k][0].cpu() != want['semantic_occ_%ds' % k][0].cpu()).sum()) for k in range(3)]
-        q.put((rank, same))
+        q.put((rank, same, {k: v for k, v in st.items() if 'bytes' in k}))
     finally:
         dist.destroy_process_group()
 
@@ -63,16 +64,46 @@ def test_sharded_lift_and_decode_two_ranks_equal_single_process(full):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert sorted(r for r, _ in res) == [0, 1]
+    assert sorted(r[0] for r in res) == [0, 1]
     # voxels that differ from the single-process result, per state (7 with the adjacent frame, 3 without).  The sharded pass
     # exchanges fp32 values and re-splits the concatenated buffer under ONE exponent, the single process keeps each frame under the
     # exponent of its own slot: values can differ below 2^-38 of a tensor's maximum, i.e. a handful of exact ties among the 640 000
     # voxels of a full-size state (the same allowance as a separately calibrated eager pass, tests/test_gpu_range.py); both ranks
     # must hold the SAME grids
     assert res[0][1] == res[1][1], res
-    for _, diff in res:
-        print('[sharded, 2 ranks, %s] differing voxels per state: %s' % ('200x200x16' if full else 'C1 grid', diff))
+    frame_bytes = (16 * 200 * 200 if full else 8 * 100 * 100) * 32 * 4
+    for rank, diff, st in res:
+        print('[sharded, 2 ranks, %s] differing voxels per state: %s; bytes %s' % ('200x200x16' if full else 'C1 grid', diff, st))
         assert max(diff) <= (8 if full else 0), diff
+        assert st['frames_bytes_received'] == frame_bytes            # 2 frames on 2 ranks: the other rank's frame, once
+
+
+def test_sharded_lift_and_decode_eight_ranks_equal_single_process():
+    """BASELINE.json configs[3]'s world size, functionally: EIGHT gloo ranks sharing the one GPU, C1 grid, the real
+    HIP modules.  Frames 0 / 1 are lifted on ranks 0 / 1 and broadcast (each rank receives the frames it did not lift: 2 x 10.24 MB,
+    1 x on the owners -- not the 8 padded slots of round 4), states 0..6 decode on ranks 0..6, rank 7 owns no state and decodes
+    nothing; every rank ends with the single-process grids."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, False)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world))
+    frame_bytes = 8 * 100 * 100 * 32 * 4
+    for rank, diff, st in res:
+        assert diff == res[0][1], (rank, diff, res[0][1])               # every rank holds the same grids
+        assert max(diff) == 0, diff
+        assert st['frames_bytes_received'] == (1 if rank < 2 else 2) * frame_bytes, (rank, st)
+        assert st['frames_bytes_sent'] == (7 * frame_bytes if rank < 2 else 0), (rank, st)
+        assert st['states_bytes_received'] == 7 * 100 * 100 * 8, (rank, st)
+    print('[sharded, 8 ranks, C1 grid] all ranks equal the single-process result; bytes received per rank: %s'
+          % [r[2]['frames_bytes_received'] for r in res])
 
 
 def _rccl_worker(port, q, full=False):
@@ -112,8 +143,8 @@ def test_rccl_device_tensor_all_gathers_world_size_1(full):
     p.join(60)
     assert p.exitcode == 0
     assert backend == 'nccl' and on_dev and max(same) <= (8 if full else 0), (backend, same)       # (ties: see the two-rank test)
-    assert set(t) == {'lift', 'gather_frames', 'encoder', 'decode', 'gather_states'}, t
-    print('[sharded, RCCL world 1, %s] phase ms: %s' % ('200x200x16' if full else 'C1 grid', {k: round(v, 3) for k, v in t.items()}))
+    assert {k for k in t if 'bytes' not in k} == {'lift', 'gather_frames', 'encoder', 'decode', 'gather_states'}, t
+    print('[sharded, RCCL world 1, %s] phase ms / bytes: %s' % ('200x200x16' if full else 'C1 grid', {k: round(v, 3) for k, v in t.items()}))
 
 
 def _syncbn_worker(rank, world, port, q):

@@ -1,4 +1,4 @@
-"""N>1 paths on CPU: world_size-2 gloo process groups exercising the sharding/gather logic of
+"""N>1 paths on CPU: world_size-2 and world_size-8 gloo process groups exercising the sharding/gather logic of
 preworld_amd.parallel with stand-in compute (no GPU kernels are called here)."""
 import os
 import socket
@@ -31,34 +31,49 @@ def _decode(f):
     return f.argmax(-1).to(torch.uint8)
 
 
-def _worker(rank, world, port, n_states, q):
+def _worker(rank, world, port, n_states, n_frames, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         g = torch.Generator().manual_seed(0)
         v0 = torch.randn(6, 5, 4, 18, generator=g)
-        states = parallel.decode_states_sharded(v0, _forecast, _decode, n_states)
+        decoded = []
+
+        def decode(f):
+            decoded.append(1)
+            return _decode(f)
+        st = {}
+        states = parallel.decode_states_sharded(v0, _forecast, decode, n_states, grid_like=((6, 5, 4), torch.uint8, 'cpu'), stats=st)
         seq = [_decode(v0 if k == 0 else _forecast(v0, k)) for k in range(n_states)]
         ok1 = all(torch.equal(a, b) for a, b in zip(states, seq))
-        frames = [torch.full((3,), float(f)) for f in range(3)]
-        lifted = parallel.lift_frames_sharded(frames, lambda fr: fr.repeat(4).view(4, 3) * 2.0 + rank * 0,
-                                              (4, 3), torch.float32, 'cpu')
+        # a rank decodes exactly its own states -- none at all if it owns none (rank 7 of 8 with 7 states)
+        ok1 = ok1 and len(decoded) == len(parallel.owned_states(n_states, rank, world))
+        frames = [torch.full((3,), float(f)) for f in range(n_frames)]
+        lifts = []
+
+        def lift(fr):
+            lifts.append(1)
+            return fr.repeat(4).view(4, 3) * 2.0
+        lifted = parallel.lift_frames_sharded(frames, lift, (4, 3), torch.float32, 'cpu', stats=st)
         ok2 = all(torch.equal(l, frames[f].repeat(4).view(4, 3) * 2.0) for f, l in enumerate(lifted))
+        n_mine = len(range(rank, n_frames, world))
+        ok2 = ok2 and len(lifts) == n_mine
+        # the exchange delivers every frame this rank did not lift exactly once: (F - own) x 48 bytes, no padding slots
+        ok2 = ok2 and st['frames_bytes_received'] == (n_frames - n_mine) * 48 and st['frames_bytes_sent'] == n_mine * (world - 1) * 48
         q.put((rank, ok1, ok2, parallel.owned_states(n_states, rank, world)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_states', [7, 2])
-def test_state_sharded_decode_world2(n_states):
+def _run(world, n_states, n_frames):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_states, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_states, n_frames, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -67,6 +82,20 @@ def test_state_sharded_decode_world2(n_states):
         assert ok1 and ok2, (rank, ok1, ok2)
         owned += mine
     assert sorted(owned) == list(range(n_states))       # every state decoded exactly once
+
+
+@pytest.mark.parametrize('n_states,n_frames', [(7, 3), (2, 2)])
+def test_state_sharded_decode_world2(n_states, n_frames):
+    """3 frames on 2 ranks: one full round through all_gather_into_tensor + one broadcast"""
+    _run(2, n_states, n_frames)
+
+
+@pytest.mark.parametrize('n_frames', [2, 11])
+def test_sharded_world8(n_frames):
+    """BASELINE.json configs[3]'s world size: 7 states on 8 ranks -- rank 7 owns none, decodes nothing and still
+    takes part in the all_gather -- and 2 frames on 8 ranks: two broadcasts, each rank receives the frames it did not lift and no
+    padding (round 4 moved 8 slots per rank); 11 frames: one full round + a partial one."""
+    _run(8, 7, n_frames)
 
 
 def test_single_process_fallbacks():

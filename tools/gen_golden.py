@@ -1054,7 +1054,7 @@ def _run_reference_detector(E, tag, det, post_ft, with_prev, sd, inputs, variant
     hot_missing = [k for k in missing if 'depth_net' not in k and 'num_batches_tracked' not in k and not k.startswith('semantic_loss')]
     assert not hot_missing and not unexpected, (hot_missing[:5], unexpected[:5])
     model.eval()
-    dn = E.install_image_side(model, seed=0)
+    dn = E.install_image_side(model, seed=0, variant=variant)
     rec, logits = {}, []
     model.final_conv.register_forward_hook(lambda m, i, o: rec.update(bev=i[0].detach(), vf=o.detach()))
     model.occupancy_head.register_forward_hook(lambda m, i, o: logits.append(o['output_voxels'][0].detach()))
@@ -1161,7 +1161,7 @@ def _gen_e2e_train_variant(E, sd, variant, runs, fname):
         model.train()
         if hasattr(model, 'set_epoch'):
             model.set_epoch(E.TRAIN_EPOCH)                      # the epoch hook's call (:156-157): epoch 7 -> future intervals 0, 1, 2
-        E.install_image_side(model, seed=0)
+        E.install_image_side(model, seed=0, variant=variant)
         kw = E.train_kwargs(0, det, variant=variant)
         losses = model.forward_train(None, [dict()], img_inputs=inputs, **kw)
         total = sum(losses.values())
