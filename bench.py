@@ -218,7 +218,9 @@ def _pmc_traffic(kernel):
     process; profiles/*_pmc_traffic.json says how they were collected and corrected), newest round first."""
     prof = os.path.join(ROOT, 'profiles')
     for name in sorted((f for f in os.listdir(prof) if f.endswith('_pmc_traffic.json')), reverse=True):
-        by = json.load(open(os.path.join(prof, name))).get('by_kernel', {})
+        doc = json.load(open(os.path.join(prof, name)))
+        by = doc.get('by_kernel', {})
+        name = '%s, library build id %s' % (name, doc.get('build_id') or 'not recorded')
         if kernel == 'k_lss_pool_slots':
             # ops.lss_lift_pool is probed as ONE unit (5 launches, the library reports its last kernel): traffic of all five
             ents = [v for k, v in by.items() if k.startswith('k_lss_')]
@@ -441,6 +443,20 @@ def c5_result(args, quick=False):
     return res
 
 
+def _sub_json(cmd, env, pick, timeout=600):
+    """run a bench command in its own process, take the last JSON line it prints, return pick(line) (or {'error': ...}: an extra figure
+    must not take the headline line down)"""
+    import subprocess
+    try:
+        out = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        if out.returncode != 0 or not lines:
+            return {'error': 'rc %d: %s' % (out.returncode, out.stderr[-300:])}
+        return pick(json.loads(lines[-1]))
+    except Exception as e:                                                # noqa: BLE001
+        return {'error': repr(e)[:300]}
+
+
 def extra_figures(args, dev):
     """compact C2, C5 and training-step figures for the driver's record, measured AFTER the headline's timed region (BASELINE.json configs[1], [4]):
     C2 = single frame, PreWorld detector, 1 state (captured step, two in flight, rotating inputs like the headline); C5 = the render
@@ -485,6 +501,23 @@ def extra_figures(args, dev):
         ex['train'] = finetune_step(dev)
     except Exception as e:                                                # noqa: BLE001
         ex['train'] = {'error': repr(e)[:300]}
+    torch.cuda.empty_cache()
+    ex['f32_exact'] = _sub_json([sys.executable, os.path.abspath(__file__), '--steps', '10', '--warmup', '3', '--settle-s', '1', '--no-extra',
+                                 '--no-cpu-baseline'], dict(PW_PRECISION='f32'),
+                                lambda r: dict(workload='C3 under PW_PRECISION=f32: every product an exact-fp32 MFMA (Winograd / direct conv '
+                                                        'kernels, k_occ_head_wino, k_forecast), same captured step, same rotating inputs',
+                                               samples_per_s=r['value'], ms_per_step=r['ms_per_step'], steps=r['steps'], dtype=r['dtype'],
+                                               roofline_kernel=r['roofline'].get('kernel'), roofline_frac=r['roofline'].get('frac')))
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'bench_image_path.py')
+    img = {}
+    for amp in ('none', 'bf16'):
+        img['image_side_' + ('f32' if amp == 'none' else 'bf16_autocast')] = _sub_json(
+            [sys.executable, tool, '--steps', '5', '--amp', amp], {},
+            lambda r: dict(samples_per_s=r['value'], ms_per_sample=r['ms_per_sample'], image_branch_ms=r['image_branch_ms'],
+                           voxel_path_ms=r['voxel_path_ms']))
+    img['what'] = ('image -> occupancy, serial, 1 GPU: 6 cams x 3 frames of 3x512x1408 through Swin-B + FPN_LSS + DepthNet with the stereo cost '
+                   'volume (PyTorch-ROCm, preworld_amd/image_encoder.py; OUTSIDE the measured path, SURVEY 8a) + the captured hot path')
+    ex['image_to_occ'] = img
     torch.cuda.empty_cache()
     return ex
 
@@ -790,7 +823,8 @@ def main():
     # every replay of the timed region stayed inside its calibrated activation ranges (pipeline.CapturedSample.ranges_ok: the
     # exponent table + recorded maxima the replays delivered to pinned host memory)
     ranges_ok = (audit['recalibrations'] == 0) if graph is not None and precision() == 'h2' else None
-    assert ranges_ok is not False or os.environ.get('PW_BENCH_ABLATION') == '1', 'replays left their calibrated activation ranges: %s' % audit   # (ablation builds, tools/ablate_step.sh, skip kernels)
+    ablation = os.environ.get('PW_BENCH_ABLATION') == '1'          # tools/ablate_step.sh: variant libraries that skip kernels; the line says so
+    assert ranges_ok is not False or ablation, 'replays left their calibrated activation ranges: %s' % audit
 
     # sanity on the produced states (cheap, outside the timed region)
     key0 = 'semantic_occ_0s' if args.config == 'C3' else 'semantic_occ'
@@ -842,7 +876,9 @@ def main():
                                 'the owners (2 frames on 8 ranks), uint8 states by one all_gather (harness.simple_test_sharded)' % world)
                 if sharded else
                 'replicas x%d (independent samples, no data-path collective)' % world,
-                'note': ' OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else None,
+                'note': (' OVERSUBSCRIBED development run, %d GPU(s): not a measurement' % n_dev if oversubscribed else
+                         'ABLATION RUN (PW_BENCH_ABLATION=1: a variant library skips kernels, outputs are garbage): timing experiment, not a '
+                         'measurement' if ablation else None),
                 'excluded': 'image backbone + DepthNet (stay on PyTorch, SURVEY 8a)',
                 'activation_ranges': ('per-tensor power-of-two exponents calibrated on each captured step\'s warm-up sample (ops.RangeCtx); '
                                       'every replay re-records each tensor\'s maximum and a kernel inside the graph tallies the replays '

@@ -27,10 +27,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// partial[block] = {sum w^2, sum bi, kept samples, 1 + last kept ray of the block (0: none)}
+// partial[block] = {sum w^2, sum bi, kept samples, 1 + last kept ray of the block (0: none) AS INT BITS -- a float holds a ray index
+// exactly only below 2^24}
 __global__ void __launch_bounds__(256) k_distortion_fwd(const float* __restrict__ w, const float* __restrict__ s, int R, int S,
                                                         float4* __restrict__ partial) {
-  __shared__ float red[4][4];
+  __shared__ float red[4][3];
+  __shared__ int last[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ray = blockIdx.x * 4 + wave;
   float a = 0.f, b = 0.f, n = 0.f;
@@ -51,37 +53,37 @@ __global__ void __launch_bounds__(256) k_distortion_fwd(const float* __restrict_
     }
   }
   a = wave_sum(a); b = wave_sum(b); n = wave_sum(n);
-  if (lane == 0) { red[wave][0] = a; red[wave][1] = b; red[wave][2] = n; red[wave][3] = (ray < R && n > 0.f) ? (float)(ray + 1) : 0.f; }
+  if (lane == 0) { red[wave][0] = a; red[wave][1] = b; red[wave][2] = n; last[wave] = (ray < R && n > 0.f) ? ray + 1 : 0; }
   __syncthreads();
   if (threadIdx.x == 0)
     partial[blockIdx.x] = make_float4(red[0][0] + red[1][0] + red[2][0] + red[3][0], red[0][1] + red[1][1] + red[2][1] + red[3][1],
                                       red[0][2] + red[1][2] + red[2][2] + red[3][2],
-                                      fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])));
+                                      __int_as_float(max(max(last[0], last[1]), max(last[2], last[3]))));
 }
 
 // loss[0] = ((1/3) A / n_kept + 2 B) / n_rays;  scal = {(2/3) / n_kept / n_rays, 2 / n_rays}: the two coefficients of the gradient
 __global__ void __launch_bounds__(256) k_distortion_finish(const float4* __restrict__ partial, int nb, float* __restrict__ loss,
                                                            float* __restrict__ scal) {
   __shared__ double red[3][256];
-  __shared__ float rmax[256];
+  __shared__ int rmax[256];
   double a = 0.0, b = 0.0, n = 0.0;
-  float m = 0.f;
+  int m = 0;
   for (int i = threadIdx.x; i < nb; i += 256) {
     const float4 p = partial[i];
-    a += (double)p.x; b += (double)p.y; n += (double)p.z; m = fmaxf(m, p.w);
+    a += (double)p.x; b += (double)p.y; n += (double)p.z; m = max(m, __float_as_int(p.w));
   }
   red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = n; rmax[threadIdx.x] = m;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
     if ((int)threadIdx.x < st) {
       red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st];
-      red[2][threadIdx.x] += red[2][threadIdx.x + st]; rmax[threadIdx.x] = fmaxf(rmax[threadIdx.x], rmax[threadIdx.x + st]);
+      red[2][threadIdx.x] += red[2][threadIdx.x + st]; rmax[threadIdx.x] = max(rmax[threadIdx.x], rmax[threadIdx.x + st]);
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     const double nk = red[2][0] < 1.0 ? 1.0 : red[2][0];             // kept.sum().clamp_min(1)
-    const double nr = rmax[0] > 0.f ? (double)rmax[0] : 1.0;         // no ray kept anything: 1
+    const double nr = rmax[0] > 0 ? (double)rmax[0] : 1.0;         // no ray kept anything: 1
     loss[0] = (float)(((1.0 / 3.0) * red[0][0] / nk + 2.0 * red[1][0]) / nr);
     scal[0] = (float)((2.0 / 3.0) / nk / nr);
     scal[1] = (float)(2.0 / nr);

@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256) k_lovasz_keys(VoxArgs a, long long n_vox,
     for (int c = 0; c < a.C; ++c) {
       if (ign_in && c == a.ignore) continue;
       unsigned k = LV_KEY_INVALID;
-      if (valid) k = lv_key(fabsf((c == t ? 1.f : 0.f) - a.x[off + c * a.sc]));
+      // probas are softmax outputs in [0, 1] (precondition of losses.lovasz_softmax); an error above 1 would wrap in the 27-bit key: clamped
+      if (valid) k = lv_key(fminf(fabsf((c == t ? 1.f : 0.f) - a.x[off + c * a.sc]), 1.f));
       const size_t pos = (size_t)seg_of(c, a.ignore, a.C) * (size_t)n_vox + (size_t)u;      // walk order: coalesced (ties sort in it)
       w.keys_in[pos] = ((unsigned)c << LV_KEY_BITS) | k;
       w.vals_in[pos] = (unsigned)v;

@@ -393,8 +393,13 @@ class BEVStereo4DOCC(nn.Module):
 def _zero_weight_of(mlp):
     """the zero-weight `loss_sup_*` term of an attribute MLP that nothing else consumes (fine-tune configs: if_render=False): the
     reference evaluates the MLP on all 640 000 voxels, a soft-target cross entropy, multiplies by 0. and back-propagates zeros through
-    both; value and gradients are known without any of it (round 4: -3 ms of the voxel-side training step)."""
+    both; value and gradients are known without any of it (round 4: -3 ms of the voxel-side training step).  One behavioural
+    difference, by design: a non-finite MLP output makes the reference's term NaN (0. * inf); this term stays 0."""
     ps = [p for p in mlp.parameters() if p.requires_grad]
+    if not ps:                                     # a frozen MLP: the reference's `loss_sup * 0.` is a plain zero there too
+        any_t = next(iter(mlp.parameters()), None)
+        any_t = next(iter(mlp.buffers()), None) if any_t is None else any_t
+        return torch.zeros((), device=any_t.device if any_t is not None else None)
     return _ZeroTerm.apply(*ps)
 
 

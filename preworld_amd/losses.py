@@ -161,7 +161,9 @@ class _Lovasz(torch.autograd.Function):
 
 def lovasz_softmax(probas, labels, classes='present', per_image=False, ignore=None, camera_mask=None):
     """Drop-in for mmdet3d/models/detectors/lovasz_softmax.py:157-174 as loss_voxel calls it (preworld.py:155):
-    probas (B,C,X,Y,Z) softmax probabilities, labels (B,X,Y,Z); classes='present', per_image=False only."""
+    probas (B,C,X,Y,Z) softmax probabilities, labels (B,X,Y,Z); classes='present', per_image=False only.
+    Precondition: probas in [0, 1] (what a softmax delivers).  The sort key holds errors |fg - p| in [0, 1] (larger ones are clamped
+    to 1) and the gradient takes its sign from fg alone (d|fg - p| / dp = -1 for fg = 1, +1 for fg = 0, true only inside [0, 1])."""
     if classes != 'present' or per_image:
         raise NotImplementedError("only classes='present', per_image=False (the reference's call) is built")
     if probas.dim() != 5:

@@ -72,7 +72,7 @@ class LSSViewTransformer(nn.Module):
         return fr
 
     def _grid(self):
-        key = (id(self.grid_lower_bound), id(self.grid_interval), id(self.grid_size))
+        key = tuple((id(t), t._version, t.data_ptr()) for t in (self.grid_lower_bound, self.grid_interval, self.grid_size))
         if getattr(self, '_grid_host', (None,))[0] != key:                 # host copies of the three 3-vectors, made once
             self._grid_host = (key, ([float(v) for v in self.grid_lower_bound], [float(v) for v in self.grid_interval],
                                      [int(v) for v in self.grid_size]))

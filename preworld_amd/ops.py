@@ -1364,6 +1364,8 @@ def distortion_loss(weights, s):
     through pw_distortion_loss_backward."""
     if weights.dim() != 2 or s.numel() != weights.shape[1]:
         raise _lib.PreworldHipError('distortion_loss: weights (R, S), s (S,)')
+    if weights.shape[0] == 0 or weights.shape[1] == 0:          # an empty ray batch: flatten_eff_distloss' sums are empty, the loss 0
+        return weights.sum() * 0.0
     return _Distortion.apply(_chk_t(weights), _chk_t(s.reshape(-1)))
 
 

@@ -19,6 +19,8 @@ Kernels:
 Everything is fp32 channels-last (B, D, H, W, C); the per-sample dense layers (and per-voxel ones of unusual width) are library GEMMs (torch.matmul /
 F.linear).  `ConvModule3d.forward_cl`, `BasicBlock3D.forward_cl`, `CustomResNet3D`, `LSSFPN3D`, `OccHead.forward` dispatch here
 when the module is in training mode; `PreWorld.forward_train` / `PreWorld4DTraj.forward_train` (detectors.py) compose them."""
+import os
+
 import torch
 
 from . import _lib, ops
@@ -117,19 +119,34 @@ def conv3d_dgrad(dy, w, x_shape, stride=1, accumulate=None):
     return dx
 
 
+def _amax_key(t):
+    return (t.data_ptr(), t._version, t.numel())
+
+
 def _amax_of(t):
     """the 256 partial maxima a BatchNorm kernel recorded when it wrote this tensor (BatchNormCL: y forward, dx backward), or None.
     They ride on the tensor object: autograd hands the same object to the consuming Function; a tensor that was summed, padded or
-    copied on the way simply arrives without them and gets an absmax pass, and so does one that was modified in place afterwards (the
-    tensor's version counter is recorded with the maxima)."""
+    copied on the way simply arrives without them and gets an absmax pass, and so does one that was modified in place afterwards or
+    re-pointed: the record is keyed on (data_ptr, version counter, numel).  A write through an alias that does not share the version
+    counter (`y.data`) is not seen by the key; PW_AMAX_CHECK=1 (tests) compares every recorded maximum with a fresh pw_absmax2 pass."""
     rec = getattr(t, '_pw_amax', None)
-    if rec is None or rec[1] != t._version:           # written to in place since the maxima were recorded: they no longer describe it
+    if rec is None or rec[1] != _amax_key(t):         # written to in place / re-pointed since the maxima were recorded
         return None
+    if _AMAX_CHECK:
+        fresh = torch.empty(512, device=t.device, dtype=_f32)
+        _lib.call('pw_absmax2', ops._p(_cl(t, 't')), t.numel(), ops._p(_cl(t, 't')), 0, ops._p(fresh), ops._stream())
+        got, want = float(rec[0].max()), float(fresh[:256].max())
+        _AMAX_STATS['checked'] += 1
+        assert got == want, 'recorded absmax %r does not describe the tensor (fresh pass: %r)' % (got, want)
     return rec[0]
 
 
+_AMAX_CHECK = os.environ.get('PW_AMAX_CHECK', '0') == '1'
+_AMAX_STATS = {'checked': 0}
+
+
 def _set_amax(t, amax):
-    t._pw_amax = (amax, t._version)
+    t._pw_amax = (amax, _amax_key(t))
 
 
 def conv3d_wgrad(x, dy, w_shape, stride=1, x_amax=None):

@@ -155,6 +155,9 @@ def test_dropin_forward_train_matches_reference_forward_train(tag, det, variant)
         net.set_epoch(E.TRAIN_EPOCH)
     E.install_image_side(net, seed=0, variant=variant)
     inputs = tuple(t.to(DEV) for t in E.img_inputs(0, variant))
+    # every maximum a BatchNorm kernel recorded for the split-fp16 weight gradient is compared with a fresh pw_absmax2 pass
+    from preworld_amd import train
+    train._AMAX_CHECK, train._AMAX_STATS['checked'] = variant == 'small', 0
     losses = net(return_loss=True, img_inputs=inputs, img_metas=[dict()], **E.train_kwargs(0, det, DEV, variant))
     assert sorted(losses.keys()) == list(G[tag + '_keys']), sorted(losses.keys())
     for k, v in losses.items():
@@ -164,6 +167,9 @@ def test_dropin_forward_train_matches_reference_forward_train(tag, det, variant)
     total = sum(losses.values())
     assert abs(float(total) - float(G[tag + '_total'])) <= 1e-4 * abs(float(G[tag + '_total']))
     total.backward()
+    if variant == 'small':
+        assert train._AMAX_STATS['checked'] > 0
+    train._AMAX_CHECK = False
     for name, p in E.grad_probes(net, det):
         g = p.grad.detach().reshape(-1)
         want = G['%s_grad_%s' % (tag, name)]

@@ -33,7 +33,9 @@ def main(vdir, dst):
         by[k] = dict(fetch_reported_bytes=int(fr), fetch_bytes=int(fr * (2 if k.startswith(WIDE) else 1)),
                      write_bytes=int(w.get(k, (0, 0.0))[1]), dispatches=f.get(k, w.get(k))[0],
                      fetch_doubled=bool(k.startswith(WIDE)))
-    json.dump({'_note': __doc__, 'source': vdir, 'by_kernel': by}, open(dst, 'w'), indent=1)
+    bid = vdir + '/build_id.txt'       # written on the GPU box by the profile script: hash of the sources the profiled library was built from
+    json.dump({'_note': __doc__, 'source': vdir, 'build_id': open(bid).read().strip() if os.path.exists(bid) else None, 'by_kernel': by},
+              open(dst, 'w'), indent=1)
     print('wrote', dst, len(by), 'kernels')
 
 
