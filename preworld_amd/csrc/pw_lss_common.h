@@ -69,23 +69,19 @@ __device__ __forceinline__ void fma4_nc(float4& acc, const float4& f, float d) {
 }
 
 
-// frustum point i -> voxel id (or -1): get_lidar_coor + the index half of voxel_pooling_prepare_v2 (view_transformer.py:114-153,
-// :226-245), one multiply / add at a time in the oracle's order
-__device__ __forceinline__ int32_t lss_voxel_of_point(int64_t i, int N, int64_t DHW, const float* __restrict__ frustum,
-                                                      const float* __restrict__ ipr, const float* __restrict__ ptr,
-                                                      const float* __restrict__ comb, const float* __restrict__ trn,
-                                                      const float* __restrict__ bda, const GridParams& gp,
-                                                      float* __restrict__ coor_out) {
-  int cam = (int)(i / DHW);
-  int64_t p = i - (int64_t)cam * DHW;
-  int b = cam / N;
-  const float* fr = frustum + p * 3;
+// frustum entry (fr0, fr1, fr2) = (x pixel, y pixel, depth) of camera `cam` -> voxel id (or -1): get_lidar_coor + the index half of
+// voxel_pooling_prepare_v2 (view_transformer.py:114-153, :226-245), one multiply / add at a time in the oracle's order.  o_out (or null)
+// receives the point in ego coordinates.
+__device__ __forceinline__ int32_t lss_voxel_of_fr(float fr0, float fr1, float fr2, int cam, int b, const float* __restrict__ ipr,
+                                                   const float* __restrict__ ptr, const float* __restrict__ comb,
+                                                   const float* __restrict__ trn, const float* __restrict__ bda, const GridParams& gp,
+                                                   float* __restrict__ o_out) {
   const float* M = ipr + cam * 9;
   const float* C = comb + cam * 9;
   const float* T = trn + cam * 3;
   const float* PT = ptr + cam * 3;
   const float* A = bda + b * 9;
-  float p0 = fr[0] - PT[0], p1 = fr[1] - PT[1], p2 = fr[2] - PT[2];
+  float p0 = fr0 - PT[0], p1 = fr1 - PT[1], p2 = fr2 - PT[2];
   float q[3], r[3], o[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -112,10 +108,10 @@ __device__ __forceinline__ int32_t lss_voxel_of_point(int64_t i, int N, int64_t 
     acc += A[k * 3 + 2] * r[2];
     o[k] = acc;
   }
-  if (coor_out) {
-    coor_out[i * 3 + 0] = o[0];
-    coor_out[i * 3 + 1] = o[1];
-    coor_out[i * 3 + 2] = o[2];
+  if (o_out) {
+    o_out[0] = o[0];
+    o_out[1] = o[1];
+    o_out[2] = o[2];
   }
   float fx = (o[0] - gp.lx) / gp.ix;
   float fy = (o[1] - gp.ly) / gp.iy;
@@ -129,6 +125,18 @@ __device__ __forceinline__ int32_t lss_voxel_of_point(int64_t i, int N, int64_t 
     v = ((b * gp.gz + z) * gp.gy + y) * gp.gx + x;
   }
   return v;
+}
+
+// frustum point i -> voxel id (or -1)
+__device__ __forceinline__ int32_t lss_voxel_of_point(int64_t i, int N, int64_t DHW, const float* __restrict__ frustum,
+                                                      const float* __restrict__ ipr, const float* __restrict__ ptr,
+                                                      const float* __restrict__ comb, const float* __restrict__ trn,
+                                                      const float* __restrict__ bda, const GridParams& gp,
+                                                      float* __restrict__ coor_out) {
+  int cam = (int)(i / DHW);
+  int64_t p = i - (int64_t)cam * DHW;
+  const float* fr = frustum + p * 3;
+  return lss_voxel_of_fr(fr[0], fr[1], fr[2], cam, cam / N, ipr, ptr, comb, trn, bda, gp, coor_out ? coor_out + i * 3 : nullptr);
 }
 
 // one lane's 4 channels (quad `sub`) of voxel row v: fp32, or split-fp16 (h2, pw_h2.h) for the fp16-matrix-core encoder
