@@ -140,22 +140,6 @@ int pw_lss_lift_pool(int B, int N, int D, int H, int W, const float* frustum, co
                      const float* feat, int c, void* workspace, size_t workspace_bytes, float* out, int out_h2,
                      int32_t* out_rng, void* stream);
 
-/* The same call as a VOXEL-DRIVEN GATHER (round 5, the default of the inference path; csrc/pw_lss_gather.hip): every voxel projects
- * its box into the cameras, the (camera, depth plane, feature pixel) candidates inside the projected bounds are put through the
- * reference's forward arithmetic and count iff they land in the voxel; candidates are visited in ascending point id, so the sums
- * run in the reference's order without a sort.  No atomics on the data path, no per-voxel slots, 3 launches, the grid written once
- * (HBM traffic ~1.05 x the algorithmic 90 MB at the C3 shape, where pw_lss_lift_pool moves 2.0 x).  Same arguments, same results
- * bit for bit.  Preconditions: cam2imgs pinhole ([[fx, s, cx], [0, fy, cy], [0, 0, 1]]), post_rots / post_trans an image-plane
- * augmentation (third row / column of post_rot = (0, 0, 1), post_trans z = 0) -- checked ON THE DEVICE, a violation fills the
- * output with NaN; frustum separable (x by column, y by row, depth by plane: create_frustum) -- the caller's to check (the Python
- * wrapper does, once per frustum tensor, and takes pw_lss_lift_pool otherwise); B * N <= 32 cameras. */
-size_t pw_lss_lift_gather_workspace_bytes(int64_t n_voxels, int BN);
-int pw_lss_lift_gather(int B, int N, int D, int H, int W, const float* frustum, const float* sensor2ego,
-                       const float* cam2imgs, const float* post_rots, const float* post_trans, const float* bda,
-                       const float* lower3_host, const float* interval3_host, int gx, int gy, int gz, const float* depth,
-                       const float* feat, int c, void* workspace, size_t workspace_bytes, float* out, int out_h2,
-                       int32_t* out_rng, void* stream);
-
 /* ---------------------------------------------------------------------------------------
  * A6-A9, A11  3-D convolution on channels-last activations, exact-fp32 MFMA implicit GEMM.
  * Replaces torch Conv3d(+BatchNorm3d eval)(+residual)(+ReLU) as composed by

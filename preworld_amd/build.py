@@ -23,7 +23,6 @@ EXTRA = {
     # geometry / pooling must round exactly like the oracle: no FMA contraction
     'pw_lss.hip': ['-ffp-contract=off'],
     'pw_lss_fused.hip': ['-ffp-contract=off'],
-    'pw_lss_gather.hip': ['-ffp-contract=off'],
     'pw_render.hip': ['-ffp-contract=off'],
     'pw_stereo.hip': ['-ffp-contract=off'],
 }

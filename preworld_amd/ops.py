@@ -174,40 +174,13 @@ def bev_pool_dense(depth, feat, vs, out=None, out_h2=False):
     return H2(out, orng) if out_h2 else out
 
 
-# PW_LSS=slots: the point-driven lift of rounds 3-4 (pw_lss_lift_pool) instead of the voxel-driven gather; PW_LSS=sort is read in modules.py
-_LSS_ALGO = 'gather' if os.environ.get('PW_LSS', 'slots') == 'gather' else 'slots'
-_FRUSTUM_SEPARABLE = {}
-
-
-def _frustum_is_separable(frustum):
-    """x depends on the column only, y on the row only, depth on the plane only, all three uniformly spaced
-    (create_frustum, view_transformer.py:84-112) -- what pw_lss_lift_gather's candidate bounds and its LDS tables assume.  One device reduction + one
-    host read per frustum TENSOR (keyed on data_ptr / version): the frustum is a module attribute, not a per-sample input."""
-    key = (frustum.data_ptr(), frustum._version, tuple(frustum.shape), str(frustum.device))
-    r = _FRUSTUM_SEPARABLE.get(key)
-    if r is None:
-        D, H, W, _ = frustum.shape
-        ok = (frustum[..., 0] == frustum[0, 0, :, 0].view(1, 1, W)).all() & (frustum[..., 1] == frustum[0, :, 0, 1].view(1, H, 1)).all() \
-            & (frustum[..., 2] == frustum[:, 0, 0, 2].view(D, 1, 1)).all()
-        for t in (frustum[0, 0, :, 0], frustum[0, :, 0, 1], frustum[:, 0, 0, 2]):
-            if t.numel() > 1:                     # uniformly spaced (linspace / arange): index = (value - first) / step within 1 %
-                step = t[1] - t[0]
-                i = torch.arange(t.numel(), device=t.device, dtype=t.dtype)
-                ok = ok & (step > 0) & ((t - (t[0] + i * step)).abs() <= 0.01 * step).all()
-        if len(_FRUSTUM_SEPARABLE) > 64:
-            _FRUSTUM_SEPARABLE.clear()
-        r = _FRUSTUM_SEPARABLE[key] = bool(ok.item())
-    return r
-
-
 def lss_lift_pool(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, lower, interval, grid_size, depth, feat,
-                  out=None, out_h2=False, algo=None):
+                  out=None, out_h2=False):
     """get_lidar_coor + voxel_pooling_prepare_v2 + bev_pool_v2 forward of one batch of frames in one call (inference, C == 32;
     view_transformer.py:114-153, :203-261, bev_pool_cuda.cu:21-48): the same bits as lss_camera_matrices -> lss_voxel_index ->
-    segment_sort -> bev_pool_dense.  depth (B,N,D,H,W), feat (B,N,H,W,C) fp32; returns (n_voxels, C) fp32 or an ops.H2 (out_h2).
-    algo: 'gather' (default: pw_lss_lift_gather, voxel-driven, 3 launches, no atomics; needs a separable frustum and B * N <= 32 cameras,
-    checks pinhole intrinsics / image-plane augmentation on the device and poisons the output with NaN otherwise) or 'slots'
-    (pw_lss_lift_pool, rounds 3-4: point-driven, returning atomics + id slots, 5 launches; PW_LSS=slots forces it)."""
+    segment_sort -> bev_pool_dense in 5 launches.  depth (B,N,D,H,W), feat (B,N,H,W,C) fp32; returns (n_voxels, C) fp32 or an
+    ops.H2 (out_h2).  (A voxel-driven gather form was built and measured in round 5 -- same bits, 1.2 x instead of 2.0 x the
+    algorithmic HBM bytes, but instruction-bound at 2-3 x the time: profiles/r05_lss_gather_experiment.md, commit 69d8f73.)"""
     B, N = sensor2ego.shape[:2]
     D, H, W, _ = frustum.shape
     C = feat.shape[-1]
@@ -218,20 +191,10 @@ def lss_lift_pool(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, low
     orng = None
     if out_h2:
         out, orng = _out_h2(out, dev)
-    algo = algo or _LSS_ALGO
-    if algo == 'gather' and not (B * N <= 32 and W + H + D <= 4096 and _frustum_is_separable(frustum)):
-        algo = 'slots'
-    f = lambda t: t.contiguous().float()
-    if algo == 'gather':
-        nbytes = _lib.call_size('pw_lss_lift_gather_workspace_bytes', n_vox, B * N)
-        name = 'pw_lss_lift_gather'
-    elif algo == 'slots':
-        nbytes = _lib.call_size('pw_lss_lift_pool_workspace_bytes', B * N * D * H * W, n_vox, B * N)
-        name = 'pw_lss_lift_pool'
-    else:
-        raise _lib.PreworldHipError("lss_lift_pool: algo must be 'gather' or 'slots'")
+    nbytes = _lib.call_size('pw_lss_lift_pool_workspace_bytes', B * N * D * H * W, n_vox, B * N)
     ws = _workspace(nbytes, dev)
-    _lib.call(name, B, N, D, H, W, _chk(frustum, _f32, 'frustum'), _chk(f(sensor2ego), _f32, 'sensor2ego'),
+    f = lambda t: t.contiguous().float()
+    _lib.call('pw_lss_lift_pool', B, N, D, H, W, _chk(frustum, _f32, 'frustum'), _chk(f(sensor2ego), _f32, 'sensor2ego'),
               _chk(f(cam2imgs), _f32, 'cam2imgs'), _chk(f(post_rots), _f32, 'post_rots'), _chk(f(post_trans), _f32, 'post_trans'),
               _chk(f(bda), _f32, 'bda'), _host3(lower), _host3(interval), int(grid_size[0]), int(grid_size[1]),
               int(grid_size[2]), _chk(depth, _f32, 'depth'), _chk(feat, _f32, 'feat'), C, _p(ws), nbytes,

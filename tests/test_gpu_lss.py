@@ -165,12 +165,10 @@ def _rig_cfg(cfg):
     return S.GRID_CONFIG_FULL, 6, 2, rig
 
 
-@pytest.mark.parametrize('algo', ['gather', 'slots'])
 @pytest.mark.parametrize('cfg', ['C1', 'full', 'full_adj_b2', 'full_aug'])
-def test_lift_pool_slots_bit_exact_vs_oracle_and_sort_path(cfg, algo):
-    """ops.lss_lift_pool -- 'gather': the voxel-driven form of round 5 (pw_lss_lift_gather: candidate bounds + the reference's forward
-    arithmetic as the membership test, no atomics); 'slots': id slots + in-group sort (pw_lss_lift_pool) -- at the BASELINE sizes, and
-    with a rotated / scaled image augmentation per camera and a rotated + scaled bda ('full_aug'): the pooled fp32 sums equal the oracle's
+def test_lift_pool_slots_bit_exact_vs_oracle_and_sort_path(cfg):
+    """ops.lss_lift_pool (id slots + in-group sort, no sort kernels) at the BASELINE sizes, and with a rotated / scaled image
+    augmentation per camera and a rotated + scaled bda ('full_aug', round 5): the pooled fp32 sums equal the oracle's
     and the sort-based path's bit for bit; the h2 form equals the sort-based path's h2 bytes and range maximum; two runs agree
     (the slot arrival order differs from run to run, the result must not)."""
     gc, N, B, rig = _rig_cfg(cfg)
@@ -184,21 +182,20 @@ def test_lift_pool_slots_bit_exact_vs_oracle_and_sort_path(cfg, algo):
     d_t, f_t = T(depth), T(featc)
     cams = [T(rig[k]) for k in ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda')]
     out = torch.full((n_vox, 32), float('nan'), device=DEV)          # every voxel must be written
-    got = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t, out=out, algo=algo)
+    got = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t, out=out)
     np.testing.assert_array_equal(got.view(B, size[2], size[1], size[0], 32).permute(0, 4, 1, 2, 3).cpu().numpy(), o_bev)
-    again = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t, algo=algo)
+    again = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t)
     assert torch.equal(got, again)
     vs = vsort(vox, n_vox, D, H * W)
     ref_h2 = ops.bev_pool_dense(d_t, f_t, vs, out_h2=True)
-    got_h2 = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t, out_h2=True, algo=algo)
+    got_h2 = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t, out_h2=True)
     assert torch.equal(got_h2.buf.view(torch.int32), ref_h2.buf.view(torch.int32))
     a, b = ops.slot_state(ref_h2.rng), ops.slot_state(got_h2.rng)
     assert a == b and b[1] > 0
 
 
-@pytest.mark.parametrize('algo', ['gather', 'slots'])
 @pytest.mark.parametrize('case', ['one_voxel', 'ragged', 'all_outside'])
-def test_lift_pool_slots_edge_cases(case, algo):
+def test_lift_pool_slots_edge_cases(case):
     """the heavy-voxel classes of ops.lss_lift_pool at their extremes: every frustum point in ONE voxel (a 5 632-point segment:
     block sort in two LDS passes), a ragged tiny frustum (point count not a multiple of 64, voxel count not a multiple of 64),
     and a rig that looks away from the grid (nothing kept: all zeros)."""
@@ -219,7 +216,7 @@ def test_lift_pool_slots_edge_cases(case, algo):
     depth = rs.random_sample((1, N, D, H, W)).astype(np.float32)
     featc = rs.standard_normal((1, N, H, W, 32)).astype(np.float32)
     cams = [T(rig[k]) for k in ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda')]
-    got = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, T(depth), T(featc), algo=algo)
+    got = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, T(depth), T(featc))
     ipr, comb, tr = O.camera_matrices(rig['sensor2ego'], rig['intrin'], rig['post_rot'])
     coor = O.lidar_coor(fr, ipr, rig['post_tran'].reshape(-1, 3), comb, tr, rig['bda'], 1, N)
     want = O.voxel_pooling_prepare_v2(coor, lower, interval, size)
@@ -233,31 +230,6 @@ def test_lift_pool_slots_edge_cases(case, algo):
         if case == 'one_voxel':
             assert len(want[0]) == N * D * H * W > 4096
     np.testing.assert_array_equal(got.view(*shape).permute(0, 4, 1, 2, 3).cpu().numpy(), o_bev)
-
-
-def test_lift_gather_poisons_the_output_when_its_preconditions_fail():
-    """pw_lss_lift_gather bounds its candidates with a pinhole camera model: a cam2img with a non-zero third row, or a post_rot that
-    mixes depth into the image plane, is detected on the device and the output filled with NaN (loud), never silently wrong; the
-    same inputs through algo='slots' (no such assumption) equal the oracle.  A frustum that is not separable is routed to 'slots' by
-    the wrapper (test_lift_pool_slots_class_boundaries scatters its points)."""
-    gc, N, B, rig = _rig_cfg('C1')
-    fr, lower, interval, size, vox, coor = _prepare(gc, S.INPUT_SIZE, S.DOWNSAMPLE, rig, B, N)
-    depth, feat = S.lift_inputs(7, B=B, N=N)
-    featc = np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2))
-    for key, (i, j) in (('intrin', (2, 0)), ('post_rot', (0, 2))):
-        bad = {k: v.copy() for k, v in rig.items()}
-        bad[key][0, 0, i, j] = 1e-4
-        cams = [T(bad[k]) for k in ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda')]
-        got = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, T(depth), T(featc), algo='gather')
-        assert bool(torch.isnan(got).all()), key
-        got_h2 = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, T(depth), T(featc), algo='gather', out_h2=True)
-        assert ops.slot_state(got_h2.rng)[1] > 65504 or not np.isfinite(ops.slot_state(got_h2.rng)[1])      # the range audit sees it
-        ref = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, T(depth), T(featc), algo='slots')
-        ipr, comb, tr = O.camera_matrices(bad['sensor2ego'], bad['intrin'], bad['post_rot'])
-        c2 = O.lidar_coor(fr, ipr, bad['post_tran'].reshape(-1, 3), comb, tr, bad['bda'], 1, N)
-        want = O.voxel_pooling_prepare_v2(c2, lower, interval, size)
-        o_bev = O.bev_pool_v2(depth, featc, want[1], want[2], want[0], (1, size[2], size[1], size[0], 32), want[3], want[4])
-        np.testing.assert_array_equal(ref.view(1, size[2], size[1], size[0], 32).permute(0, 4, 1, 2, 3).cpu().numpy(), o_bev)
 
 
 def test_lift_pool_slots_class_boundaries():

@@ -49,10 +49,3 @@ ref = ops.bev_pool_dense(d_t, f_t, vs)
 got = ops.lss_lift_pool(fr, *cams, lower, interval, size, d5, f_t)
 print('lss_lift_pool (5 launches, whole frame): fp32 %.1f us | h2 %.1f us | same bits as the sort path: %s' % (
     t_fused, t_fused_h2, bool(torch.equal(ref, got))), flush=True)
-# the voxel-driven gather (round 5, ops.lss_lift_pool's default): 3 launches, no atomics
-t_slots = timeit(lambda: ops.lss_lift_pool(fr, *cams, lower, interval, size, d5, f_t, out=out, out_h2=True, algo='slots'))
-t_gather = timeit(lambda: ops.lss_lift_pool(fr, *cams, lower, interval, size, d5, f_t, out=out, out_h2=True, algo='gather'))
-t_gather32 = timeit(lambda: ops.lss_lift_pool(fr, *cams, lower, interval, size, d5, f_t, out=out, algo='gather'))
-got_g = ops.lss_lift_pool(fr, *cams, lower, interval, size, d5, f_t, algo='gather')
-print('lss_lift_pool whole frame, h2 output: slots (5 launches) %.1f us | gather (3 launches) %.1f us (fp32 out %.1f us) = %.2f TB/s of the '
-      '90.0 MB algorithmic | same bits: %s' % (t_slots, t_gather, t_gather32, 90.0e6 / t_gather * 1e-6, bool(torch.equal(ref, got_g))), flush=True)
