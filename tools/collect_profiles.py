@@ -24,7 +24,7 @@ def main(v, what):
         lines.append('* %s: %s' % (f, out[0] if out else 'n/a'))
     with open(os.path.join(dst, v + '_bench_kernel_stats.md'), 'w') as o:
         o.write('# %s — rocprofv3 --kernel-trace --stats of bench.py (C3, 1x MI355X), %s\n\n' % (v, what))
-        o.write('Command set: `V=%s bash tools/run_profiles_r04.sh` (one gpurun call).  bench lines of the same build:\n\n' % v)
+        o.write('Command set: `V=%s bash tools/run_profiles_%s.sh` (one gpurun call).  bench lines of the same build:\n\n' % (v, v[:3]))
         o.write('\n'.join(lines) + '\n\n')
         o.write('## strictly serial (--in-flight 1): kernel time per step == wall time per step\n\n' + rd('kernel_stats_serial.md') + '\n')
         o.write('## default (2 samples in flight): kernels of the two streams overlap, so the sum exceeds wall time\n\n' + rd('kernel_stats.md') + '\n')
@@ -34,7 +34,7 @@ def main(v, what):
                 '--steps 4 --warmup 1 --settle-s 0 --no-cpu-baseline`; tables by tools/rocpd_pmc.py (KB per dispatch for the TCC counters). '
                 'FETCH_SIZE is reported at half the bytes for 16 B/lane reads on gfx950 (doubled in profiles/rNN_pmc_traffic.json for the '
                 'MFMA kernels); WRITE_SIZE exact. Matrix-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).\n\n' % v)
-        for c in ('FETCH_SIZE', 'WRITE_SIZE', 'MFMA', 'SQ', 'C5_FETCH_SIZE', 'C5_WRITE_SIZE'):
+        for c in ("FETCH_SIZE", "WRITE_SIZE", "MFMA", "SQ", "C5_FETCH_SIZE", "C5_WRITE_SIZE"):
             if os.path.exists(os.path.join(src, 'pmc_%s.md' % c)):
                 o.write('## %s%s\n%s\n' % (c, ' (bench.py --config C5: the render head)' if c.startswith('C5') else '', rd('pmc_%s.md' % c)))
     shutil.copy(os.path.join(src, 'layers_h2.txt'), os.path.join(dst, v + '_layers_h2.txt'))
