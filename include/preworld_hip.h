@@ -276,6 +276,13 @@ int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, cons
 int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* tailpk, float inv2,
                    uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H, int W, int Cin, int n_mid,
                    int n_hid, int n_cls, const int32_t* x_rng, float mid_a, float mid_b, float hid_a, float hid_b, void* stream);
+/* the same with the uint8 grids written through caller-given BYTE strides (b, d, h, w) -- e.g. a (Z,Y,X) result stored as the (X,Y,Z)-contiguous
+ * array detectors/preworld_temporal_traj.py:311-366 hands out, directly into a row of the host-payload buffer (no transposing copy);
+ * out_strides4_host NULL = contiguous; out_span_bytes = bytes from occ / geo to the end of their buffer (store bounds).  logits stay contiguous. */
+int pw_occ_head_h2_strided(const float* x, const float* wpk, const float* scale, const float* bias, const float* tailpk,
+                           float inv2, uint8_t* occ, float* logits, uint8_t* geo, const int64_t* out_strides4_host,
+                           int64_t out_span_bytes, int empty_idx, int B, int D, int H, int W, int Cin, int n_mid, int n_hid,
+                           int n_cls, const int32_t* x_rng, float mid_a, float mid_b, float hid_a, float hid_b, void* stream);
 
 /* A10  state-conditioned forecast (mmdet3d/models/detectors/preworld_temporal_traj.py:329-368).
  * pw_forecast_pack: fusion_head.{0,2}.weight ([128][64], [32][128]) -> per-lane MFMA operand

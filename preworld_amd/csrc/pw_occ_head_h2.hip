@@ -102,6 +102,7 @@ struct OhTailW {                 // per-lane resident operands of the 16 -> 8 ->
 struct OhPend {                  // the tile whose tail is in flight
   f32x4 mid[4];                  // relu(BN(conv)): channels 4 g + r of voxel i of group m
   unsigned vox[4];               // voxel index of (group m, i), PIPE_OOB when outside the volume / nothing pending
+  unsigned ovx[4];               // byte offset of that voxel in the occ / geo grids (== vox unless the caller gave strides)
 };
 
 __device__ __forceinline__ void oh_split(const f32x4& v, h4& hi, h4& lo) {
@@ -183,7 +184,7 @@ __device__ __forceinline__ void oh_tail_b(const OhCtx& c, const OccTail& tail, c
     oh_pick(best, idx, __uint_as_float(vb[1]), (int)vi[1]);
   }
   const unsigned vox = pe.vox[M];
-  const unsigned vb = g == 0 ? vox : PIPE_OOB;                      // one of the voxel's four lanes writes the bytes
+  const unsigned vb = g == 0 ? pe.ovx[M] : PIPE_OOB;                // one of the voxel's four lanes writes the bytes
   __builtin_amdgcn_raw_buffer_store_b8((unsigned char)idx, c.occr, vb, 0, 0);
   __builtin_amdgcn_raw_buffer_store_b8(idx != tail.empty_idx ? (unsigned char)0 : (unsigned char)(tail.n_cls - 1), c.geor, vb, 0, 0);
   if constexpr (LOGITS) {
@@ -243,8 +244,9 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
   c.lds3 = (lds3_t)lds;
   const unsigned nvox = (unsigned)((size_t)a.B * a.D * a.H * a.W);
   c.xr = make_rsrc(a.x, nvox * (unsigned)(KC * 4));
-  c.occr = make_rsrc(tail.occ, nvox);
-  c.geor = make_rsrc(tail.geo, tail.geo ? nvox : 0u);
+  const unsigned obytes = tail.span ? tail.span : nvox;
+  c.occr = make_rsrc(tail.occ, obytes);
+  c.geor = make_rsrc(tail.geo, tail.geo ? obytes : 0u);
   c.lgr = make_rsrc(tail.logits, tail.logits ? nvox * 72u : 0u);
   c.wave = wave; c.g = g;
   const int e_in = rng_exp(a.x_rng);        // (the load goes out here; first use behind the prologue's halo DMA)
@@ -348,6 +350,7 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
   for (int m = 0; m < 4; ++m) {
     pe.mid[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     pe.vox[m] = PIPE_OOB;
+    pe.ovx[m] = PIPE_OOB;
   }
   for (int stage = 0;; ++stage) {
     const unsigned bufoff = (stage & 1) ? (unsigned)PIPE_BUF_BYTES : 0u;
@@ -391,7 +394,9 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
         for (int r = 0; r < 4; ++r) pe.mid[m][r] = fmaxf(fmaf(acc[m][r], sc[r], bi[r]), 0.f);
         const int oh = t.h0 + m + 4 * (i >> 3);                       // group m = output rows {m, m + 4}
         const unsigned vx = (unsigned)(((t.b * a.Do + od) * a.Ho + oh) * a.Wo + ow);
-        pe.vox[m] = (okdw & (oh < a.Ho)) ? vx : PIPE_OOB;
+        const bool okv = okdw & (oh < a.Ho);
+        pe.vox[m] = okv ? vx : PIPE_OOB;
+        pe.ovx[m] = okv ? (tail.span ? (unsigned)(t.b * tail.sb + od * tail.sd + oh * tail.sh + ow * tail.sw) : vx) : PIPE_OOB;
       }
       f32x4 L[4][2];
       oh_tail_a(tw, pe, L);
@@ -415,6 +420,17 @@ PW_API int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, 
                           float inv2, uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H, int W,
                           int Cin, int n_mid, int n_hid, int n_cls, const int32_t* x_rng, float mid_a, float mid_b, float hid_a,
                           float hid_b, void* stream) {
+  return pw_occ_head_h2_strided(x, wpk, scale, bias, tailpk, inv2, occ, logits, geo, nullptr, 0, empty_idx, B, D, H, W, Cin, n_mid, n_hid,
+                                n_cls, x_rng, mid_a, mid_b, hid_a, hid_b, stream);
+}
+
+// out_strides4_host: byte strides of occ AND geo along (b, d, h, w) -- e.g. (2 XYZ, 1, Z, Y Z) writes state b's (Z, Y, X) result as
+// the (X, Y, Z)-contiguous grid the reference hands out, straight into row 2 b of a (n, 2, X, Y, Z) payload buffer -- or NULL =
+// contiguous (B, D, H, W); out_span_bytes: bytes from occ / geo to the end of the buffer they point into (bounds of the stores).
+PW_API int pw_occ_head_h2_strided(const float* x, const float* wpk, const float* scale, const float* bias, const float* tailpk,
+                                  float inv2, uint8_t* occ, float* logits, uint8_t* geo, const int64_t* out_strides4_host,
+                                  int64_t out_span_bytes, int empty_idx, int B, int D, int H, int W, int Cin, int n_mid, int n_hid,
+                                  int n_cls, const int32_t* x_rng, float mid_a, float mid_b, float hid_a, float hid_b, void* stream) {
   PW_CHECK_ARG(x && wpk && scale && bias && tailpk && occ, "pw_occ_head_h2: null pointer");
   PW_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "pw_occ_head_h2: bad shape");
   if (Cin != KC || n_mid != 16 || n_hid != 8 || n_cls != 18) {
@@ -436,7 +452,14 @@ PW_API int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, 
   if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
   const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
   PW_CHECK_ARG(nblk < (1ll << 20), "pw_occ_head_h2: too many tiles");
-  OccTail t = {nullptr, nullptr, nullptr, nullptr, occ, logits, geo, empty_idx, n_mid, n_hid, n_cls};
+  OccTail t = {nullptr, nullptr, nullptr, nullptr, occ, logits, geo, empty_idx, n_mid, n_hid, n_cls, 0, 0, 0, 0, 0u};
+  if (out_strides4_host) {
+    const int64_t* q = out_strides4_host;
+    const int64_t last = (B - 1) * q[0] + (D - 1) * q[1] + (H - 1) * q[2] + (W - 1) * q[3];
+    PW_CHECK_ARG(q[0] >= 0 && q[1] > 0 && q[2] > 0 && q[3] > 0 && last < out_span_bytes && out_span_bytes < (1ll << 31),
+                 "pw_occ_head_h2_strided: strides must be positive and stay inside out_span_bytes (< 2 GiB)");
+    t.sb = (int)q[0]; t.sd = (int)q[1]; t.sh = (int)q[2]; t.sw = (int)q[3]; t.span = (unsigned)out_span_bytes;
+  }
   PipeArgs p = {};
   p.ngroups = 1; p.n_items = (int)nblk;
   p.m_ng = magic_of(1); p.m_tw = magic_of(a.tiles_w); p.m_th = magic_of(a.tiles_h); p.m_td = magic_of(a.tiles_d);

@@ -14,6 +14,10 @@ struct OccTail {
   uint8_t* geo;         // [B*D*H*W] geo_occ or null
   int empty_idx;
   int n_mid, n_hid, n_cls;
+  // k_occ_head_h2 only (pw_occ_head_h2_strided): byte strides of occ / geo along (b, d, h, w) and the span of the buffers they live in;
+  // all zero = contiguous (B, D, H, W)
+  int sb, sd, sh, sw;
+  unsigned span;
 };
 
 #endif  // PW_OCC_TAIL_H_

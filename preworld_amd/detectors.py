@@ -693,13 +693,26 @@ class PreWorld4DTraj(_PreWorldCommon):
         feats = [v0]
         B = v0.shape[0]
         # OccHead on state 0, then on ALL forecast states in one launch (they are one contiguous (n_steps*B, Z, Y, X, C)
-        # buffer): one persistent-kernel prologue and one partial last round of tiles instead of n_steps of each
-        outs = [self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True)]
+        # buffer): one persistent-kernel prologue and one partial last round of tiles instead of n_steps of each.
+        # B == 1 (the reference's test-time batch) on the split-fp16 path: the kernel writes every state's semantic / geo grid
+        # straight into a (n_states, 2, X, Y, Z) buffer -- the reference's (X,Y,Z)-contiguous arrays in payload order -- through
+        # byte strides, so the host payload needs no transposing gather afterwards (it was a 46 us copy in every step)
+        Zd, Yd, Xd = v0.shape[1:4]
+        grids = None
+        if B == 1 and isinstance(v0, ops.H2) and precision() == 'h2':
+            grids = torch.empty(n_steps + 1, 2, Xd, Yd, Zd, device=v0.buf.device, dtype=torch.uint8)
+            zyx = lambda t: t.permute(0, 3, 2, 1)                          # (n, X, Y, Z) storage as the kernel's (n, Z, Y, X)  # noqa: E731
+            o0 = self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True,
+                                               occ_out=zyx(grids[0:1, 0]), geo_out=zyx(grids[0:1, 1]))
+        else:
+            o0 = self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True)
+        outs = [o0]
         if n_steps > 0:
             states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps, out_h2=isinstance(v0, ops.H2))
             feats += [states[k] for k in range(n_steps)]
+            extra = dict(occ_out=zyx(grids[1:, 0]), geo_out=zyx(grids[1:, 1])) if grids is not None else {}
             o = self.occupancy_head.decode_cl(states.view((n_steps * B,) + tuple(v0.shape[1:])), want_logits=want_logits,
-                                              transposed=True, want_geo=True)
+                                              transposed=True, want_geo=True, **extra)
             outs += [tuple(t[k * B:(k + 1) * B] for t in o) for k in range(n_steps)]
         logits_all = []
         for k, out in enumerate(outs):
@@ -714,6 +727,8 @@ class PreWorld4DTraj(_PreWorldCommon):
         if want_logits:
             res['logits'] = logits_all
         res['voxel_feats'] = feats
+        if grids is not None:
+            res['grids'] = grids                   # rows in the order of the semantic_occ_* / geo_occ_* keys above
         return res
 
     # ---- preworld_temporal_traj.py:224-301: density/semantic-MLP decode (if_post_finetune=False).

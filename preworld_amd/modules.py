@@ -744,12 +744,13 @@ class OccHead(nn.Module):
         wpk, s0 = packs[1 if transposed else 0]
         return wpk, s0, b0, tailpk, inv2, bounds
 
-    def decode_cl(self, x_cl, want_logits=False, transposed=False, want_geo=False):
+    def decode_cl(self, x_cl, want_logits=False, transposed=False, want_geo=False, occ_out=None, geo_out=None):
         """x_cl (B,D,H,W,C) channels-last (fp32 tensor or ops.H2) -> uint8 argmax (B,D,H,W) [, logits (B,D,H,W,18)].
         The reference feeds (1,C,X,Y,Z), i.e. kernel axes (kD,kH,kW) <-> (X,Y,Z).  With
         transposed=True, x_cl is the encoder's native (B,Z,Y,X,C) buffer and the kernel taps are
         permuted instead of the 82 MB activation; the result is then the
-        (Z,Y,X) array whose .permute(0,3,2,1) view is the reference's (X,Y,Z) output."""
+        (Z,Y,X) array whose .permute(0,3,2,1) view is the reference's (X,Y,Z) output.  occ_out / geo_out (split-fp16 path only):
+        uint8 (B,D,H,W) destinations of any strides, written in place (ops.occ_head_h2)."""
         if self.training:
             raise NotImplementedError('OccHead HIP path is eval-only')
         import os
@@ -759,7 +760,9 @@ class OccHead(nn.Module):
             # split-fp16 kernel (k_occ_head_h2); an fp32 input is converted first (30 us at 16x200x200, still ahead)
             wpk, s0, b0, tailpk, inv2, bounds = self._folded_h2(transposed)
             return ops.occ_head_h2(x_cl if is_h2 else ops.f32_to_h2(x_cl.contiguous()), wpk, s0, b0, tailpk, inv2, bounds,
-                                   want_logits=want_logits, want_geo=want_geo, empty_idx=self.empty_idx)
+                                   want_logits=want_logits, want_geo=want_geo, empty_idx=self.empty_idx, occ=occ_out, geo=geo_out)
+        if occ_out is not None or geo_out is not None:
+            raise NotImplementedError('occ_out / geo_out are built for the split-fp16 OccHead kernel')
         if is_h2:
             x_cl = ops.h2_to_f32(x_cl)
         # fp32: the 32->16 conv runs as Winograd F(2x2x2,3x3x3) (k_occ_head_wino) on grids with enough 4x8x8 tiles to

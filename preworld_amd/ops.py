@@ -859,21 +859,37 @@ def pack_occ_tail_h2(w1, s1, b1, w2):
     return torch.cat([pk, s1p, b1p]).contiguous(), 1.0 / S2
 
 
-def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, bounds, want_logits=False, occ=None, want_geo=False, empty_idx=17):
+def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, bounds, want_logits=False, occ=None, want_geo=False, empty_idx=17, geo=None):
     """OccHead (occupancy_head.py:124-177) on the fp16 matrix cores: x = ops.H2 (B,D,H,W,32); wpk from pack_occ_weight_h2;
     scale (16,) MUST already contain the packer's inv_scale; (tailpk, inv2) from pack_occ_tail_h2; bounds from occ_head_bounds.
-    Returns like occ_head_fused."""
+    Returns like occ_head_fused.  occ / geo: optional uint8 (B,D,H,W) destinations with ARBITRARY (equal) strides -- e.g. the
+    .permute(0,3,2,1) view of an (B,X,Y,Z)-contiguous payload buffer: the kernel then writes the reference's (X,Y,Z) arrays in
+    place (pw_occ_head_h2_strided) and no transposing copy is needed afterwards."""
     if not isinstance(x, H2):
         raise _lib.PreworldHipError('occ_head_h2 takes an ops.H2 input (ops.f32_to_h2)')
     B, D, H, W, Cin = x.shape
+    if geo is not None:
+        want_geo = True
     if occ is None:
         occ = torch.empty(B, D, H, W, device=x.device, dtype=torch.uint8)
     logits = torch.empty(B, D, H, W, 18, device=x.device, dtype=_f32) if want_logits else None
-    geo = torch.empty(B, D, H, W, device=x.device, dtype=torch.uint8) if want_geo else None
+    if want_geo and geo is None:
+        geo = torch.empty(occ.shape, device=x.device, dtype=torch.uint8).as_strided(occ.shape, occ.stride()) if not occ.is_contiguous() \
+            else torch.empty(B, D, H, W, device=x.device, dtype=torch.uint8)
     if tailpk.numel() != 800 or scale.numel() < 16 or bias.numel() < 16:
         raise _lib.PreworldHipError('occ_head_h2: tailpk (800,), scale / bias (16,) expected')
-    _lib.call('pw_occ_head_h2', _chk(x.buf, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
-              _chk(bias, _f32, 'bias'), _chk(tailpk, _f32, 'tailpk'), float(inv2), _p(occ), _p(logits), _p(geo),
+    for t in (occ, geo):
+        if t is not None and (tuple(t.shape) != (B, D, H, W) or t.dtype != torch.uint8 or not t.is_cuda):
+            raise _lib.PreworldHipError('occ_head_h2: occ / geo must be uint8 device tensors of shape (B, D, H, W)')
+    strides, span = None, 0
+    if not occ.is_contiguous() or (geo is not None and not geo.is_contiguous()):
+        if geo is not None and tuple(geo.stride()) != tuple(occ.stride()):
+            raise _lib.PreworldHipError('occ_head_h2: occ and geo must have the same strides')
+        st = [int(v) for v in occ.stride()]
+        strides = (ctypes.c_int64 * 4)(*st)
+        span = 1 + sum((n - 1) * v for n, v in zip((B, D, H, W), st))
+    _lib.call('pw_occ_head_h2_strided', _chk(x.buf, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
+              _chk(bias, _f32, 'bias'), _chk(tailpk, _f32, 'tailpk'), float(inv2), _p(occ), _p(logits), _p(geo), strides, int(span),
               int(empty_idx), B, D, H, W, Cin, 16, 8, 18, _rng(x), float(bounds[0]), float(bounds[1]), float(bounds[2]),
               float(bounds[3]), _stream())
     out = (occ,) + ((logits,) if want_logits else ()) + ((geo,) if want_geo else ())

@@ -61,7 +61,12 @@ class CapturedSample:
         out = self.net.simple_test_from_lift(*args, **kw)
         if self.d2h:
             keys = [k for k in out if k.startswith(('semantic_occ', 'geo_occ'))]
-            dev = torch.stack([out[k][0] for k in keys])                  # (n_grids, X, Y, Z) contiguous uint8
+            g = out.get('grids')
+            if g is not None and g.numel() == len(keys) * out[keys[0]][0].numel() and all(
+                    out[k][0].data_ptr() == g.data_ptr() + i * out[k][0].numel() for i, k in enumerate(keys)):
+                dev = g.view((len(keys),) + tuple(out[keys[0]][0].shape))  # the kernels wrote the payload rows in place
+            else:
+                dev = torch.stack([out[k][0] for k in keys])              # (n_grids, X, Y, Z) contiguous uint8
             if self.host is None:
                 self.host = torch.empty(dev.shape, dtype=torch.uint8, pin_memory=True)
                 self.host_keys = keys

@@ -172,6 +172,16 @@ def test_captured_sample_replays_like_eager():
         assert torch.equal(got2[k], want2[k]), k
         assert int((got1[k] != own1[k]).sum()) <= 8 and int((got2[k] != own2[k]).sum()) <= 8, k
     assert any(not torch.equal(got1[k], got2[k]) for k in got1)
+    # the host payload (d2h=True): the OccHead kernels write the 14 (X,Y,Z)-contiguous grids in place into one buffer (no gather copy
+    # in the step); its rows equal the result dict's grids, in key order
+    capd = CapturedSample(net, f1, e1, n_steps=6, d2h=True)
+    res = capd.run(f2, e2)
+    torch.cuda.synchronize()
+    assert 'grids' in res and len(capd.host_keys) == 14 and tuple(capd.host.shape) == (14,) + tuple(res['semantic_occ_0s'][0].shape)
+    for i, k in enumerate(capd.host_keys):
+        assert res[k][0].is_contiguous() and torch.equal(capd.host[i], res[k][0].cpu()), k
+        if k.startswith('semantic_occ'):
+            assert torch.equal(res[k][0], got2[k]), k
 
 
 def test_two_samples_in_flight_do_not_interfere():

@@ -403,6 +403,12 @@ def test_occ_head_h2_matches_direct_and_oracle(shape):
     np.testing.assert_array_equal(geo_h.cpu().numpy(), np.where(occ_h.cpu().numpy() != 17, 0, 17).astype(np.uint8))
     occ_only = ops.occ_head_h2(xh, wpk, *hargs)
     assert torch.equal(occ_only, occ_h)                      # deterministic, logits optional
+    # strided destinations (pw_occ_head_h2_strided): the (D,H,W) result written as the transposed (W,H,D)-contiguous array -- the
+    # reference's (X,Y,Z) payload -- into rows of a (B, 2, W, H, D) buffer; bytes outside the rows stay untouched
+    buf = torch.full((B, 2, W, H, D + 3), 255, dtype=torch.uint8, device=DEV)[..., :D]        # rows with a gap after every line
+    o2, g2 = ops.occ_head_h2(xh, wpk, *hargs, occ=buf[:, 0].permute(0, 3, 2, 1), geo=buf[:, 1].permute(0, 3, 2, 1))
+    assert torch.equal(buf[:, 0], occ_h.permute(0, 3, 2, 1)) and torch.equal(buf[:, 1], geo_h.permute(0, 3, 2, 1))
+    assert o2.data_ptr() == buf.data_ptr() and bool((buf._base.reshape(B, 2, W, H, D + 3)[..., D:] == 255).all())
     d1, h1, w1_ = min(D, 6), min(H, 12), min(W, 12)
     xc = x[:1, :d1, :h1, :w1_].permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
     mid = np.maximum(O.conv3d(xc, w0.cpu().numpy()) * s0.cpu().numpy()[None, :, None, None, None]
