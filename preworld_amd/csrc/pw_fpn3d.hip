@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
         if (j <= wlast) dst[j - wbase][i] = ld0 * (lh0 * v00[t] + lh1 * v01[t]) + ld1 * (lh0 * v10[t] + lh1 * v11[t]);
       }
     };
+#ifndef PW_X_FPN_NOSTAGE     // (timing-only ablation: the kernel without its low-resolution staging)
     // source-column windows of the two segments at both levels
     wb2[0] = (int)(sw2 * (float)ow0); wb4[0] = (int)(sw4 * (float)ow0);
     wb2[1] = 0; wb4[1] = 0;
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(256) k_fpn3d_fuse(ConvArgs a, FpnArgs f, long 
       stage(std::integral_constant<int, 10>{}, f.y16, f.D2, f.H2, f.W2, sd2, sh2, cols[wave][1][0], 0, min((int)(sw2 * (float)(31 - n0)) + 1, f.W2 - 1));
       stage(std::integral_constant<int, 6>{}, f.y32, f.D4, f.H4, f.W4, sd4, sh4, cols[wave][1][1], 0, min((int)(sw4 * (float)(31 - n0)) + 1, f.W4 - 1));
     }
+#endif
   }
   f32x16 acc;
 #pragma unroll
