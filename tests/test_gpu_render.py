@@ -522,6 +522,24 @@ def test_render_backward_terminating_rays_whole_tensor_vs_checker():
         check_close(algo + ': d loss / d color', gg[..., 19:22].permute(2, 1, 0, 3), cg[2].grad.numpy(), 5e-4)
 
 
+def test_reference_sampling_4096_rays_mixed_scene_vs_oracle():
+    """the reference's own sampling (417 candidates per ray, sample_ray + cumdist mask) on 4 096 rays of the mixed scene -- 47 % of
+    them terminate -- against the C oracle: kept sample sets equal off the near-tie rays, weights / alphainv_last / renders within the
+    opaque-regime bounds (a tenth of the 38 400-ray shape bench.py times; the oracle takes 4 s)"""
+    head = _head()
+    grids = S.render_grids_mixed(91)
+    R = 4096
+    o, d = S.rays_mixed(92, R)
+    grid = M.pack_attribute_grid(*[T(a) for a in grids])
+    out = head.render(grid, T(o), T(d), torch.eye(3), want_debug=True)
+    res, depth, sem, col = _oracle_render(o, d, np.eye(3, dtype=np.float32), *grids)
+    tie = O.render_near_tie_rays(res)
+    assert 0.3 < float((res['alphainv_last'] < 1e-3).mean()) < 0.7 and tie.sum() < 0.01 * R
+    dense = np.zeros((R, 417), np.float32)
+    dense[res['ray_id'], res['step_id']] = res['weights']
+    _check_terminating_forward('4096x417 mixed', out, dense, res['alphainv_last'], depth, sem, col, np.bincount(res['ray_id'], minlength=R), tie)
+
+
 def test_c5_literal_shape_mixed_scene_vs_oracle():
     """BASELINE configs[4] literal shape (6 x 512 rays x 96 uniform samples in t in (0, 2)) on the mixed scene: ~12 % of the rays
     terminate (96 coarse steps of 0.81 m put one or two samples into the 0.8 m ground slab; at the reference's 417 samples 49 % do)"""
