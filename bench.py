@@ -522,7 +522,7 @@ def extra_figures(args, dev):
     return ex
 
 
-def finetune_step(dev, n=6):
+def finetune_step(dev, n=10):
     """The voxel side of PreWorld.forward_train for the fine-tune configs at the C3 shape (preworld.py:229-309; the composition of
     tools/bench_train.py): pooling of the key frame under autograd and of the adjacent frame without, pre_process, CustomResNet3D,
     LSSFPN3D, final_conv, OccHead with batch-statistics BatchNorm, loss_voxel (CE + sem_scal + geo_scal + focal + Lovasz), backward
@@ -551,16 +551,19 @@ def finetune_step(dev, n=6):
         losses = net.forward_train_from_feats(net.bev_encoder_cl(torch.cat([adj, key], -1)), voxel_semantics=sem)
         sum(losses.values()).backward()
         return losses
-    for _ in range(2):
+    for _ in range(3):
         out = step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
+    per = []
+    for _ in range(n):                                  # every step timed on its own: the figure is the MEDIAN (an eager step of ~560 launches
+        t0 = time.perf_counter()                        # picks up allocator / host hiccups: 14.8 .. 16.8 ms seen for the same build)
         step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.median(per))
     return dict(workload='voxel side of PreWorld.forward_train, fine-tune config, C3 shape (6 cams, key + adjacent, 200x200x16), forward + '
-                         'backward, eager (no graph capture)', ms_per_step=round(ms, 2), steps=n,
+                         'backward, eager (no graph capture); median of the steps', ms_per_step=round(ms, 2), steps=n,
+                ms_min=round(min(per), 2), ms_max=round(max(per), 2),
                 losses={k: round(float(v), 4) for k, v in out.items() if 'sup' not in k})
 
 
@@ -598,12 +601,13 @@ def pretrain_step_ms(dev, args):
         for _ in range(2):
             losses = step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 5
+        n, per = 7, []
         for _ in range(n):
+            t0 = time.perf_counter()
             step()
-        torch.cuda.synchronize()
-        return {'ms': round((time.perf_counter() - t0) / n * 1e3, 2), 'rays': R, 'samples_per_ray': 417,
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) * 1e3)
+        return {'ms': round(float(np.median(per)), 2), 'ms_min': round(min(per), 2), 'ms_max': round(max(per), 2), 'rays': R, 'samples_per_ray': 417,
                 'what': 'final_conv + OccHead + attribute MLPs + NerfHead losses, forward + backward, 1 sample, eager',
                 'losses': {k: round(float(v.detach()), 4) for k, v in losses.items() if 'sup' not in k}}
     except Exception as e:                                            # noqa: BLE001  (an extra figure must not take the bench line down)
