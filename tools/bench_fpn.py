@@ -1,6 +1,8 @@
 """k_fpn3d_fuse at the C3 shape, split-fp16 in / out (what the captured step runs): time and achieved HBM rate of the 163.8 MB.
 Round 5: 69.6 us = 2.36 TB/s; a variant without the low-resolution staging (tools/build_variant.py fpn_nostage --only=pw_fpn3d.hip
--DPW_X_FPN_NOSTAGE, results garbage) 50.9 us = 3.22 TB/s: the staging costs 19 us, the streaming part itself sits at 0.40 of HBM peak."""
+-DPW_X_FPN_NOSTAGE, results garbage) 50.9 us = 3.22 TB/s: the staging costs 19 us, the streaming part itself sits at 0.40 of HBM peak.
+Staging with 16-byte loads (20 instead of 64 load instructions per wave, same arithmetic) measured 70.3 us: the cost is the dependent
+latency chain per 32-voxel wave, not the instruction count; not adopted."""
 import os
 import sys
 
