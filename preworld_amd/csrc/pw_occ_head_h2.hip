@@ -58,6 +58,26 @@ __device__ __forceinline__ void oh_dma_row(const ConvArgs& a, rsrc_t xr, lds3_t 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst + 1024, 4, v1, soff, 0, 0);
 }
 
+// the same row inside the tap loop, with the per-stage part of the address arithmetic hoisted (OhCtx::dm_base / dm_pitch) and the row's
+// (d, h) split done on compile-time constants + one carry -- ~10 instead of ~22 scalar instructions per row; a single wave per SIMD pays
+// 4 cycles of issue for each of them (k_conv3d_h2's h2_dma_row does the same)
+template <int K>
+__device__ __forceinline__ void oh_dma_row_fast(const ConvArgs& a, rsrc_t xr, lds3_t lds3, const PipeDma& dm, unsigned base, unsigned pitch,
+                                                int wave) {
+  constexpr int c1 = (4 * K) / TH, c2 = (4 * K) % TH;
+  const int t = c2 + wave;                                   // wave-uniform
+  const int carry = t >= TH ? 1 : 0;
+  const int dd = c1 + carry, hh = t - TH * carry;
+  const bool rok = (int)dm.live & (int)((unsigned)(dm.d0 - 1 + dd) < (unsigned)a.D) & (int)((unsigned)(dm.h0 - 1 + hh) < (unsigned)a.H);
+  const unsigned soff = base + (unsigned)(dd * a.H + hh) * pitch;      // rows outside the volume: every lane is out of range
+  const int par = (hh >> 2) & 1;
+  const unsigned v0 = rok ? (par ? dm.voff[1][0] : dm.voff[0][0]) : PIPE_OOB;
+  const unsigned v1 = rok ? (par ? dm.voff[1][1] : dm.voff[0][1]) : PIPE_OOB;
+  lds3_t dst = lds3 + (dm.ldsbuf + (unsigned)(c1 * TH + c2) * OH_ROW_BYTES + (unsigned)wave * OH_ROW_BYTES);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, v0, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst + 1024, 4, v1, soff, 0, 0);
+}
+
 // the 6 x {hi, lo} activation fragments of (kd, kw): R[j][p] = plane p of halo rows {j, j + 4} of d-slice wave + kd
 template <int KD, int KW>
 __device__ __forceinline__ void oh_read_group(lds3_t lds3, const unsigned (&ad)[3][2][2], h8 (&R)[6][2]) {
@@ -90,6 +110,7 @@ struct OhCtx {
   lds3_t lds3;
   rsrc_t xr, occr, geor, lgr;
   PipeDma dm;
+  unsigned dm_base, dm_pitch;    // next stage's halo: byte offset of row (d0 - 1, h0 - 1) at wbase; bytes per h row
   int wave, g;
   float inv2;
 };
@@ -203,8 +224,13 @@ template <int G>
 __device__ __forceinline__ void oh_step(const ConvArgs& a, const OhCtx& c, const unsigned (&ad)[3][2][2], const h8 (&wh)[27],
                                         const h8 (&wl)[27], h8 (&Rc)[6][2], h8 (&Rn)[6][2], f32x4 (&acc)[4]) {
   if constexpr (G + 1 < 9) oh_read_group<(G + 1) / 3, (G + 1) % 3>(c.lds3, ad, Rn);
+#ifdef PW_X_OH_OLD_DMA          // (A/B build: the row addressing of rounds 2-4)
   if constexpr (2 * G < PIPE_ROWS_PER_WAVE) oh_dma_row<2 * G>(a, c.xr, c.lds3, c.dm, c.wave);
   if constexpr (2 * G + 1 < PIPE_ROWS_PER_WAVE) oh_dma_row<2 * G + 1>(a, c.xr, c.lds3, c.dm, c.wave);
+#else
+  if constexpr (2 * G < PIPE_ROWS_PER_WAVE) oh_dma_row_fast<2 * G>(a, c.xr, c.lds3, c.dm, c.dm_base, c.dm_pitch, c.wave);
+  if constexpr (2 * G + 1 < PIPE_ROWS_PER_WAVE) oh_dma_row_fast<2 * G + 1>(a, c.xr, c.lds3, c.dm, c.dm_base, c.dm_pitch, c.wave);
+#endif
   oh_mfma_group<G / 3, G % 3>(wh, wl, Rc, acc);
   // one scheduling region: a fragment read after every third MFMA
 #pragma unroll
@@ -376,6 +402,8 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
     pipe_lane_offsets(a, tn.w0, lane, c.dm.voff);
     c.dm.b = tn.b; c.dm.d0 = tn.d0; c.dm.h0 = tn.h0; c.dm.wbase = tn.w0 > 0 ? tn.w0 - 1 : 0;
     c.dm.ch = 0; c.dm.ldsbuf = (unsigned)PIPE_BUF_BYTES - bufoff; c.dm.live = has_next;
+    c.dm_pitch = (unsigned)(a.W * KC) * 4u;
+    c.dm_base = (unsigned)(((((tn.b * a.D + tn.d0 - 1) * a.H + tn.h0 - 1) * a.W + c.dm.wbase) * KC) * 4);
 
     oh_step<0>(a, c, ad, wh, wl, R0, R1, acc);
 
