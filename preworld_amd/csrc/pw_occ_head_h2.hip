@@ -270,11 +270,13 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
   c.lds3 = (lds3_t)lds;
   const unsigned nvox = (unsigned)((size_t)a.B * a.D * a.H * a.W);
   c.xr = make_rsrc(a.x, nvox * (unsigned)(KC * 4));
-  const unsigned obytes = tail.span ? tail.span : nvox;
+  const unsigned obytes = tail.span;
   c.occr = make_rsrc(tail.occ, obytes);
   c.geor = make_rsrc(tail.geo, tail.geo ? obytes : 0u);
   c.lgr = make_rsrc(tail.logits, tail.logits ? nvox * 72u : 0u);
   c.wave = wave; c.g = g;
+  // this lane's share of a uint8 grid offset (the host always passes strides: contiguous (B, D, H, W) when the caller gave none)
+  const int lane_ovx = wave * tail.sd + (i & 7) * tail.sw + 4 * (i >> 3) * tail.sh;
   const int e_in = rng_exp(a.x_rng);        // (the load goes out here; first use behind the prologue's halo DMA)
 
   // fragment addresses: [kw][j >= 4][plane] for halo rows {j, j + 4} (row-pair base at j = 0 / immediates add (kd, j))
@@ -416,6 +418,7 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
     {
       const int od = t.d0 + wave, ow = t.w0 + (i & 7);
       const bool okdw = od < a.Do && ow < a.Wo;
+      const int obase = t.b * tail.sb + t.d0 * tail.sd + t.h0 * tail.sh + t.w0 * tail.sw;      // wave-uniform part of the grid offsets
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
         const unsigned vx = (unsigned)(((t.b * a.Do + od) * a.Ho + oh) * a.Wo + ow);
         const bool okv = okdw & (oh < a.Ho);
         pe.vox[m] = okv ? vx : PIPE_OOB;
-        pe.ovx[m] = okv ? (tail.span ? (unsigned)(t.b * tail.sb + od * tail.sd + oh * tail.sh + ow * tail.sw) : vx) : PIPE_OOB;
+        pe.ovx[m] = okv ? (unsigned)(obase + lane_ovx + m * tail.sh) : PIPE_OOB;
       }
       f32x4 L[4][2];
       oh_tail_a(tw, pe, L);
@@ -480,7 +483,8 @@ PW_API int pw_occ_head_h2_strided(const float* x, const float* wpk, const float*
   if (const char* e = getenv("PW_CONV_PROBE")) a.probe = (long long*)strtoull(e, nullptr, 0);
   const long long nblk = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
   PW_CHECK_ARG(nblk < (1ll << 20), "pw_occ_head_h2: too many tiles");
-  OccTail t = {nullptr, nullptr, nullptr, nullptr, occ, logits, geo, empty_idx, n_mid, n_hid, n_cls, 0, 0, 0, 0, 0u};
+  OccTail t = {nullptr, nullptr, nullptr, nullptr, occ, logits, geo, empty_idx, n_mid, n_hid, n_cls, D * H * W, H * W, W, 1,
+               (unsigned)((size_t)B * D * H * W)};
   if (out_strides4_host) {
     const int64_t* q = out_strides4_host;
     const int64_t last = (B - 1) * q[0] + (D - 1) * q[1] + (H - 1) * q[2] + (W - 1) * q[3];

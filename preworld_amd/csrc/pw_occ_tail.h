@@ -15,7 +15,7 @@ struct OccTail {
   int empty_idx;
   int n_mid, n_hid, n_cls;
   // k_occ_head_h2 only (pw_occ_head_h2_strided): byte strides of occ / geo along (b, d, h, w) and the span of the buffers they live in;
-  // all zero = contiguous (B, D, H, W)
+  // contiguous (B, D, H, W): (D H W, H W, W, 1) and B D H W
   int sb, sd, sh, sw;
   unsigned span;
 };
