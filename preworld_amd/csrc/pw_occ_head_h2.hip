@@ -417,15 +417,15 @@ __global__ void __launch_bounds__(256, 1) k_occ_head_h2(ConvArgs a, PipeArgs p, 
     // tail of this tile: the four groups' chains are independent and interleave in one scheduling region
     {
       const int od = t.d0 + wave, ow = t.w0 + (i & 7);
-      const bool okdw = od < a.Do && ow < a.Wo;
+      const bool okdw = od < a.D && ow < a.W;
       const int obase = t.b * tail.sb + t.d0 * tail.sd + t.h0 * tail.sh + t.w0 * tail.sw;      // wave-uniform part of the grid offsets
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) pe.mid[m][r] = fmaxf(fmaf(acc[m][r], sc[r], bi[r]), 0.f);
         const int oh = t.h0 + m + 4 * (i >> 3);                       // group m = output rows {m, m + 4}
-        const unsigned vx = (unsigned)(((t.b * a.Do + od) * a.Ho + oh) * a.Wo + ow);
-        const bool okv = okdw & (oh < a.Ho);
+        const unsigned vx = (unsigned)(((t.b * a.D + od) * a.H + oh) * a.W + ow);
+        const bool okv = okdw & (oh < a.H);
         pe.vox[m] = okv ? vx : PIPE_OOB;
         pe.ovx[m] = okv ? (unsigned)(obase + lane_ovx + m * tail.sh) : PIPE_OOB;
       }
