@@ -726,6 +726,37 @@ def nerf_losses(res, depth, sem, col, target_depth, target_sem, target_col, clas
     return out
 
 
+def nerf_head_forward(density, semantic, color, rays, bda, class_weights, consts=None, if_temporal=False, interval=0,
+                      use_depth_sup=True, weight_depth=1.0, weight_semantic=1.0, weight_color=1.0, weight_entropy_last=0.01,
+                      weight_distortion=0.01):
+    """NerfHead.forward (nerf_head.py:355-420), numpy: density (B,X,Y,Z), semantic (B,X,Y,Z,17), color (B,X,Y,Z,3), rays (B,R,16),
+    bda (B,3,3).  Per batch element: lidar depths beyond 52 m are dropped (:379, in place on `rays` as the reference does), rays
+    with gt_depth > 0 are rendered (:380, :172-174), compute_loss[_temporal] (:271-329), the per-key sum over the batch divided by
+    the batch size (:411-418).  Pinned by tests/golden/nerf_losses_small.npz (the imported reference's own forward)."""
+    consts = consts or NerfConsts()
+    sfx = '_%ds' % int(interval) if if_temporal else ''
+    weights = dict(loss_render_depth=weight_depth, loss_render_semantic=weight_semantic, loss_render_color=weight_color,
+                   loss_sdf_entropy=1.0, loss_sdf_distortion=1.0)            # (nerf_losses applies the last two itself)
+    losses = {}
+    for b in range(rays.shape[0]):
+        gt_depth = rays[b, :, 2]
+        gt_depth[gt_depth > 52] = 0
+        m = gt_depth > 0
+        res = render_one_scene(_f32(rays[b, :, 4:7][m]), _f32(rays[b, :, 7:10][m]), bda[b], density[b], semantic[b], color[b], consts)
+        depth, sem, col = render_outputs(res, consts)
+        single = nerf_losses(res, depth, sem, col, gt_depth[m], rays[b, :, 3][m], rays[b, :, 13:16][m], class_weights,
+                             weight_entropy_last, weight_distortion)
+        if not use_depth_sup:
+            single.pop('loss_render_depth')
+        if not weight_entropy_last > 0:
+            single.pop('loss_sdf_entropy')
+        if not weight_distortion > 0:
+            single.pop('loss_sdf_distortion')
+        for k, v in single.items():
+            losses[k + sfx] = losses.get(k + sfx, 0.0) + v * weights[k]
+    return {k: v / semantic.shape[0] for k, v in losses.items()}
+
+
 # --------------------------------------------------------------------------- metric
 CLASS_NAMES = ['others', 'barrier', 'bicycle', 'bus', 'car', 'construction_vehicle', 'motorcycle',
                'pedestrian', 'traffic_cone', 'trailer', 'truck', 'driveable_surface', 'other_flat',

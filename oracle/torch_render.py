@@ -89,3 +89,42 @@ def objective_coefficients(seed, R, S):
     return dict(depth=torch.randn(R, generator=g) * 0.1, semantic=torch.randn(R, 17, generator=g),
                 color=torch.randn(R, 3, generator=g), alphainv_last=torch.randn(R, generator=g),
                 weights=torch.randn(R, S, generator=g))
+
+
+def nerf_head_forward(density, semantic, color, rays, bda, class_weights, if_temporal=False, interval=0, weight_entropy_last=0.01,
+                      weight_distortion=0.01):
+    """differentiable NerfHead.forward (nerf_head.py:355-420, compute_loss[_temporal] :271-329, silog_loss / l1_loss nerf/utils.py:71-87,
+    the distortion term as oracle.flatten_eff_distloss restates the absent torch_efficient_distloss) on top of render(): torch tensors
+    density (B,X,Y,Z), semantic (B,X,Y,Z,17), color (B,X,Y,Z,3) that may require grad; rays (B,R,16) / bda (B,3,3) numpy.  All loss weights
+    1 except the two given.  Pinned by tests/golden/nerf_losses_small.npz: loss values AND grid gradients of the imported reference."""
+    sfx = '_%ds' % int(interval) if if_temporal else ''
+    cw = torch.from_numpy(np.asarray(class_weights)).float()
+    t_tab = torch.from_numpy(O.NerfConsts().t_table())
+    s_tab = 1 - 1 / (1 + t_tab)
+    losses = {}
+    for b in range(rays.shape[0]):
+        gt_depth = rays[b, :, 2]
+        gt_depth[gt_depth > 52] = 0
+        m = gt_depth > 0
+        out = render(np.ascontiguousarray(rays[b, :, 4:7][m]), np.ascontiguousarray(rays[b, :, 7:10][m]), bda[b], density[b], semantic[b], color[b])
+        tgt_d, tgt_s, tgt_c = [torch.from_numpy(np.ascontiguousarray(a)) for a in (gt_depth[m], rays[b, :, 3][m], rays[b, :, 13:16][m])]
+        d = torch.log(out['depth'] + 1e-7) - torch.log(tgt_d)
+        single = {'loss_render_depth': torch.sqrt((d ** 2).mean() - 0.85 * d.mean() ** 2),
+                  'loss_render_semantic': F.cross_entropy(out['semantic'], tgt_s.long(), weight=cw),
+                  'loss_render_color': torch.sum(torch.mean(torch.abs(out['color'] - tgt_c), dim=0))}
+        if weight_entropy_last > 0:
+            p = out['alphainv_last'].clamp(1e-6, 1 - 1e-6)
+            single['loss_sdf_entropy'] = weight_entropy_last * -(p * torch.log(p) + (1 - p) * torch.log(1 - p)).mean()
+        if weight_distortion > 0:
+            w = out['weights']                                            # (R,S) dense, 0 where culled: kept <=> w > 1e-7
+            kept = w > 0
+            n_max = int(kept.sum())
+            ray_of = torch.nonzero(kept.any(1)).reshape(-1)
+            n_rays = int(ray_of.max()) + 1 if len(ray_of) else 1
+            w_pre = torch.cumsum(w, 1) - w
+            wm_pre = torch.cumsum(w * s_tab, 1) - w * s_tab
+            single['loss_sdf_distortion'] = weight_distortion * ((1 / 3) * (1 / max(n_max, 1)) * w.pow(2)
+                                                                   + 2 * w * (s_tab * w_pre - wm_pre)).sum() / n_rays
+        for k, v in single.items():
+            losses[k + sfx] = losses[k + sfx] + v if k + sfx in losses else v
+    return {k: v / semantic.shape[0] for k, v in losses.items()}

@@ -51,27 +51,32 @@ def _pose(yaw, t):
     return m
 
 
-def img_inputs(seed=0, variant='small'):
+def _img_inputs_one(seed=0, variant='small', b=0):
     """the 7-tuple `img_inputs` the dataset pipeline delivers (datasets/pipelines/loading.py:1091-1123): imgs (B, N*T, 3, H, W)
     camera-major / frame-minor, sensor2egos / ego2globals (B, T*N, 4, 4) frame-major, intrins, post_rots, post_trans, bda.
-    T = 3 frames (key, adjacent, extra stereo reference) with a moving ego; per-camera image augmentation; a BEV augmentation."""
-    rs = np.random.RandomState(1000 + seed)
+    T = 3 frames (key, adjacent, extra stereo reference) with a moving ego; per-camera image augmentation; a BEV augmentation.
+    b > 0 (further batch elements, round 6): another ego track, other image / BEV augmentations, its own random image."""
+    rs = np.random.RandomState(1000 + seed + 100 * b)
     T = 3
     rig = S.synthetic_rig(6, dtype=np.float64)
     cams = VARIANTS[variant]['cams']
     N_CAMS = len(cams)
     s2e = np.stack([rig['sensor2ego'][0, cams]] * T, 0)                      # (T, N, 4, 4): same rig every frame
-    e2g = np.stack([np.stack([_pose(0.10 - 0.03 * t, [10.0 - 2.4 * t, 5.0 - 0.3 * t, 0.2])] * N_CAMS, 0) for t in range(T)], 0)
+    e2g = np.stack([np.stack([_pose(0.10 - 0.03 * t - 0.4 * b, [10.0 - 2.4 * t + 7.0 * b, 5.0 - 0.3 * t + 1.1 * b * t, 0.2])] * N_CAMS, 0)
+                    for t in range(T)], 0)
     K = np.stack([rig['intrin'][0, cams]] * T, 0)
     v = VARIANTS[variant]
     ks = v.get('k_scale', 0.25)                                                                 # 0.25: a 128 x 352 image
     K[..., 0, 0] *= ks; K[..., 1, 1] *= ks; K[..., 0, 2] *= ks; K[..., 1, 2] *= ks
     r0, dr = v.get('post_rot', (0.9, 0.05))
     tx, ty, dty = v.get('post_tran', (3.0, -20.0, 2.0))
+    r0, ty = r0 * (1.0 - 0.06 * b), ty * (1.0 + 0.25 * b)
     pr = np.stack([np.stack([np.diag([r0 + dr * n, r0 + dr * n, 1.0]) for n in range(N_CAMS)], 0)] * T, 0)
     pt = np.stack([np.stack([np.array([tx * n, ty + dty * n, 0.0]) for n in range(N_CAMS)], 0)] * T, 0)
-    a = 0.05
-    bda = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]) * np.array([1.02, 1.02, 1.0])[None, :]
+    a = 0.05 - 0.12 * b
+    bda = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]) * np.array([1.02 - 0.05 * b, 1.02 - 0.05 * b, 1.0])[None, :]
+    if b % 2:                                                                                   # flip_dy of the BEV augmentation (loading.py:1048-1062)
+        bda = np.diag([1.0, -1.0, 1.0]) @ bda
     f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))       # noqa: E731
     if v.get('input_size') is None:
         imgs = torch.from_numpy(rs.standard_normal((1, N_CAMS * T, 3) + INPUT_SIZE).astype(np.float32))
@@ -80,6 +85,12 @@ def img_inputs(seed=0, variant='small'):
     return (imgs, f32(s2e.reshape(1, T * N_CAMS, 4, 4)), f32(e2g.reshape(1, T * N_CAMS, 4, 4)),
             f32(K.reshape(1, T * N_CAMS, 3, 3)), f32(pr.reshape(1, T * N_CAMS, 3, 3)), f32(pt.reshape(1, T * N_CAMS, 3)),
             f32(bda[None]))
+
+
+def img_inputs(seed=0, variant='small', batch=1):
+    """`batch` samples collated along dim 0 (samples_per_gpu = 2 in configs/preworld/nuscenes/preworld-7frame-finetune.py:58)"""
+    ones = [_img_inputs_one(seed, variant, b) for b in range(batch)]
+    return ones[0] if batch == 1 else tuple(torch.cat([o[i] for o in ones], 0) for i in range(7))
 
 
 def ego_states(seed=0):
@@ -140,18 +151,83 @@ def grid_shape(variant='small'):
     return tuple(int(round((g[a][1] - g[a][0]) / g[a][2])) for a in 'xyz')
 
 
-def train_kwargs(seed, detector, device='cpu', variant='small'):
+def train_kwargs(seed, detector, device='cpu', variant='small', batch=1):
     """the keyword arguments forward_train reads (preworld.py:256-263, preworld_temporal_traj.py:412-524): voxel_semantics (B,X,Y,Z),
     mask_camera, and for the temporal detector temporal_semantics[k]['voxel_semantics'], temporal_ego_states, temporal_trajs"""
     rs = np.random.RandomState(3000 + seed)
     X, Y, Z = grid_shape(variant)
-    sem = lambda: torch.from_numpy(rs.randint(0, 18, (1, X, Y, Z))).to(device)       # noqa: E731
+    sem = lambda: torch.from_numpy(rs.randint(0, 18, (batch, X, Y, Z))).to(device)       # noqa: E731
     kw = dict(voxel_semantics=sem(), mask_camera=None)
     if detector == 'PreWorld4DTraj':
         kw['temporal_semantics'] = [dict(voxel_semantics=sem()) for _ in range(7)]
-        kw['temporal_ego_states'] = [torch.from_numpy(S.ego_state(40 + seed)).to(device)]
-        kw['temporal_trajs'] = torch.from_numpy(rs.standard_normal((1, 6, 2)).astype(np.float32)).to(device)
+        kw['temporal_ego_states'] = [torch.from_numpy(np.concatenate([S.ego_state(40 + seed + 7 * b) for b in range(batch)], 0)).to(device)]
+        kw['temporal_trajs'] = torch.from_numpy(rs.standard_normal((batch, 6, 2)).astype(np.float32)).to(device)
     return kw
+
+
+# ---- pre-training (round 6, VERDICT r05 item 1): the flags of configs/preworld/nuscenes/preworld-7frame-pretrain.py:10-33 and
+# nuscenes-temporal/preworld-7frame-pretrain-traj.py (the same with use_lss_depth_loss=False): rendering losses with the released
+# NerfHead weights, the voxel losses replaced by the zero-weight loss_sup_voxel, the LSS depth loss
+NERF_HEAD_CFG = dict(type='NerfHead', point_cloud_range=[-40., -40., -1., 40., 40., 5.4], voxel_size=0.4, scene_center=[0, 0, 2.2],
+                     radius=39, use_depth_sup=True, weight_depth=1.0, weight_semantic=1.0, weight_color=1.0,
+                     weight_entropy_last=0.01, weight_distortion=0.01)
+
+
+def pretrain_cfg(detector):
+    return dict(final_softplus=True, use_lss_depth_loss=detector == 'PreWorld', use_3d_loss=False, if_render=True, if_post_finetune=False,
+                weight_voxel_ce=0.0, weight_voxel_sem_scal=0.0, weight_voxel_geo_scal=0.0, weight_voxel_lovasz=0.0, empty_idx=17,
+                use_focal_loss=False, nerf_head=dict(NERF_HEAD_CFG))
+
+
+PRETRAIN_EPOCH = 4   # PreWorld4DTraj with rendering: epoch 4 -> future intervals 0, 1, 2, i.e. temporal_rays[1..3] (:436-440)
+PRETRAIN_RAYS = 160  # rays per sample (38 400 / 19 200 in the configs)
+
+
+def ray_batch(seed, batch, R=PRETRAIN_RAYS):
+    """`rays` (B, R, 16) in the layout NerfHead.forward slices (nerf_head.py:362-367; datasets/ray.py builds it): [2] lidar depth --
+    a tenth of the rays 0 (no label), a tenth beyond the 52 m cut of :379 -- [3] semantic label 0..16, [4:7] origin, [7:10] direction,
+    [13:16] colour; the other columns (pixel coordinates, camera id) are not read"""
+    rs = np.random.RandomState(4000 + seed)
+    rays = np.zeros((batch, R, 16), np.float32)
+    for b in range(batch):
+        o, d = S.rays_mixed(4100 + 10 * seed + b, R, n_special=0)
+        depth = rs.uniform(1.0, 50.0, R)
+        depth[rs.rand(R) < 0.1] = 0.0
+        far = rs.rand(R) < 0.1
+        depth[far] = rs.uniform(52.5, 70.0, int(far.sum()))
+        rays[b, :, 0:2] = rs.uniform(0, 100, (R, 2))
+        rays[b, :, 2], rays[b, :, 3], rays[b, :, 4:7], rays[b, :, 7:10] = depth, rs.randint(0, 17, R), o, d
+        rays[b, :, 13:16] = rs.uniform(0, 1, (R, 3))
+    return torch.from_numpy(rays)
+
+
+def pretrain_kwargs(seed, detector, device='cpu', variant='small', batch=2):
+    """what forward_train reads under the pre-train flags: `rays` (preworld.py:289), `gt_depth` (B,N,H,W) for the LSS depth loss
+    (:303-304, view_transformer.py:736-789), `voxel_semantics` (asserted in range, weight 0), and for the temporal detector
+    `temporal_rays[k]` for the forecast states (preworld_temporal_traj.py:510) with ego states and trajectories"""
+    kw = train_kwargs(seed, detector, device, variant, batch)
+    kw['rays'] = ray_batch(seed, batch).to(device)
+    if detector == 'PreWorld4DTraj':
+        kw['temporal_rays'] = [ray_batch(seed + 10 * (k + 1), batch).to(device) for k in range(7)]
+    rs = np.random.RandomState(5000 + seed)
+    H, W = input_size(variant)
+    n = len(VARIANTS[variant]['cams'])
+    gd = rs.uniform(0.5, 60.0, (batch, n, H, W)).astype(np.float32)
+    gd[rs.rand(batch, n, H, W) < 0.97] = 0.0                               # projected lidar: sparse
+    kw['gt_depth'] = torch.from_numpy(gd).to(device)
+    return kw
+
+
+def opaque_density_state(sd, gain=16.0, shift=-8.0):
+    """the synthetic density_mlp never leaves the transparent regime (softplus of O(1) numbers against act_shift = -13.8): scale and shift
+    its output row 0 so that part of the volume is opaque and rays TERMINATE (T < 1e-3, render_utils_kernel.cu:591-603) under the
+    pre-train fixtures.  Returns a copy of the state dict."""
+    sd = dict(sd)
+    w, b = np.array(sd['density_mlp.2.weight'], copy=True), np.array(sd['density_mlp.2.bias'], copy=True)
+    w[0] *= gain
+    b[0] = b[0] * gain + shift
+    sd['density_mlp.2.weight'], sd['density_mlp.2.bias'] = w, b
+    return sd
 
 
 def grad_probes(model, detector):
@@ -162,4 +238,19 @@ def grad_probes(model, detector):
     if detector == 'PreWorld4DTraj':
         pr += [('fusion_head0', model.fusion_head[0].weight), ('plan_head0', model.plan_head[0].weight),
                ('traj_head2', model.traj_head[2].weight), ('downscale1', model.downscale.downscale1.weight)]
+    return pr
+
+
+def pretrain_grad_probes(model, detector):
+    """the parameters the rendering losses reach: the three attribute MLPs, final_conv, the encoder, (temporal) the forecast heads;
+    the OccHead only through the zero-weight loss_sup_voxel (its gradient is exactly zero)"""
+    pr = [('final_conv', model.final_conv.conv.weight), ('density_mlp0', model.density_mlp[0].weight), ('density_mlp2', model.density_mlp[2].weight),
+          ('semantic_mlp0', model.semantic_mlp[0].weight), ('semantic_mlp2', model.semantic_mlp[2].weight),
+          ('color_mlp0', model.color_mlp[0].weight), ('color_mlp2', model.color_mlp[2].weight),
+          ('encoder_l0_conv1', model.img_bev_encoder_backbone.layers[0][0].conv1.conv.weight),
+          ('pre_process_conv2', model.pre_process_net.layers[0][0].conv2.conv.weight),
+          ('occ_conv', model.occupancy_head.occ_convs[0][0].weight)]
+    if detector == 'PreWorld4DTraj':
+        pr += [('fusion_head0', model.fusion_head[0].weight), ('plan_head0', model.plan_head[0].weight),
+               ('traj_head2', model.traj_head[2].weight)]
     return pr

@@ -194,6 +194,49 @@ def test_nerf_head_losses_vs_oracle():
         assert abs(float(losses[k]) - ol[k]) <= 2e-3 * abs(ol[k]) + 1e-6, (k, float(losses[k]), ol[k])
 
 
+@pytest.mark.parametrize('tag', ['plain', 'temporal', 'nodist'])
+def test_nerf_head_forward_matches_reference_forward(tag):
+    """VERDICT r05 item 1 (row A19): the drop-in NerfHead.forward -- fused render kernel + ops.RenderRays backward + the loss
+    composition of modules.py -- against the REFERENCE'S OWN NerfHead.forward / compute_loss / compute_loss_temporal
+    (nerf_head.py:271-329,355-420; tests/golden/nerf_losses_small.npz from tools/gen_golden.py gen_nerf_losses): B = 2 on two
+    mixed-opacity scenes where rays terminate, lidar depths beyond 52 m cut in place, the released loss weights, keys with and
+    without the `_{k}s` suffix, every loss value, and d sum(losses) / d (density, semantic, colour) at sampled voxels of both batch
+    elements (autograd through grid_sample, Raw2Alpha, Alphas2Weights, segment sums, silog / CE / L1 / entropy / distortion)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nerf_losses_small.npz'))
+    head = M.NerfHead(point_cloud_range=[-40., -40., -1., 40., 40., 5.4], voxel_size=0.4, scene_center=[0, 0, 2.2], radius=39,
+                      use_depth_sup=True, weight_depth=1.0, weight_semantic=1.0, weight_color=1.0, weight_entropy_last=0.01,
+                      weight_distortion=0.0 if tag == 'nodist' else 0.01).to(DEV)
+    np.testing.assert_allclose(head.class_weights.numpy(), g['class_weights'], rtol=1e-7)
+    grids = [S.render_grids_mixed(int(sd)) for sd in g['grid_seeds']]
+    density, semantic, color = [T(np.stack([gr[i] for gr in grids], 0)).requires_grad_() for i in range(3)]
+    rays = T(g['rays'].copy())
+    kw = dict(if_temporal=True, interval=2) if tag == 'temporal' else {}
+    losses = head(density, semantic, color, rays=rays, bda=T(g['bda']), **kw)
+    assert bool((rays[..., 2] <= 52).all())                        # the reference cuts the caller's tensor in place (:379)
+    assert sorted(losses.keys()) == list(g[tag + '_keys']), sorted(losses.keys())
+    for k, v in losses.items():
+        want = float(g['%s_%s' % (tag, k)])
+        print('[nerf losses] %-8s %-28s %.7f   reference NerfHead.forward %.7f' % (tag, k, float(v), want))
+        assert abs(float(v) - want) <= 2e-4 * abs(want) + 1e-9, (k, float(v), want)
+    total = sum(losses.values())
+    assert abs(float(total) - float(g[tag + '_total'])) <= 2e-4 * abs(float(g[tag + '_total']))
+    total.backward()
+    for b in range(2):
+        vox = torch.from_numpy(g['%s_b%d_voxels' % (tag, b)].astype(np.int64)).to(DEV)
+        for name, gr in zip(('density', 'semantic', 'color'), (density, semantic, color)):
+            got = gr.grad[b][vox[:, 0], vox[:, 1], vox[:, 2]].cpu().numpy()
+            want = g['%s_b%d_g_%s' % (tag, b, name)]
+            err = float(np.abs(got - want).max() / np.abs(want).max())
+            print('[nerf losses] %-8s batch %d d / d %-8s max err / max %.2e' % (tag, b, name, err))
+            assert err <= 5e-4, (tag, b, name, err)
+        for name, gr, key in (('density', density, 'abs_density'), ('semantic', semantic, 'abs_semantic'), ('color', color, 'abs_color')):
+            got = gr.grad[b].double().abs().sum() if name == 'density' else gr.grad[b].double().abs().sum((0, 1, 2))
+            np.testing.assert_allclose(got.cpu().numpy(), g['%s_b%d_%s' % (tag, b, key)], rtol=2e-3)
+        assert int((density.grad[b] != 0).sum()) == int(g['%s_b%d_n_nonzero' % (tag, b)]) or \
+            abs(int((density.grad[b] != 0).sum()) - int(g['%s_b%d_n_nonzero' % (tag, b)])) <= 64
+
+
 @pytest.mark.parametrize('R,S_', [(37, 417), (5, 64), (130, 96), (4, 1)])
 def test_distortion_loss_and_gradient_vs_torch_float64(R, S_):
     """ops.distortion_loss (pw_distortion_loss / _backward: one pass each way) against the plain torch composition of

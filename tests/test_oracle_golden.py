@@ -345,3 +345,51 @@ def test_metric_miou(golden):
     miou, iu = m.count_miou()
     assert miou == float(g['miou'])
     np.testing.assert_allclose(iu, g['iou'], rtol=1e-12)
+
+
+def _nerf_losses_inputs(g):
+    grids = [S.render_grids_mixed(int(sd)) for sd in g['grid_seeds']]
+    return [np.stack([gr[i] for gr in grids], 0) for i in range(3)]
+
+
+@pytest.mark.parametrize('tag', ['plain', 'temporal', 'nodist'])
+def test_nerf_head_forward_losses(golden, tag):
+    """the oracle's NerfHead.forward restatement against the imported reference's own forward
+    (tests/golden/nerf_losses_small.npz, tools/gen_golden.py gen_nerf_losses): B = 2, lidar depths beyond 52 m cut, rays that
+    terminate, compute_loss and compute_loss_temporal, the division by the batch size"""
+    g = golden('nerf_losses_small.npz')
+    density, semantic, color = _nerf_losses_inputs(g)
+    cw = g['class_weights']
+    kw = dict(if_temporal=True, interval=2) if tag == 'temporal' else {}
+    rays = g['rays'].copy()
+    out = O.nerf_head_forward(density, semantic, color, rays, g['bda'], cw, weight_distortion=0.0 if tag == 'nodist' else 0.01, **kw)
+    assert (rays[..., 2] <= 52).all() and (g['rays'][..., 2] > 52).sum() > 20
+    assert sorted(out) == list(g[tag + '_keys'])
+    for k, v in out.items():
+        want = float(g['%s_%s' % (tag, k)])
+        print('[nerf losses] %-8s %-28s oracle %.7f   reference NerfHead.forward %.7f' % (tag, k, v, want))
+        assert abs(v - want) <= 2e-4 * abs(want) + 1e-9, (k, v, want)
+    assert int(g['b0_n_terminated']) >= 40
+
+
+def test_nerf_head_forward_gradients(golden):
+    """the differentiable checker (oracle/torch_render.py nerf_head_forward) against the reference's autograd through its own
+    NerfHead.forward: d sum(losses) / d density, semantic, colour grids at the fixture's sampled voxels, both batch elements"""
+    import torch
+    from oracle import torch_render as TR
+    g = golden('nerf_losses_small.npz')
+    grids = [torch.from_numpy(a).requires_grad_() for a in _nerf_losses_inputs(g)]
+    cw = g['class_weights']
+    out = TR.nerf_head_forward(*grids, g['rays'].copy(), g['bda'], cw)
+    for k, v in out.items():
+        assert abs(float(v) - float(g['plain_' + k])) <= 2e-4 * abs(float(g['plain_' + k])) + 1e-9, k
+    sum(out.values()).backward()
+    for b in range(2):
+        vox = g['plain_b%d_voxels' % b].astype(np.int64)
+        ix = (vox[:, 0], vox[:, 1], vox[:, 2])
+        for name, gr in zip(('density', 'semantic', 'color'), grids):
+            got, want = gr.grad[b].numpy()[ix], g['plain_b%d_g_%s' % (b, name)]
+            err = np.abs(got - want).max() / np.abs(want).max()
+            print('[nerf losses] batch %d d / d %-8s max err / max %.2e' % (b, name, err))
+            assert err <= 2e-3, (b, name, err)
+        assert abs(float(grids[0].grad[b].double().abs().sum()) / float(g['plain_b%d_abs_density' % b]) - 1) <= 2e-3

@@ -1182,6 +1182,174 @@ def _gen_e2e_train_variant(E, sd, variant, runs, fname):
     save(fname, **out)
 
 
+def _flatten_eff_distloss(w, m, interval, ray_id):
+    """torch_efficient_distloss.flatten_eff_distloss (un-vendored third-party dependency, requirements.txt:27, version unpinned;
+    PARITY UNPINNED as SURVEY 8c allows): restated from the package's published algorithm -- the Mip-NeRF-360 distortion loss
+    by exclusive per-ray prefix sums, loss = sum_i [(1/3) interval w_i^2 + 2 w_i (m_i W_i - WM_i)] / (max(ray_id) + 1) -- in
+    differentiable torch ops (the package's hand-written backward is the analytic gradient of this expression).  ray_id sorted."""
+    n_rays = ray_id.max() + 1
+    wm = w * m
+    first = torch.ones_like(ray_id, dtype=torch.bool)
+    first[1:] = ray_id[1:] != ray_id[:-1]
+    start = torch.cummax(torch.where(first, torch.arange(len(w)), torch.zeros_like(ray_id)), 0).values
+    cw, cwm = torch.cumsum(w, 0), torch.cumsum(wm, 0)
+    w_pre = (cw - w) - (cw - w)[start]
+    wm_pre = (cwm - wm) - (cwm - wm)[start]
+    return ((1 / 3) * interval * w.pow(2) + 2 * w * (m * w_pre - wm_pre)).sum() / n_rays
+
+
+def _grad_samples(grads, seed, n=1024):
+    """values of gradient grids at seeded non-zero voxels + sums (grads: density (X,Y,Z), semantic (X,Y,Z,17), color (X,Y,Z,3))"""
+    rng = np.random.RandomState(seed)
+    nz = torch.nonzero(grads[0].abs() > 0).numpy()
+    pick = nz[rng.choice(len(nz), min(n, len(nz)), replace=False)]
+    ix = tuple(torch.from_numpy(pick[:, i]) for i in range(3))
+    return dict(voxels=pick.astype(np.int16), g_density=grads[0][ix].numpy(), g_semantic=grads[1][ix].numpy(), g_color=grads[2][ix].numpy(),
+                sum_density=np.float64(grads[0].double().sum()), abs_density=np.float64(grads[0].double().abs().sum()),
+                abs_semantic=grads[1].double().abs().sum((0, 1, 2)).numpy(), abs_color=grads[2].double().abs().sum((0, 1, 2)).numpy(),
+                n_nonzero=np.int64(len(nz)))
+
+
+def gen_nerf_losses(nh):
+    """the imported reference NerfHead.forward (nerf_head.py:355-420) itself -- the gt_depth > 52 cut (:379),
+    the per-batch loop and the division by the batch size (:365-419), compute_loss / compute_loss_temporal (:271-329) with
+    silog_loss / l1_loss (nerf/utils.py:71-87), n_max = len(results['t']) as the distortion interval (:296-297) -- at B = 2 on two
+    mixed-opacity scenes (rays that terminate), with the released config's weights (preworld-7frame-pretrain.py:22-33), once plain
+    and once with if_temporal=True, interval=2.  Stored: every loss value, the gradient of sum(losses) w.r.t. the density /
+    semantic / colour grids at sampled voxels + sums, per batch element.  torch_efficient_distloss is absent: see
+    _flatten_eff_distloss (third-party, unpinned); the fixture also stores the run with weight_distortion=0."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import _e2e_stub as E
+    nh.flatten_eff_distloss = _flatten_eff_distloss
+    cfg = dict(E.NERF_HEAD_CFG)
+    cfg.pop('type')
+    B, R = 2, 192
+    grids = [S.render_grids_mixed(71 + b) for b in range(B)]
+    rays = np.zeros((B, R, 16), np.float32)
+    rs = np.random.RandomState(73)
+    for b in range(B):
+        o, d = S.rays_mixed(74 + b, R)
+        depth = rs.uniform(1.0, 50.0, R)
+        depth[rs.rand(R) < 0.1] = 0.0
+        far = rs.rand(R) < 0.12
+        depth[far] = rs.uniform(52.5, 70.0, int(far.sum()))
+        rays[b, :, 2], rays[b, :, 3], rays[b, :, 4:7], rays[b, :, 7:10] = depth, rs.randint(0, 17, R), o, d
+        rays[b, :, 13:16] = rs.uniform(0, 1, (R, 3))
+    bda = np.stack([np.array([[0.98, 0.05, 0.0], [-0.05, 0.98, 0.0], [0.0, 0.0, 1.0]], np.float32),
+                    np.array([[1.01, -0.03, 0.0], [-0.03, -1.01, 0.0], [0.0, 0.0, 1.0]], np.float32)])
+    out = dict(rays=rays, bda=bda, grid_seeds=np.array([71, 72], np.int64), class_weights=nh.NerfHead(**cfg).class_weights.numpy())
+    for tag, extra, wd in (('plain', {}, 0.01), ('temporal', dict(if_temporal=True, interval=2), 0.01), ('nodist', {}, 0.0)):
+        head = nh.NerfHead(**dict(cfg, weight_distortion=wd))
+        g = [[torch.from_numpy(gr[i]) for gr in grids] for i in range(3)]
+        density, semantic, color = [torch.stack(x, 0).requires_grad_() for x in g]
+        r = torch.from_numpy(rays.copy())
+        losses = head(density, semantic, color, rays=r, bda=torch.from_numpy(bda), **extra)
+        assert bool((r[..., 2] <= 52).all())                                     # the in-place cut reached the caller's tensor
+        total = sum(losses.values())
+        total.backward()
+        out[tag + '_keys'] = np.array(sorted(losses.keys()))
+        for k, v in losses.items():
+            out['%s_%s' % (tag, k)] = np.float64(v.detach())
+            print('  nerf_losses %-8s %-28s %.7f' % (tag, k, float(v)))
+        out[tag + '_total'] = np.float64(total.detach())
+        for b in range(B):
+            for k, v in _grad_samples([density.grad[b], semantic.grad[b], color.grad[b]], 75 + b).items():
+                out['%s_b%d_%s' % (tag, b, k)] = v
+    # what the scene does to the rays (for the record): the last run's per-ray transmittance on batch element 0
+    with torch.no_grad():
+        m = torch.from_numpy(rays[0, :, 2]) > 0
+        m &= torch.from_numpy(rays[0, :, 2]) <= 52
+        res = head.render_one_scene(torch.from_numpy(rays[0, :, 4:7]), torch.from_numpy(rays[0, :, 7:10]), torch.from_numpy(bda[0]),
+                                    *[torch.from_numpy(a) for a in grids[0]], mask=m)
+    last = res['alphainv_last'].numpy()
+    out['b0_n_rays'], out['b0_n_terminated'] = np.int64(len(last)), np.int64((last < 1e-3).sum())
+    print('  nerf_losses: batch 0 renders %d of %d rays, %d terminate' % (len(last), R, int((last < 1e-3).sum())))
+    save('nerf_losses_small.npz', **out)
+
+
+def _run_reference_forward_train(E, sd, det, cfg_extra, kw, inputs, variant, epoch, probes_fn, tag, out):
+    cfg = E.model_cfg(det, True, True, variant=variant)
+    cfg.update(cfg_extra)
+    model = _build_from_cfg(cfg)
+    own = set(model.state_dict().keys())
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if k in own}, strict=False)
+    assert not unexpected
+    model.train()
+    if hasattr(model, 'set_epoch'):
+        model.set_epoch(epoch)
+    E.install_image_side(model, seed=0, variant=variant)
+    stats = []
+    if getattr(model, 'if_render', False):
+        # what the scene does to the rays, in train() mode: per NerfHead batch element (rays rendered, terminated at T < 1e-3, partly opaque)
+        for name in ('compute_loss', 'compute_loss_temporal'):
+            def wrap(results, *a, _f=getattr(model.nerf_head, name)):
+                last = results['alphainv_last'].detach()
+                stats.append((len(last), int((last < 1e-3).sum()), int(((last >= 1e-3) & (last < 0.99)).sum())))
+                return _f(results, *a)
+            setattr(model.nerf_head, name, wrap)
+    losses = model.forward_train(None, [dict()] * inputs[0].shape[0], img_inputs=inputs, **kw)
+    total = sum(losses.values())
+    total.backward()
+    if stats:
+        out[tag + '_render_stats'] = np.array(stats, np.int32)
+        print('  %s: (rays, terminated, partly opaque) per NerfHead batch element: %s' % (tag, stats))
+    out[tag + '_keys'] = np.array(sorted(losses.keys()))
+    for k, v in losses.items():
+        out['%s_%s' % (tag, k)] = np.float64(v.detach())
+        print('  %-6s %-30s %.7f' % (tag, k, float(v)))
+    out[tag + '_total'] = np.float64(total.detach())
+    for name, p in probes_fn(model, det):
+        assert p.grad is not None, name
+        g = p.grad.detach().reshape(-1)
+        out['%s_grad_%s' % (tag, name)] = g.numpy().copy() if g.numel() <= 40000 else g[::7].numpy().copy()
+        out['%s_gradnorm_%s' % (tag, name)] = np.float64(p.grad.double().norm())
+    for name, bn in (('occ', model.occupancy_head.occ_convs[0][1]), ('enc', model.img_bev_encoder_backbone.layers[0][0].conv1.bn),
+                     ('pre', model.pre_process_net.layers[0][0].conv1.bn)):
+        out['%s_%s_bn_running_mean' % (tag, name)] = bn.running_mean.numpy().copy()
+        out['%s_%s_bn_running_var' % (tag, name)] = bn.running_var.numpy().copy()
+        out['%s_%s_bn_batches' % (tag, name)] = np.int64(bn.num_batches_tracked)
+    return model
+
+
+def gen_e2e_pretrain(vtm, occ, nh):
+    """the reference's OWN PreWorld.forward_train (preworld.py:229-309) and PreWorld4DTraj.forward_train
+    (preworld_temporal_traj.py:372-530) under the PRE-TRAIN flags of configs/preworld/nuscenes/preworld-7frame-pretrain.py:10-33 /
+    nuscenes-temporal/preworld-7frame-pretrain-traj.py (if_render=True, if_post_finetune=False, render weights 1 / 1 / 1 / 0.01 /
+    0.01, use_lss_depth_loss True / False), train() mode, **B = 2** (samples_per_gpu=2, :58), epoch 4 for the temporal detector
+    (temporal_rays[1..3] feed the forecast states).  Branches run here for the first time: loss_sup_voxel x 0 (preworld.py:130-135),
+    NerfHead.forward on the MLP outputs (:287-290), get_depth_loss (:303-304), the `_{k}s` render keys.  density_mlp's output row is
+    rescaled (tests/_e2e_stub.py opaque_density_state) so that a good part of the rays terminate."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import _e2e_stub as E
+    vtm.BasicBlock = _RefBasicBlock
+    load_detectors(occ)
+    nh.flatten_eff_distloss = _flatten_eff_distloss
+    sd = E.opaque_density_state(S.synth_state_dict(0))
+    inputs = E.img_inputs(0, 'small', batch=2)
+    out = {}
+    for tag, det in (('pw', 'PreWorld'), ('p4d', 'PreWorld4DTraj')):
+        kw = E.pretrain_kwargs(0, det, batch=2)
+        _run_reference_forward_train(E, sd, det, E.pretrain_cfg(det), kw, inputs, 'small', E.PRETRAIN_EPOCH, E.pretrain_grad_probes, tag, out)
+    save('e2e_pretrain_small.npz', **out)
+
+
+def gen_e2e_train_b2(vtm, occ):
+    """the fine-tune forward_train of both reference detectors at the reference's training batch,
+    samples_per_gpu = 2 (configs/preworld/nuscenes/preworld-7frame-finetune.py:58): BatchNorm statistics over two samples, the per-batch
+    OccHead loop (preworld.py:240-247), (B,X,Y,Z) labels.  Same flags / epoch as e2e_train_small.npz."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import _e2e_stub as E
+    vtm.BasicBlock = _RefBasicBlock
+    load_detectors(occ)
+    sd = S.synth_state_dict(0)
+    inputs = E.img_inputs(0, 'small', batch=2)
+    out = {}
+    for tag, det in (('pw', 'PreWorld'), ('p4d', 'PreWorld4DTraj')):
+        _run_reference_forward_train(E, sd, det, E.TRAIN_CFG, E.train_kwargs(0, det, batch=2), inputs, 'small', E.TRAIN_EPOCH,
+                                     E.grad_probes, tag, out)
+    save('e2e_train_small_b2.npz', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shim()
@@ -1227,6 +1395,12 @@ def main():
         gen_e2e(vtm, occ)
     if want('e2e_train'):
         gen_e2e_train(vtm, occ)
+    if want('nerf_losses'):
+        gen_nerf_losses(nh)
+    if want('e2e_pretrain'):
+        gen_e2e_pretrain(vtm, occ, nh)
+    if want('e2e_train_b2'):
+        gen_e2e_train_b2(vtm, occ)
     if only:
         return
     gen_kat(bp)
