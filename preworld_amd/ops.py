@@ -27,11 +27,25 @@ def _chk(t, dtype, name):
         raise _lib.PreworldHipError('%s must be %s, got %s' % (name, dtype, t.dtype))
     if not t.is_contiguous():
         raise _lib.PreworldHipError('%s must be contiguous' % name)
-    return ctypes.c_void_p(t.data_ptr())
+    return _ptr(t)
+
+
+class _Ptr(ctypes.c_void_p):
+    """A device-pointer argument that keeps its tensor alive until the argument list is dropped, i.e. until the kernel has been
+    enqueued.  Round 6: `_chk(x.contiguous(), ...)` on a NON-contiguous x used to pass the address of a temporary that was freed
+    before the call -- the caching allocator handed the same block to the next temporary of the same call and its copy overwrote the
+    first (four camera tensors of a B = 2 batch aliasing one buffer: found by the reference-class B = 2 fixtures).  After the
+    enqueue a reuse is stream-ordered behind the kernel and safe."""
+
+
+def _ptr(t):
+    p = _Ptr(t.data_ptr())
+    p._keep = t
+    return p
 
 
 def _p(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    return _ptr(t) if t is not None else None
 
 
 def _host3(vals):

@@ -469,3 +469,25 @@ def test_accelerate_reuses_the_sort_and_notices_new_camera_tensors():
         n2 = len(calls)
         e, _ = vt.view_transform(inp2, d, f)
         assert len(calls) == n2 + 1 and torch.equal(e, want)
+
+
+def test_lift_pool_with_non_contiguous_camera_tensors():
+    """Round 6 regression (found by the reference-class B = 2 training fixtures): prepare_inputs hands the view transformer per-frame
+    SLICES of the (B, T, N, ...) pose tensors -- non-contiguous as soon as B > 1 -- and ops.lss_lift_pool made contiguous temporaries
+    whose addresses outlived them: the four camera tensors of a call aliased one allocator block.  The pointer arguments now keep
+    their tensors alive (ops._Ptr); strided inputs must give the bits of contiguous ones."""
+    gc, N, B, rig = _rig_cfg('full_adj_b2')
+    fr, lower, interval, size, vox, coor = _prepare(gc, S.INPUT_SIZE, S.DOWNSAMPLE, rig, B, N)
+    depth, feat = S.lift_inputs(7, B=B, N=N)
+    d_t, f_t = T(depth), T(np.ascontiguousarray(feat.transpose(0, 1, 3, 4, 2)))
+    cams = [T(rig[k]) for k in ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda')]
+    want = ops.lss_lift_pool(T(fr), *cams, lower, interval, size, d_t, f_t)
+
+    def strided(t):                                   # the (B, T, N, ...)[:, fid] slice prepare_inputs produces, T = 3
+        big = torch.randn((t.shape[0], 3) + tuple(t.shape[1:]), device=DEV)
+        big[:, 1] = t
+        v = big[:, 1]
+        assert not v.is_contiguous()
+        return v
+    got = ops.lss_lift_pool(T(fr), *[strided(c) for c in cams[:4]], cams[4], lower, interval, size, d_t, f_t)
+    assert torch.equal(got, want)
