@@ -490,6 +490,21 @@ PW_API int pw_occ_head_h2_strided(const float* x, const float* wpk, const float*
     const int64_t last = (B - 1) * q[0] + (D - 1) * q[1] + (H - 1) * q[2] + (W - 1) * q[3];
     PW_CHECK_ARG(q[0] >= 0 && q[1] > 0 && q[2] > 0 && q[3] > 0 && last < out_span_bytes && out_span_bytes < (1ll << 31),
                  "pw_occ_head_h2_strided: strides must be positive and stay inside out_span_bytes (< 2 GiB)");
+    // no two voxels may share a byte: sorted by stride, every axis must step over the whole extent of the axes below it
+    // (batch stride 0 with B > 1, or any interleaving that overlaps, would be a write race)
+    {
+      int64_t st[4] = {q[0], q[1], q[2], q[3]};
+      int64_t ex[4] = {B, D, H, W};
+      for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j)
+          if (st[j] < st[i]) { int64_t s_ = st[i]; st[i] = st[j]; st[j] = s_; s_ = ex[i]; ex[i] = ex[j]; ex[j] = s_; }
+      int64_t reach = 0;                                   // last byte offset the smaller-stride axes can reach
+      for (int i = 0; i < 4; ++i) {
+        if (ex[i] == 1) continue;                          // a singleton axis never steps: its stride is irrelevant
+        PW_CHECK_ARG(st[i] > reach, "pw_occ_head_h2_strided: output strides overlap (two voxels would store to the same byte)");
+        reach += (ex[i] - 1) * st[i];
+      }
+    }
     t.sb = (int)q[0]; t.sd = (int)q[1]; t.sh = (int)q[2]; t.sw = (int)q[3]; t.span = (unsigned)out_span_bytes;
   }
   PipeArgs p = {};

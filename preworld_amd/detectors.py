@@ -318,9 +318,10 @@ class BEVStereo4DOCC(nn.Module):
         return x if isinstance(x, ops.H2) == out_h2 else (ops.f32_to_h2(x) if out_h2 else as_f32(x))
 
     # ---- bevdet_occ.py:167-269 (frame loop, [adj, key] concat, with_prev=False -> zeros)
-    def extract_bev_feat_cl(self, frames, out_h2=False):
+    def extract_bev_feat_cl(self, frames, out_h2=False, side_work=None):
         """frames: list ordered [key, adj, ...] of dicts(depth, tran_feat, sensor2keyego, intrin,
-        post_rot, post_tran, bda).  Returns the bev_encoder output, channels-last (B,Z,Y,X,C)."""
+        post_rot, post_tran, bda).  Returns the bev_encoder output, channels-last (B,Z,Y,X,C).  side_work: an optional callable
+        that depends on neither frame; it is run once behind the adjacent frame's lift (on the side stream when the lifts fork)."""
         # channel order [adjacent ..., key] (bevdet_occ.py:266): every frame's pre_process output is
         # written straight into its channel slice of ONE buffer (row stride n*C), no torch.cat copy.
         # In the 'h2' precision that buffer is in split-fp16 storage (an all-zero slice is zeros there too).
@@ -360,23 +361,22 @@ class BEVStereo4DOCC(nn.Module):
                 x[..., lo:hi].zero_()
         # work that depends on neither frame (PreWorld4DTraj: the forecast's per-sample prologue, a one-block 20 us kernel that would
         # otherwise run alone in front of the forecast) rides on the side stream behind the adjacent frame's lift
-        extra = self.__dict__.pop('_side_work', None)
-        if extra is not None:
+        if side_work is not None:
             if fork:
                 with torch.cuda.stream(side):
-                    extra()
+                    side_work()
             else:
-                extra()
+                side_work()
         self.lift_frame_cl(out=sl((n - 1) * C, n * C), out_h2=h2, **f0)
         if fork:
             main.wait_stream(side)
         self.__dict__['_lift_warm'] = True
         return self.bev_encoder_cl(ops.H2(x, xslot) if h2 else x, out_h2=out_h2)
 
-    def extract_voxel_feat_cl(self, frames, out_h2=False):
+    def extract_voxel_feat_cl(self, frames, out_h2=False, side_work=None):
         """... followed by final_conv: conv + bias + ReLU (preworld.py:72-79), channels-last (B,Z,Y,X,out_dim); out_h2: keep
         the result in h2 storage (ops.H2) for the split-fp16 forecast / OccHead kernels."""
-        return self.final_conv.forward_cl(self.extract_bev_feat_cl(frames, out_h2=precision() == 'h2'),
+        return self.final_conv.forward_cl(self.extract_bev_feat_cl(frames, out_h2=precision() == 'h2', side_work=side_work),
                                           out_h2=out_h2 and precision() == 'h2')
 
     # ---- bevdet_occ.py:281-301: final_conv -> predicter MLP -> argmax(softmax) (softmax is monotone: argmax of logits)
@@ -642,17 +642,18 @@ class PreWorld4DTraj(_PreWorldCommon):
                                                             fh[2].weight.float().contiguous()))
 
     # ---- preworld_temporal_traj.py:329-368: all recursion steps in one kernel
-    def forecast_cl(self, v_cl, ego_states, n_steps=6, out_h2=False):
+    def forecast_cl(self, v_cl, ego_states, n_steps=6, out_h2=False, prologue=None):
         """v_cl (B,Z,Y,X,C), fp32 tensor or ops.H2; ego_states (B,1,21) (always temporal_ego_states[0], :331).
-        Returns states (n_steps,B,Z,Y,X,C) (ops.H2 with out_h2 on the split-fp16 path) and the ego feature (B,32)."""
+        Returns states (n_steps,B,Z,Y,X,C) (ops.H2 with out_h2 on the split-fp16 path) and the ego feature (B,32).
+        prologue: (ego feature, c1p) of ops.forecast_prologue for THESE ego states if the caller launched it early (handed over
+        explicitly -- ADVICE r05: it used to travel through attributes of the shared module and could go stale)."""
         ph, fh = self.plan_head, self.fusion_head
         B = v_cl.shape[0]
         ego = ego_states.reshape(B, -1).float().contiguous()
         plan = [(ph[0].weight.contiguous(), ph[0].bias), (ph[2].weight.contiguous(), ph[2].bias),
                 (ph[4].weight.contiguous(), ph[4].bias)]
-        pro = self.__dict__.pop('_fc_prologue', None)             # launched early by _simple_test_from_lift (same ego states)
-        if pro is not None and pro[0] is ego_states:
-            ef, c1p = pro[1], pro[2]
+        if prologue is not None:                                  # launched early by _simple_test_from_lift, on the lift's side stream
+            ef, c1p = prologue
             if ef.is_cuda and not torch.cuda.is_current_stream_capturing():     # allocated under the side stream, consumed on this one
                 ef.record_stream(torch.cuda.current_stream(ef.device))
                 c1p.record_stream(torch.cuda.current_stream(ef.device))
@@ -677,16 +678,15 @@ class PreWorld4DTraj(_PreWorldCommon):
 
     def _simple_test_from_lift(self, frames, temporal_ego_states, n_steps=6, want_logits=False):
         # post-finetune decode: final_conv -> forecast -> OccHead stay in h2 storage end to end on the split-fp16 path
+        early, side_work = [], None
         if self.if_post_finetune and n_steps > 0:
-            def prologue():                                           # plan_head + the hoisted ego term: depends on the ego state only
+            def side_work():                                          # plan_head + the hoisted ego term: depends on the ego state only
                 ph, fh = self.plan_head, self.fusion_head
                 ego = temporal_ego_states.reshape(temporal_ego_states.shape[0], -1).float().contiguous()
                 plan = [(ph[0].weight.contiguous(), ph[0].bias), (ph[2].weight.contiguous(), ph[2].bias), (ph[4].weight.contiguous(), ph[4].bias)]
                 ef, _, c1p = ops.forecast_prologue(ego, plan, fh[0].weight.contiguous(), fh[0].bias)
-                self.__dict__['_fc_prologue'] = (temporal_ego_states, ef, c1p)
-            self.__dict__['_side_work'] = prologue
-        v0 = self.extract_voxel_feat_cl(frames, out_h2=self.if_post_finetune)      # (B,Z,Y,X,C)
-        self.__dict__.pop('_side_work', None)
+                early.append((ef, c1p))
+        v0 = self.extract_voxel_feat_cl(frames, out_h2=self.if_post_finetune, side_work=side_work)      # (B,Z,Y,X,C)
         if not self.if_post_finetune:
             return self._simple_test_attributes(v0, temporal_ego_states, n_steps)
         res = {}
@@ -708,7 +708,8 @@ class PreWorld4DTraj(_PreWorldCommon):
             o0 = self.occupancy_head.decode_cl(v0, want_logits=want_logits, transposed=True, want_geo=True)
         outs = [o0]
         if n_steps > 0:
-            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps, out_h2=isinstance(v0, ops.H2))
+            states, _ = self.forecast_cl(v0, temporal_ego_states, n_steps, out_h2=isinstance(v0, ops.H2),
+                                         prologue=early[0] if early else None)
             feats += [states[k] for k in range(n_steps)]
             extra = dict(occ_out=zyx(grids[1:, 0]), geo_out=zyx(grids[1:, 1])) if grids is not None else {}
             o = self.occupancy_head.decode_cl(states.view((n_steps * B,) + tuple(v0.shape[1:])), want_logits=want_logits,

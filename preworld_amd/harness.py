@@ -145,7 +145,7 @@ def simple_test_sharded(net, frames, ego, n_steps=6, group=None, gather_on_host=
         # final_conv -> forecast -> OccHead keep h2 storage like simple_test_from_lift (post-finetune decode)
         v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.f32_to_h2(x) if h2 else x, out_h2=h2), out_h2=h2)
         mark('encoder')
-        return parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k, out_h2=h2)[0][k - 1], decode,
+        return parallel.decode_states_sharded(v0, lambda v, k: net.forecast_cl(v, ego, k, out_h2=h2)[0], decode,
                                               n_steps + 1, group, mark=mark, stats=timings,
                                               grid_like=((int(size[0]), int(size[1]), int(size[2])), torch.uint8,
                                                          'cpu' if gather_on_host else f0['depth'].device))

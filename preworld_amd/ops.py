@@ -888,8 +888,8 @@ def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, bounds, want_logits=False, oc
         occ = torch.empty(B, D, H, W, device=x.device, dtype=torch.uint8)
     logits = torch.empty(B, D, H, W, 18, device=x.device, dtype=_f32) if want_logits else None
     if want_geo and geo is None:
-        geo = torch.empty(occ.shape, device=x.device, dtype=torch.uint8).as_strided(occ.shape, occ.stride()) if not occ.is_contiguous() \
-            else torch.empty(B, D, H, W, device=x.device, dtype=torch.uint8)
+        # (empty_strided sizes the storage for the gapped / interleaved strides; as_strided over a dense allocation did not)
+        geo = torch.empty_strided(tuple(occ.shape), tuple(occ.stride()), device=x.device, dtype=torch.uint8)
     if tailpk.numel() != 800 or scale.numel() < 16 or bias.numel() < 16:
         raise _lib.PreworldHipError('occ_head_h2: tailpk (800,), scale / bias (16,) expected')
     for t in (occ, geo):
@@ -902,6 +902,7 @@ def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, bounds, want_logits=False, oc
         st = [int(v) for v in occ.stride()]
         strides = (ctypes.c_int64 * 4)(*st)
         span = 1 + sum((n - 1) * v for n, v in zip((B, D, H, W), st))
+        # (the C side rejects overlapping stride sets -- two voxels storing to one byte would race)
     _lib.call('pw_occ_head_h2_strided', _chk(x.buf, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
               _chk(bias, _f32, 'bias'), _chk(tailpk, _f32, 'tailpk'), float(inv2), _p(occ), _p(logits), _p(geo), strides, int(span),
               int(empty_idx), B, D, H, W, Cin, 16, 8, 18, _rng(x), float(bounds[0]), float(bounds[1]), float(bounds[2]),

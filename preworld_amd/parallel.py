@@ -7,7 +7,7 @@ RCCL over xGMI on ROCm, 'gloo' in the CPU tests).
 * state-sharded decode (latency mode for ONE sample, BASELINE.json configs[3]): every rank holds
   the encoder output v0; rank r owns the output states {r, r+W, ...}.  State k is k applications
   of the pointwise residual MLP (preworld_temporal_traj.py:335-342) followed by OccHead, so a
-  rank recomputes the cheap recursion locally up to its largest owned state and decodes only its
+  rank runs the cheap recursion locally ONCE up to its largest owned state and decodes only its
   own states; ONE all_gather of uint8 grids (0.64 MB each) assembles the 7 states everywhere.
 * frame-sharded lift (the literal north_star wording): input frame f (key / adjacent) is lifted,
   pooled and pre-processed on rank f % W and the (B,Z,Y,X,32) fp32 features (81.92 MB each) reach
@@ -47,18 +47,24 @@ def _global_rank(group, r):
 
 
 def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark=_no_mark, grid_like=None, stats=None):
-    """v0: encoder output on every rank.  forecast_fn(v0, k) -> state-k features (k >= 1 applications
-    of the recursion); decode_fn(features) -> uint8 occupancy grid.  Returns the list of all
-    n_states grids (identical on every rank).  grid_like = (shape, dtype, device) of a decoded grid: a rank that owns no
-    state (world > n_states: rank 7 of 8 with 7 states) sizes its empty slot from it and decodes NOTHING.
+    """v0: encoder output on every rank.  forecast_fn(v0, k) -> the features of states 1 .. k as a sequence `s` with s[j - 1] = state j
+    (ONE pass of the recursion up to k: the forecast kernel writes every intermediate state anyway); decode_fn(features) -> uint8
+    occupancy grid.  A rank runs the recursion once, up to its LARGEST owned state (round 6: it used to restart from v0 for every
+    owned state -- 0 + 1 + ... + 6 = 21 steps at world 1 instead of 6).  Returns the list of all n_states grids (identical on every
+    rank).  grid_like = (shape, dtype, device) of a decoded grid: a rank that owns no state (world > n_states: rank 7 of 8 with 7
+    states) sizes its empty slot from it and decodes NOTHING; required on EVERY rank as soon as world > n_states, checked before any
+    compute or collective so that all ranks fail together instead of one leaving the others inside all_gather.
     stats (dict): receives 'states_bytes_received' = bytes of other ranks' slots that reach this rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world > n_states and grid_like is None:
+        raise ValueError('decode_states_sharded: %d ranks for %d states -- some rank owns no state; pass grid_like on every rank'
+                         % (world, n_states))
     mine = owned_states(n_states, rank, world)
     local = {}
+    states = forecast_fn(v0, max(mine)) if mine and max(mine) > 0 else None
     for k in mine:
-        feats = v0 if k == 0 else forecast_fn(v0, k)
-        local[k] = decode_fn(feats)
+        local[k] = decode_fn(v0 if k == 0 else states[k - 1])
     mark('decode')
     if world == 1 and not ALWAYS_COLLECTIVE:
         return [local[k] for k in range(n_states)]
@@ -67,10 +73,8 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark
     if local:
         ref = next(iter(local.values()))
         shape, dtype, device = tuple(ref.shape), ref.dtype, ref.device
-    elif grid_like is not None:
-        shape, dtype, device = tuple(grid_like[0]), grid_like[1], torch.device(grid_like[2])
     else:
-        raise ValueError('decode_states_sharded: rank %d of %d owns none of the %d states and was given no grid_like' % (rank, world, n_states))
+        shape, dtype, device = tuple(grid_like[0]), grid_like[1], torch.device(grid_like[2])
     send = torch.zeros((slots,) + shape, dtype=dtype, device=device)
     for i, k in enumerate(mine):
         send[i] = local[k]

@@ -409,6 +409,17 @@ def test_occ_head_h2_matches_direct_and_oracle(shape):
     o2, g2 = ops.occ_head_h2(xh, wpk, *hargs, occ=buf[:, 0].permute(0, 3, 2, 1), geo=buf[:, 1].permute(0, 3, 2, 1))
     assert torch.equal(buf[:, 0], occ_h.permute(0, 3, 2, 1)) and torch.equal(buf[:, 1], geo_h.permute(0, 3, 2, 1))
     assert o2.data_ptr() == buf.data_ptr() and bool((buf._base.reshape(B, 2, W, H, D + 3)[..., D:] == 255).all())
+    # a strided occ with an auto-allocated geo (storage sized for the gapped strides), and overlapping stride sets refused
+    buf2 = torch.full((B, 2, W, H, D + 3), 255, dtype=torch.uint8, device=DEV)[..., :D]
+    o3, g3 = ops.occ_head_h2(xh, wpk, *hargs, occ=buf2[:, 0].permute(0, 3, 2, 1), want_geo=True)
+    assert tuple(g3.stride()) == tuple(o3.stride()) and torch.equal(g3, geo_h) and torch.equal(o3, occ_h)
+    if B > 1:
+        with pytest.raises(Exception, match='overlap'):
+            ops.occ_head_h2(xh, wpk, *hargs, occ=buf2[:1, 0].permute(0, 3, 2, 1).expand(B, D, H, W))          # batch stride 0
+    if H > 1 and W > 1:
+        flat = torch.zeros(B * D * H * W, dtype=torch.uint8, device=DEV)
+        with pytest.raises(Exception, match='overlap'):                                                       # h and w both step by D
+            ops.occ_head_h2(xh, wpk, *hargs, occ=flat.as_strided((B, D, H, W), (D * H * W, 1, D, D)))
     d1, h1, w1_ = min(D, 6), min(H, 12), min(W, 12)
     xc = x[:1, :d1, :h1, :w1_].permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
     mid = np.maximum(O.conv3d(xc, w0.cpu().numpy()) * s0.cpu().numpy()[None, :, None, None, None]

@@ -474,9 +474,13 @@ def _check_terminating_forward(name, out, want_dense, want_last, want_depth, wan
     assert np.abs(w[tie] - want_dense[tie]).max(initial=0) <= 1.1e-3
     np.testing.assert_allclose(out['alphainv_last'].cpu().numpy()[ok], want_last[ok], rtol=2e-3, atol=1e-7)
     assert ((out['alphainv_last'].cpu().numpy() < 1e-3) == (want_last < 1e-3))[ok].all()      # the same rays terminate
-    check_close(name + ' depth', out['depth'], want_depth, 2e-4, atol=1.1e-3 * 39 * float(tie.any()))
-    check_close(name + ' semantic', out['semantic'], want_sem, 2e-4, atol=5e-3 * float(tie.any()))
-    check_close(name + ' color', out['color'], want_col, 2e-4, atol=5e-3 * float(tie.any()))
+    # rays without a near-tie at the tight bound; a near-tie ray may gain / lose one sample of weight <= 1.1e-3 (the wide
+    # bound used to apply to ALL rays as soon as one tie existed)
+    for key, want_, wide in (('depth', want_depth, 1.1e-3 * 39), ('semantic', want_sem, 5e-3), ('color', want_col, 5e-3)):
+        got_ = out[key].cpu().numpy()
+        check_close(name + ' ' + key, got_[ok], want_[ok], 2e-4)
+        if tie.any():
+            check_close(name + ' ' + key + ' (near-tie rays)', got_[tie], want_[tie], 2e-4, atol=wide)
 
 
 @pytest.mark.parametrize('tag', ['mixed', 'void'])

@@ -27,6 +27,19 @@ def _forecast(v0, k):
     return v
 
 
+STEPS = [0]
+
+
+def _forecast_states(v0, k):
+    """the contract of decode_states_sharded's forecast_fn: states 1 .. k from ONE pass of the recursion"""
+    out, v = [], v0
+    for _ in range(k):
+        v = v + torch.tanh(v * 0.5 + 0.1)
+        STEPS[0] += 1
+        out.append(v)
+    return out
+
+
 def _decode(f):
     return f.argmax(-1).to(torch.uint8)
 
@@ -44,7 +57,10 @@ def _worker(rank, world, port, n_states, n_frames, q):
             decoded.append(1)
             return _decode(f)
         st = {}
-        states = parallel.decode_states_sharded(v0, _forecast, decode, n_states, grid_like=((6, 5, 4), torch.uint8, 'cpu'), stats=st)
+        STEPS[0] = 0
+        states = parallel.decode_states_sharded(v0, _forecast_states, decode, n_states, grid_like=((6, 5, 4), torch.uint8, 'cpu'), stats=st)
+        mine = parallel.owned_states(n_states, rank, world)
+        assert STEPS[0] == (max(mine) if mine else 0)          # ONE recursion up to the largest owned state (round 6), not one per state
         seq = [_decode(v0 if k == 0 else _forecast(v0, k)) for k in range(n_states)]
         ok1 = all(torch.equal(a, b) for a, b in zip(states, seq))
         # a rank decodes exactly its own states -- none at all if it owns none (rank 7 of 8 with 7 states)
@@ -100,6 +116,37 @@ def test_sharded_world8(n_frames):
 
 def test_single_process_fallbacks():
     v0 = torch.randn(3, 3, 3, 18)
-    out = parallel.decode_states_sharded(v0, _forecast, _decode, 4)
-    assert len(out) == 4 and torch.equal(out[2], _decode(_forecast(v0, 2)))
+    STEPS[0] = 0
+    out = parallel.decode_states_sharded(v0, _forecast_states, _decode, 4)
+    assert len(out) == 4 and torch.equal(out[2], _decode(_forecast(v0, 2))) and STEPS[0] == 3        # 3 steps, not 0 + 1 + 2 + 3
     assert parallel.owned_states(7, 3, 8) == [3] and parallel.owned_states(7, 7, 8) == []
+
+
+def _worker_no_grid_like(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        try:
+            parallel.decode_states_sharded(torch.randn(2, 2, 2, 18), _forecast_states, _decode, 2)       # 3 ranks, 2 states, no grid_like
+            q.put((rank, 'returned'))
+        except ValueError:
+            q.put((rank, 'raised'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_missing_grid_like_fails_on_every_rank_before_the_collective():
+    """with more ranks than states and no grid_like, EVERY rank raises before any compute or collective (round 5: only the
+    rank without a state raised, after the others had entered all_gather -- they hung until the timeout)"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_no_grid_like, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, 'raised'), (1, 'raised'), (2, 'raised')]
