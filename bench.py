@@ -760,8 +760,18 @@ def main():
     frames, ego = make_inputs(dev, seed=0 if sharded else rank, n_frames=n_frames)
 
     phase_ms, phase_bytes = {}, {}
+    ss = None
+    if sharded and not args.no_graph:
+        # round 6: the three compute phases between the two collectives as hipGraphs, ranges calibrated once + audited on the device
+        from preworld_amd.pipeline import ShardedSample
+        ss = ShardedSample(net, frames, ego, n_steps=n_steps_fc, gather_on_host=oversubscribed)
+        ss_sets = [make_inputs(dev, seed=4000 + j, n_frames=n_frames) for j in range(3)]        # the same 3 samples on every rank, rotating
+        ss_i = [0]
 
     def step():
+        if ss is not None:
+            ss_i[0] += 1
+            return ss.run(*ss_sets[ss_i[0] % 3])
         if sharded:
             return harness.simple_test_sharded(net, frames, ego, n_steps=n_steps_fc, gather_on_host=oversubscribed)
         if args.config == 'C3':
@@ -790,7 +800,10 @@ def main():
         try:
             with KernelProbe() as probe:
                 for _ in range(n_probe):
-                    step()
+                    if ss is not None:                       # (the captured phases cannot be probed launch by launch: the eager form)
+                        harness.simple_test_sharded(net, frames, ego, n_steps=n_steps_fc, gather_on_host=oversubscribed)
+                    else:
+                        step()
         finally:
             if lift_streams is None:
                 os.environ.pop('PW_LIFT_STREAMS')
@@ -896,7 +909,10 @@ def main():
         acc = {}
         for _ in range(5):
             t = {}
-            harness.simple_test_sharded(net, frames, ego, n_steps=n_steps_fc, gather_on_host=oversubscribed, timings=t)
+            if ss is not None:
+                ss.run(*ss_sets[0], timings=t)
+            else:
+                harness.simple_test_sharded(net, frames, ego, n_steps=n_steps_fc, gather_on_host=oversubscribed, timings=t)
             for k, v in t.items():
                 acc[k] = acc.get(k, 0.0) + v / 5
         phase_ms = {k: round(v, 4) for k, v in acc.items() if 'bytes' not in k}
@@ -904,7 +920,10 @@ def main():
 
     # every replay of the timed region stayed inside its calibrated activation ranges (pipeline.CapturedSample.ranges_ok: the
     # exponent table + recorded maxima the replays delivered to pinned host memory)
-    ranges_ok = (audit['recalibrations'] == 0) if graph is not None and precision() == 'h2' else None
+    if ss is not None:
+        bad = ss.bad_replays()
+        audit = dict(replays_audited=int(bad[1]), recalibrations=int(bad[0]))
+    ranges_ok = (audit['recalibrations'] == 0) if audit is not None and precision() == 'h2' else None
     ablation = os.environ.get('PW_BENCH_ABLATION') == '1'          # tools/ablate_step.sh: variant libraries that skip kernels; the line says so
     assert ranges_ok is not False or ablation, 'replays left their calibrated activation ranges: %s' % audit
 
@@ -944,7 +963,9 @@ def main():
                 'launch': ('hipGraph replay, %d independent sample(s) in flight on %d HIP stream(s); %d distinct input sets rotate through '
                            'the captured steps, each step copies its inputs (16 MB D2D) into the static buffers inside the timed region'
                            % (M, M, N_SETS))
-                if graph is not None else 'eager',
+                if graph is not None else
+                ('three hipGraphs per rank (own frames\' lift | encoder | forecast + decode of the owned states) around the two collectives '
+                 '(pipeline.ShardedSample); 3 input sets rotate, each step copies its inputs into the static buffers') if ss is not None else 'eager',
                 'replay_same_inputs': replay_only,
                 'recalibrations': audit['recalibrations'] if audit else None,
                 'replays_audited': audit['replays_audited'] if audit else None,

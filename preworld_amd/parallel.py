@@ -46,6 +46,35 @@ def _global_rank(group, r):
     return dist.get_global_rank(group, r) if group is not None else r
 
 
+def gather_states(local, n_states, group=None, grid_like=None, stats=None, send=None, recv=None):
+    """the one all_gather of the state-sharded decode: `local` = {k: uint8 grid} of this rank's owned states -> list of all n_states grids.
+    Every rank pads to the same number of slots (0.64 MB per slot at 200 x 200 x 16).  send / recv: optional preallocated buffers
+    ((slots,) + shape and a list of `world` such tensors) so that a captured pass can write into / read from fixed addresses."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = owned_states(n_states, rank, world)
+    slots = (n_states + world - 1) // world
+    if send is None:
+        if local:
+            ref = next(iter(local.values()))
+            shape, dtype, device = tuple(ref.shape), ref.dtype, ref.device
+        else:
+            shape, dtype, device = tuple(grid_like[0]), grid_like[1], torch.device(grid_like[2])
+        send = torch.zeros((slots,) + shape, dtype=dtype, device=device)
+        for i, k in enumerate(mine):
+            send[i] = local[k]
+    if recv is None:
+        recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    if stats is not None:
+        stats['states_bytes_received'] = (world - 1) * send.numel() * send.element_size()
+    out = [None] * n_states
+    for r in range(world):
+        for i, k in enumerate(owned_states(n_states, r, world)):
+            out[k] = recv[r][i]
+    return out
+
+
 def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark=_no_mark, grid_like=None, stats=None):
     """v0: encoder output on every rank.  forecast_fn(v0, k) -> the features of states 1 .. k as a sequence `s` with s[j - 1] = state j
     (ONE pass of the recursion up to k: the forecast kernel writes every intermediate state anyway); decode_fn(features) -> uint8
@@ -68,26 +97,68 @@ def decode_states_sharded(v0, forecast_fn, decode_fn, n_states, group=None, mark
     mark('decode')
     if world == 1 and not ALWAYS_COLLECTIVE:
         return [local[k] for k in range(n_states)]
-    # pad every rank to the same number of slots so one all_gather moves everything (0.64 MB per slot at 200 x 200 x 16)
-    slots = (n_states + world - 1) // world
-    if local:
-        ref = next(iter(local.values()))
-        shape, dtype, device = tuple(ref.shape), ref.dtype, ref.device
-    else:
-        shape, dtype, device = tuple(grid_like[0]), grid_like[1], torch.device(grid_like[2])
-    send = torch.zeros((slots,) + shape, dtype=dtype, device=device)
-    for i, k in enumerate(mine):
-        send[i] = local[k]
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
+    out = gather_states(local, n_states, group, grid_like, stats)
     mark('gather_states')
-    if stats is not None:
-        stats['states_bytes_received'] = (world - 1) * send.numel() * send.element_size()
-    out = [None] * n_states
-    for r in range(world):
-        for i, k in enumerate(owned_states(n_states, r, world)):
-            out[k] = recv[r][i]
     return out
+
+
+def exchange_frames(lifted, F, out_shape, dtype, device, group=None, via_host=False, stats=None, static=None):
+    """the frame exchange of the sharded lift: `lifted` = {f: this rank's lifted frames (f % W == rank)} -> list of all F frames on every
+    rank.  Full rounds through ONE all_gather_into_tensor, the F % W frames of a partial round by broadcasts from their owners (see
+    lift_frames_sharded).  static: optional dict the call keeps its receive buffers in ('recv' for the all_gather, 'bcast%d' per
+    broadcast frame) -- a captured pass reads the frames at fixed addresses, so every call must deliver into the same tensors."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    out_shape = tuple(out_shape)
+    n_full = F // world
+    xdev = 'cpu' if via_host else device
+    outs = [None] * F
+    frame_bytes = dtype.itemsize
+    for d in out_shape:
+        frame_bytes *= d
+    received = sent = 0
+    static = static if static is not None else {}
+
+    def buf(key, shape, dev):
+        t = static.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != torch.device(dev):
+            t = static[key] = torch.empty(shape, dtype=dtype, device=dev)
+        return t
+
+    def to_device(key, t):
+        if not via_host:
+            return t
+        d = buf(key + '_dev', t.shape, device)
+        d.copy_(t, non_blocking=True)
+        return d
+    if n_full:
+        send = (lifted[rank][None] if n_full == 1 else torch.stack([lifted[j * world + rank] for j in range(n_full)], 0)).to(xdev)
+        recv = buf('recv', (world * n_full,) + out_shape, xdev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        recv = recv.view((world, n_full) + out_shape)
+        for j in range(n_full):
+            for r in range(world):
+                outs[j * world + r] = lifted[j * world + r] if r == rank else to_device('recv%d_%d' % (r, j), recv[r, j])
+        received += (world - 1) * n_full * frame_bytes
+        sent += (world - 1) * n_full * frame_bytes
+    works = []
+    for f in range(n_full * world, F):
+        owner = f % world
+        if owner == rank:
+            b = lifted[f].to(xdev) if via_host else lifted[f]
+        else:
+            b = buf('bcast%d' % f, out_shape, xdev)
+        works.append((f, owner, b, dist.broadcast(b, src=_global_rank(group, owner), group=group, async_op=True)))
+    for f, owner, b, w in works:
+        w.wait()
+        outs[f] = lifted[f] if owner == rank else to_device('bcast%d' % f, b)
+        if owner == rank:
+            sent += (world - 1) * frame_bytes
+        else:
+            received += frame_bytes
+    if stats is not None:
+        stats['frames_bytes_received'], stats['frames_bytes_sent'] = received, sent
+    return outs
 
 
 def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, via_host=False, mark=_no_mark, stats=None):
@@ -117,35 +188,6 @@ def lift_frames_sharded(frames, lift_fn, out_shape, dtype, device, group=None, v
         assert tuple(buf.shape) == out_shape
         lifted[f] = buf.contiguous()
     mark('lift')
-    xdev = 'cpu' if via_host else device
-    outs = [None] * F
-    frame_bytes = dtype.itemsize
-    for d in out_shape:
-        frame_bytes *= d
-    received = sent = 0
-    if n_full:
-        send = (lifted[rank][None] if n_full == 1 else torch.stack([lifted[j * world + rank] for j in range(n_full)], 0)).to(xdev)
-        recv = torch.empty((world * n_full,) + out_shape, dtype=dtype, device=xdev)
-        dist.all_gather_into_tensor(recv, send, group=group)
-        recv = recv.view((world, n_full) + out_shape)
-        for j in range(n_full):
-            for r in range(world):
-                outs[j * world + r] = lifted[j * world + r] if r == rank else recv[r, j].to(device)
-        received += (world - 1) * n_full * frame_bytes
-        sent += (world - 1) * n_full * frame_bytes
-    works = []
-    for f in range(n_full * world, F):
-        owner = f % world
-        buf = lifted[f].to(xdev) if owner == rank else torch.empty(out_shape, dtype=dtype, device=xdev)
-        works.append((f, owner, buf, dist.broadcast(buf, src=_global_rank(group, owner), group=group, async_op=True)))
-    for f, owner, buf, w in works:
-        w.wait()
-        outs[f] = lifted[f] if owner == rank else buf.to(device)
-        if owner == rank:
-            sent += (world - 1) * frame_bytes
-        else:
-            received += frame_bytes
+    outs = exchange_frames(lifted, F, out_shape, dtype, device, group, via_host, stats)
     mark('gather_frames')
-    if stats is not None:
-        stats['frames_bytes_received'], stats['frames_bytes_sent'] = received, sent
     return outs

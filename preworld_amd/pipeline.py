@@ -130,3 +130,189 @@ class CapturedSample:
             for d, s in zip(dsts, srcs):
                 d.copy_(s, non_blocking=True)
         return self.replay()
+
+
+class ShardedSample:
+    """BASELINE.json configs[3] -- ONE sample across the ranks of a node (frames lifted on different ranks, RCCL exchange of the
+    per-frame voxel features before the encoder, states forecast + decoded round-robin, all_gather of the uint8 grids; the reference's
+    join point is bevdet_occ.py:266-267, its result gather apis/test.py:198-223) -- as three captured compute phases between the two
+    collectives (round 6; harness.simple_test_sharded is the eager form: ~60 launches + a calibration all-reduce and a host sync per
+    call):
+        graph A   this rank's frames: LSS lift + pooling + pre_process -> fp32 features in static buffers   (nothing on other ranks)
+        exchange  parallel.exchange_frames: all_gather_into_tensor (full rounds) / broadcasts from the owners (partial round)
+        graph B   cat [adjacent ..., key] -> one h2 split -> CustomResNet3D -> LSSFPN3D -> final_conv
+        graph C   ONE pass of the forecast recursion up to this rank's largest owned state, OccHead on its owned states -> uint8 slots
+        gather    parallel.gather_states: one all_gather of the 0.64 MB slots
+    Activation ranges: calibrated ONCE at construction (ops.ranged over eager passes; the ranks agree through a MIN all-reduce per
+    calibration pass, as the passes contain collectives), then every replay re-records its maxima and the device-side audit tallies
+    the replays that left the window (bad_replays(), like CapturedSample) -- no host sync and no collective for the ranges per sample.
+    run(frames, ego) copies a sample's inputs (every rank holds all of them) into the static buffers and returns the reference's
+    result dict; timings (dict) receives the phases' milliseconds from HIP events and the payload bytes."""
+
+    def __init__(self, net, frames, ego, n_steps=6, group=None, gather_on_host=False):
+        import torch.distributed as dist
+        from . import parallel
+        from .modules import as_f32, precision
+        self.net, self.n_steps, self.group, self.via_host = net, n_steps, group, gather_on_host
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collective = self.world > 1 or parallel.ALWAYS_COLLECTIVE
+        vt = net.img_view_transformer
+        _, _, size = vt._grid()
+        self.size = [int(v) for v in size]
+        n = net.num_adj + 1
+        self.frames = [{k: v.clone() for k, v in f.items()} for f in (frames[:n] if net.with_prev else frames[:1])]
+        self.ego = ego.clone()
+        self.dev = self.ego.device
+        self.F = len(self.frames)
+        f0 = self.frames[0]
+        self.B, self.C, self.n = f0['sensor2keyego'].shape[0], vt.out_channels, n
+        self.h2 = precision() == 'h2' and self.C % 32 == 0
+        self.n_states = n_steps + 1
+        self.mine_f = list(range(self.rank, self.F, self.world))
+        self.mine_s = parallel.owned_states(self.n_states, self.rank, self.world)
+        self.shape = (self.B, self.size[2], self.size[1], self.size[0], self.C)
+        self._as_f32, self._par = as_f32, parallel
+        self.static = {}                                        # receive buffers of the frame exchange (fixed addresses)
+        self.rctx = ops.RangeCtx(self.dev)
+        self.host_rng = torch.zeros(tuple(self.rctx.compact.shape), dtype=torch.int32, pin_memory=True)
+        slots = (self.n_states + self.world - 1) // self.world
+        gdev = 'cpu' if gather_on_host else self.dev
+        self.send = torch.zeros((slots, self.size[0], self.size[1], self.size[2]), dtype=torch.uint8, device=self.dev)
+        self.send_x = self.send if not gather_on_host else torch.zeros(self.send.shape, dtype=torch.uint8, pin_memory=True)
+        self.recv = [torch.empty(self.send.shape, dtype=torch.uint8, device=gdev) for _ in range(self.world)]
+        self.lifted, self.v0, self.all_frames = {}, None, None
+        # calibration: eager passes with the collectives inside, all ranks agree on whether another pass runs
+        with torch.no_grad():
+            ops.ranged(self._eager_pass, self.rctx,
+                       agree=lambda ok: parallel.all_agree(ok, self.dev, group, gather_on_host))
+        torch.cuda.synchronize()
+        # capture: the same pass cut at the collectives; slots are handed out in call order, so A -> B -> C under ONE begin()
+        self.gA, self.gB, self.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        kw = dict(capture_error_mode='thread_local')
+        with torch.no_grad(), ops.use_range(self.rctx):
+            with torch.cuda.graph(self.gA, **kw):
+                self.rctx.begin()
+                self._phase_lift()
+            pool = self.gA.pool()
+            self.all_frames = self._exchange()                  # eager, now: graph B is captured on the buffers it delivers into
+            with torch.cuda.graph(self.gB, pool=pool, **kw):
+                self._phase_encoder()
+            with torch.cuda.graph(self.gC, pool=pool, **kw):
+                self._phase_decode()
+                self.rctx.fold()
+                self.rctx.audit()
+                self.host_rng.copy_(self.rctx.compact, non_blocking=True)
+        torch.cuda.synchronize()
+
+    # ---- the three compute phases (shared by the eager calibration pass and the captures)
+    def _phase_lift(self):
+        for f in self.mine_f:
+            # fp32 values travel: an h2 buffer means nothing without its rank-local exponent ((hi + lo) * 2^e is exact)
+            self.lifted[f] = self._as_f32(self.net.lift_frame_cl(out_h2=self.h2, **self.frames[f])).contiguous()
+
+    def _exchange(self, stats=None):
+        if not self.collective:
+            return [self.lifted[f] for f in range(self.F)]
+        return self._par.exchange_frames(self.lifted, self.F, self.shape, torch.float32, self.dev, self.group, self.via_host, stats,
+                                         static=self.static)
+
+    def _phase_encoder(self):
+        lifted, C, n = self.all_frames, self.C, self.n
+        net, h2 = self.net, self.h2
+        # [adjacent ..., key] (bevdet_occ.py:266): every frame goes straight into its channel slice of ONE buffer -- on the split-fp16
+        # path as ONE h2 tensor under ONE range slot of this pass's table (the same data, hence the same exponent, on every rank)
+        x = torch.empty(self.shape[:-1] + (n * C,), device=self.dev, dtype=torch.float32)
+        slot = ops.new_slot(self.dev) if h2 else None
+        for j in range(n):                                                      # frame j sits at channel block n - 1 - j
+            lo, hi = (n - 1 - j) * C, (n - j) * C
+            if j < len(lifted):
+                if h2:
+                    ops.f32_to_h2(lifted[j], out=ops.H2(x[..., lo:hi], slot))
+                else:
+                    x[..., lo:hi].copy_(lifted[j])
+            else:
+                x[..., lo:hi].zero_()                                           # with_prev=False: zeros (bevdet_occ.py:243-258)
+        self.v0 = net.final_conv.forward_cl(net.bev_encoder_cl(ops.H2(x, slot) if h2 else x, out_h2=h2), out_h2=h2)
+
+    def _phase_decode(self):
+        net = self.net
+        if not self.mine_s:
+            return
+        kmax = max(self.mine_s)
+        states = net.forecast_cl(self.v0, self.ego, kmax, out_h2=self.h2)[0] if kmax > 0 else None
+        inplace = self.h2 and self.B == 1       # the kernel writes a (Z,Y,X) result as the (X,Y,Z)-contiguous payload grid, in place
+        i = 0
+        while i < len(self.mine_s):
+            k = self.mine_s[i]
+            run = 1                              # consecutive owned forecast states decode in ONE launch (world 1: states 1 .. 6)
+            while k > 0 and i + run < len(self.mine_s) and self.mine_s[i + run] == k + run:
+                run += 1
+            if k == 0:
+                feats = self.v0
+            elif run == 1:
+                feats = states[k - 1]
+            else:
+                feats = states.view((states.shape[0] * self.B,) + tuple(self.v0.shape[1:]))[(k - 1) * self.B:(k - 1 + run) * self.B]
+            dst = self.send[i:i + run]
+            if inplace:
+                net.occupancy_head.decode_cl(feats, transposed=True, occ_out=dst.permute(0, 3, 2, 1))
+            else:
+                occ = net.occupancy_head.decode_cl(feats, transposed=True)
+                dst.copy_(occ.permute(0, 3, 2, 1).reshape(run, self.B, *dst.shape[1:])[:, 0])      # batch element 0 (:306)
+            i += run
+
+    def _gather(self, stats=None):
+        if not self.collective:
+            return [self.send[i] for i in range(self.n_states)]
+        if self.via_host:
+            self.send_x.copy_(self.send, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        return self._par.gather_states(None, self.n_states, self.group, stats=stats, send=self.send_x, recv=self.recv)
+
+    def _eager_pass(self):
+        self._phase_lift()
+        self.all_frames = self._exchange()
+        self._phase_encoder()
+        self._phase_decode()
+        return self._gather()
+
+    def run(self, frames=None, ego=None, timings=None):
+        """one sample: optional new inputs into the static buffers, A -> exchange -> B -> C -> gather.  Returns
+        {'semantic_occ_%ds': [(X,Y,Z) uint8]} (static buffers: consume before the next run)."""
+        if frames is not None:
+            dsts, srcs = [self.ego], [ego]
+            for dst, src in zip(self.frames, frames):
+                for k, v in src.items():
+                    dsts.append(dst[k])
+                    srcs.append(v)
+            ops.copy_many(dsts, srcs)
+        ev = []
+
+        def mark(name):
+            if timings is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+        mark('start')
+        self.gA.replay()
+        mark('lift')
+        got = self._exchange(timings)
+        assert all(a.data_ptr() == b.data_ptr() for a, b in zip(got, self.all_frames)), 'frame exchange left its static buffers'
+        mark('gather_frames')
+        self.gB.replay()
+        mark('encoder')
+        self.gC.replay()
+        mark('decode')
+        grids = self._gather(timings)
+        mark('gather_states')
+        if timings is not None:
+            torch.cuda.synchronize()
+            for (_, a), (name, b) in zip(ev[:-1], ev[1:]):
+                timings[name] = a.elapsed_time(b)
+        return {'semantic_occ_%ds' % k: [g] for k, g in enumerate(grids)}
+
+    def bad_replays(self):
+        """(passes that left their calibrated activation ranges, passes audited) since capture (synchronises)"""
+        torch.cuda.synchronize()
+        return self.rctx.audited()

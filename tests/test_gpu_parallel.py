@@ -39,6 +39,24 @@ def _worker(rank, world, port, q, full=False):
         st = {}
         got = harness.simple_test_sharded(net, frames, ego, n_steps=6, gather_on_host=True, timings=st)
         same = [int((got['semantic_occ_%ds' % k][0].cpu() != want['semantic_occ_%ds' % k][0].cpu()).sum()) for k in range(7)]
+        # round 6: the same mode as three captured phases around the two collectives (pipeline.ShardedSample), calibrated once; first on
+        # the calibration sample, then on ANOTHER sample copied into the static buffers
+        from preworld_amd.pipeline import ShardedSample
+        ss = ShardedSample(net, frames, ego, n_steps=6, gather_on_host=True)
+        got = ss.run()
+        same_g = [int((got['semantic_occ_%ds' % k][0].cpu() != want['semantic_occ_%ds' % k][0].cpu()).sum()) for k in range(7)]
+        frames2 = harness.lifted_frames(6, 6 if full else 1, dev)
+        ego2 = torch.from_numpy(S.ego_state(6)).to(dev)
+        with torch.no_grad():
+            want2 = net.simple_test_from_lift(frames2, ego2, n_steps=6)
+        st2 = {}
+        got = ss.run(frames2, ego2, timings=st2)
+        same_g += [int((got['semantic_occ_%ds' % k][0].cpu() != want2['semantic_occ_%ds' % k][0].cpu()).sum()) for k in range(7)]
+        bad = ss.bad_replays()
+        assert bad[0] == 0 and bad[1] == 2, bad
+        assert st2['frames_bytes_received'] == st['frames_bytes_received'] and st2['states_bytes_received'] == st['states_bytes_received']
+        same += same_g
+        del ss
         # with_prev=False (C2's frame handling): the adjacent frame is dropped, its channel slice is zeros
         net.with_prev = False
         with torch.no_grad():
@@ -65,7 +83,8 @@ def test_sharded_lift_and_decode_two_ranks_equal_single_process(full):
         p.join(60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
-    # voxels that differ from the single-process result, per state (7 with the adjacent frame, 3 without).  The sharded pass
+    # voxels that differ from the single-process result, per state (7 eager with the adjacent frame, 2 x 7 through the captured
+    # phases of pipeline.ShardedSample -- calibration sample, then a second sample -- and 3 without the adjacent frame).  The sharded pass
     # exchanges fp32 values and re-splits the concatenated buffer under ONE exponent, the single process keeps each frame under the
     # exponent of its own slot: values can differ below 2^-38 of a tensor's maximum, i.e. a handful of exact ties among the 640 000
     # voxels of a full-size state (the same allowance as a separately calibrated eager pass, tests/test_gpu_range.py); both ranks
@@ -125,6 +144,16 @@ def _rccl_worker(port, q, full=False):
         got = harness.simple_test_sharded(net, frames, ego, n_steps=6, timings=t)
         torch.cuda.synchronize()
         same = [int((got['semantic_occ_%ds' % k][0] != want['semantic_occ_%ds' % k][0]).sum()) for k in range(7)]
+        # the captured form (pipeline.ShardedSample) over RCCL: device-tensor collectives between the three graphs
+        from preworld_amd.pipeline import ShardedSample
+        ss = ShardedSample(net, frames, ego, n_steps=6)
+        t2 = {}
+        got = ss.run(timings=t2)
+        got = ss.run(frames, ego, timings=t2)
+        torch.cuda.synchronize()
+        same += [int((got['semantic_occ_%ds' % k][0] != want['semantic_occ_%ds' % k][0]).sum()) for k in range(7)]
+        assert ss.bad_replays() == (0, 2)
+        t['captured'] = {k: round(v, 3) for k, v in t2.items()}
         q.put((dist.get_backend(), same, bool(got['semantic_occ_0s'][0].is_cuda), t))
     finally:
         dist.destroy_process_group()
@@ -143,8 +172,11 @@ def test_rccl_device_tensor_all_gathers_world_size_1(full):
     p.join(60)
     assert p.exitcode == 0
     assert backend == 'nccl' and on_dev and max(same) <= (8 if full else 0), (backend, same)       # (ties: see the two-rank test)
+    cap = t.pop('captured')
     assert {k for k in t if 'bytes' not in k} == {'lift', 'gather_frames', 'encoder', 'decode', 'gather_states'}, t
-    print('[sharded, RCCL world 1, %s] phase ms / bytes: %s' % ('200x200x16' if full else 'C1 grid', {k: round(v, 3) for k, v in t.items()}))
+    assert {k for k in cap if 'bytes' not in k} == {'lift', 'gather_frames', 'encoder', 'decode', 'gather_states'}, cap
+    print('[sharded, RCCL world 1, %s] eager phase ms / bytes: %s' % ('200x200x16' if full else 'C1 grid', {k: round(v, 3) for k, v in t.items()}))
+    print('[sharded, RCCL world 1, %s] captured (pipeline.ShardedSample) phase ms / bytes: %s' % ('200x200x16' if full else 'C1 grid', cap))
 
 
 def _syncbn_worker(rank, world, port, q):

@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dev = 'cuda:0'
 torch.manual_seed(0)
 cin = int(os.environ.get('CIN', 32)); cout = int(os.environ.get('COUT', 32))
-x = torch.randn(1, 16, 200, 200, cin, device=dev)
+dims = [int(v) for v in os.environ.get('DIMS', '16,200,200').split(',')]          # DIMS=4,50,50 CIN=128 COUT=128: a small-grid layer
+x = torch.randn(1, dims[0], dims[1], dims[2], cin, device=dev)
 nblk = 256
 buf = torch.zeros(nblk * 8 * 16 * 4 + 8 * 27, dtype=torch.int64, device=dev)
 os.environ['PW_CONV_PROBE'] = str(buf.data_ptr())
