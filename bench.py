@@ -523,10 +523,22 @@ def extra_figures(args, dev):
             res3 = net3._to_numpy(net3.simple_test_from_lift(*sets3[i % 3], n_steps=6))
         e = time.perf_counter() - t0
         assert len(res3) == 14 and res3['semantic_occ_6s'][0].shape == (200, 200, 16)
+        # ... and the same entry with net.capture_replay (PreWorld4DTraj.simple_test_captured): the module's own hipGraph of the hot path,
+        # range-checked on the host after every call, the 14 grids copied out of the pinned buffer
+        for j in range(3):
+            net3.simple_test_captured(*sets3[j])
+        t0 = time.perf_counter()
+        for i in range(n):
+            res4 = net3.simple_test_captured(*sets3[i % 3])
+        e4 = time.perf_counter() - t0
+        n_diff = int(sum(int((res4[k][0] != res3[k][0]).sum()) for k in res3))
         ex['dropin_simple_test'] = dict(
             workload='C3 through PreWorld4DTraj.simple_test_from_lift + _to_numpy (the drop-in module API downstream of the image side), eager, '
                      'one sample at a time, 3 rotating input sets, host payload = 14 numpy uint8 grids', ms_per_sample=round(e / n * 1e3, 4),
-            samples_per_s=round(n / e, 2), steps=n)
+            samples_per_s=round(n / e, 2), steps=n,
+            captured=dict(what='the same entry with net.capture_replay = True (simple_test_captured: the module replays its own hipGraph, host '
+                               'range check + payload copy per call, one sample at a time)', ms_per_sample=round(e4 / n * 1e3, 4),
+                          samples_per_s=round(n / e4, 2), voxels_differing_from_eager=n_diff))
         del net3, sets3
     except Exception as e:                                                # noqa: BLE001
         ex['dropin_simple_test'] = {'error': repr(e)[:300]}
@@ -674,6 +686,22 @@ def pretrain_step_ms(dev, args):
             return losses
         if args == 'step':                                            # tools/diag_train_ops.py: just the closure
             return step
+        net_t = harness.build_model(cfg, S.synth_state_dict(0), dev).train()      # the unscaled (transparent) scene of rounds 2-5, for comparison
+
+        def step_t():
+            net_t.zero_grad(set_to_none=True)
+            losses = net_t.forward_train_from_feats(feat.clone().requires_grad_(), voxel_semantics=sem, rays=rays_t.clone(), bda=bda)
+            sum(losses.values()).backward()
+        for _ in range(2):
+            step_t()
+        torch.cuda.synchronize()
+        per_t = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            step_t()
+            torch.cuda.synchronize()
+            per_t.append((time.perf_counter() - t0) * 1e3)
+        del net_t
         for _ in range(2):
             losses = step()
         torch.cuda.synchronize()
@@ -686,7 +714,9 @@ def pretrain_step_ms(dev, args):
         return {'ms': round(float(np.median(per)), 2), 'ms_min': round(min(per), 2), 'ms_max': round(max(per), 2), 'rays': R, 'samples_per_ray': 417,
                 'what': 'final_conv + OccHead + attribute MLPs + NerfHead losses, forward + backward, 1 sample, eager; density_mlp output '
                         'rescaled so that rays terminate (terminated_frac measured on the step itself)',
-                'terminated_frac': stats.get('terminated_frac'), 'scene': stats, 'unscaled_scene': transparent_stats,
+                'terminated_frac': stats.get('terminated_frac'), 'scene': stats,
+                'unscaled_scene': dict(transparent_stats, ms=round(float(np.median(per_t)), 2),
+                                       note='no ray terminates: every sample of every ray is kept and goes through the backward'),
                 'losses': {k: round(float(v.detach()), 4) for k, v in losses.items() if 'sup' not in k}}
     except Exception as e:                                            # noqa: BLE001  (an extra figure must not take the bench line down)
         return {'error': repr(e)[:300]}

@@ -256,3 +256,46 @@ def test_dropin_forward_train_pretrain_matches_reference(tag, det):
     assert st[:, 1].sum() >= 10 and st[:, 2].sum() >= 100
     losses = net(return_loss=True, img_inputs=inputs, img_metas=[dict(), dict()], **E.pretrain_kwargs(0, det, DEV, batch=2))
     _check_forward_train(G, tag, det, net, losses, E.pretrain_grad_probes(net, det), loss_tol=3e-4)
+
+
+def test_simple_test_with_capture_replay_matches_the_reference_and_the_eager_entry():
+    """round 6: `net.capture_replay = True` routes the reference entry point simple_test() through the module's own hipGraph of the
+    hot path (PreWorld4DTraj.simple_test_captured).  Same keys, numpy uint8 payload; against the reference classes' grids
+    (e2e_small.npz) under the same near-tie rule as the eager entry; a second, different sample through the SAME captured graph
+    (inputs copied into its static buffers, ranges checked on the host) equals the eager result of that sample up to exact ties."""
+    tag = 'p4d_ft'
+    net, dn = _build('PreWorld4DTraj', True, True)
+    inputs = tuple(t.to(DEV) for t in E.img_inputs(0))
+    ego = [[t.to(DEV) for t in E.ego_states(0)[0]]]
+    net.capture_replay = True
+    with torch.no_grad():
+        res = net.simple_test(None, None, img=inputs, temporal_ego_states=ego)
+    assert sorted(res.keys()) == list(GOLD[tag + '_keys']) and len(net._captured) == 1
+    for k in res:
+        want, got = GOLD[tag + '_' + k], res[k][0]
+        assert isinstance(got, np.ndarray) and got.dtype == np.uint8 and got.shape == want.shape
+        flips = np.nonzero((got != want).reshape(-1))[0]
+        if k.startswith('semantic_occ'):
+            ti, tm, tc = GOLD['%s_%s_tie_idx' % (tag, k)], GOLD['%s_%s_tie_margin' % (tag, k)], GOLD['%s_%s_tie_cls' % (tag, k)]
+            tol = 2 * 2e-5 * float(GOLD['%s_%s_logit_absmax' % (tag, k)])
+            for v in flips:
+                j = np.nonzero(ti == v)[0]
+                assert j.size == 1 and got.reshape(-1)[v] == tc[j[0]] and tm[j[0]] <= tol, (k, int(v))
+        else:
+            assert flips.size <= 3, (k, flips.size)
+    # another sample (second batch element's poses, its own seeded DepthNet outputs) through the same graph vs the eager entry
+    inputs2 = tuple(t.to(DEV) for t in E._img_inputs_one(0, 'small', 1))
+    ego2 = [[torch.from_numpy(S.ego_state(47)).to(DEV)]]
+    dn.reset()
+    dn.seed = 3
+    with torch.no_grad():
+        cap = net.simple_test(None, None, img=inputs2, temporal_ego_states=ego2)
+    assert len(net._captured) == 1                                        # the same shapes: replayed, not re-captured
+    net.capture_replay = False
+    dn.reset()
+    with torch.no_grad():
+        eager = net.simple_test(None, None, img=inputs2, temporal_ego_states=ego2)
+    n_diff = sum(int((cap[k][0] != eager[k][0]).sum()) for k in eager)
+    print('[e2e] captured vs eager simple_test on a second sample: %d of %d voxels differ' % (n_diff, sum(v[0].size for v in eager.values())))
+    assert sorted(cap) == sorted(eager) and n_diff <= 8
+    assert any(int((cap[k][0] != res[k][0]).sum()) > 100 for k in cap)      # it really was another sample
