@@ -12,6 +12,17 @@ import torch
 from . import ops
 
 
+def clone_frame(f):
+    """static copy of one frame's inputs.  depthnet_tail hands the context over channels-last and says so through an attribute of the
+    tensor object (modules.LSSViewTransformer.depthnet_tail): a clone must keep it, or the lift reads the buffer channel-first"""
+    out = {}
+    for k, v in f.items():
+        out[k] = v.clone()
+        if getattr(v, '_pw_channels_last', False):
+            out[k]._pw_channels_last = True
+    return out
+
+
 def to_dev(a, dev='cuda:0'):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
@@ -31,7 +42,7 @@ class CapturedSample:
         order of `self.host_keys`) instead of the reference's 14 synchronous .cpu() calls per sample."""
         self.net, self.n_steps, self.d2h = net, n_steps, d2h
         self.host = self.host_keys = None
-        self.frames = [{k: v.clone() for k, v in f.items()} for f in frames]
+        self.frames = [clone_frame(f) for f in frames]
         self.ego = ego.clone()
         # Activation ranges of the split-fp16 path (ops.RangeCtx): this sample's own table of per-tensor exponents.  The
         # warm-up calibrates it (repeats the pass until every h2 tensor's maximum sits in the window); the captured kernels
@@ -161,7 +172,7 @@ class ShardedSample:
         _, _, size = vt._grid()
         self.size = [int(v) for v in size]
         n = net.num_adj + 1
-        self.frames = [{k: v.clone() for k, v in f.items()} for f in (frames[:n] if net.with_prev else frames[:1])]
+        self.frames = [clone_frame(f) for f in (frames[:n] if net.with_prev else frames[:1])]
         self.ego = ego.clone()
         self.dev = self.ego.device
         self.F = len(self.frames)
