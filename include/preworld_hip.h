@@ -284,21 +284,6 @@ int pw_occ_head_h2_strided(const float* x, const float* wpk, const float* scale,
                            int64_t out_span_bytes, int empty_idx, int B, int D, int H, int W, int Cin, int n_mid, int n_hid,
                            int n_cls, const int32_t* x_rng, float mid_a, float mid_b, float hid_a, float hid_b, void* stream);
 
-/* A11, "stacked" form (round 6; same reference lines, same outputs, same argument meaning as pw_occ_head_h2_strided): the 32 -> 16 conv on
- * v_mfma_f32_32x32x16_f16 with the hi and the lo plane of the weights stacked in M -- A[m][k] = hi(S_c w[c][k]) for m = c < 16, lo(...) for
- * m = 16 + c -- so that two instructions per k-step (A . x_hi, A . x_lo) give all four partial products; rows c and 16 + c of the
- * accumulator are added in the epilogue.  The packings differ from pw_occ_head_h2's (same sizes):
- *   wpk   = 27 taps x 2 k-steps x 64 lanes x 8 fp16 (55 296 bytes): lane (m = l & 31, half = l >> 5) holds channels 16 ks + 8 half + 0..7 of
- *           row m (preworld_amd.ops.pack_occ_weight_s);
- *   tailpk = 800 floats (preworld_amd.ops.pack_occ_tail_s): three 32x16 A fragments [64 lanes][8 fp16] -- [hi(S1 W1); lo(S1 W1)] (rows 0-7 /
- *           8-15, k = mid channel 8 (j >> 2) + 4 half + (j & 3)), hi(S2 W2) and lo(S2 W2) (rows 0-17, k = hidden channel 4 half + j for j < 4) --
- *           then s1 / S1 and b1 padded to 16 floats each.
- * Kernel k_occ_head_s<LOGITS> (pw_occ_head_s.hip). */
-int pw_occ_head_s(const float* x, const float* wpk, const float* scale, const float* bias, const float* tailpk,
-                  float inv2, uint8_t* occ, float* logits, uint8_t* geo, const int64_t* out_strides4_host, int64_t out_span_bytes,
-                  int empty_idx, int B, int D, int H, int W, int Cin, int n_mid, int n_hid, int n_cls, const int32_t* x_rng, float mid_a,
-                  float mid_b, float hid_a, float hid_b, void* stream);
-
 /* A10  state-conditioned forecast (mmdet3d/models/detectors/preworld_temporal_traj.py:329-368).
  * pw_forecast_pack: fusion_head.{0,2}.weight ([128][64], [32][128]) -> per-lane MFMA operand
  *   order, w1p/w2p float[4096] each (once per weight update).

@@ -16,7 +16,6 @@ from . import ops
 # PW_LSS=sort keeps the sort-based lift (pw_segment_sort + pw_bev_pool_dense) on the inference path: A/B switch for
 # ops.lss_lift_pool, which is the default for C == 32 (same bits either way, tests/test_gpu_lss.py)
 _LSS_FORM = os.environ.get('PW_LSS', 'slots')
-_OCC_FORM = os.environ.get('PW_OCC', 'h2')       # 'h2' = k_occ_head_h2 (16x16x32 MFMA), 's' = k_occ_head_s (stacked 32x32x16, round 6)
 
 
 def create_frustum(depth_cfg, input_size, downsample):
@@ -720,7 +719,7 @@ class OccHead(nn.Module):
         wpk, uwpk, s0, b0, w1, s1, b1, w2 = self._cache.get(params, build)
         return (uwpk if wino else wpk)[1 if transposed else 0], s0, b0, w1, s1, b1, w2
 
-    def _folded_h2(self, transposed=False, stacked=False):
+    def _folded_h2(self, transposed=False):
         """operands of ops.occ_head_h2: split-fp16 conv weights (both tap orders), folded BN with the weights' pre-scale
         divided out, the packed 16->8->18 tail"""
         c0, bn0 = self.occ_convs[0][0], self.occ_convs[0][1]
@@ -735,22 +734,13 @@ class OccHead(nn.Module):
             for w in (c0.weight, c0.weight.permute(0, 1, 4, 3, 2).contiguous()):
                 wpk, inv = ops.pack_occ_weight_h2(w.float())
                 packs.append((wpk, (s0 * inv).contiguous()))
-            w1m, w2m = c1.weight.reshape(c1.weight.shape[0], -1).float(), c2.weight.reshape(c2.weight.shape[0], -1).float()
-            tailpk, inv2 = ops.pack_occ_tail_h2(w1m, s1, b1, w2m)
+            tailpk, inv2 = ops.pack_occ_tail_h2(c1.weight.reshape(c1.weight.shape[0], -1).float(), s1, b1,
+                                                c2.weight.reshape(c2.weight.shape[0], -1).float())
             bounds = ops.occ_head_bounds(c0.weight, s0, b0, c1.weight.reshape(c1.weight.shape[0], -1), s1, b1)
-            # the stacked form (k_occ_head_s): the same weights in its own operand order
-            spacks = []
-            for w in (c0.weight, c0.weight.permute(0, 1, 4, 3, 2).contiguous()):
-                wpk, inv = ops.pack_occ_weight_s(w.float())
-                spacks.append((wpk, (s0 * inv).contiguous()))
-            stail, sinv2 = ops.pack_occ_tail_s(w1m, s1, b1, w2m)
-            return packs, b0.contiguous(), tailpk, inv2, bounds, spacks, stail, sinv2
+            return packs, b0.contiguous(), tailpk, inv2, bounds
         if not hasattr(self, '_cache_h2'):
             self._cache_h2 = _PackedCache()
-        packs, b0, tailpk, inv2, bounds, spacks, stail, sinv2 = self._cache_h2.get(params, build)
-        if stacked:
-            wpk, s0 = spacks[1 if transposed else 0]
-            return wpk, s0, b0, stail, sinv2, bounds
+        packs, b0, tailpk, inv2, bounds = self._cache_h2.get(params, build)
         wpk, s0 = packs[1 if transposed else 0]
         return wpk, s0, b0, tailpk, inv2, bounds
 
@@ -768,11 +758,9 @@ class OccHead(nn.Module):
         is_h2 = isinstance(x_cl, ops.H2)
         if C == 32 and (is_h2 or precision() == 'h2'):
             # split-fp16 kernel (k_occ_head_h2); an fp32 input is converted first (30 us at 16x200x200, still ahead)
-            stacked = _OCC_FORM == 's'
-            wpk, s0, b0, tailpk, inv2, bounds = self._folded_h2(transposed, stacked)
+            wpk, s0, b0, tailpk, inv2, bounds = self._folded_h2(transposed)
             return ops.occ_head_h2(x_cl if is_h2 else ops.f32_to_h2(x_cl.contiguous()), wpk, s0, b0, tailpk, inv2, bounds,
-                                   want_logits=want_logits, want_geo=want_geo, empty_idx=self.empty_idx, occ=occ_out, geo=geo_out,
-                                   stacked=stacked)
+                                   want_logits=want_logits, want_geo=want_geo, empty_idx=self.empty_idx, occ=occ_out, geo=geo_out)
         if occ_out is not None or geo_out is not None:
             raise NotImplementedError('occ_out / geo_out are built for the split-fp16 OccHead kernel')
         if is_h2:

@@ -873,56 +873,9 @@ def pack_occ_tail_h2(w1, s1, b1, w2):
     return torch.cat([pk, s1p, b1p]).contiguous(), 1.0 / S2
 
 
-def pack_occ_weight_s(w):
-    """OccHead conv weight (16, 32, 3,3,3) -> (wpk, inv_scale (16,)) for pw_occ_head_s (include/preworld_hip.h): the hi and lo planes of
-    S_c * w[c] stacked as rows c and 16 + c of a 32-row A operand; wpk[tap][ks][l][e] = row (l & 31), channel 16 ks + 8 (l >> 5) + e, as a
-    float32-typed (27, 2, 64, 4) tensor."""
-    Cout, Cin = w.shape[:2]
-    if (Cout, Cin) != (16, 32) or tuple(w.shape[2:]) != (3, 3, 3):
-        raise _lib.PreworldHipError('pack_occ_weight_s expects a (16, 32, 3, 3, 3) weight')
-    wf = w.reshape(Cout, -1).double()
-    S = torch.exp2(torch.floor(torch.log2(1023.0 / wf.abs().amax(dim=1).clamp_min(1e-30))))
-    ws = (wf * S[:, None]).view(Cout, Cin, 27)
-    hi = ws.to(torch.float16)
-    lo = (ws - hi.double()).to(torch.float16)
-    t = torch.cat([hi, lo], 0).view(32, 2, 2, 8, 27)                               # (m, ks, half, e, tap): c = 16 ks + 8 half + e
-    t = t.permute(4, 1, 2, 0, 3).contiguous()                                      # (tap, ks, half, m, e): lane = 32 half + m
-    wpk = t.view(27, 2, 64, 8).view(torch.float32).view(27, 2, 64, 4).contiguous()
-    return wpk, (1.0 / S).float()
-
-
-def pack_occ_tail_s(w1, s1, b1, w2):
-    """The 16 -> 8 (+BN+ReLU) -> 18 tail of OccHead as operands of pw_occ_head_s: w1 (8,16), s1 / b1 (8,) folded BN, w2 (18,8)
-    -> (tailpk float32 (800,), inv2).  One power-of-two pre-scale per matrix (argmax must see one common scale)."""
-    dev = w1.device
-    S1, h1, l1 = _split_planes(w1.double())
-    S2, h2_, l2 = _split_planes(w2.double())
-    lane = torch.arange(64, device=dev)
-    m, half = lane & 31, lane >> 5
-    j = torch.arange(8, device=dev)
-    a1 = torch.zeros(32, 16, dtype=torch.float16, device=dev)                       # rows 0-7 hi, 8-15 lo of S1 W1
-    a1[:8], a1[8:16] = h1, l1
-    ch = (8 * (j >> 2) + (j & 3))[None, :] + 4 * half[:, None]                      # (64, 8): the lane's mid channels in its k order
-    f1 = a1[m[:, None], ch]
-
-    def frag2(plane):
-        full = torch.zeros(32, 16, dtype=torch.float16, device=dev)                 # k < 8: hidden channel; 8..15: padding
-        full[:18, :8] = plane
-        k = torch.where(j < 4, 4 * half[:, None] + j[None, :], torch.full((64, 8), 15, device=dev))
-        return full[m[:, None], k]
-    pk = torch.stack([f1, frag2(h2_), frag2(l2)], 0).contiguous().view(torch.float32).reshape(-1)     # 3 * 64 * 4 floats
-    s1p = torch.zeros(16, dtype=_f32, device=dev)
-    b1p = torch.zeros(16, dtype=_f32, device=dev)
-    s1p[:8] = (s1.double() / S1).float()
-    b1p[:8] = b1.float()
-    return torch.cat([pk, s1p, b1p]).contiguous(), 1.0 / S2
-
-
-def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, bounds, want_logits=False, occ=None, want_geo=False, empty_idx=17, geo=None,
-                stacked=False):
+def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, bounds, want_logits=False, occ=None, want_geo=False, empty_idx=17, geo=None):
     """OccHead (occupancy_head.py:124-177) on the fp16 matrix cores: x = ops.H2 (B,D,H,W,32); wpk from pack_occ_weight_h2;
     scale (16,) MUST already contain the packer's inv_scale; (tailpk, inv2) from pack_occ_tail_h2; bounds from occ_head_bounds.
-    stacked=True: the same head on k_occ_head_s (pw_occ_head_s; wpk / tailpk then come from pack_occ_weight_s / pack_occ_tail_s).
     Returns like occ_head_fused.  occ / geo: optional uint8 (B,D,H,W) destinations with ARBITRARY (equal) strides -- e.g. the
     .permute(0,3,2,1) view of an (B,X,Y,Z)-contiguous payload buffer: the kernel then writes the reference's (X,Y,Z) arrays in
     place (pw_occ_head_h2_strided) and no transposing copy is needed afterwards."""
@@ -950,7 +903,7 @@ def occ_head_h2(x, wpk, scale, bias, tailpk, inv2, bounds, want_logits=False, oc
         strides = (ctypes.c_int64 * 4)(*st)
         span = 1 + sum((n - 1) * v for n, v in zip((B, D, H, W), st))
         # (the C side rejects overlapping stride sets -- two voxels storing to one byte would race)
-    _lib.call('pw_occ_head_s' if stacked else 'pw_occ_head_h2_strided', _chk(x.buf, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
+    _lib.call('pw_occ_head_h2_strided', _chk(x.buf, _f32, 'x'), _chk(wpk, _f32, 'wpk'), _chk(scale, _f32, 'scale'),
               _chk(bias, _f32, 'bias'), _chk(tailpk, _f32, 'tailpk'), float(inv2), _p(occ), _p(logits), _p(geo), strides, int(span),
               int(empty_idx), B, D, H, W, Cin, 16, 8, 18, _rng(x), float(bounds[0]), float(bounds[1]), float(bounds[2]),
               float(bounds[3]), _stream())

@@ -377,9 +377,8 @@ def test_occ_head_wino_matches_direct_and_oracle(shape):
     np.testing.assert_allclose(got[sl], want[sl], rtol=5e-4, atol=5e-4)
 
 
-@pytest.mark.parametrize('form', ['h2', 'stacked'])
 @pytest.mark.parametrize('shape', [(1, 16, 200, 200), (2, 5, 19, 27), (1, 4, 8, 8), (1, 16, 96, 104), (3, 2, 9, 7)])
-def test_occ_head_h2_matches_direct_and_oracle(shape, form):
+def test_occ_head_h2_matches_direct_and_oracle(shape):
     """k_occ_head_h2 (split-fp16 16x16x32 MFMA, register-resident weights, scalar-operand tail) against the direct fp32
     16x16x4 MFMA kernel: logits to split-fp16 accuracy, occupancy = argmax of its own logits (first maximum), geo_occ
     consistent, ragged grids (partial tiles in every axis); on a corner crop the logits against the oracle."""
@@ -393,42 +392,34 @@ def test_occ_head_h2_matches_direct_and_oracle(shape, form):
     w2 = T((rs.standard_normal((18, 8)) * 0.5).astype(np.float32))
     occ_d, lg_d, geo_d = ops.occ_head_fused(x, ops.pack_conv_weight16(w0), ops._pad32(s0, 1.0), ops._pad32(b0, 0.0), w1, s1, b1,
                                             w2, want_logits=True, want_geo=True)
-    # form 'stacked' (round 6): k_occ_head_s -- 32x32x16 MFMAs with the hi / lo weight rows stacked in M, its own operand packing
-    if form == 'stacked':
-        import functools
-        wpk, inv = ops.pack_occ_weight_s(w0)
-        hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_s(w1, s1, b1, w2) + (ops.occ_head_bounds(w0, s0, b0, w1, s1, b1),)
-        head = functools.partial(ops.occ_head_h2, stacked=True)
-    else:
-        wpk, inv = ops.pack_occ_weight_h2(w0)
-        hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_h2(w1, s1, b1, w2) + (ops.occ_head_bounds(w0, s0, b0, w1, s1, b1),)
-        head = ops.occ_head_h2
+    wpk, inv = ops.pack_occ_weight_h2(w0)
+    hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_h2(w1, s1, b1, w2) + (ops.occ_head_bounds(w0, s0, b0, w1, s1, b1),)
     xh = ops.f32_to_h2(x)
-    occ_h, lg_h, geo_h = head(xh, wpk, *hargs, want_logits=True, want_geo=True)
+    occ_h, lg_h, geo_h = ops.occ_head_h2(xh, wpk, *hargs, want_logits=True, want_geo=True)
     from _parity import check_argmax, check_close
     check_close('occ_head h2 logits vs direct fp32 %s' % (shape,), lg_h, lg_d, 2e-5)
     assert torch.equal(occ_h.long(), lg_h.argmax(-1))
     check_argmax('occ_head h2 vs direct %s' % (shape,), occ_h, occ_d, lg_d, 2e-4)
     np.testing.assert_array_equal(geo_h.cpu().numpy(), np.where(occ_h.cpu().numpy() != 17, 0, 17).astype(np.uint8))
-    occ_only = head(xh, wpk, *hargs)
+    occ_only = ops.occ_head_h2(xh, wpk, *hargs)
     assert torch.equal(occ_only, occ_h)                      # deterministic, logits optional
     # strided destinations (pw_occ_head_h2_strided): the (D,H,W) result written as the transposed (W,H,D)-contiguous array -- the
     # reference's (X,Y,Z) payload -- into rows of a (B, 2, W, H, D) buffer; bytes outside the rows stay untouched
     buf = torch.full((B, 2, W, H, D + 3), 255, dtype=torch.uint8, device=DEV)[..., :D]        # rows with a gap after every line
-    o2, g2 = head(xh, wpk, *hargs, occ=buf[:, 0].permute(0, 3, 2, 1), geo=buf[:, 1].permute(0, 3, 2, 1))
+    o2, g2 = ops.occ_head_h2(xh, wpk, *hargs, occ=buf[:, 0].permute(0, 3, 2, 1), geo=buf[:, 1].permute(0, 3, 2, 1))
     assert torch.equal(buf[:, 0], occ_h.permute(0, 3, 2, 1)) and torch.equal(buf[:, 1], geo_h.permute(0, 3, 2, 1))
     assert o2.data_ptr() == buf.data_ptr() and bool((buf._base.reshape(B, 2, W, H, D + 3)[..., D:] == 255).all())
     # a strided occ with an auto-allocated geo (storage sized for the gapped strides), and overlapping stride sets refused
     buf2 = torch.full((B, 2, W, H, D + 3), 255, dtype=torch.uint8, device=DEV)[..., :D]
-    o3, g3 = head(xh, wpk, *hargs, occ=buf2[:, 0].permute(0, 3, 2, 1), want_geo=True)
+    o3, g3 = ops.occ_head_h2(xh, wpk, *hargs, occ=buf2[:, 0].permute(0, 3, 2, 1), want_geo=True)
     assert tuple(g3.stride()) == tuple(o3.stride()) and torch.equal(g3, geo_h) and torch.equal(o3, occ_h)
     if B > 1:
         with pytest.raises(Exception, match='overlap'):
-            head(xh, wpk, *hargs, occ=buf2[:1, 0].permute(0, 3, 2, 1).expand(B, D, H, W))          # batch stride 0
+            ops.occ_head_h2(xh, wpk, *hargs, occ=buf2[:1, 0].permute(0, 3, 2, 1).expand(B, D, H, W))          # batch stride 0
     if H > 1 and W > 1:
         flat = torch.zeros(B * D * H * W, dtype=torch.uint8, device=DEV)
         with pytest.raises(Exception, match='overlap'):                                                       # h and w both step by D
-            head(xh, wpk, *hargs, occ=flat.as_strided((B, D, H, W), (D * H * W, 1, D, D)))
+            ops.occ_head_h2(xh, wpk, *hargs, occ=flat.as_strided((B, D, H, W), (D * H * W, 1, D, D)))
     d1, h1, w1_ = min(D, 6), min(H, 12), min(W, 12)
     xc = x[:1, :d1, :h1, :w1_].permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
     mid = np.maximum(O.conv3d(xc, w0.cpu().numpy()) * s0.cpu().numpy()[None, :, None, None, None]

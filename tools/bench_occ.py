@@ -17,8 +17,6 @@ s1 = T(rs.uniform(0.5, 1.5, 8).astype(np.float32)); b1 = T((rs.standard_normal(8
 w2 = T((rs.standard_normal((18, 8)) * 0.5).astype(np.float32))
 wpk, inv = ops.pack_occ_weight_h2(w0)
 hargs = ((s0 * inv).contiguous(), b0) + ops.pack_occ_tail_h2(w1, s1, b1, w2) + (ops.occ_head_bounds(w0, s0, b0, w1, s1, b1),)
-swpk, sinv = ops.pack_occ_weight_s(w0)
-sargs = ((s0 * sinv).contiguous(), b0) + ops.pack_occ_tail_s(w1, s1, b1, w2) + (ops.occ_head_bounds(w0, s0, b0, w1, s1, b1),)
 wino = ops.pack_conv_weight_wino(w0, cout_total=16)
 fargs = (ops._pad32(s0, 1.0), ops._pad32(b0, 0.0), w1, s1, b1, w2)
 for B in (1, 6):
@@ -28,6 +26,5 @@ for B in (1, 6):
     gf = 2 * B * 640000 * (27 * 32 * 16 + 16 * 8 + 8 * 18) / 1e9
     tw = timeit(lambda: ops.occ_head_fused(x, wino, *fargs, occ=occ, want_geo=True))
     th = timeit(lambda: ops.occ_head_h2(xh, wpk, *hargs, occ=occ, want_geo=True))
-    ts = timeit(lambda: ops.occ_head_h2(xh, swpk, *sargs, occ=occ, want_geo=True, stacked=True))
-    print('B=%d  %.1f GF   wino f32 %.1f us   h2 (16x16x32, 3 products) %.1f us (%.0f TF direct)   stacked (32x32x16, hi/lo rows in M) %.1f us (%.0f TF direct)   %s' % (
-        B, gf, tw, th, gf / th * 1e3, ts, gf / ts * 1e3, _lib.lib().pw_last_kernel().decode()), flush=True)
+    print('B=%d  %.1f GF   wino f32 %.1f us (%.0f TF)   h2 %.1f us (%.0f TF direct, %.0f executed)   %s' % (
+        B, gf, tw, gf / tw * 1e-3, th, gf / th * 1e-3, 3 * gf / th * 1e-3, _lib.lib().pw_last_kernel().decode()), flush=True)

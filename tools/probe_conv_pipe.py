@@ -17,20 +17,19 @@ nblk = 256
 buf = torch.zeros(nblk * 8 * 16 * 4 + 8 * 27, dtype=torch.int64, device=dev)
 os.environ['PW_CONV_PROBE'] = str(buf.data_ptr())
 from preworld_amd import ops  # noqa: E402
-if os.environ.get('OCC', '0') in ('1', '2'):         # k_occ_head_h2 / OCC=2: k_occ_head_s (same probe layout; no per-tap table)
+if os.environ.get('OCC', '0') == '1':         # k_occ_head_h2 (same probe layout; no per-tap table)
     import numpy as _np
     rs = _np.random.RandomState(0)
     T = lambda a: torch.from_numpy(_np.ascontiguousarray(a)).to(dev)
     w0 = T((rs.standard_normal((16, 32, 3, 3, 3)) * 0.05).astype(_np.float32))
-    stacked = os.environ['OCC'] == '2'
-    wpk, inv = (ops.pack_occ_weight_s if stacked else ops.pack_occ_weight_h2)(w0)
-    hargs = (inv.contiguous(), T(_np.zeros(16, _np.float32))) + (ops.pack_occ_tail_s if stacked else ops.pack_occ_tail_h2)(
+    wpk, inv = ops.pack_occ_weight_h2(w0)
+    hargs = (inv.contiguous(), T(_np.zeros(16, _np.float32))) + ops.pack_occ_tail_h2(
         T(rs.standard_normal((8, 16)).astype(_np.float32)), T(_np.ones(8, _np.float32)), T(_np.zeros(8, _np.float32)),
         T(rs.standard_normal((18, 8)).astype(_np.float32))) + ((30.0, 0.0, 30.0, 0.0),)
     xh = ops.f32_to_h2(x)
     for _ in range(3):
         buf.zero_()
-        ops.occ_head_h2(xh, wpk, *hargs, want_geo=True, stacked=stacked)
+        ops.occ_head_h2(xh, wpk, *hargs, want_geo=True)
 elif os.environ.get('H2', '0') == '1':        # the split-fp16 kernel k_conv3d_h2 (same probe layout)
     wh, inv = ops.pack_conv_weight_h2(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
     xh = ops.f32_to_h2(x)
@@ -75,7 +74,7 @@ for w in range(8):
         np.percentile((t[:, w, 1:9, 1] - t[:, w, 1:9, 0])[m], 90), (t[:, w, 1:9, 2] - t[:, w, 1:9, 1])[m].mean()))
 # one block, one stage: per-wave absolute times relative to stage start of wave 0
 b = 17
-if os.environ.get('OCC', '0') in ('1', '2'):
+if os.environ.get('OCC', '0') == '1':
     sys.exit(0)
 for st in (3, 4):
     base = t[b, :, st, 0].min()
