@@ -272,7 +272,7 @@ int pw_occ_head_fused(const float* x, const float* wpk, const float* scale, cons
  *   |mid| <= mid_a * 2^(16 + x_rng[0]) + mid_b with mid_a = max_c |BN scale_c| * ||w[c]||_1, mid_b = max_c |bias_c|, and
  *   |hid| <= hid_a * max|mid| + hid_b with hid_a = max_r |s1_r| * ||W1[r]||_1, hid_b = max_r |b1_r| (preworld_amd.ops computes them).
  * Kernel k_occ_head_h2<LOGITS>: v_mfma_f32_16x16x32_f16 with all conv weights register-resident; the tail runs on
- * v_mfma_f32_16x16x16_f16 inside the next tile's tap loop. */
+ * v_mfma_f32_16x16x16_f16 in registers, as a phase behind each tile's tap loop. */
 int pw_occ_head_h2(const float* x, const float* wpk, const float* scale, const float* bias, const float* tailpk, float inv2,
                    uint8_t* occ, float* logits, uint8_t* geo, int empty_idx, int B, int D, int H, int W, int Cin, int n_mid,
                    int n_hid, int n_cls, const int32_t* x_rng, float mid_a, float mid_b, float hid_a, float hid_b, void* stream);

@@ -23,11 +23,10 @@
 // 8->18 chain as split-fp16 products (3 + 2 x 3 small MFMAs per 16 voxels) on weight fragments that live in 12 VGPRs, with no
 // LDS transpose and no weight traffic; the 18 logits of a voxel end up spread over its 4 lanes (classes 4 g + r, and 16 / 17
 // in lane g = 0 of the second M-tile), argmax = local scan + two v_permlane{16,32}_swap exchanges, ties -> lowest class
-// like torch.argmax.  The tail of tile s runs INSIDE the tap loop of tile s + 1 (software pipeline: ~65 VALU and 9 small
-// MFMAs per 36-MFMA group, placed by sched_group_barrier), stores are bounds-checked by out-of-range buffer offsets, so the
-// whole stage is one branch-free scheduling region per (kd, kw) group.  A first version with the tail as a separate phase
-// (LDS transpose, one voxel per lane, fp32 FMAs with scalar-loaded weights) spent 3.2 k of 11.5 k cycles per tile there,
-// almost all of it s_load latency.
+// like torch.argmax.  The tail of a tile is a phase of its own behind the stage's barrier (2.7 k of the 10.6 k cycles of a stage,
+// profiles/r06_stage_probes.txt): with one wave per SIMD a 4-pass MFMA blocks the wave's in-order issue for its 16 cycles, so tail
+// instructions moved into the next tile's tap loop cost there what they save here (round 2 measured both interleavings: slower /
+// equal; DESIGN_HISTORY.md 5.2).  Stores are bounds-checked by out-of-range buffer offsets, so the tail is one branch-free region.
 #include "pw_h2.h"
 #include "pw_occ_tail.h"
 
