@@ -539,6 +539,32 @@ class _PreWorldCommon(BEVStereo4DOCC):
         side drives."""
         return self._voxel_losses_train(as_f32(self.final_conv.forward_cl(bev_feat_cl)), **kwargs)
 
+    def simple_test_captured(self, frames, temporal_ego_states=None, n_steps=None, copy=True):
+        """The reference-API result -- {'semantic_occ[_ks]' / 'geo_occ[_ks]': [numpy uint8 (X,Y,Z)]} -- through a hipGraph of the hot path
+        that this module captures on first use for the inputs' shapes (pipeline.CapturedSample with the host payload inside the
+        graph) and replays afterwards: no per-launch host work and no calibration pass per call.  Every call is range-checked on the
+        host copy of the exponent table the replay delivers (run_checked: a sample outside the calibrated window is re-calibrated
+        eagerly and replayed once).  Opt-in: `net.capture_replay = True` routes simple_test() here (round 6; the eager entry pays
+        ~60 launches of host work and its per-call calibration sync -- bench.py `extra.dropin_simple_test`).  PreWorld4DTraj passes its
+        ego states (B,1,21) and decodes n_steps (default 6) forecast states; PreWorld has neither.  copy=False returns views of the
+        pinned buffer the next call overwrites."""
+        from .pipeline import CapturedSample
+        temporal = hasattr(self, 'forecast_cl')
+        n_steps = (6 if n_steps is None else n_steps) if temporal else 0
+        ego = temporal_ego_states if temporal else frames[0]['bda'].new_zeros(1)          # (CapturedSample keeps a static copy)
+        key = tuple((k, tuple(v.shape), v.dtype, str(v.device)) for f in frames for k, v in sorted(f.items())) + (n_steps,)
+        cache = self.__dict__.setdefault('_captured', {})
+        cap = cache.get(key)
+        if cap is None:
+            if len(cache) >= 4:                                         # a handful of input shapes at most (static buffers are ~1.5 GB each)
+                cache.pop(next(iter(cache)))
+            cap = cache[key] = CapturedSample(self, frames, ego, n_steps=n_steps, d2h=True)
+        cap.run_checked(frames, ego)
+        host = cap.host.numpy()
+        if copy:
+            host = host.copy()
+        return {k: [host[i]] for i, k in enumerate(cap.host_keys)}
+
     @staticmethod
     def _to_numpy(res):
         """the reference's payload: every grid a numpy uint8 (X,Y,Z) array (one D2H copy for all of them)"""
@@ -573,6 +599,8 @@ class PreWorld(_PreWorldCommon):
 
     def simple_test(self, points, img_metas, img=None, rescale=False, **kwargs):
         frames = self.lift_inputs_from_images(self.prepare_inputs(img, stereo=True))
+        if getattr(self, 'capture_replay', False) and self.if_post_finetune:
+            return self.simple_test_captured(frames)
         return self._to_numpy(self.simple_test_from_lift(frames))
 
     def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
@@ -802,24 +830,3 @@ class PreWorld4DTraj(_PreWorldCommon):
             return self.simple_test_captured(frames, temporal_ego_states[0])
         return self._to_numpy(self.simple_test_from_lift(frames, temporal_ego_states[0]))
 
-    def simple_test_captured(self, frames, temporal_ego_states, n_steps=6, copy=True):
-        """The reference-API result -- {'semantic_occ_ks' / 'geo_occ_ks': [numpy uint8 (X,Y,Z)]} -- through a hipGraph of the hot path
-        that this module captures on first use for the inputs' shapes (pipeline.CapturedSample with the host payload inside the
-        graph) and replays afterwards: no per-launch host work and no calibration pass per call.  Every call is range-checked on the
-        host copy of the exponent table the replay delivers (run_checked: a sample outside the calibrated window is re-calibrated
-        eagerly and replayed once).  Opt-in: `net.capture_replay = True` routes simple_test() here (round 6; the eager entry costs
-        ~2 x the captured step in launch overhead and its per-call calibration sync -- bench.py `extra.dropin_simple_test`).
-        copy=False returns views of the pinned buffer the next call overwrites."""
-        from .pipeline import CapturedSample
-        key = tuple((k, tuple(v.shape), v.dtype, str(v.device)) for f in frames for k, v in sorted(f.items())) + (n_steps,)
-        cache = self.__dict__.setdefault('_captured', {})
-        cap = cache.get(key)
-        if cap is None:
-            if len(cache) >= 4:                                         # a handful of input shapes at most (static buffers are ~1.5 GB each)
-                cache.pop(next(iter(cache)))
-            cap = cache[key] = CapturedSample(self, frames, temporal_ego_states, n_steps=n_steps, d2h=True)
-        cap.run_checked(frames, temporal_ego_states)
-        host = cap.host.numpy()
-        if copy:
-            host = host.copy()
-        return {k: [host[i]] for i, k in enumerate(cap.host_keys)}

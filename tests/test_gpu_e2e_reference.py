@@ -299,3 +299,29 @@ def test_simple_test_with_capture_replay_matches_the_reference_and_the_eager_ent
     print('[e2e] captured vs eager simple_test on a second sample: %d of %d voxels differ' % (n_diff, sum(v[0].size for v in eager.values())))
     assert sorted(cap) == sorted(eager) and n_diff <= 8
     assert any(int((cap[k][0] != res[k][0]).sum()) > 100 for k in cap)      # it really was another sample
+
+
+def test_preworld_simple_test_with_capture_replay_matches_the_reference():
+    """the single-time-step detector through the same opt-in (PreWorld.simple_test -> simple_test_captured, no ego states, 1 state)
+    against the reference class's grids (e2e_small.npz, run `pw_ft`)"""
+    tag = 'pw_ft'
+    net, dn = _build('PreWorld', True, True)
+    inputs = tuple(t.to(DEV) for t in E.img_inputs(0))
+    net.capture_replay = True
+    with torch.no_grad():
+        res = net.simple_test(None, None, img=inputs)
+        dn.reset()
+        res2 = net.simple_test(None, None, img=inputs)              # second call: replay
+    assert sorted(res.keys()) == list(GOLD[tag + '_keys']) and len(net._captured) == 1
+    for k in res:
+        want, got = GOLD[tag + '_' + k], res[k][0]
+        assert got.dtype == np.uint8 and got.shape == want.shape and np.array_equal(got, res2[k][0])
+        flips = np.nonzero((got != want).reshape(-1))[0]
+        if k.startswith('semantic_occ'):
+            ti, tm, tc = GOLD['%s_%s_tie_idx' % (tag, k)], GOLD['%s_%s_tie_margin' % (tag, k)], GOLD['%s_%s_tie_cls' % (tag, k)]
+            tol = 2 * 2e-5 * float(GOLD['%s_%s_logit_absmax' % (tag, k)])
+            for v in flips:
+                j = np.nonzero(ti == v)[0]
+                assert j.size == 1 and got.reshape(-1)[v] == tc[j[0]] and tm[j[0]] <= tol, (k, int(v))
+        else:
+            assert flips.size <= 3, (k, flips.size)
