@@ -567,6 +567,13 @@ def extra_figures(args, dev):
                                                roofline_note='roofline_frac = DIRECT-FORM FLOP/s / 157.3 TF fp32-MFMA peak; the dominant kernel '
                                                              'is Winograd F(2,3)^3, which executes 8/27 of them, so frac can exceed 1; '
                                                              'roofline_executed_frac = FLOPs the matrix pipe executes / peak'))
+    # BASELINE configs[3] at world 1 (its own process: it initialises a 1-rank RCCL group): pipeline.ShardedSample, three graphs per rank
+    ex['sharded_w1'] = _sub_json([sys.executable, os.path.abspath(__file__), '--mode', 'sharded', '--steps', '30', '--warmup', '5', '--settle-s', '1',
+                                  '--no-extra', '--no-cpu-baseline'], dict(MASTER_PORT=str(29600 + os.getpid() % 300)),
+                                 lambda r: dict(workload='C3 sample in the sharded latency mode (frames / states owned round-robin, two collectives), '
+                                                         'world 1: every phase on this GPU, collectives trivial', samples_per_s=r['value'],
+                                                ms_per_step=r['ms_per_step'], steps=r['steps'], phase_ms_rank0=r['config']['sharded_phase_ms_rank0'],
+                                                recalibrations=r['config']['recalibrations'], replays_audited=r['config']['replays_audited']))
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'bench_image_path.py')
     img = {}
     for amp in ('none', 'bf16'):
