@@ -552,7 +552,8 @@ class _PreWorldCommon(BEVStereo4DOCC):
         temporal = hasattr(self, 'forecast_cl')
         n_steps = (6 if n_steps is None else n_steps) if temporal else 0
         ego = temporal_ego_states if temporal else frames[0]['bda'].new_zeros(1)          # (CapturedSample keeps a static copy)
-        key = tuple((k, tuple(v.shape), v.dtype, str(v.device)) for f in frames for k, v in sorted(f.items())) + (n_steps,)
+        key = tuple((k, tuple(v.shape), v.dtype, str(v.device), bool(getattr(v, '_pw_channels_last', False)))
+                    for f in frames for k, v in sorted(f.items())) + (n_steps,)
         cache = self.__dict__.setdefault('_captured', {})
         cap = cache.get(key)
         if cap is None:
