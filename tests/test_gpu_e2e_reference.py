@@ -325,3 +325,39 @@ def test_preworld_simple_test_with_capture_replay_matches_the_reference():
                 assert j.size == 1 and got.reshape(-1)[v] == tc[j[0]] and tm[j[0]] <= tol, (k, int(v))
         else:
             assert flips.size <= 3, (k, flips.size)
+
+
+@pytest.mark.parametrize('tag,det', [('p4d_ft', 'PreWorld4DTraj'), ('pw_ft', 'PreWorld')])
+def test_simple_test_on_a_collated_batch_of_two_returns_sample_zero(tag, det):
+    """the reference's simple_test indexes batch element 0 of everything it returns (preworld_temporal_traj.py:306, preworld.py:216): fed
+    a collated batch of TWO samples, the drop-in must return sample 0's grids -- the reference fixture's, under the near-tie rule --
+    while every kernel of the path runs at B = 2 (non-contiguous per-frame pose slices, two-sample lifts, batch-strided decode)."""
+    net, dn = _build(det, True, True)
+    inputs = tuple(t.to(DEV) for t in E.img_inputs(0, batch=2))
+    ego = [[torch.from_numpy(np.concatenate([S.ego_state(40), S.ego_state(47)], 0)).to(DEV)]]
+
+    class TwoSampleDepthNet(type(dn)):                       # sample 0 gets the fixture's seeded DepthNet output, sample 1 another
+        def forward(self, x, mlp_input, stereo_metas=None):
+            n = x.shape[0] // 2
+            a = super().forward(x[:n], mlp_input[:1], stereo_metas)
+            self.k -= 1
+            self.seed += 5
+            b = super().forward(x[n:], mlp_input[1:], stereo_metas)
+            self.seed -= 5
+            return torch.cat([a, b], 0)
+    dn.__class__ = TwoSampleDepthNet
+    with torch.no_grad():
+        res = net.simple_test(None, None, img=inputs, **(dict(temporal_ego_states=ego) if det == 'PreWorld4DTraj' else {}))
+    assert sorted(res.keys()) == list(GOLD[tag + '_keys'])
+    for k in res:
+        want, got = GOLD[tag + '_' + k], res[k][0]
+        assert got.shape == want.shape
+        flips = np.nonzero((got != want).reshape(-1))[0]
+        if k.startswith('semantic_occ'):
+            ti, tm, tc = GOLD['%s_%s_tie_idx' % (tag, k)], GOLD['%s_%s_tie_margin' % (tag, k)], GOLD['%s_%s_tie_cls' % (tag, k)]
+            tol = 2 * 2e-5 * float(GOLD['%s_%s_logit_absmax' % (tag, k)])
+            for v in flips:
+                j = np.nonzero(ti == v)[0]
+                assert j.size == 1 and got.reshape(-1)[v] == tc[j[0]] and tm[j[0]] <= tol, (k, int(v))
+        else:
+            assert flips.size <= 3, (k, flips.size)
