@@ -496,7 +496,12 @@ class _PreWorldCommon(BEVStereo4DOCC):
         voxel_semantics = kwargs['voxel_semantics'] if voxel_semantics is None else voxel_semantics
         head = self.occupancy_head
         nb = voxel_feats_cl.shape[0]                 # (a batch slice of an autograd tensor costs a zero fill + copy of it backward)
-        parts = [train.occ_head_forward(head, voxel_feats_cl if nb == 1 else voxel_feats_cl[b:b + 1], transposed=True) for b in range(nb)]
+        # pre-training (if_post_finetune=False): the head only feeds `loss_sup_voxel = CE x 0.` (preworld.py:130-135).  Its forward still
+        # runs -- the BatchNorms see every batch and their running statistics move, as in the reference -- but outside autograd: the
+        # backward through conv / BN / 1x1 layers would multiply zeros (round 6; value and zero-valued parameter gradients are restored
+        # below, like the attribute MLPs' zero-weight terms of round 4)
+        with torch.enable_grad() if self.if_post_finetune else torch.no_grad():
+            parts = [train.occ_head_forward(head, voxel_feats_cl if nb == 1 else voxel_feats_cl[b:b + 1], transposed=True) for b in range(nb)]
         logits = parts[0] if len(parts) == 1 else torch.cat(parts, 0)               # (B,Z,Y,X,18); per batch element as :240-247
         occ_preds = logits.permute(0, 4, 3, 2, 1)                                   # (B,18,X,Y,Z) view, as :240-247 stacks them
         # the attribute MLPs act per voxel: applied to the (Z,Y,X) buffer as 1x1x1 convs on the MFMA kernels (train.mlp_cl), their
@@ -521,7 +526,7 @@ class _PreWorldCommon(BEVStereo4DOCC):
             out.update({k + sfx: v for k, v in lv.items()})
         else:
             cw = torch.cat([cw17, torch.zeros(1, device=cw17.device)]).to(occ_preds)
-            out['loss_sup_voxel' + sfx] = L.CE_ssc_loss(occ_preds, voxel_semantics, cw, 255) * 0.
+            out['loss_sup_voxel' + sfx] = L.CE_ssc_loss(occ_preds, voxel_semantics, cw, 255) * 0. + _zero_weight_of(head)
         if self.if_render:
             extra = {} if interval is None else dict(if_temporal=True, interval=interval)
             out.update(self.nerf_head(density, semantic, color, if_pretrain=self.if_pretrain, dataset_type=self.dataset_type,
